@@ -1,0 +1,346 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the REFERENCE itself.
+
+Runs only in the build container (needs /root/reference, CPU only).  The
+reference is imported unmodified; the only harness-side shims are the ones
+listed in SURVEY.md Appendix E (``Tensor.cuda`` redirect so the hard-coded
+``.cuda()`` calls work on CPU).  What is committed are the *numbers* this
+script produces (inputs + expected outputs) together with this script -- never
+reference source.
+
+Protocol:
+  model(pretrained=False, 'ivit' layers) <- synthetic float weights (i-vit_amd/synth.py)
+  -> eval, one calibration forward on a seeded batch (initialises x_min/x_max)
+  -> snap every QuantAct range to +-127*2^p  ("pow2-calibrated" regime)
+  -> freeze_model -> golden forward with hooks on every QuantAct / Shiftmax / ShiftGELU.
+Each golden forward is compared against the CPU oracle (oracle/oracle.py) on
+the spot; the script fails if any tap or logit differs.
+
+Usage:  python oracle/gen_golden.py [ops] [deit_tiny] [deit_small] [deit_base] [vit_base]
+"""
+import hashlib
+import importlib
+import json
+import os
+import sys
+import time
+import zlib
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+# ---- shim 1: hard-coded .cuda() -> stay on the tensor's device
+torch.Tensor.cuda = lambda self, device=None, *a, **k: self if device is None else self.to(device)
+sys.path.insert(0, "/root/reference")
+import models as ref_models  # noqa: E402
+import models.quantization_utils as rq  # noqa: E402
+from models.quantization_utils.quant_utils import (SymmetricQuantFunction, batch_frexp,  # noqa: E402
+                                                    fixedpoint_mul, symmetric_linear_quantization_params)
+
+synth = importlib.import_module("i-vit_amd.synth")
+from oracle import oracle as orc  # noqa: E402
+
+torch.set_grad_enabled(False)
+
+
+def crc(a):
+    return zlib.crc32(np.ascontiguousarray(a, dtype=np.int32).tobytes())
+
+
+def to_int(y, scale):
+    """Integer view of a fake-quant float tensor (exact for the scales used here)."""
+    return torch.round(y / scale).to(torch.int64).numpy().astype(np.int32)
+
+
+# ----------------------------------------------------------------------------- op-level KATs
+
+def gen_ops():
+    rng = np.random.default_rng(20260101)
+    out = {}
+
+    # --- batch_frexp + fixedpoint_mul (QuantAct requant), per-channel / per-tensor / identity
+    cases = []
+    for ci, (rows, Cn, per_ch, ident, bits, zmag) in enumerate([
+            (64, 96, True, False, 8, 3.0e5), (64, 96, False, False, 8, 2.0e4), (32, 192, False, True, 8, 200),
+            (32, 48, True, False, 16, 3.0e5), (16, 40, False, True, 16, 127), (64, 64, True, False, 8, 9.0e8),
+            (8, 32, False, False, 32, 1.0e6)]):
+        z = np.rint(rng.normal(0, zmag / 3, size=(1, rows, Cn))).astype(np.float32)
+        if ci == 5:  # LayerNorm-sized inputs (24 significant bits)
+            z = z.astype(np.float32)
+        pre = (rng.uniform(0.5, 2.0, size=Cn if per_ch else 1) * 2.0 ** rng.integers(-20, -8)).astype(np.float32)
+        if ci == 5:
+            pre = (rng.uniform(0.5, 1.5, size=Cn) * np.float32(np.sqrt(np.float32(Cn))) / 2 ** 30).astype(np.float32)
+        q = 2 ** (bits - 1) - 1
+        target = np.abs(z * pre).max() / q * rng.uniform(0.6, 1.3)
+        zsf = np.float32(2.0 ** np.ceil(np.log2(target)))
+        x = torch.from_numpy(z) * torch.from_numpy(pre)  # producer output v*scale (float32)
+        # the consumer recovers z_int = round(x/pre) -- keep the value the reference sees
+        z_seen = torch.round(x / torch.from_numpy(pre)).numpy()
+        kw = {}
+        if ident:
+            z2 = rng.integers(-128, 128, size=(1, rows, Cn)).astype(np.float32)
+            pre2 = np.float32(2.0 ** rng.integers(-6, -2))
+            kw = dict(identity=torch.from_numpy(z2) * pre2, identity_scaling_factor=torch.tensor([pre2]))
+        y = fixedpoint_mul.apply(x, torch.from_numpy(pre), bits, "symmetric", torch.tensor([zsf]),
+                                 kw.get("identity"), kw.get("identity_scaling_factor"))
+        new_scale = torch.from_numpy(pre).double() / torch.tensor([zsf]).float().double()
+        m, e = batch_frexp(new_scale.view(1, 1, -1))
+        c = f"rq{ci}_"
+        out[c + "z"] = z_seen.astype(np.float32).reshape(rows, Cn)
+        out[c + "pre"] = pre
+        out[c + "zsf"] = np.float32(zsf)
+        out[c + "bits"] = np.int32(bits)
+        out[c + "m"] = m.numpy().reshape(-1).astype(np.float64)
+        out[c + "e"] = e.numpy().reshape(-1).astype(np.int32)
+        if ident:
+            out[c + "z2"] = z2.reshape(rows, Cn).astype(np.int32)
+            out[c + "pre2"] = pre2
+        out[c + "out"] = y.numpy().reshape(rows, Cn).astype(np.int32)
+        cases.append(ci)
+    out["rq_cases"] = np.array(cases, np.int32)
+
+    # --- tie cases of the dyadic rounding: z*m/2^e exactly at .5 (half-to-even)
+    pre = np.array([2.0 ** -9], np.float32)
+    zsf = np.float32(2.0 ** -5)   # ratio 1/16 -> m = 2^30, e = 34
+    z = np.arange(-64, 65, dtype=np.float32).reshape(1, 1, -1) * 8
+    y = fixedpoint_mul.apply(torch.from_numpy(z) * pre[0], torch.from_numpy(pre), 8, "symmetric", torch.tensor([zsf]))
+    out["rqtie_z"] = z.reshape(1, -1)
+    out["rqtie_pre"] = pre
+    out["rqtie_zsf"] = zsf
+    out["rqtie_out"] = y.numpy().reshape(1, -1).astype(np.int32)
+
+    # --- SymmetricQuantFunction (input-mode QuantAct and weight quantisation)
+    x = rng.normal(0, 1.0, size=(4, 257)).astype(np.float32)
+    s = np.float32(4.0 / 127.0)
+    out["qs_x"] = x
+    out["qs_s"] = s
+    out["qs_out"] = SymmetricQuantFunction.apply(torch.from_numpy(x), 8, torch.tensor([s]), False).numpy().astype(np.int32)
+
+    # --- QuantLinear end to end (weight/bias quantisation + integer GEMM)
+    lin = rq.QuantLinear(80, 24)
+    W = rng.normal(0, 0.05, size=(24, 80)).astype(np.float32)
+    b = rng.normal(0, 0.05, size=(24,)).astype(np.float32)
+    lin.weight.data = torch.from_numpy(W)
+    lin.bias.data = torch.from_numpy(b)
+    s_in = np.float32(2.0 ** -4)
+    xin = rng.integers(-128, 128, size=(1, 10, 80)).astype(np.float32)
+    yl, sl = lin(torch.from_numpy(xin) * s_in, torch.tensor([s_in]))
+    out["lin_W"], out["lin_b"], out["lin_sin"], out["lin_x"] = W, b, s_in, xin.reshape(10, 80).astype(np.int32)
+    out["lin_wint"] = lin.weight_integer.numpy().astype(np.int32)
+    out["lin_bint"] = lin.bias_integer.numpy().astype(np.int32)
+    out["lin_sw"] = lin.fc_scaling_factor.numpy().astype(np.float32)
+    out["lin_sacc"] = sl.numpy().astype(np.float32)
+    out["lin_acc"] = torch.round(yl / sl).numpy().reshape(10, 24).astype(np.int32)
+
+    # --- QuantConv2d 16x16/16 as used by PatchEmbed
+    conv = rq.QuantConv2d(3, 8, kernel_size=16, stride=16)
+    Wc = rng.normal(0, 0.02, size=(8, 3, 16, 16)).astype(np.float32)
+    bc = rng.normal(0, 0.02, size=(8,)).astype(np.float32)
+    conv.weight.data = torch.from_numpy(Wc)
+    conv.bias.data = torch.from_numpy(bc)
+    xin = rng.integers(-128, 128, size=(2, 3, 32, 32)).astype(np.float32)
+    s_in = np.float32(2.0 ** -5)
+    yc, sc = conv(torch.from_numpy(xin) * s_in, torch.tensor([s_in]))
+    out["conv_W"], out["conv_b"], out["conv_sin"], out["conv_x"] = Wc, bc, s_in, xin.astype(np.int32)
+    out["conv_acc"] = torch.round(yc / sc).numpy().astype(np.int32)  # [2,8,2,2]
+    out["conv_sacc"] = sc.numpy().reshape(-1).astype(np.float32)
+
+    # --- QuantMatMul
+    mm = rq.QuantMatMul()
+    a = rng.integers(-128, 128, size=(2, 3, 17, 64)).astype(np.float32)
+    bb = rng.integers(-128, 128, size=(2, 3, 64, 17)).astype(np.float32)
+    sa = np.float32(2.0 ** -4)
+    ym, sm = mm(torch.from_numpy(a) * sa, torch.tensor([sa]), torch.from_numpy(bb) * sa, torch.tensor([sa]))
+    out["mm_a"], out["mm_b"] = a.astype(np.int32), bb.astype(np.int32)
+    out["mm_out"] = torch.round(ym / sm).numpy().astype(np.int32)
+    out["mm_s"] = sm.numpy().astype(np.float32)
+
+    # --- IVITIntLayerNorm (float output of the module, bit exact) and LN -> QuantAct(8)
+    for ci, (rows, Cn, lo, hi, p) in enumerate([(40, 192, -128, 128, -4), (24, 768, -128, 128, -5),
+                                                (16, 384, -40, 41, -3), (8, 96, -30000, 30000, -9)]):
+        ln = rq.IVITIntLayerNorm(Cn)
+        gamma = rng.uniform(0.5, 1.5, size=Cn).astype(np.float32)
+        beta = rng.normal(0, 0.1, size=Cn).astype(np.float32)
+        ln.weight.data = torch.from_numpy(gamma)
+        ln.bias.data = torch.from_numpy(beta)
+        k = rng.integers(lo, hi, size=(1, rows, Cn)).astype(np.float32)
+        k[0, 0, :] = 5          # constant row: var = 0
+        k[0, 1, :] = np.where(np.arange(Cn) % 2 == 0, 3, 4)  # mean exactly x.5 -> tie
+        s = np.float32(2.0 ** p)
+        yl, sl = ln(torch.from_numpy(k) * s, torch.tensor([s]))
+        qa = rq.QuantAct()
+        zsf = 2.0 ** np.ceil(np.log2(np.abs(yl.numpy()).max() / 127))
+        qa.x_min.fill_(-127 * zsf)
+        qa.x_max.fill_(127 * zsf)
+        qa.fix()
+        yq, sq = qa(yl, sl)
+        c = f"ln{ci}_"
+        out[c + "k"] = k.reshape(rows, Cn).astype(np.int32)
+        out[c + "gamma"], out[c + "beta"], out[c + "s"] = gamma, beta, s
+        out[c + "y_bits"] = yl.numpy().reshape(rows, Cn).view(np.int32)      # float32 bit pattern
+        out[c + "sln"] = sl.detach().numpy().reshape(-1).astype(np.float32)
+        out[c + "bias_int"] = ln.bias_integer.numpy().astype(np.float32)
+        out[c + "q_sf"] = np.float32(sq.item())
+        out[c + "q_out"] = torch.round(yq / sq).numpy().reshape(rows, Cn).astype(np.int32)
+    out["ln_cases"] = np.arange(4, dtype=np.int32)
+
+    # --- IVITIntGELU
+    for ci, (rows, L, p, lo, hi) in enumerate([(32, 768, -4, -128, 128), (16, 3072, -5, -128, 128),
+                                               (16, 384, -3, -128, 128), (8, 256, -6, -128, 128),
+                                               (8, 100, -2, -128, 128), (4, 64, -4, -128, -100)]):
+        g = rq.IVITIntGELU()
+        k = rng.integers(lo, hi, size=(1, rows, L)).astype(np.float32)
+        if ci == 3:
+            k[0, :, :] = np.arange(-128, 128)
+        s = np.float32(2.0 ** p)
+        yg, sg = g(torch.from_numpy(k) * s, torch.tensor([s]))
+        c = f"gelu{ci}_"
+        out[c + "k"] = k.reshape(rows, L).astype(np.int32)
+        out[c + "s"] = s
+        out[c + "out"] = torch.round(yg / sg).numpy().reshape(rows, L).astype(np.int32)
+        out[c + "sout"] = np.float32(sg.item())
+    out["gelu_cases"] = np.arange(6, dtype=np.int32)
+
+    # --- IVITIntSoftmax
+    for ci, (rows, L, p, sd) in enumerate([(64, 197, -2, 30), (64, 197, -3, 50), (32, 49, -2, 25),
+                                           (16, 197, -1, 8), (16, 197, 0, 4), (8, 64, -4, 60), (8, 197, -5, 70)]):
+        sm = rq.IVITIntSoftmax()
+        k = np.clip(np.rint(rng.normal(0, sd, size=(1, 1, rows, L))), -128, 127).astype(np.float32)
+        k[0, 0, 0, :] = 7   # uniform row
+        k[0, 0, 1, :] = -128
+        k[0, 0, 1, 3] = 127  # one-hot row
+        s = np.float32(2.0 ** p)
+        ys, ss = sm(torch.from_numpy(k) * s, torch.tensor([s]))
+        c = f"sm{ci}_"
+        out[c + "k"] = k.reshape(rows, L).astype(np.int32)
+        out[c + "s"] = s
+        out[c + "out"] = torch.round(ys / ss).numpy().reshape(rows, L).astype(np.int32)
+    out["sm_cases"] = np.arange(7, dtype=np.int32)
+
+    np.savez_compressed(os.path.join(GOLD, "ops_kat.npz"), **out)
+    print("ops_kat.npz written:", len(out), "arrays")
+
+
+# ----------------------------------------------------------------------------- whole model
+
+MODEL_PLAN = {
+    # tag: (factory name, weight seed, calib seed, calib batch, image seed, n golden images, full taps?)
+    "deit_tiny": ("deit_tiny_patch16_224", 11, 101, 4, 1001, 8, True),
+    "deit_small": ("deit_small_patch16_224", 12, 102, 4, 1002, 4, False),
+    "deit_base": ("deit_base_patch16_224", 13, 103, 4, 1003, 4, False),
+    "vit_base": ("vit_base_patch16_224", 14, 104, 2, 1004, 2, False),
+}
+
+
+def gen_model(tag):
+    factory, wseed, cseed, cb, iseed, nimg, full = MODEL_PLAN[tag]
+    cfg = synth.MODEL_CONFIGS[factory]
+    t0 = time.time()
+    model = getattr(ref_models, factory)(pretrained=False, gelu_type="ivit", softmax_type="ivit",
+                                         layernorm_type="ivit")
+    fs = synth.make_float_state(factory, wseed)
+    missing, unexpected = model.load_state_dict({k: torch.from_numpy(v) for k, v in fs.items()}, strict=False)
+    assert not unexpected, unexpected
+    assert all(("scaling_factor" in k or "integer" in k or "x_min" in k or "x_max" in k) for k in missing), missing
+    model.eval()
+    # calibration forward (running_stat defaults to True)
+    model(torch.from_numpy(synth.make_images(cb, cseed)))
+    # pow2 snap
+    ranges = {}
+    for name, mod in model.named_modules():
+        if isinstance(mod, rq.QuantAct):
+            mx = float(torch.max(-mod.x_min, mod.x_max))
+            assert mx > 0, name
+            p = int(np.ceil(np.log2(mx / 127.0)))
+            mod.x_max.fill_(127.0 * 2.0 ** p)
+            mod.x_min.fill_(-127.0 * 2.0 ** p)
+            ranges[name] = (np.float32(mod.x_min.item()), np.float32(mod.x_max.item()))
+    assert list(ranges) == synth.qact_names(cfg["depth"]), "QuantAct order drifted"
+    ref_models.freeze_model(model)
+
+    taps = {}
+
+    def hook(name):
+        def fn(mod, inp, outp):
+            y, s = outp
+            taps[name] = to_int(y, s)
+        return fn
+
+    for name, mod in model.named_modules():
+        if isinstance(mod, (rq.QuantAct, rq.IVITIntSoftmax, rq.IVITIntGELU)):
+            mod.register_forward_hook(hook(name))
+
+    imgs = synth.make_images(nimg, iseed)
+    y = model(torch.from_numpy(imgs))
+    s_head = (model.head.fc_scaling_factor * model.qact2.act_scaling_factor).float()
+    logits_int = torch.round(y / s_head).to(torch.int64).numpy().astype(np.int32)
+    logits_f32 = y.numpy().astype(np.float32)
+    top1 = y.argmax(dim=1).numpy().astype(np.int64)
+    t_ref = time.time() - t0
+
+    # ---- check the oracle against the reference right here
+    t1 = time.time()
+    om = orc.OracleViT(fs, ranges, cfg["embed_dim"], cfg["depth"], cfg["num_heads"])
+    otaps = {}
+    res = om.forward(imgs, otaps)
+    bad = [n for n in taps if n in otaps and not np.array_equal(taps[n].reshape(-1), otaps[n].reshape(-1))]
+    miss = [n for n in taps if n not in otaps]
+    assert not miss, miss
+    assert not bad, f"oracle != reference at {bad[:5]} ({len(bad)} taps)"
+    assert np.array_equal(res["logits_int32"], logits_int), "INT32 logits differ"
+    assert np.array_equal(res["logits_f32"].view(np.int32), logits_f32.view(np.int32)), "float logits differ"
+    assert np.array_equal(res["top1"], top1)
+    print(f"[{tag}] reference {t_ref:.1f}s, oracle {time.time()-t1:.1f}s: {len(taps)} taps + logits bit-equal; "
+          f"max|acc|={om.max_acc} softmax rows with sum>=2^24: {om.softmax_inexact_rows}")
+    assert om.max_acc < 2 ** 24
+
+    names = sorted(taps)
+    out = {
+        "meta": np.array(json.dumps(dict(tag=tag, factory=factory, weight_seed=wseed, calib_seed=cseed,
+                                         calib_batch=cb, image_seed=iseed, n_images=nimg, qkv_gain=synth.QKV_GAIN,
+                                         max_abs_acc=om.max_acc, softmax_inexact_rows=om.softmax_inexact_rows,
+                                         torch=torch.__version__, numpy=np.__version__))),
+        "range_names": np.array(list(ranges)),
+        "x_min": np.array([v[0] for v in ranges.values()], np.float32),
+        "x_max": np.array([v[1] for v in ranges.values()], np.float32),
+        "logits_int32": logits_int,
+        "logits_f32_bits": logits_f32.view(np.int32),
+        "top1": top1,
+        "tap_names": np.array(names),
+        "tap_crc32": np.array([crc(taps[n]) for n in names], np.uint32),
+        "tap_absmax": np.array([int(np.abs(taps[n]).max()) for n in names], np.int64),
+    }
+    # digests of the derived integer weights guard the synthetic generator against drift
+    wn, wd = [], []
+    for name, mod in model.named_modules():
+        if isinstance(mod, (rq.QuantLinear, rq.QuantConv2d)):
+            for buf in ("weight_integer", "bias_integer"):
+                wn.append(f"{name}.{buf}")
+                wd.append(hashlib.sha256(getattr(mod, buf).numpy().astype(np.int32).tobytes()).hexdigest()[:16])
+    out["wint_names"], out["wint_sha"] = np.array(wn), np.array(wd)
+    if full:  # a few complete taps of image 0 for debugging kernels stage by stage
+        for n in ["qact_input", "patch_embed.qact", "qact1", "blocks.0.qact1", "blocks.0.attn.qact1",
+                  "blocks.0.attn.qact_attn1", "blocks.0.attn.int_softmax", "blocks.0.attn.qact2",
+                  "blocks.0.attn.qact3", "blocks.0.qact2", "blocks.0.qact3", "blocks.0.mlp.qact_gelu",
+                  "blocks.0.mlp.act", "blocks.0.mlp.qact1", "blocks.0.mlp.qact2", "blocks.0.qact4",
+                  "blocks.11.qact4", "qact2"]:
+            t = taps[n][:1]
+            dt = np.int8 if np.abs(t).max() <= 127 and t.min() >= -128 else np.int16
+            out["full/" + n] = t.astype(dt)
+    np.savez_compressed(os.path.join(GOLD, f"{tag}.npz"), **out)
+    print(f"[{tag}] wrote fixtures; top1 = {top1.tolist()}")
+
+
+if __name__ == "__main__":
+    os.makedirs(GOLD, exist_ok=True)
+    what = sys.argv[1:] or ["ops", "deit_tiny", "deit_small", "deit_base", "vit_base"]
+    for w in what:
+        if w == "ops":
+            gen_ops()
+        else:
+            gen_model(w)
