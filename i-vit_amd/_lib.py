@@ -1,0 +1,99 @@
+"""ctypes binding of libivit_hip.so (the C ABI declared in include/ivit_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a call
+returns a non-zero status this module raises.  ``build()`` (re)compiles the
+library in-tree with hipcc for gfx950; it is what ``__graft_entry__.build()``
+calls.  The library is git-ignored but travels to the GPU box with the tree.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libivit_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+i64, i32, u32, f32, vp = C.c_int64, C.c_int32, C.c_uint32, C.c_float, C.c_void_p
+ci = C.c_int
+
+# name -> argtypes, exactly the prototypes of include/ivit_hip.h
+SIGNATURES = {
+    "ivit_quantize_input_f32_i8": [vp, vp, i64, f32, vp],
+    "ivit_quantize_patchify_f32_i8": [vp, vp, ci, ci, ci, ci, f32, vp],
+    "ivit_gemm_i8_requant": [vp, i64, vp, i64, vp, vp, vp, vp, i64, ci, ci, ci, vp],
+    "ivit_gemm_i8_requant_residual": [vp, i64, vp, i64, vp, vp, vp, vp, i64, u32, i32, u32, i32, vp, i64, ci, ci, ci, vp],
+    "ivit_gemm_i8_requant_qkv": [vp, i64, vp, i64, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp],
+    "ivit_gemm_i8_i32": [vp, i64, vp, i64, vp, vp, i64, ci, ci, ci, vp],
+    "ivit_attention_fused_i8": [vp, vp, ci, ci, ci, ci, u32, i32, f32, u32, i32, vp],
+    "ivit_layernorm_i8": [vp, i64, ci, ci, vp, vp, vp, vp, vp, i64, vp],
+    "ivit_layernorm_i32_f32": [vp, i64, ci, ci, vp, vp, vp, i64, vp],
+    "ivit_shiftgelu_i8": [vp, i64, ci, ci, f32, u32, i32, vp, i64, vp],
+    "ivit_shiftgelu_i8_i32": [vp, i64, ci, ci, f32, vp, i64, vp],
+    "ivit_shiftgelu_build_lut": [f32, u32, i32, vp, vp],
+    "ivit_shiftgelu_lut_i8": [vp, i64, ci, ci, vp, vp, i64, vp],
+    "ivit_shiftmax_i8": [vp, i64, ci, ci, f32, vp, i64, vp],
+    "ivit_requant_i32": [vp, i64, ci, vp, vp, ci, vp, vp, vp, ci, ci, vp, vp],
+    "ivit_residual_requant_i8": [vp, u32, i32, vp, u32, i32, vp, i64, vp],
+    "ivit_embed_assemble_i8": [vp, vp, vp, u32, i32, vp, ci, ci, ci, vp],
+    "ivit_head_argmax": [vp, vp, ci, ci, vp, vp, vp],
+    "ivit_bgemm_qk_i8": [vp, vp, vp, ci, ci, ci, ci, vp],
+    "ivit_bgemm_pv_i8": [vp, vp, vp, ci, ci, ci, ci, vp],
+    "ivit_f32_to_i32": [vp, i64, ci, vp, ci, ci, vp, vp],
+    "ivit_i32_to_f32": [vp, i64, ci, vp, ci, vp, vp],
+}
+
+
+class IvitError(RuntimeError):
+    pass
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile csrc/*.hip -> libivit_hip.so (hipcc --offload-arch=gfx950)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
+    srcs.append(os.path.join(_HERE, "..", "include", "ivit_hip.h"))
+    stale = force or not os.path.exists(LIB_PATH) or any(
+        os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if stale:
+        cmd = ["make", "-C", CSRC, "-j4"] + ([] if verbose else ["-s"])
+        subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Load the library (never builds implicitly; never falls back)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise IvitError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                            "(there is no CPU / PyTorch fallback for the integer ViT path)")
+        L = C.CDLL(LIB_PATH)
+        L.ivit_version.restype = ci
+        L.ivit_last_error_string.restype = C.c_char_p
+        for name, args in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the symbol is not exported
+            fn.argtypes = args
+            fn.restype = ci
+        _lib = L
+    return _lib
+
+
+def call(name: str, *args):
+    L = lib()
+    rc = getattr(L, name)(*args)
+    if rc != 0:
+        raise IvitError(f"{name} failed ({rc}): {L.ivit_last_error_string().decode()}")
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    return None if t is None else C.c_void_p(t.data_ptr())

@@ -1,0 +1,112 @@
+// common.h -- shared host/device helpers of libivit_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ivit_hip.h"
+
+#define IVIT_EXPORT extern "C" __attribute__((visibility("default")))
+
+// ---- host side -------------------------------------------------------------------------------
+void ivit_set_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
+
+#define IVIT_REQUIRE(cond, ...)            \
+    do {                                   \
+        if (!(cond)) {                     \
+            ivit_set_error(__VA_ARGS__);   \
+            return IVIT_ERR_INVALID;       \
+        }                                  \
+    } while (0)
+
+#define IVIT_CHECK_LAUNCH(name)                                                       \
+    do {                                                                              \
+        hipError_t err__ = hipGetLastError();                                         \
+        if (err__ != hipSuccess) {                                                    \
+            ivit_set_error("%s: launch failed: %s", name, hipGetErrorString(err__));  \
+            return IVIT_ERR_LAUNCH;                                                   \
+        }                                                                             \
+        return IVIT_OK;                                                               \
+    } while (0)
+
+static inline hipStream_t ivit_stream(ivit_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+// A dyadic requantiser passed by value: M = m * 2^-e as an exact double.
+static inline double ivit_dyadic_to_double(uint32_t m, int32_t e) { return __builtin_ldexp((double)m, -e); }
+
+// ---- device side -----------------------------------------------------------------------------
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+#define IVIT_DEV __device__ __forceinline__
+
+// 2^52 + 2^51: adding it to |v| < 2^51 rounds v to an integer (RNE) and leaves that integer,
+// two's complement, in the low mantissa bits.
+#define IVIT_MAGIC 6755399441055744.0
+
+IVIT_DEV double dyadic_mult(uint32_t m, int32_t e) { return __builtin_ldexp((double)m, -e); }
+
+IVIT_DEV int clamp_i32(int v, int lo, int hi) { return min(max(v, lo), hi); }
+
+// out = RNE(z * m / 2^e) for |z*m| < 2^53 and |z*M| < 2^31 (GEMM accumulators, int8 operands):
+// the reference's double product (quant_utils.py:229) is exact in that range, so one fused
+// multiply-add against the magic constant performs the single RNE rounding of :230.
+IVIT_DEV int requant_exact(int z, double M)
+{
+    double t = __builtin_fma((double)z, M, IVIT_MAGIC);
+    return (int)(unsigned)__double_as_longlong(t);
+}
+
+// General form, bit-faithful to quant_utils.py:229-230 for any float-representable z:
+// the product rounds to 53 bits first (as the reference's float64 multiply does), then RNE.
+IVIT_DEV double requant_double(double z, double M)
+{
+    double p = z * M;  // M = m * 2^-e: same rounding as z*m, then exact scaling
+    return __builtin_rint(p);
+}
+
+IVIT_DEV int wave_reduce_max_i32(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+    return v;
+}
+
+IVIT_DEV int wave_reduce_sum_i32(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// int_exp_shift of the reference (ivit_modules.py:89-103 / :150-162) for one integer d <= 0,
+// x0 = floor(-1/s) (negative), n = 23 (GELU) or 15 (softmax).  Every intermediate is an exact
+// small integer or half-integer in the reference's float32 arithmetic, so integer ops reproduce it:
+//   x = d + floor(d/2) - floor(d/16); x = max(x, n*x0); q = floor(x/x0); r = x - x0*q;
+//   e = floor((r/2 - x0) * 2^(n-q))
+IVIT_DEV unsigned shiftexp_int(int d, int x0, int n)
+{
+    int x = d + (d >> 1) - (d >> 4);
+    x = max(x, n * x0);
+    int ax = -x, a0 = -x0;            // both >= 0
+    int q = ax / a0;                  // floor(x/x0) for x<=0, x0<0
+    int r = x - x0 * q;               // in (x0, 0]
+    // (r/2 - x0) * 2^(n-q) = (r - 2*x0) * 2^(n-q-1); n-q >= 0
+    int t = r - 2 * x0;               // > 0
+    int sh = n - q - 1;
+    unsigned e = (sh >= 0) ? ((unsigned)t << sh) : ((unsigned)t >> 1);  // floor for sh = -1
+    return e;
+}
+
+// The same for any sign of d, as a float32 value (ShiftGELU evaluates exp_int(-max) whose argument
+// is positive for rows with a negative maximum, ivit_modules.py:115; the value may exceed 2^32 and
+// overflows to +inf exactly where the reference's float32 2**(n-q) does).
+IVIT_DEV float shiftexp_f32(int d, int x0, int n)
+{
+    int x = d + (d >> 1) - (d >> 4);
+    x = max(x, n * x0);
+    const int a0 = -x0;
+    const int q = (x <= 0) ? ((-x) / a0) : -((x + a0 - 1) / a0);  // floor(x / x0)
+    const int r = x - x0 * q;                                       // in (x0, 0]
+    const int t = r - 2 * x0;                                       // 2 * (r/2 - x0) > 0
+    return ldexpf((float)t, n - q - 1);
+}

@@ -1,0 +1,334 @@
+// gemm.hip -- INT8 GEMM on v_mfma_i32_32x32x32_i8 with the QuantAct requantiser fused in the
+// epilogue.  Replaces QuantLinear.forward / QuantConv2d.forward + the QuantAct that follows
+// (/root/reference/models/quantization_utils/quant_modules.py:186-226, 302-387, 478-511;
+//  fixedpoint_mul quant_utils.py:193-253).
+//
+// Formulation: out^T[n][t] = W[n][:] . A[t][:]  -- the weight rows are the MFMA "A" operand and the
+// activation rows the "B" operand (both K-contiguous, so both fragments are one 16-byte LDS read).
+// The 32x32 accumulator tile then has the TOKEN on the lane (col = lane & 31) and 4 consecutive
+// CHANNELS in each register quad (row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)), which is what the
+// int8 epilogue wants: 4 requantised channels pack into one dword.
+//
+// Block tile 128 tokens x 128 channels x 64 bytes of K, 4 waves (2 x 2, 64 x 64 each = 2 x 2 MFMA
+// tiles), two LDS stages filled through registers (global_load_dwordx4 -> ds_write_b128), XOR
+// swizzled so that every ds_read_b128 fragment read is bank-conflict free.  The epilogue stages the
+// int8 tile through LDS so that global stores (and the residual loads) are 16 B per lane, row
+// contiguous.  Block ids are remapped so that the 8 XCDs each walk a contiguous range of tiles
+// (token panel reuse in the XCD-private L2).
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128;  // tokens per block
+constexpr int BN = 128;  // channels per block
+constexpr int BK = 64;   // K bytes per stage
+constexpr int NT = 256;
+constexpr int STAGE_BYTES = (BM + BN) * BK;  // 16 KiB
+constexpr int W_OFF = BM * BK;               // weight tile behind the token tile
+constexpr int CS_STRIDE = 132;               // epilogue tile row stride (33 dwords: conflict-free)
+constexpr int SMEM_BYTES = 2 * STAGE_BYTES;  // 32 KiB >= 128 * 132
+
+enum { EPI_RQ = 0, EPI_RESID = 1, EPI_QKV = 2, EPI_I32 = 3 };
+
+struct GemmArgs {
+    const int8_t* A;
+    int64_t lda;
+    const int8_t* W;
+    int64_t ldw;
+    const int32_t* bias;
+    const uint32_t* m;
+    const int32_t* e;
+    void* out;
+    int64_t ldo;
+    const int8_t* res;
+    int64_t ldr;
+    double M_main, M_res;
+    int M, N, K;
+    int tokens, heads, head_dim;
+    int tiles_m, tiles_n;
+};
+
+// byte offset of 16-byte chunk c (0..3) of tile row r; rows are 64 B, four rows per 256-B bank row.
+IVIT_DEV int swz(int r, int c) { return r * BK + ((c ^ ((r >> 2) & 3)) << 4); }
+
+IVIT_DEV int pack4_i8(int a, int b, int c, int d)
+{
+    return (a & 0xff) | ((b & 0xff) << 8) | ((c & 0xff) << 16) | ((d & 0xff) << 24);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(NT) void gemm_i8_kernel(GemmArgs g)
+{
+    __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
+
+    // ---- XCD-aware block -> tile map (bijective for any block count)
+    const int nblk = g.tiles_m * g.tiles_n;
+    const int bid = blockIdx.x;
+    const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
+    const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int tm = lid / g.tiles_n, tn = lid - tm * g.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int h = lane >> 5, l31 = lane & 31;
+
+    // ---- staging: thread moves chunks (row = tid/4 + 64 i, c = tid%4) of both tiles
+    const int srow = tid >> 2, sc = tid & 3;
+    const int8_t* ap[2];
+    const int8_t* wp[2];
+    int soff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int r = srow + 64 * i;
+        int ar = min(m0 + r, g.M - 1);
+        int wr = min(n0 + r, g.N - 1);
+        ap[i] = g.A + (int64_t)ar * g.lda + 16 * sc;
+        wp[i] = g.W + (int64_t)wr * g.ldw + 16 * sc;
+        soff[i] = swz(r, sc);
+    }
+
+    // ---- accumulators start from the int32 bias (QuantLinear adds bias_integer to the product)
+    v16i acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int cn = n0 + 64 * wn + 32 * i + 8 * (r >> 2) + 4 * h + (r & 3);
+            int b = (g.bias != nullptr && cn < g.N) ? g.bias[cn] : 0;
+            acc[i][0][r] = b;
+            acc[i][1][r] = b;
+        }
+
+    v4i ra[2], rw[2];
+    const int nk = g.K / BK;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        ra[i] = *reinterpret_cast<const v4i*>(ap[i]);
+        rw[i] = *reinterpret_cast<const v4i*>(wp[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        *reinterpret_cast<v4i*>(smem + soff[i]) = ra[i];
+        *reinterpret_cast<v4i*>(smem + W_OFF + soff[i]) = rw[i];
+    }
+    __syncthreads();
+
+    // fragment rows of this lane
+    const int wrow0 = 64 * wn + l31, arow0 = 64 * wm + l31;
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int st = (kt & 1) * STAGE_BYTES;
+        if (kt + 1 < nk) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                ra[i] = *reinterpret_cast<const v4i*>(ap[i] + (int64_t)(kt + 1) * BK);
+                rw[i] = *reinterpret_cast<const v4i*>(wp[i] + (int64_t)(kt + 1) * BK);
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            v4i wf[2], af[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                wf[i] = *reinterpret_cast<const v4i*>(smem + st + W_OFF + swz(wrow0 + 32 * i, 2 * ks + h));
+                af[i] = *reinterpret_cast<const v4i*>(smem + st + swz(arow0 + 32 * i, 2 * ks + h));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[i], af[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) {
+            const int sn = ((kt + 1) & 1) * STAGE_BYTES;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                *reinterpret_cast<v4i*>(smem + sn + soff[i]) = ra[i];
+                *reinterpret_cast<v4i*>(smem + sn + W_OFF + soff[i]) = rw[i];
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue
+    if constexpr (EPI == EPI_I32) {
+        int32_t* out = reinterpret_cast<int32_t*>(g.out);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                int t = m0 + 64 * wm + 32 * j + l31;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    int c0 = n0 + 64 * wn + 32 * i + 8 * q + 4 * h;
+                    if (t < g.M && c0 < g.N) {
+                        v4i v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                        *reinterpret_cast<v4i*>(out + (int64_t)t * g.ldo + c0) = v;
+                    }
+                }
+            }
+        return;
+    } else {
+        // requantise (per channel) -> int8, 4 channels per dword, into the LDS tile Cs[token][channel]
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int cl = 64 * wn + 32 * i + 8 * q + 4 * h;  // local channel of the quad
+                const int c0 = n0 + cl;
+                double Mc[4];
+                if (c0 < g.N) {
+                    uint4 m4 = *reinterpret_cast<const uint4*>(g.m + c0);
+                    int4 e4 = *reinterpret_cast<const int4*>(g.e + c0);
+                    Mc[0] = dyadic_mult(m4.x, e4.x);
+                    Mc[1] = dyadic_mult(m4.y, e4.y);
+                    Mc[2] = dyadic_mult(m4.z, e4.z);
+                    Mc[3] = dyadic_mult(m4.w, e4.w);
+                } else {
+                    Mc[0] = Mc[1] = Mc[2] = Mc[3] = 0.0;
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    int b[4];
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        // quant_utils.py:229-230: float64 product (53-bit rounding), /2^e, round-half-even
+                        double p = (double)acc[i][j][4 * q + jj] * Mc[jj];
+                        double t = p + IVIT_MAGIC;
+                        b[jj] = clamp_i32((int)(unsigned)__double_as_longlong(t), -128, 127);
+                    }
+                    const int tl = 64 * wm + 32 * j + l31;
+                    *reinterpret_cast<int*>(smem + tl * CS_STRIDE + cl) = pack4_i8(b[0], b[1], b[2], b[3]);
+                }
+            }
+        __syncthreads();
+
+        int8_t* out = reinterpret_cast<int8_t*>(g.out);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int q = tid + NT * it;
+            const int tl = q >> 3, cc = q & 7;
+            const int t = m0 + tl, cn = n0 + 16 * cc;
+            if (t >= g.M || cn >= g.N) continue;
+            const int* src = reinterpret_cast<const int*>(smem + tl * CS_STRIDE + 16 * cc);
+            int v[4] = {src[0], src[1], src[2], src[3]};
+            if constexpr (EPI == EPI_RESID) {
+                const int4 rv = *reinterpret_cast<const int4*>(g.res + (int64_t)t * g.ldr + cn);
+                const int rr[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    int o[4];
+#pragma unroll
+                    for (int bb = 0; bb < 4; ++bb) {
+                        int k3 = (int)(int8_t)(v[d] >> (8 * bb));
+                        int xr = (int)(int8_t)(rr[d] >> (8 * bb));
+                        // quant_utils.py:229-245: two independently rounded products, then the sum
+                        int s = requant_exact(k3, g.M_main) + requant_exact(xr, g.M_res);
+                        o[bb] = clamp_i32(s, -128, 127);
+                    }
+                    v[d] = pack4_i8(o[0], o[1], o[2], o[3]);
+                }
+            }
+            int64_t off;
+            if constexpr (EPI == EPI_QKV) {
+                const int cdim = g.heads * g.head_dim;
+                const int which = cn / cdim, rem = cn - which * cdim;
+                const int hh = rem / g.head_dim, d0 = rem - hh * g.head_dim;
+                const int b = t / g.tokens, tok = t - b * g.tokens;
+                const int nb = g.M / g.tokens;
+                off = ((((int64_t)which * nb + b) * g.heads + hh) * g.tokens + tok) * g.head_dim + d0;
+            } else {
+                off = (int64_t)t * g.ldo + cn;
+            }
+            *reinterpret_cast<int4*>(out + off) = make_int4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
+template <int EPI>
+int launch_gemm(GemmArgs& g, const char* name, ivit_stream_t stream)
+{
+    IVIT_REQUIRE(g.A && g.W && g.out, "%s: NULL operand", name);
+    IVIT_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0, "%s: empty problem M=%d N=%d K=%d", name, g.M, g.N, g.K);
+    IVIT_REQUIRE(g.K % BK == 0, "%s: K=%d must be a multiple of %d", name, g.K, BK);
+    IVIT_REQUIRE(g.lda >= g.K && g.ldw >= g.K && g.lda % 16 == 0 && g.ldw % 16 == 0,
+                 "%s: lda=%lld ldw=%lld must be >= K and multiples of 16", name, (long long)g.lda, (long long)g.ldw);
+    IVIT_REQUIRE(((uintptr_t)g.A % 16 == 0) && ((uintptr_t)g.W % 16 == 0) && ((uintptr_t)g.out % 16 == 0),
+                 "%s: operands must be 16-byte aligned", name);
+    if (EPI == EPI_I32) {
+        IVIT_REQUIRE(g.N % 4 == 0 && g.ldo % 4 == 0 && g.ldo >= g.N, "%s: N=%d ldo=%lld must be multiples of 4", name,
+                     g.N, (long long)g.ldo);
+    } else {
+        IVIT_REQUIRE(g.m && g.e, "%s: NULL requantiser table", name);
+        IVIT_REQUIRE(g.N % 16 == 0, "%s: N=%d must be a multiple of 16", name, g.N);
+        IVIT_REQUIRE(((uintptr_t)g.m % 16 == 0) && ((uintptr_t)g.e % 16 == 0), "%s: m/e tables must be 16-byte aligned",
+                     name);
+    }
+    if (EPI == EPI_RQ || EPI == EPI_RESID)
+        IVIT_REQUIRE(g.ldo >= g.N && g.ldo % 16 == 0, "%s: ldo=%lld must be >= N and a multiple of 16", name,
+                     (long long)g.ldo);
+    if (EPI == EPI_RESID)
+        IVIT_REQUIRE(g.res && g.ldr >= g.N && g.ldr % 16 == 0 && ((uintptr_t)g.res % 16 == 0),
+                     "%s: residual operand missing or misaligned", name);
+    if (EPI == EPI_QKV) {
+        IVIT_REQUIRE(g.tokens > 0 && g.heads > 0 && g.head_dim > 0 && g.head_dim % 16 == 0,
+                     "%s: bad head geometry tokens=%d heads=%d head_dim=%d", name, g.tokens, g.heads, g.head_dim);
+        IVIT_REQUIRE(g.N == 3 * g.heads * g.head_dim && g.M % g.tokens == 0,
+                     "%s: N=%d != 3*heads*head_dim or M=%d %% tokens=%d != 0", name, g.N, g.M, g.tokens);
+    }
+    g.tiles_m = (g.M + BM - 1) / BM;
+    g.tiles_n = (g.N + BN - 1) / BN;
+    hipLaunchKernelGGL(gemm_i8_kernel<EPI>, dim3(g.tiles_m * g.tiles_n), dim3(NT), 0, ivit_stream(stream), g);
+    IVIT_CHECK_LAUNCH(name);
+}
+
+}  // namespace
+
+IVIT_EXPORT int ivit_gemm_i8_requant(const int8_t* A, int64_t lda, const int8_t* W, int64_t ldw, const int32_t* bias,
+                                     const uint32_t* m, const int32_t* e, int8_t* out, int64_t ldo, int M, int N,
+                                     int K, ivit_stream_t stream)
+{
+    GemmArgs g{};
+    g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.m = m; g.e = e;
+    g.out = out; g.ldo = ldo; g.M = M; g.N = N; g.K = K;
+    return launch_gemm<EPI_RQ>(g, "ivit_gemm_i8_requant", stream);
+}
+
+IVIT_EXPORT int ivit_gemm_i8_requant_residual(const int8_t* A, int64_t lda, const int8_t* W, int64_t ldw,
+                                              const int32_t* bias, const uint32_t* m, const int32_t* e,
+                                              const int8_t* res, int64_t ldr, uint32_t m_main, int32_t e_main,
+                                              uint32_t m_res, int32_t e_res, int8_t* out, int64_t ldo, int M, int N,
+                                              int K, ivit_stream_t stream)
+{
+    GemmArgs g{};
+    g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.m = m; g.e = e;
+    g.out = out; g.ldo = ldo; g.res = res; g.ldr = ldr; g.M = M; g.N = N; g.K = K;
+    g.M_main = ivit_dyadic_to_double(m_main, e_main);
+    g.M_res = ivit_dyadic_to_double(m_res, e_res);
+    IVIT_REQUIRE(g.M_main < 1048576.0 && g.M_res < 1048576.0,
+                 "ivit_gemm_i8_requant_residual: residual multiplier >= 2^20 is outside the int8 fast path");
+    return launch_gemm<EPI_RESID>(g, "ivit_gemm_i8_requant_residual", stream);
+}
+
+IVIT_EXPORT int ivit_gemm_i8_requant_qkv(const int8_t* A, int64_t lda, const int8_t* W, int64_t ldw,
+                                         const int32_t* bias, const uint32_t* m, const int32_t* e, int8_t* qkv,
+                                         int tokens, int heads, int head_dim, int M, int N, int K,
+                                         ivit_stream_t stream)
+{
+    GemmArgs g{};
+    g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.m = m; g.e = e;
+    g.out = qkv; g.ldo = 0; g.M = M; g.N = N; g.K = K;
+    g.tokens = tokens; g.heads = heads; g.head_dim = head_dim;
+    return launch_gemm<EPI_QKV>(g, "ivit_gemm_i8_requant_qkv", stream);
+}
+
+IVIT_EXPORT int ivit_gemm_i8_i32(const int8_t* A, int64_t lda, const int8_t* W, int64_t ldw, const int32_t* bias,
+                                 int32_t* out, int64_t ldo, int M, int N, int K, ivit_stream_t stream)
+{
+    GemmArgs g{};
+    g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias;
+    g.out = out; g.ldo = ldo; g.M = M; g.N = N; g.K = K;
+    return launch_gemm<EPI_I32>(g, "ivit_gemm_i8_i32", stream);
+}

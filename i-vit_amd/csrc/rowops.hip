@@ -1,0 +1,719 @@
+// rowops.hip -- row-wise integer kernels: I-LayerNorm, ShiftGELU, stand-alone Shiftmax, and the
+// small element-wise pieces around them.  All are one-wavefront-per-row (64 lanes), reductions by
+// cross-lane exchange, HBM-bound by design (1 byte in + 1 byte out per element).
+// Reference: /root/reference/models/quantization_utils/ivit_modules.py (IVITIntLayerNorm :30-65,
+// IVITIntGELU :89-126, IVITIntSoftmax :150-179), quant_utils.py (fixedpoint_mul :193-253,
+// SymmetricQuantFunction :79-97).
+//
+// Float32 / float64 instructions appear below ONLY where the reference's own float emulation
+// rounds (24-bit products, correctly rounded quotients, the float64 requant product); each such
+// site is a single IEEE operation on exactly representable operands, compiled with
+// -ffp-contract=off, and is listed in DESIGN.md.
+#include "common.h"
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int WPB = NT / 64;  // waves (rows in flight) per block
+
+IVIT_DEV int sx8(int v, int byte) { return (int)(int8_t)(v >> (8 * byte)); }
+
+IVIT_DEV int pack4(int a, int b, int c, int d)
+{
+    return (a & 0xff) | ((b & 0xff) << 8) | ((c & 0xff) << 16) | ((d & 0xff) << 24);
+}
+
+static inline int grid_for_rows(int64_t rows)
+{
+    int64_t blocks = (rows + WPB - 1) / WPB;
+    return (int)(blocks < 4096 ? blocks : 4096);
+}
+
+// ------------------------------------------------------------------------------------------------
+// I-LayerNorm
+// ------------------------------------------------------------------------------------------------
+struct LnArgs {
+    const void* x;
+    int64_t ldx;
+    int rows, C;
+    const float* bias_int;
+    const float* s_ln;
+    const uint32_t* m;
+    const int32_t* e;
+    void* out;
+    int64_t ldo;
+};
+
+// Per-row statistics exactly as ivit_modules.py:36-51 computes them.
+//   sum  : exact integer sum of the row
+//   returns mean_int and factor = floor(2^31 / std_int) (float32)
+IVIT_DEV void ln_mean(int sum, int C, int& mean_int)
+{
+    // :37  x_int.mean() in float32 (= sum / C, the sum of integers is exact below 2^24), torch.round
+    float mean = (float)sum / (float)C;
+    mean_int = (int)rintf(mean);
+}
+
+IVIT_DEV float ln_factor(long long var)
+{
+    // :45-49  ten Newton steps; var_int / k promotes to float32, all divisions correctly rounded
+    float varf = (float)var;
+    float t = 65536.0f;
+#pragma unroll 1
+    for (int it = 0; it < 10; ++it) t = floorf((t + floorf(varf / t)) * 0.5f);
+    // :51  (2**31-1)/std  ==  reciprocal(std) * 2^31 in float32
+    return floorf((1.0f / t) * 2147483648.0f);
+}
+
+// int8 in -> int8 out, NJ dwords (4 channels each) per lane, per-channel constants kept in registers
+// across the rows a wave processes.
+template <int NJ>
+__global__ __launch_bounds__(NT) void layernorm_i8_kernel(LnArgs a)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int C = a.C, nd = C >> 2;
+    float bias[NJ][4], sln[NJ][4];
+    double rs[NJ][4], Mq[NJ][4];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        int d = lane + 64 * j;
+        if (d < nd) {
+            const float4 b4 = *reinterpret_cast<const float4*>(a.bias_int + 4 * d);
+            const float4 s4 = *reinterpret_cast<const float4*>(a.s_ln + 4 * d);
+            const uint4 m4 = *reinterpret_cast<const uint4*>(a.m + 4 * d);
+            const int4 e4 = *reinterpret_cast<const int4*>(a.e + 4 * d);
+            bias[j][0] = b4.x; bias[j][1] = b4.y; bias[j][2] = b4.z; bias[j][3] = b4.w;
+            sln[j][0] = s4.x; sln[j][1] = s4.y; sln[j][2] = s4.z; sln[j][3] = s4.w;
+            Mq[j][0] = dyadic_mult(m4.x, e4.x); Mq[j][1] = dyadic_mult(m4.y, e4.y);
+            Mq[j][2] = dyadic_mult(m4.z, e4.z); Mq[j][3] = dyadic_mult(m4.w, e4.w);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) rs[j][c] = 1.0 / (double)sln[j][c];
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { bias[j][c] = 0.f; sln[j][c] = 1.f; rs[j][c] = 1.0; Mq[j][c] = 0.0; }
+        }
+    }
+    const int8_t* xin = reinterpret_cast<const int8_t*>(a.x);
+    int8_t* out = reinterpret_cast<int8_t*>(a.out);
+    for (int row = blockIdx.x * WPB + wave; row < a.rows; row += gridDim.x * WPB) {
+        const int* xr = reinterpret_cast<const int*>(xin + (int64_t)row * a.ldx);
+        int w[NJ];
+        int sum = 0;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            int d = lane + 64 * j;
+            w[j] = (d < nd) ? xr[d] : 0;
+            sum += sx8(w[j], 0) + sx8(w[j], 1) + sx8(w[j], 2) + sx8(w[j], 3);
+        }
+        sum = wave_reduce_sum_i32(sum);
+        int mean_int;
+        ln_mean(sum, C, mean_int);
+        int var = 0;  // <= 4096 * 255^2 < 2^31
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            if (lane + 64 * j < nd) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    int dlt = sx8(w[j], c) - mean_int;
+                    var += dlt * dlt;
+                }
+            }
+        }
+        var = wave_reduce_sum_i32(var);
+        const float factor = ln_factor((long long)var);
+        int* orow = reinterpret_cast<int*>(out + (int64_t)row * a.ldo);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            int d = lane + 64 * j;
+            if (d < nd) {
+                int o[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float dl = (float)(sx8(w[j], c) - mean_int);
+                    float v = floorf((dl * factor) * 0.5f);          // :52  float32 product, /2, floor
+                    float y = v + bias[j][c];                          // :61  float32 add
+                    float x = y * sln[j][c];                           // :63  float32 product
+                    // quant_utils.py:220  z = round(x / s): the correctly rounded float32 quotient,
+                    // obtained as RN24(RN53(x * RN53(1/s))) (no midpoint can lie within 2^-52 of x/s)
+                    float qf = (float)((double)x * rs[j][c]);
+                    float z = rintf(qf);
+                    double p = (double)z * Mq[j][c];                   // :229 float64 product
+                    double t = p + IVIT_MAGIC;                         // :230 round half to even
+                    o[c] = clamp_i32((int)(unsigned)__double_as_longlong(t), -128, 127);
+                }
+                orow[d] = pack4(o[0], o[1], o[2], o[3]);
+            }
+        }
+    }
+}
+
+// module-level form: int32 in (8- or 16-bit values), float32 out = y * s_ln (ivit_modules.py:63)
+__global__ __launch_bounds__(NT) void layernorm_i32_f32_kernel(LnArgs a)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int C = a.C;
+    const int32_t* xin = reinterpret_cast<const int32_t*>(a.x);
+    float* out = reinterpret_cast<float*>(a.out);
+    for (int row = blockIdx.x * WPB + wave; row < a.rows; row += gridDim.x * WPB) {
+        const int32_t* xr = xin + (int64_t)row * a.ldx;
+        // float32 sum of integers (exact below 2^24; 16-bit rows may exceed it: then this is
+        // RN24 of the exact sum)
+        int sum = 0;  // |sum| < 2^31 for C <= 4096 and 16-bit values
+        for (int c = lane; c < C; c += 64) sum += xr[c];
+        sum = wave_reduce_sum_i32(sum);
+        float mean = (float)sum / (float)C;
+        int mean_int = (int)rintf(mean);
+        long long var = 0;
+        for (int c = lane; c < C; c += 64) {
+            long long d = (long long)xr[c] - mean_int;
+            var += d * d;
+        }
+        // 64-bit wave reduction
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            int vlo = __shfl_xor((int)(var & 0xffffffffll), o);
+            int vhi = __shfl_xor((int)(var >> 32), o);
+            var += ((long long)vhi << 32) | (unsigned)vlo;
+        }
+        const float factor = ln_factor(var);
+        for (int c = lane; c < C; c += 64) {
+            float dl = (float)(xr[c] - mean_int);
+            float v = floorf((dl * factor) * 0.5f);
+            float y = v + a.bias_int[c];
+            out[(int64_t)row * a.ldo + c] = y * a.s_ln[c];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// ShiftGELU
+// ------------------------------------------------------------------------------------------------
+// One element of IVITIntGELU.forward (ivit_modules.py:105-123): returns sigmoid_int in [0,127].
+//   e  = exp_int(k - kmax), em = exp_int(-kmax)  (both exact integers)
+IVIT_DEV int gelu_sigmoid(float e, float em)
+{
+    float S = e + em;                                            // :116 float32 add
+    S = fminf(S, 2147483648.0f);                                 // :118
+    float factor = floorf((1.0f / S) * 2147483648.0f);           // :119
+    float pr = e * factor;                                       // :120 float32 product
+    return (int)(((unsigned)pr) >> 24);                          //      floor(. / 2^24)
+}
+
+struct GeluArgs {
+    const int8_t* x;
+    int64_t ldx;
+    int rows, L;
+    int x0;      // floor(-1/(s*1.702))
+    double Mq;   // per-tensor requantiser (mlp.qact1)
+    const int8_t* lut;
+    void* out;
+    int64_t ldo;
+};
+
+// direct arithmetic; OUT_I32: module-level int32 output k*sig, else fused requant -> int8
+template <bool OUT_I32>
+__global__ __launch_bounds__(NT) void shiftgelu_kernel(GeluArgs a)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int row = blockIdx.x * WPB + wave; row < a.rows; row += gridDim.x * WPB) {
+        const int8_t* xr = a.x + (int64_t)row * a.ldx;
+        int kmax = -128;
+        for (int i = lane; i < a.L; i += 64) kmax = max(kmax, (int)xr[i]);
+        kmax = wave_reduce_max_i32(kmax);                         // :110
+        const float em = shiftexp_f32(-kmax, a.x0, 23);           // :115
+        for (int i = lane; i < a.L; i += 64) {
+            int k = xr[i];
+            float e = shiftexp_f32(k - kmax, a.x0, 23);           // :111-113
+            int sig = gelu_sigmoid(e, em);
+            int v = k * sig;                                      // :123
+            if (OUT_I32) {
+                reinterpret_cast<int32_t*>(a.out)[(int64_t)row * a.ldo + i] = v;
+            } else {
+                reinterpret_cast<int8_t*>(a.out)[(int64_t)row * a.ldo + i] =
+                    (int8_t)clamp_i32(requant_exact(v, a.Mq), -128, 127);
+            }
+        }
+    }
+}
+
+// lut[(kmax+128)*256 + (k+128)] for every (kmax, k <= kmax); entries with k > kmax are unused (0).
+__global__ __launch_bounds__(NT) void shiftgelu_lut_kernel(GeluArgs a)
+{
+    const int idx = blockIdx.x * NT + threadIdx.x;  // 65536 entries
+    const int kmax = (idx >> 8) - 128, k = (idx & 255) - 128;
+    int8_t r = 0;
+    if (k <= kmax) {
+        // exp_int(-kmax): int_exp_shift clamps at n*x0, positive arguments included (:95 torch.max)
+        float em = shiftexp_f32(-kmax, a.x0, 23);
+        float e = shiftexp_f32(k - kmax, a.x0, 23);
+        int v = k * gelu_sigmoid(e, em);
+        r = (int8_t)clamp_i32(requant_exact(v, a.Mq), -128, 127);
+    }
+    reinterpret_cast<int8_t*>(a.out)[idx] = r;
+}
+
+// table form: row max by wave reduction, the row's 256-byte table slice staged in LDS, byte gather
+__global__ __launch_bounds__(NT) void shiftgelu_lut_apply_kernel(GeluArgs a)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char tab[WPB][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nd = a.L >> 2;
+    for (int row = blockIdx.x * WPB + wave; row < a.rows; row += gridDim.x * WPB) {
+        const int* xr = reinterpret_cast<const int*>(a.x + (int64_t)row * a.ldx);
+        int* orow = reinterpret_cast<int*>(reinterpret_cast<int8_t*>(a.out) + (int64_t)row * a.ldo);
+        int kmax = -128;
+        for (int d = lane; d < nd; d += 64) {
+            int w = xr[d];
+            kmax = max(max(kmax, sx8(w, 0)), max(sx8(w, 1), max(sx8(w, 2), sx8(w, 3))));
+        }
+        kmax = wave_reduce_max_i32(kmax);
+        reinterpret_cast<int*>(tab[wave])[lane] =
+            reinterpret_cast<const int*>(a.lut + (int64_t)(kmax + 128) * 256)[lane];
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the table slice is in LDS
+        for (int d = lane; d < nd; d += 64) {
+            unsigned w = (unsigned)xr[d] ^ 0x80808080u;  // k + 128 per byte
+            unsigned r = (unsigned)tab[wave][w & 255] | ((unsigned)tab[wave][(w >> 8) & 255] << 8) |
+                         ((unsigned)tab[wave][(w >> 16) & 255] << 16) | ((unsigned)tab[wave][w >> 24] << 24);
+            orow[d] = (int)r;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// stand-alone Shiftmax (module-level)
+// ------------------------------------------------------------------------------------------------
+struct SmArgs {
+    const int8_t* x;
+    int64_t ldx;
+    int rows, L, x0;
+    int8_t* out;
+    int64_t ldo;
+};
+
+__global__ __launch_bounds__(NT) void shiftmax_kernel(SmArgs a)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int row = blockIdx.x * WPB + wave; row < a.rows; row += gridDim.x * WPB) {
+        const int8_t* xr = a.x + (int64_t)row * a.ldx;
+        int kmax = -128;
+        for (int i = lane; i < a.L; i += 64) kmax = max(kmax, (int)xr[i]);
+        kmax = wave_reduce_max_i32(kmax);
+        unsigned long long sum = 0;
+        for (int i = lane; i < a.L; i += 64) sum += shiftexp_int((int)xr[i] - kmax, a.x0, 15);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            unsigned lo = (unsigned)__shfl_xor((int)(sum & 0xffffffffull), o);
+            unsigned hi = (unsigned)__shfl_xor((int)(sum >> 32), o);
+            sum += ((unsigned long long)hi << 32) | lo;
+        }
+        float S = (float)sum;                                     // :171 (RN24 of the exact sum)
+        S = fminf(S, 2147483648.0f);                              // :173
+        const float factor = floorf((1.0f / S) * 2147483648.0f);  // :174
+        for (int i = lane; i < a.L; i += 64) {
+            unsigned e = shiftexp_int((int)xr[i] - kmax, a.x0, 15);
+            float pr = (float)e * factor;                         // :175
+            a.out[(int64_t)row * a.ldo + i] = (int8_t)(((unsigned)pr) >> 24);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// element-wise pieces
+// ------------------------------------------------------------------------------------------------
+IVIT_DEV int quant_sym_i8(float x, float inv_scale)
+{
+    float v = rintf(inv_scale * x);  // quant_utils.py:49 round(1./scale * input)
+    v = fminf(fmaxf(v, -128.0f), 127.0f);
+    return (int)v;
+}
+
+__global__ __launch_bounds__(NT) void quantize_kernel(const float* x, int8_t* out, int64_t n, float inv_scale)
+{
+    int64_t i = ((int64_t)blockIdx.x * NT + threadIdx.x) * 4;
+    const int64_t stride = (int64_t)gridDim.x * NT * 4;
+    for (; i + 3 < n; i += stride) {
+        float4 v = *reinterpret_cast<const float4*>(x + i);
+        *reinterpret_cast<int*>(out + i) = pack4(quant_sym_i8(v.x, inv_scale), quant_sym_i8(v.y, inv_scale),
+                                                 quant_sym_i8(v.z, inv_scale), quant_sym_i8(v.w, inv_scale));
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (int64_t t = n & ~(int64_t)3; t < n; ++t) out[t] = (int8_t)quant_sym_i8(x[t], inv_scale);
+}
+
+// img [B, chans, hw, hw] -> A [B*gh*gw, chans*patch*patch]; one thread quantises 4 consecutive kw
+__global__ __launch_bounds__(NT) void patchify_kernel(const float* img, int8_t* A, int batch, int chans, int hw,
+                                                      int patch, float inv_scale)
+{
+    const int g = hw / patch;
+    const int pw4 = patch >> 2;
+    const int64_t total = (int64_t)batch * chans * hw * (hw >> 2);  // groups of 4 pixels
+    const int K = chans * patch * patch;
+    for (int64_t q = (int64_t)blockIdx.x * NT + threadIdx.x; q < total; q += (int64_t)gridDim.x * NT) {
+        // source order (coalesced float4 reads): b, c, y, x4
+        int x4 = (int)(q % (hw >> 2));
+        int64_t r = q / (hw >> 2);
+        int y = (int)(r % hw);
+        r /= hw;
+        int c = (int)(r % chans);
+        int b = (int)(r / chans);
+        float4 v = *reinterpret_cast<const float4*>(img + (((int64_t)b * chans + c) * hw + y) * hw + 4 * x4);
+        int px = x4 / pw4, kw = (x4 - px * pw4) * 4;
+        int py = y / patch, kh = y - py * patch;
+        int64_t row = ((int64_t)b * g + py) * g + px;
+        int col = (c * patch + kh) * patch + kw;
+        *reinterpret_cast<int*>(A + row * K + col) = pack4(quant_sym_i8(v.x, inv_scale), quant_sym_i8(v.y, inv_scale),
+                                                           quant_sym_i8(v.z, inv_scale), quant_sym_i8(v.w, inv_scale));
+    }
+}
+
+// cls row + position embedding, vit_quant.py:290-296 (see ivit_hip.h)
+__global__ __launch_bounds__(NT) void embed_kernel(const int8_t* patch, const int16_t* pos_add, const int8_t* cls_row,
+                                                   double Mq, int8_t* out, int batch, int tokens, int C)
+{
+    const int cd = C >> 2;
+    const int64_t total = (int64_t)batch * tokens * cd;
+    for (int64_t q = (int64_t)blockIdx.x * NT + threadIdx.x; q < total; q += (int64_t)gridDim.x * NT) {
+        int d = (int)(q % cd);
+        int64_t r = q / cd;
+        int tok = (int)(r % tokens);
+        int b = (int)(r / tokens);
+        int res;
+        if (tok == 0) {
+            res = *reinterpret_cast<const int*>(cls_row + 4 * d);
+        } else {
+            int w = *reinterpret_cast<const int*>(patch + ((int64_t)b * (tokens - 1) + tok - 1) * C + 4 * d);
+            const int16_t* pa = pos_add + (int64_t)tok * C + 4 * d;
+            int o[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) o[c] = clamp_i32(requant_exact(sx8(w, c), Mq) + (int)pa[c], -128, 127);
+            res = pack4(o[0], o[1], o[2], o[3]);
+        }
+        *reinterpret_cast<int*>(out + ((int64_t)b * tokens + tok) * C + 4 * d) = res;
+    }
+}
+
+// classifier: logits_f32 = float(acc) * s_acc (quant_modules.py:225-226); arg-max, first index on ties
+__global__ __launch_bounds__(NT) void head_argmax_kernel(const int32_t* acc, const float* s_acc, int batch, int N,
+                                                         float* logits, int32_t* top1)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int row = blockIdx.x * WPB + wave; row < batch; row += gridDim.x * WPB) {
+        float best = -__builtin_inff();
+        int bi = 0x7fffffff;
+        for (int n = lane; n < N; n += 64) {
+            float v = (float)acc[(int64_t)row * N + n] * s_acc[n];
+            if (logits) logits[(int64_t)row * N + n] = v;
+            if (v > best) { best = v; bi = n; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            float ob = __shfl_xor(best, o);
+            int oi = __shfl_xor(bi, o);
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        if (lane == 0) top1[row] = bi;
+    }
+}
+
+// generic QuantAct on int32 (fixedpoint_mul), bit-faithful general form
+__global__ __launch_bounds__(NT) void requant_i32_kernel(const int32_t* z, int64_t rows, int C, const uint32_t* m,
+                                                         const int32_t* e, int n_me, const int32_t* z2,
+                                                         const uint32_t* m2, const int32_t* e2, int n_me2, int bits,
+                                                         int32_t* out)
+{
+    const int64_t total = rows * C;
+    const double lo = -__builtin_ldexp(1.0, bits - 1), hi = __builtin_ldexp(1.0, bits - 1) - 1.0;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+        int c = (int)(i % C);
+        int im = (n_me == 1) ? 0 : c;
+        double o = requant_double((double)z[i], dyadic_mult(m[im], e[im]));
+        if (z2) {
+            int i2 = (n_me2 == 1) ? 0 : c;
+            o = requant_double((double)z2[i], dyadic_mult(m2[i2], e2[i2])) + o;
+        }
+        o = fmin(fmax(o, lo), hi);
+        out[i] = (int32_t)o;
+    }
+}
+
+__global__ __launch_bounds__(NT) void residual_requant_kernel(const int8_t* a, double Ma, const int8_t* b, double Mb,
+                                                              int8_t* out, int64_t n)
+{
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT)
+        out[i] = (int8_t)clamp_i32(requant_exact(a[i], Ma) + requant_exact(b[i], Mb), -128, 127);
+}
+
+__global__ __launch_bounds__(NT) void f32_to_i32_kernel(const float* x, int64_t rows, int C, const float* s, int n_s,
+                                                        int mode, int32_t* z)
+{
+    const int64_t total = rows * C;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+        float q = x[i] / s[n_s == 1 ? 0 : (int)(i % C)];  // correctly rounded float32 quotient
+        q = (mode == 0) ? rintf(q) : truncf(q);
+        q = fminf(fmaxf(q, -2147483648.0f), 2147483520.0f);
+        z[i] = (int32_t)q;
+    }
+}
+
+__global__ __launch_bounds__(NT) void i32_to_f32_kernel(const int32_t* z, int64_t rows, int C, const float* s, int n_s,
+                                                        float* y)
+{
+    const int64_t total = rows * C;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT)
+        y[i] = (float)z[i] * s[n_s == 1 ? 0 : (int)(i % C)];
+}
+
+// module-level QuantMatMul: small batched products, one output element per thread (not the hot path:
+// the engine uses the fused MFMA attention kernel)
+template <bool PV>
+__global__ __launch_bounds__(NT) void bgemm_kernel(const int8_t* X, const int8_t* Y, int32_t* O, int batch, int Tq,
+                                                   int Tk, int D)
+{
+    const int cols = PV ? D : Tk, red = PV ? Tk : D;
+    const int64_t total = (int64_t)batch * Tq * cols;
+    for (int64_t idx = (int64_t)blockIdx.x * NT + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * NT) {
+        int j = (int)(idx % cols);
+        int64_t r = idx / cols;
+        int i = (int)(r % Tq);
+        int b = (int)(r / Tq);
+        const int8_t* xr = X + ((int64_t)b * Tq + i) * red;
+        int acc = 0;
+        if (PV) {
+            const int8_t* yb = Y + (int64_t)b * Tk * D + j;
+            for (int k = 0; k < red; ++k) acc += (int)xr[k] * (int)yb[(int64_t)k * D];
+        } else {
+            const int8_t* yr = Y + ((int64_t)b * Tk + j) * D;
+            for (int k = 0; k < red; ++k) acc += (int)xr[k] * (int)yr[k];
+        }
+        O[idx] = acc;
+    }
+}
+
+static inline int ew_grid(int64_t n)
+{
+    int64_t b = (n + NT - 1) / NT;
+    return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+
+static int gelu_x0(float s, const char* who, int* x0_out)
+{
+    IVIT_REQUIRE(s > 0.0f, "%s: scale must be positive", who);
+    const float s_sig = s * 1.702f;                                   // ivit_modules.py:108
+    const float x0f = __builtin_floorf((1.0f / s_sig) * -1.0f);       // :94
+    IVIT_REQUIRE(x0f <= -1.0f && x0f >= -255.0f, "%s: x0=%g outside [-255,-1] (scale %g)", who, (double)x0f, (double)s);
+    *x0_out = (int)x0f;
+    return IVIT_OK;
+}
+
+}  // namespace
+
+// ================================================================================================
+IVIT_EXPORT int ivit_layernorm_i8(const int8_t* x, int64_t ldx, int rows, int C, const float* bias_int,
+                                  const float* s_ln, const uint32_t* m, const int32_t* e, int8_t* out, int64_t ldo,
+                                  ivit_stream_t stream)
+{
+    IVIT_REQUIRE(x && out && bias_int && s_ln && m && e, "ivit_layernorm_i8: NULL operand");
+    IVIT_REQUIRE(rows > 0 && C > 0 && C % 4 == 0 && C <= 4096, "ivit_layernorm_i8: rows=%d C=%d unsupported", rows, C);
+    IVIT_REQUIRE(ldx % 4 == 0 && ldo % 4 == 0 && ldx >= C && ldo >= C && ((uintptr_t)x % 4 == 0) &&
+                     ((uintptr_t)out % 4 == 0),
+                 "ivit_layernorm_i8: rows must be 4-byte aligned");
+    IVIT_REQUIRE(((uintptr_t)bias_int % 16 == 0) && ((uintptr_t)s_ln % 16 == 0) && ((uintptr_t)m % 16 == 0) &&
+                     ((uintptr_t)e % 16 == 0),
+                 "ivit_layernorm_i8: per-channel tables must be 16-byte aligned");
+    LnArgs a{x, ldx, rows, C, bias_int, s_ln, m, e, out, ldo};
+    const int nj = (C / 4 + 63) / 64;
+    const int grid = grid_for_rows(rows);
+    hipStream_t st = ivit_stream(stream);
+    if (nj <= 1) hipLaunchKernelGGL(layernorm_i8_kernel<1>, dim3(grid), dim3(NT), 0, st, a);
+    else if (nj <= 2) hipLaunchKernelGGL(layernorm_i8_kernel<2>, dim3(grid), dim3(NT), 0, st, a);
+    else if (nj <= 3) hipLaunchKernelGGL(layernorm_i8_kernel<3>, dim3(grid), dim3(NT), 0, st, a);
+    else if (nj <= 4) hipLaunchKernelGGL(layernorm_i8_kernel<4>, dim3(grid), dim3(NT), 0, st, a);
+    else if (nj <= 8) hipLaunchKernelGGL(layernorm_i8_kernel<8>, dim3(grid), dim3(NT), 0, st, a);
+    else hipLaunchKernelGGL(layernorm_i8_kernel<16>, dim3(grid), dim3(NT), 0, st, a);
+    IVIT_CHECK_LAUNCH("ivit_layernorm_i8");
+}
+
+IVIT_EXPORT int ivit_layernorm_i32_f32(const int32_t* x, int64_t ldx, int rows, int C, const float* bias_int,
+                                       const float* s_ln, float* out, int64_t ldo, ivit_stream_t stream)
+{
+    IVIT_REQUIRE(x && out && bias_int && s_ln, "ivit_layernorm_i32_f32: NULL operand");
+    IVIT_REQUIRE(rows > 0 && C > 0 && C <= 4096 && ldx >= C && ldo >= C, "ivit_layernorm_i32_f32: bad shape");
+    LnArgs a{x, ldx, rows, C, bias_int, s_ln, nullptr, nullptr, out, ldo};
+    hipLaunchKernelGGL(layernorm_i32_f32_kernel, dim3(grid_for_rows(rows)), dim3(NT), 0, ivit_stream(stream), a);
+    IVIT_CHECK_LAUNCH("ivit_layernorm_i32_f32");
+}
+
+IVIT_EXPORT int ivit_shiftgelu_i8(const int8_t* x, int64_t ldx, int rows, int L, float s, uint32_t m, int32_t e,
+                                  int8_t* out, int64_t ldo, ivit_stream_t stream)
+{
+    IVIT_REQUIRE(x && out && rows > 0 && L > 0 && ldx >= L && ldo >= L, "ivit_shiftgelu_i8: bad operand");
+    GeluArgs a{};
+    a.x = x; a.ldx = ldx; a.rows = rows; a.L = L; a.out = out; a.ldo = ldo;
+    a.Mq = ivit_dyadic_to_double(m, e);
+    IVIT_REQUIRE(a.Mq < 65536.0, "ivit_shiftgelu_i8: requant multiplier too large");
+    int rc = gelu_x0(s, "ivit_shiftgelu_i8", &a.x0);
+    if (rc) return rc;
+    hipLaunchKernelGGL(shiftgelu_kernel<false>, dim3(grid_for_rows(rows)), dim3(NT), 0, ivit_stream(stream), a);
+    IVIT_CHECK_LAUNCH("ivit_shiftgelu_i8");
+}
+
+IVIT_EXPORT int ivit_shiftgelu_i8_i32(const int8_t* x, int64_t ldx, int rows, int L, float s, int32_t* out,
+                                      int64_t ldo, ivit_stream_t stream)
+{
+    IVIT_REQUIRE(x && out && rows > 0 && L > 0 && ldx >= L && ldo >= L, "ivit_shiftgelu_i8_i32: bad operand");
+    GeluArgs a{};
+    a.x = x; a.ldx = ldx; a.rows = rows; a.L = L; a.out = out; a.ldo = ldo; a.Mq = 0.0;
+    int rc = gelu_x0(s, "ivit_shiftgelu_i8_i32", &a.x0);
+    if (rc) return rc;
+    hipLaunchKernelGGL(shiftgelu_kernel<true>, dim3(grid_for_rows(rows)), dim3(NT), 0, ivit_stream(stream), a);
+    IVIT_CHECK_LAUNCH("ivit_shiftgelu_i8_i32");
+}
+
+IVIT_EXPORT int ivit_shiftgelu_build_lut(float s, uint32_t m, int32_t e, int8_t* lut, ivit_stream_t stream)
+{
+    IVIT_REQUIRE(lut, "ivit_shiftgelu_build_lut: NULL table");
+    GeluArgs a{};
+    a.out = lut;
+    a.Mq = ivit_dyadic_to_double(m, e);
+    IVIT_REQUIRE(a.Mq < 65536.0, "ivit_shiftgelu_build_lut: requant multiplier too large");
+    int rc = gelu_x0(s, "ivit_shiftgelu_build_lut", &a.x0);
+    if (rc) return rc;
+    hipLaunchKernelGGL(shiftgelu_lut_kernel, dim3(65536 / NT), dim3(NT), 0, ivit_stream(stream), a);
+    IVIT_CHECK_LAUNCH("ivit_shiftgelu_build_lut");
+}
+
+IVIT_EXPORT int ivit_shiftgelu_lut_i8(const int8_t* x, int64_t ldx, int rows, int L, const int8_t* lut, int8_t* out,
+                                      int64_t ldo, ivit_stream_t stream)
+{
+    IVIT_REQUIRE(x && out && lut, "ivit_shiftgelu_lut_i8: NULL operand");
+    IVIT_REQUIRE(rows > 0 && L > 0 && L % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && ldx >= L && ldo >= L &&
+                     ((uintptr_t)x % 4 == 0) && ((uintptr_t)out % 4 == 0) && ((uintptr_t)lut % 4 == 0),
+                 "ivit_shiftgelu_lut_i8: rows=%d L=%d must be 4-byte aligned rows", rows, L);
+    GeluArgs a{};
+    a.x = x; a.ldx = ldx; a.rows = rows; a.L = L; a.lut = lut; a.out = out; a.ldo = ldo;
+    hipLaunchKernelGGL(shiftgelu_lut_apply_kernel, dim3(grid_for_rows(rows)), dim3(NT), 0, ivit_stream(stream), a);
+    IVIT_CHECK_LAUNCH("ivit_shiftgelu_lut_i8");
+}
+
+IVIT_EXPORT int ivit_shiftmax_i8(const int8_t* x, int64_t ldx, int rows, int L, float s, int8_t* out, int64_t ldo,
+                                 ivit_stream_t stream)
+{
+    IVIT_REQUIRE(x && out && rows > 0 && L > 1 && ldx >= L && ldo >= L, "ivit_shiftmax_i8: bad operand (L must be > 1)");
+    IVIT_REQUIRE(s > 0.0f, "ivit_shiftmax_i8: scale must be positive");
+    const float x0f = __builtin_floorf((1.0f / s) * -1.0f);
+    IVIT_REQUIRE(x0f <= -1.0f && x0f >= -65535.0f, "ivit_shiftmax_i8: x0=%g outside [-65535,-1]", (double)x0f);
+    SmArgs a{x, ldx, rows, L, (int)x0f, out, ldo};
+    hipLaunchKernelGGL(shiftmax_kernel, dim3(grid_for_rows(rows)), dim3(NT), 0, ivit_stream(stream), a);
+    IVIT_CHECK_LAUNCH("ivit_shiftmax_i8");
+}
+
+IVIT_EXPORT int ivit_quantize_input_f32_i8(const float* x, int8_t* out, int64_t n, float inv_scale,
+                                           ivit_stream_t stream)
+{
+    IVIT_REQUIRE(x && out && n > 0, "ivit_quantize_input_f32_i8: bad operand");
+    IVIT_REQUIRE(((uintptr_t)x % 16 == 0) && ((uintptr_t)out % 4 == 0), "ivit_quantize_input_f32_i8: misaligned");
+    hipLaunchKernelGGL(quantize_kernel, dim3(ew_grid(n / 4 + 1)), dim3(NT), 0, ivit_stream(stream), x, out, n,
+                       inv_scale);
+    IVIT_CHECK_LAUNCH("ivit_quantize_input_f32_i8");
+}
+
+IVIT_EXPORT int ivit_quantize_patchify_f32_i8(const float* img, int8_t* A, int batch, int chans, int hw, int patch,
+                                              float inv_scale, ivit_stream_t stream)
+{
+    IVIT_REQUIRE(img && A && batch > 0 && chans > 0, "ivit_quantize_patchify_f32_i8: bad operand");
+    IVIT_REQUIRE(patch > 0 && patch % 4 == 0 && hw % patch == 0, "ivit_quantize_patchify_f32_i8: hw=%d patch=%d", hw,
+                 patch);
+    IVIT_REQUIRE(((uintptr_t)img % 16 == 0) && ((uintptr_t)A % 4 == 0), "ivit_quantize_patchify_f32_i8: misaligned");
+    const int64_t total = (int64_t)batch * chans * hw * (hw / 4);
+    hipLaunchKernelGGL(patchify_kernel, dim3(ew_grid(total)), dim3(NT), 0, ivit_stream(stream), img, A, batch, chans,
+                       hw, patch, inv_scale);
+    IVIT_CHECK_LAUNCH("ivit_quantize_patchify_f32_i8");
+}
+
+IVIT_EXPORT int ivit_embed_assemble_i8(const int8_t* patch, const int16_t* pos_add, const int8_t* cls_row, uint32_t m,
+                                       int32_t e, int8_t* out, int batch, int tokens, int C, ivit_stream_t stream)
+{
+    IVIT_REQUIRE(patch && pos_add && cls_row && out, "ivit_embed_assemble_i8: NULL operand");
+    IVIT_REQUIRE(batch > 0 && tokens > 1 && C > 0 && C % 4 == 0, "ivit_embed_assemble_i8: bad shape");
+    IVIT_REQUIRE(((uintptr_t)patch % 4 == 0) && ((uintptr_t)out % 4 == 0) && ((uintptr_t)cls_row % 4 == 0) &&
+                     ((uintptr_t)pos_add % 8 == 0),
+                 "ivit_embed_assemble_i8: misaligned");
+    const double Mq = ivit_dyadic_to_double(m, e);
+    IVIT_REQUIRE(Mq < 1048576.0, "ivit_embed_assemble_i8: requant multiplier too large");
+    const int64_t total = (int64_t)batch * tokens * (C / 4);
+    hipLaunchKernelGGL(embed_kernel, dim3(ew_grid(total)), dim3(NT), 0, ivit_stream(stream), patch, pos_add, cls_row,
+                       Mq, out, batch, tokens, C);
+    IVIT_CHECK_LAUNCH("ivit_embed_assemble_i8");
+}
+
+IVIT_EXPORT int ivit_head_argmax(const int32_t* acc, const float* s_acc, int batch, int N, float* logits_f32,
+                                 int32_t* top1, ivit_stream_t stream)
+{
+    IVIT_REQUIRE(acc && s_acc && top1 && batch > 0 && N > 0, "ivit_head_argmax: bad operand");
+    hipLaunchKernelGGL(head_argmax_kernel, dim3(grid_for_rows(batch)), dim3(NT), 0, ivit_stream(stream), acc, s_acc,
+                       batch, N, logits_f32, top1);
+    IVIT_CHECK_LAUNCH("ivit_head_argmax");
+}
+
+IVIT_EXPORT int ivit_requant_i32(const int32_t* z, int64_t rows, int C, const uint32_t* m, const int32_t* e, int n_me,
+                                 const int32_t* z2, const uint32_t* m2, const int32_t* e2, int n_me2, int bits,
+                                 int32_t* out, ivit_stream_t stream)
+{
+    IVIT_REQUIRE(z && m && e && out && rows > 0 && C > 0, "ivit_requant_i32: bad operand");
+    IVIT_REQUIRE(n_me == 1 || n_me == C, "ivit_requant_i32: n_me=%d must be 1 or C=%d", n_me, C);
+    IVIT_REQUIRE(z2 == nullptr || (m2 && e2 && (n_me2 == 1 || n_me2 == C)), "ivit_requant_i32: bad identity branch");
+    IVIT_REQUIRE(bits == 8 || bits == 16 || bits == 32 || bits == 4, "ivit_requant_i32: bits=%d", bits);
+    hipLaunchKernelGGL(requant_i32_kernel, dim3(ew_grid(rows * C)), dim3(NT), 0, ivit_stream(stream), z, rows, C, m, e,
+                       n_me, z2, m2, e2, n_me2, bits, out);
+    IVIT_CHECK_LAUNCH("ivit_requant_i32");
+}
+
+IVIT_EXPORT int ivit_residual_requant_i8(const int8_t* a, uint32_t m_a, int32_t e_a, const int8_t* b, uint32_t m_b,
+                                         int32_t e_b, int8_t* out, int64_t n, ivit_stream_t stream)
+{
+    IVIT_REQUIRE(a && b && out && n > 0, "ivit_residual_requant_i8: bad operand");
+    const double Ma = ivit_dyadic_to_double(m_a, e_a), Mb = ivit_dyadic_to_double(m_b, e_b);
+    IVIT_REQUIRE(Ma < 1048576.0 && Mb < 1048576.0, "ivit_residual_requant_i8: multiplier too large");
+    hipLaunchKernelGGL(residual_requant_kernel, dim3(ew_grid(n)), dim3(NT), 0, ivit_stream(stream), a, Ma, b, Mb, out,
+                       n);
+    IVIT_CHECK_LAUNCH("ivit_residual_requant_i8");
+}
+
+IVIT_EXPORT int ivit_bgemm_qk_i8(const int8_t* Q, const int8_t* K, int32_t* S, int batch, int Tq, int Tk, int D,
+                                 ivit_stream_t stream)
+{
+    IVIT_REQUIRE(Q && K && S && batch > 0 && Tq > 0 && Tk > 0 && D > 0, "ivit_bgemm_qk_i8: bad operand");
+    hipLaunchKernelGGL(bgemm_kernel<false>, dim3(ew_grid((int64_t)batch * Tq * Tk)), dim3(NT), 0, ivit_stream(stream),
+                       Q, K, S, batch, Tq, Tk, D);
+    IVIT_CHECK_LAUNCH("ivit_bgemm_qk_i8");
+}
+
+IVIT_EXPORT int ivit_bgemm_pv_i8(const int8_t* P, const int8_t* V, int32_t* O, int batch, int Tq, int Tk, int D,
+                                 ivit_stream_t stream)
+{
+    IVIT_REQUIRE(P && V && O && batch > 0 && Tq > 0 && Tk > 0 && D > 0, "ivit_bgemm_pv_i8: bad operand");
+    hipLaunchKernelGGL(bgemm_kernel<true>, dim3(ew_grid((int64_t)batch * Tq * D)), dim3(NT), 0, ivit_stream(stream), P,
+                       V, O, batch, Tq, Tk, D);
+    IVIT_CHECK_LAUNCH("ivit_bgemm_pv_i8");
+}
+
+IVIT_EXPORT int ivit_f32_to_i32(const float* x, int64_t rows, int C, const float* s, int n_s, int mode, int32_t* z,
+                                ivit_stream_t stream)
+{
+    IVIT_REQUIRE(x && s && z && rows > 0 && C > 0 && (n_s == 1 || n_s == C) && (mode == 0 || mode == 1),
+                 "ivit_f32_to_i32: bad operand");
+    hipLaunchKernelGGL(f32_to_i32_kernel, dim3(ew_grid(rows * C)), dim3(NT), 0, ivit_stream(stream), x, rows, C, s, n_s,
+                       mode, z);
+    IVIT_CHECK_LAUNCH("ivit_f32_to_i32");
+}
+
+IVIT_EXPORT int ivit_i32_to_f32(const int32_t* z, int64_t rows, int C, const float* s, int n_s, float* y,
+                                ivit_stream_t stream)
+{
+    IVIT_REQUIRE(z && s && y && rows > 0 && C > 0 && (n_s == 1 || n_s == C), "ivit_i32_to_f32: bad operand");
+    hipLaunchKernelGGL(i32_to_f32_kernel, dim3(ew_grid(rows * C)), dim3(NT), 0, ivit_stream(stream), z, rows, C, s, n_s,
+                       y);
+    IVIT_CHECK_LAUNCH("ivit_i32_to_f32");
+}

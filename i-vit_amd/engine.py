@@ -1,0 +1,230 @@
+"""Integer-only DeiT/ViT forward on MI355X: int8 activations end to end, every operator a
+hand-written HIP kernel reached through the C ABI (include/ivit_hip.h).
+
+Dataflow = the reference's frozen-model forward
+(/root/reference/models/vit_quant.py:285-312, Attention :61-90, Block :142-155,
+ /root/reference/models/layers_quant.py:145-154, 191-203), restated on integers:
+
+  images f32 --quantize+im2col--> int8 [B*196, 768]
+    --GEMM(patch_embed.proj)+requant(patch_embed.qact)--> int8 [B*196, C]
+    --cls/pos assemble (qact_pos, qact1)--> x int8 [B*197, C]
+  12 x { LN+requant -> GEMM qkv (+requant, head-major) -> fused attention
+         -> GEMM proj (+requant +residual requant) -> LN+requant -> GEMM fc1 (+requant)
+         -> ShiftGELU table gather (+requant) -> GEMM fc2 (+requant +residual requant) }
+    --LN(cls rows)+requant--> GEMM head --> INT32 logits --scale+argmax--> top-1
+
+There is no fallback path: a missing libivit_hip.so or a kernel error raises.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _lib
+from .prepare import LayerNormParams, LinearParams, dyadic, f32, quant_sym, requant_host, sym_scale
+from .synth import IMG_SIZE, NUM_CLASSES, NUM_PATCHES, NUM_TOKENS, PATCH
+
+
+def _np(v):
+    if isinstance(v, torch.Tensor):
+        return v.detach().cpu().numpy()
+    return np.asarray(v)
+
+
+class IntViTEngine:
+    def __init__(self, float_state, ranges, embed_dim: int, depth: int, num_heads: int,
+                 device="cuda:0", max_batch: int = 256):
+        """float_state: name -> float32 array (the reference's state_dict names);
+        ranges: QuantAct name -> (x_min, x_max) of the frozen model."""
+        self.C, self.D, self.H = embed_dim, depth, num_heads
+        self.hd = embed_dim // num_heads
+        if self.hd != 64:
+            raise ValueError("fused attention kernel supports head_dim 64 only")
+        self.dev = torch.device(device)
+        self.max_batch = max_batch
+        _lib.lib()  # fail loudly now if the HIP library is absent
+        P = {k: _np(v).astype(np.float32) for k, v in float_state.items()}
+        R = ranges
+        C, H, hd = self.C, self.H, self.hd
+        T = NUM_TOKENS
+
+        def s(name):
+            lo, hi = R[name]
+            return sym_scale(lo, hi, 8)
+
+        def dev(a, dtype=None):
+            t = torch.from_numpy(np.ascontiguousarray(a))
+            if dtype is not None:
+                t = t.to(dtype)
+            return t.to(self.dev)
+
+        def lin_dev(lp: LinearParams, s_out):
+            m, e = lp.requant_to(s_out)
+            return dict(W=dev(lp.W8), b=dev(lp.b32), m=dev(m.view(np.int32)), e=dev(e), K=lp.K, N=lp.W8.shape[0])
+
+        def ln_dev(prefix, s_out):
+            lp = LayerNormParams(P[prefix + ".weight"], P[prefix + ".bias"], s_out)
+            return dict(bias=dev(lp.bias_int), s=dev(lp.s_ln), m=dev(lp.m.view(np.int32)), e=dev(lp.e))
+
+        def scalar_me(pre, z):
+            m, e = dyadic(pre, z)
+            return int(m[0]), int(e[0])
+
+        # ---- stem
+        s0 = s("qact_input")
+        self.inv_s0 = float(f32(1.0) / s0)
+        pe = LinearParams(P["patch_embed.proj.weight"], P["patch_embed.proj.bias"], s0)
+        s_pe = s("patch_embed.qact")
+        self.patch = lin_dev(pe, s_pe)
+        s_pos, s_x = s("qact_pos"), s("qact1")
+        m1, e1 = dyadic(s_pe, s_x)
+        m2, e2 = dyadic(s_pos, s_x)
+        kpos = quant_sym(P["pos_embed"].reshape(T, C), s_pos, 8)
+        pos_add = requant_host(kpos, m2[0], e2[0])                       # RNE(k_pos * m2 / 2^e2)
+        z_cls = np.rint((P["cls_token"].reshape(C) / s_pe).astype(f32))   # quant_utils.py:220 on the raw cls row
+        cls_row = np.clip(requant_host(z_cls, m1[0], e1[0]) + pos_add[0], -128, 127)
+        assert np.abs(pos_add).max() < 32768
+        self.pos_add = dev(pos_add.astype(np.int16))
+        self.cls_row = dev(cls_row.astype(np.int8))
+        self.embed_me = (int(m1[0]), int(e1[0]))
+
+        # ---- blocks
+        self.blocks = []
+        for i in range(depth):
+            p = f"blocks.{i}."
+            blk = {}
+            s_q1 = s(p + "qact1")
+            blk["ln1"] = ln_dev(p + "norm1", s_q1)
+            s_a1 = s(p + "attn.qact1")
+            blk["qkv"] = lin_dev(LinearParams(P[p + "attn.qkv.weight"], P[p + "attn.qkv.bias"], s_q1), s_a1)
+            s_S = f32(f32(s_a1 * s_a1) * f32(hd ** -0.5))                 # vit_quant.py:72-75
+            s_at = s(p + "attn.qact_attn1")
+            s_pv = f32(f32(1.0 / 128.0) * s_a1)                           # Shiftmax scale 2^-7 x value scale
+            s_a2 = s(p + "attn.qact2")
+            blk["attn"] = dict(ms=scalar_me(s_S, s_at), s_attn=float(s_at), mo=scalar_me(s_pv, s_a2))
+            s_a3 = s(p + "attn.qact3")
+            blk["proj"] = lin_dev(LinearParams(P[p + "attn.proj.weight"], P[p + "attn.proj.bias"], s_a2), s_a3)
+            s_b2 = s(p + "qact2")
+            blk["res1"] = scalar_me(s_a3, s_b2) + scalar_me(s_x, s_b2)
+            s_b3 = s(p + "qact3")
+            blk["ln2"] = ln_dev(p + "norm2", s_b3)
+            s_g = s(p + "mlp.qact_gelu")
+            blk["fc1"] = lin_dev(LinearParams(P[p + "mlp.fc1.weight"], P[p + "mlp.fc1.bias"], s_b3), s_g)
+            s_go = f32(s_g * f32(1.0 / 128.0))                             # ivit_modules.py:121,124
+            s_m1 = s(p + "mlp.qact1")
+            mg, eg = scalar_me(s_go, s_m1)
+            lut = torch.empty(65536, dtype=torch.int8, device=self.dev)
+            _lib.call("ivit_shiftgelu_build_lut", float(s_g), mg, eg, _lib.ptr(lut), self._stream())
+            blk["gelu_lut"] = lut
+            s_m2 = s(p + "mlp.qact2")
+            blk["fc2"] = lin_dev(LinearParams(P[p + "mlp.fc2.weight"], P[p + "mlp.fc2.bias"], s_m1), s_m2)
+            s_b4 = s(p + "qact4")
+            blk["res2"] = scalar_me(s_m2, s_b4) + scalar_me(s_b2, s_b4)
+            s_x = s_b4
+            self.blocks.append(blk)
+
+        # ---- tail
+        s_q2 = s("qact2")
+        self.ln_f = ln_dev("norm", s_q2)
+        head = LinearParams(P["head.weight"], P["head.bias"], s_q2)
+        self.head = dict(W=dev(head.W8), b=dev(head.b32), K=head.K, N=head.W8.shape[0])
+        self.head_scale = dev(head.s_acc)
+        self.int8_weight_bytes = sum(int(b[k]["W"].numel()) for b in self.blocks for k in ("qkv", "proj", "fc1", "fc2")) \
+            + int(self.patch["W"].numel()) + int(self.head["W"].numel())
+        self._alloc(max_batch)
+        torch.cuda.synchronize(self.dev)
+
+    # ------------------------------------------------------------------ plumbing
+    def _stream(self):
+        return _lib.stream_ptr()
+
+    def _alloc(self, B):
+        C, T = self.C, NUM_TOKENS
+        M = B * T
+        i8 = dict(dtype=torch.int8, device=self.dev)
+        self.ws = dict(
+            a0=torch.empty(B * NUM_PATCHES, 3 * PATCH * PATCH, **i8),
+            pe=torch.empty(B * NUM_PATCHES, C, **i8),
+            x=torch.empty(M, C, **i8), x2=torch.empty(M, C, **i8), h=torch.empty(M, C, **i8),
+            qkv=torch.empty(3 * M * C, **i8), ao=torch.empty(M, C, **i8),
+            f1=torch.empty(M, 4 * C, **i8), g=torch.empty(M, 4 * C, **i8),
+            cls=torch.empty(B, C, **i8),
+            logits=torch.empty(B, NUM_CLASSES, dtype=torch.int32, device=self.dev),
+            logits_f=torch.empty(B, NUM_CLASSES, dtype=torch.float32, device=self.dev),
+            top1=torch.empty(B, dtype=torch.int32, device=self.dev),
+        )
+
+    def _gemm(self, A, lda, lin, out, ldo, M, st):
+        _lib.call("ivit_gemm_i8_requant", _lib.ptr(A), lda, _lib.ptr(lin["W"]), lin["K"], _lib.ptr(lin["b"]),
+                  _lib.ptr(lin["m"]), _lib.ptr(lin["e"]), _lib.ptr(out), ldo, M, lin["N"], lin["K"], st)
+
+    def _gemm_res(self, A, lda, lin, res, me4, out, M, st):
+        C = self.C
+        _lib.call("ivit_gemm_i8_requant_residual", _lib.ptr(A), lda, _lib.ptr(lin["W"]), lin["K"],
+                  _lib.ptr(lin["b"]), _lib.ptr(lin["m"]), _lib.ptr(lin["e"]), _lib.ptr(res), C,
+                  me4[0], me4[1], me4[2], me4[3], _lib.ptr(out), C, M, lin["N"], lin["K"], st)
+
+    def _ln(self, x, ldx, rows, ln, out, st):
+        C = self.C
+        _lib.call("ivit_layernorm_i8", _lib.ptr(x), ldx, rows, C, _lib.ptr(ln["bias"]), _lib.ptr(ln["s"]),
+                  _lib.ptr(ln["m"]), _lib.ptr(ln["e"]), _lib.ptr(out), C, st)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, images: torch.Tensor, taps: dict | None = None):
+        """images: float32 [B,3,224,224] on the engine's device.  Returns (logits_int32 [B,1000],
+        logits_f32 [B,1000], top1 int32 [B]) -- views of the engine's workspace, valid until the
+        next call.  `taps` (debug/tests) receives clones of intermediate int8 tensors."""
+        assert images.is_cuda and images.dtype == torch.float32 and images.is_contiguous()
+        B = images.shape[0]
+        assert images.shape[1:] == (3, IMG_SIZE, IMG_SIZE) and 0 < B <= self.max_batch
+        C, H, hd, T = self.C, self.H, self.hd, NUM_TOKENS
+        M = B * T
+        ws = self.ws
+        st = self._stream()
+
+        def tap(name, t, shape):
+            if taps is not None:
+                taps[name] = t.reshape(-1)[: int(np.prod(shape))].view(shape).clone()
+
+        _lib.call("ivit_quantize_patchify_f32_i8", _lib.ptr(images), _lib.ptr(ws["a0"]), B, 3, IMG_SIZE, PATCH,
+                  self.inv_s0, st)
+        self._gemm(ws["a0"], 3 * PATCH * PATCH, self.patch, ws["pe"], C, B * NUM_PATCHES, st)
+        tap("patch_embed.qact", ws["pe"], (B, NUM_PATCHES, C))
+        _lib.call("ivit_embed_assemble_i8", _lib.ptr(ws["pe"]), _lib.ptr(self.pos_add), _lib.ptr(self.cls_row),
+                  self.embed_me[0], self.embed_me[1], _lib.ptr(ws["x"]), B, T, C, st)
+        tap("qact1", ws["x"], (B, T, C))
+        x, x2 = ws["x"], ws["x2"]
+        for i, blk in enumerate(self.blocks):
+            p = f"blocks.{i}."
+            self._ln(x, C, M, blk["ln1"], ws["h"], st)
+            tap(p + "qact1", ws["h"], (B, T, C))
+            q = blk["qkv"]
+            _lib.call("ivit_gemm_i8_requant_qkv", _lib.ptr(ws["h"]), C, _lib.ptr(q["W"]), q["K"], _lib.ptr(q["b"]),
+                      _lib.ptr(q["m"]), _lib.ptr(q["e"]), _lib.ptr(ws["qkv"]), T, H, hd, M, 3 * C, C, st)
+            tap(p + "attn.qkv_headmajor", ws["qkv"], (3, B, H, T, hd))
+            a = blk["attn"]
+            _lib.call("ivit_attention_fused_i8", _lib.ptr(ws["qkv"]), _lib.ptr(ws["ao"]), B, H, T, hd,
+                      a["ms"][0], a["ms"][1], a["s_attn"], a["mo"][0], a["mo"][1], st)
+            tap(p + "attn.qact2", ws["ao"], (B, T, C))
+            self._gemm_res(ws["ao"], C, blk["proj"], x, blk["res1"], x2, M, st)
+            tap(p + "qact2", x2, (B, T, C))
+            self._ln(x2, C, M, blk["ln2"], ws["h"], st)
+            tap(p + "qact3", ws["h"], (B, T, C))
+            self._gemm(ws["h"], C, blk["fc1"], ws["f1"], 4 * C, M, st)
+            tap(p + "mlp.qact_gelu", ws["f1"], (B, T, 4 * C))
+            _lib.call("ivit_shiftgelu_lut_i8", _lib.ptr(ws["f1"]), 4 * C, M, 4 * C, _lib.ptr(blk["gelu_lut"]),
+                      _lib.ptr(ws["g"]), 4 * C, st)
+            tap(p + "mlp.qact1", ws["g"], (B, T, 4 * C))
+            self._gemm_res(ws["g"], 4 * C, blk["fc2"], x2, blk["res2"], x, M, st)
+            tap(p + "qact4", x, (B, T, C))
+        # final LayerNorm is row-wise and only the cls row is consumed (vit_quant.py:302-304)
+        self._ln(x, T * C, B, self.ln_f, ws["cls"], st)
+        tap("qact2", ws["cls"], (B, C))
+        hd_ = self.head
+        _lib.call("ivit_gemm_i8_i32", _lib.ptr(ws["cls"]), C, _lib.ptr(hd_["W"]), hd_["K"], _lib.ptr(hd_["b"]),
+                  _lib.ptr(ws["logits"]), NUM_CLASSES, B, NUM_CLASSES, C, st)
+        _lib.call("ivit_head_argmax", _lib.ptr(ws["logits"]), _lib.ptr(self.head_scale), B, NUM_CLASSES,
+                  _lib.ptr(ws["logits_f"]), _lib.ptr(ws["top1"]), st)
+        return ws["logits"][:B], ws["logits_f"][:B], ws["top1"][:B]
+
+    __call__ = forward

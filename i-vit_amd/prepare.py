@@ -1,0 +1,93 @@
+"""Load-time (host) preparation of the integer parameters of the I-ViT path.
+
+The reference recomputes all of this inside every forward call
+(/root/reference/models/quantization_utils/quant_modules.py:202-220, 371-372, 486-504;
+quant_utils.py:151-175, 221-228); they are constants of a frozen model, so the
+MI355X path derives them once on the host, in the same float32 / float64
+arithmetic, and keeps only integers and dyadic (m, e) pairs on the device.
+
+numpy float32 scalars/arrays are IEEE single: `a * b`, `a / b`, np.rint,
+np.floor, np.sqrt round exactly like the torch CPU ops they restate.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+f32 = np.float32
+EPS32 = np.finfo(np.float32).eps
+
+
+def sym_scale(x_min, x_max, bits: int = 8) -> np.float32:
+    """symmetric_linear_quantization_params, quant_utils.py:52-70."""
+    n = f32(2 ** (bits - 1) - 1)
+    mx = max(-f32(x_min), f32(x_max))
+    return max(f32(f32(mx) / n), f32(EPS32))
+
+
+def weight_scale(W2d: np.ndarray, bits: int = 8) -> np.ndarray:
+    """Per-output-row weight scale, quant_modules.py:204-212 / 488-498."""
+    W2d = np.asarray(W2d, dtype=f32)
+    n = f32(2 ** (bits - 1) - 1)
+    mx = np.maximum(-W2d.min(axis=1), W2d.max(axis=1)).astype(f32)
+    return np.maximum((mx / n).astype(f32), f32(EPS32))
+
+
+def quant_sym(x: np.ndarray, scale, bits: int = 8) -> np.ndarray:
+    """SymmetricQuantFunction.forward, quant_utils.py:79-97: clamp(round(1./scale * x), -n-1, n).
+    `scale` broadcasts against x (per-row weights: pass scale[:, None])."""
+    x = np.asarray(x, dtype=f32)
+    rs = (f32(1.0) / np.asarray(scale, dtype=f32)).astype(f32)
+    q = np.rint((rs * x).astype(f32))
+    lo, hi = f32(-(2.0 ** (bits - 1))), f32(2.0 ** (bits - 1) - 1)  # hi rounds to 2^31 for 32 bit, as in torch
+    q = np.clip(q, lo, hi)
+    return np.minimum(q.astype(np.float64), 2.0 ** 31 - 1).astype(np.int64).astype(np.int32)
+
+
+def dyadic(pre_sf, z_sf):
+    """(m, e) of fixedpoint_mul / batch_frexp (quant_utils.py:151-175, 221-228):
+    new_scale = double(pre_sf)/double(float(z_sf)) = mant * 2^exp; m = round_half_up(mant*2^31); e = 31-exp."""
+    pre = np.atleast_1d(np.asarray(pre_sf, dtype=f32)).astype(np.float64)
+    ns = pre / np.float64(f32(z_sf))
+    mant, ex = np.frexp(ns)
+    m = np.floor(mant * 2.0 ** 31 + 0.5)
+    assert np.all(m >= 2 ** 30) and np.all(m <= 2 ** 31), "degenerate requant ratio"
+    return m.astype(np.uint32), (31 - ex).astype(np.int32)
+
+
+def requant_host(z, m, e) -> np.ndarray:
+    """RNE(z*m/2^e) in float64 exactly as quant_utils.py:229-230 (used for load-time constants)."""
+    return np.rint(np.asarray(z, np.float64) * np.asarray(m, np.float64) / np.exp2(np.asarray(e, np.float64)))
+
+
+class LinearParams:
+    """Integer weights of a QuantLinear / QuantConv2d given the (fixed) input scale."""
+
+    def __init__(self, W: np.ndarray, b, s_in):
+        W2 = np.asarray(W, dtype=f32).reshape(W.shape[0], -1)
+        self.sw = weight_scale(W2)
+        self.W8 = quant_sym(W2, self.sw[:, None], 8).astype(np.int8)
+        self.s_acc = (self.sw * f32(s_in)).astype(f32)  # bias_scaling_factor, quant_modules.py:217
+        self.b32 = None if b is None else quant_sym(np.asarray(b, f32), self.s_acc, 32)
+        self.K = W2.shape[1]
+
+    def requant_to(self, s_out):
+        m, e = dyadic(self.s_acc, s_out)
+        if np.any(e < 31):
+            raise ValueError("GEMM requantiser with multiplier > 1 (e < 31) is outside the kernels' contract")
+        return m, e
+
+
+class LayerNormParams:
+    """Constants of IVITIntLayerNorm (ivit_modules.py:31-33, 53-62) + the QuantAct behind it."""
+
+    def __init__(self, gamma, beta, s_out):
+        gamma = np.asarray(gamma, f32)
+        beta = np.asarray(beta, f32)
+        C = gamma.shape[0]
+        dim_sqrt = np.sqrt(f32(C)).astype(f32)
+        sf = f32(dim_sqrt / f32(2 ** 30))
+        self.bias_int = np.floor(((beta / gamma).astype(f32) / sf).astype(f32)).astype(f32)
+        self.s_ln = (sf * gamma).astype(f32)
+        self.m, self.e = dyadic(self.s_ln, s_out)
+        if np.any(self.e < 31):
+            raise ValueError("LayerNorm requantiser with multiplier > 1 is outside the kernel's contract")

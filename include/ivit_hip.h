@@ -1,0 +1,182 @@
+/*
+ * ivit_hip.h -- C ABI of libivit_hip.so: the MI355X (gfx950) integer-only ViT
+ * operators that replace the hot path of lionnus/I-ViT
+ * (models/quantization_utils/{quant_modules,ivit_modules,quant_utils}.py).
+ *
+ * The reference has no native interface at all (it is pure PyTorch, float32
+ * "fake-quant" emulation), so each entry point below cites the Python code it
+ * replaces; INTEGRATION.md shows the ctypes stub a maintainer of the reference
+ * would add.  Conventions:
+ *   - every function returns 0 on success, a negative IVIT_ERR_* code otherwise;
+ *     ivit_last_error_string() describes the last failure on the calling thread;
+ *   - all pointers are DEVICE pointers (hipMalloc / torch tensor .data_ptr())
+ *     unless a parameter is documented as host scalar; the library allocates
+ *     nothing and keeps no state: the caller owns inputs, outputs and tables;
+ *   - launches are asynchronous on `stream` (a hipStream_t passed as void*;
+ *     NULL = the default stream); functions are re-entrant;
+ *   - integer tensors are row-major; `ld*` are leading dimensions in ELEMENTS;
+ *   - a dyadic requantiser is the pair (m, e) of the reference's batch_frexp
+ *     (quant_utils.py:151-175): out = RNE(z * m / 2^e), 2^30 <= m <= 2^31,
+ *     e = 31 - exponent.  Per-channel tables are `const uint32_t* m,
+ *     const int32_t* e`; per-tensor requantisers are passed by value.
+ */
+#ifndef IVIT_HIP_H
+#define IVIT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IVIT_OK 0
+#define IVIT_ERR_INVALID (-1)     /* bad argument (shape, alignment, NULL)        */
+#define IVIT_ERR_UNSUPPORTED (-2) /* valid request this build has no kernel for  */
+#define IVIT_ERR_LAUNCH (-3)      /* HIP reported an error at launch              */
+
+typedef void* ivit_stream_t; /* hipStream_t */
+
+int ivit_version(void);
+const char* ivit_last_error_string(void);
+
+/* ---- input quantisation ---------------------------------------------------------------
+ * QuantAct input mode = SymmetricQuantFunction.forward (quant_utils.py:79-97,
+ * linear_quantize :13-49):  q = clamp(round(inv_scale * x), -128, 127), inv_scale = fl(1/s)
+ * computed by the caller in float32. */
+int ivit_quantize_input_f32_i8(const float* x, int8_t* out, int64_t n, float inv_scale, ivit_stream_t stream);
+
+/* The same fused with the im2col of PatchEmbed's strided convolution
+ * (layers_quant.py:197-198, quant_modules.py:506-511):
+ *   img [B, chans, hw, hw] float32 -> A [B*(hw/patch)^2, chans*patch*patch] int8,
+ *   column order (c, kh, kw) = the flattening of the conv weight [out, c, kh, kw]. */
+int ivit_quantize_patchify_f32_i8(const float* img, int8_t* A, int batch, int chans, int hw, int patch,
+                                  float inv_scale, ivit_stream_t stream);
+
+/* ---- INT8 GEMM on v_mfma_i32_32x32x32_i8 with fused epilogues -------------------------------
+ * QuantLinear.forward / QuantConv2d.forward (quant_modules.py:186-226, 478-511) followed by
+ * the QuantAct that always consumes them (quant_modules.py:302-387 -> fixedpoint_mul,
+ * quant_utils.py:193-253).
+ *   acc[t][n] = sum_k A[t][k] * W[n][k] + bias[n]          (exact int32)
+ * A [M, K] int8 (lda), W [N, K] int8 (ldw), bias [N] int32 or NULL.  K % 64 == 0.
+ */
+
+/* out[t][n] = clamp8(RNE(acc * m[n] / 2^e[n]));  N % 16 == 0 */
+int ivit_gemm_i8_requant(const int8_t* A, int64_t lda, const int8_t* W, int64_t ldw, const int32_t* bias,
+                         const uint32_t* m, const int32_t* e, int8_t* out, int64_t ldo,
+                         int M, int N, int K, ivit_stream_t stream);
+
+/* as above, then the two-operand QuantAct of the residual connection
+ * (vit_quant.py:147,153; quant_utils.py:232-245):
+ *   k = clamp8(RNE(acc * m[n] / 2^e[n]))
+ *   out = clamp8(RNE(k * m_main / 2^e_main) + RNE(res[t][n] * m_res / 2^e_res)) */
+int ivit_gemm_i8_requant_residual(const int8_t* A, int64_t lda, const int8_t* W, int64_t ldw,
+                                  const int32_t* bias, const uint32_t* m, const int32_t* e,
+                                  const int8_t* res, int64_t ldr, uint32_t m_main, int32_t e_main,
+                                  uint32_t m_res, int32_t e_res, int8_t* out, int64_t ldo,
+                                  int M, int N, int K, ivit_stream_t stream);
+
+/* as ivit_gemm_i8_requant but the output is written head-major for the attention kernel:
+ * N = 3 * heads * head_dim, row t = b * tokens + tok  ->
+ *   qkv[which][b][h][tok][d],  n = which*heads*head_dim + h*head_dim + d
+ * (the reshape/permute of vit_quant.py:65-71).  head_dim % 16 == 0. */
+int ivit_gemm_i8_requant_qkv(const int8_t* A, int64_t lda, const int8_t* W, int64_t ldw, const int32_t* bias,
+                             const uint32_t* m, const int32_t* e, int8_t* qkv, int tokens, int heads,
+                             int head_dim, int M, int N, int K, ivit_stream_t stream);
+
+/* raw accumulators (classifier head; module-level QuantLinear): out int32 [M, N], N % 4 == 0 */
+int ivit_gemm_i8_i32(const int8_t* A, int64_t lda, const int8_t* W, int64_t ldw, const int32_t* bias,
+                     int32_t* out, int64_t ldo, int M, int N, int K, ivit_stream_t stream);
+
+/* ---- fused attention core -------------------------------------------------------------------
+ * vit_quant.py:72-85: matmul_1 (q.k^T) -> qact_attn1 -> IVITIntSoftmax (Shiftmax,
+ * ivit_modules.py:150-179) -> matmul_2 (P.v) -> qact2, per (image, head), never
+ * materialising the [B,H,T,T] score tensor.
+ *   qkv   [3][B][H][T][head_dim] int8 (as written by ivit_gemm_i8_requant_qkv)
+ *   out   [B*T, H*head_dim] int8, column h*head_dim + d (the transpose(1,2).reshape of :83)
+ *   (m_s, e_s): requantiser of q.k^T into the Shiftmax input (8 bit)
+ *   s_attn: float32 scale of the Shiftmax input (x0 = floor(-1/s_attn), n = 15)
+ *   (m_o, e_o): requantiser of P.v into the 8-bit output.
+ * Supported: head_dim 64, 160 < tokens <= 224. */
+int ivit_attention_fused_i8(const int8_t* qkv, int8_t* out, int batch, int heads, int tokens, int head_dim,
+                            uint32_t m_s, int32_t e_s, float s_attn, uint32_t m_o, int32_t e_o,
+                            ivit_stream_t stream);
+
+/* ---- I-LayerNorm + the QuantAct behind it ---------------------------------------------------
+ * IVITIntLayerNorm.forward (ivit_modules.py:30-65) then QuantAct (fixedpoint_mul).
+ *   x [rows, C] int8 (ldx), per channel: bias_int[c] = floor((beta/gamma)/(sqrt(C)/2^30)),
+ *   s_ln[c] = (sqrt(C)/2^30)*gamma[c] (both float32, prepared by the caller as the reference
+ *   computes them, :53-62), (m[c], e[c]) requantiser s_ln[c] -> output scale.
+ *   out [rows, C] int8 (ldo).  C % 4 == 0, C <= 4096. */
+int ivit_layernorm_i8(const int8_t* x, int64_t ldx, int rows, int C, const float* bias_int, const float* s_ln,
+                      const uint32_t* m, const int32_t* e, int8_t* out, int64_t ldo, ivit_stream_t stream);
+
+/* module-level form: int32 input (8 or 16 bit values), float32 output y*s_ln (ivit_modules.py:63) */
+int ivit_layernorm_i32_f32(const int32_t* x, int64_t ldx, int rows, int C, const float* bias_int,
+                           const float* s_ln, float* out, int64_t ldo, ivit_stream_t stream);
+
+/* ---- ShiftGELU -----------------------------------------------------------------------------
+ * IVITIntGELU.forward (ivit_modules.py:89-126, n = 23, output_bit = 8) on rows of L int8 values
+ * with input scale s, followed by the per-tensor QuantAct (m, e) -> int8.
+ * Direct arithmetic form: */
+int ivit_shiftgelu_i8(const int8_t* x, int64_t ldx, int rows, int L, float s, uint32_t m, int32_t e,
+                      int8_t* out, int64_t ldo, ivit_stream_t stream);
+/* module-level form: int32 output k*sigmoid_int (ivit_modules.py:123), no requant */
+int ivit_shiftgelu_i8_i32(const int8_t* x, int64_t ldx, int rows, int L, float s, int32_t* out, int64_t ldo,
+                          ivit_stream_t stream);
+/* Table form used by the engine: for a fixed (s, m, e) the result depends only on (row max, k):
+ * lut[(kmax+128)*256 + (k+128)] = int8 result.  Build once per layer at load time ... */
+int ivit_shiftgelu_build_lut(float s, uint32_t m, int32_t e, int8_t* lut /* [256*256] */, ivit_stream_t stream);
+/* ... then per call: wave-per-row max reduction + LDS-staged table row + byte gather.  L % 4 == 0. */
+int ivit_shiftgelu_lut_i8(const int8_t* x, int64_t ldx, int rows, int L, const int8_t* lut, int8_t* out,
+                          int64_t ldo, ivit_stream_t stream);
+
+/* ---- stand-alone Shiftmax (module-level IVITIntSoftmax, ivit_modules.py:164-179) -----------------
+ * x [rows, L] int8 with scale s -> out [rows, L] int8 in [0, 127] (scale 2^-7). L <= 1024. */
+int ivit_shiftmax_i8(const int8_t* x, int64_t ldx, int rows, int L, float s, int8_t* out, int64_t ldo,
+                     ivit_stream_t stream);
+
+/* ---- generic QuantAct on integers (fixedpoint_mul, quant_utils.py:193-253) ---------------------
+ * z [rows, C] int32; (m,e) per channel (n_me == C) or per tensor (n_me == 1); optional identity
+ * branch z2 with (m2,e2) (n_me2 in {0,1,C}); bits in {8,16,32}; out int32 [rows, C]. */
+int ivit_requant_i32(const int32_t* z, int64_t rows, int C, const uint32_t* m, const int32_t* e, int n_me,
+                     const int32_t* z2, const uint32_t* m2, const int32_t* e2, int n_me2, int bits,
+                     int32_t* out, ivit_stream_t stream);
+
+/* int8 two-operand form (Block.qact2 / qact4 as a stand-alone op) */
+int ivit_residual_requant_i8(const int8_t* a, uint32_t m_a, int32_t e_a, const int8_t* b, uint32_t m_b,
+                             int32_t e_b, int8_t* out, int64_t n, ivit_stream_t stream);
+
+/* ---- cls token + position embedding (vit_quant.py:290-296) -------------------------------------
+ * patch [B*(T-1), C] int8 (PatchEmbed output); out [B*T, C] int8:
+ *   out[b][0][:]   = cls_row[:]                    (constant, prepared by the caller)
+ *   out[b][1+p][c] = clamp8(RNE(patch*m/2^e) + pos_add[1+p][c])
+ * pos_add [T, C] int16 = RNE(qact_pos(pos_embed) * m_pos / 2^e_pos) prepared by the caller. */
+int ivit_embed_assemble_i8(const int8_t* patch, const int16_t* pos_add, const int8_t* cls_row, uint32_t m,
+                           int32_t e, int8_t* out, int batch, int tokens, int C, ivit_stream_t stream);
+
+/* ---- classifier output (quant_modules.py:225-226; scripts/inference.py:249-250) ----------------
+ * logits_f32[b][n] = fl(float(acc[b][n]) * s_acc[n]); top1[b] = argmax_n logits_f32 (first max).
+ * logits_f32 may be NULL. */
+int ivit_head_argmax(const int32_t* acc, const float* s_acc, int batch, int N, float* logits_f32,
+                     int32_t* top1, ivit_stream_t stream);
+
+/* ---- module-level QuantMatMul (quant_modules.py:404-409): batched int8 matmul -> int32 ----------
+ * qk: S[b][i][j] = sum_d Q[b][i][d] * K[b][j][d];  pv: O[b][i][d] = sum_j P[b][i][j] * V[b][j][d].
+ * All operands dense row-major per batch entry. */
+int ivit_bgemm_qk_i8(const int8_t* Q, const int8_t* K, int32_t* S, int batch, int Tq, int Tk, int D,
+                     ivit_stream_t stream);
+int ivit_bgemm_pv_i8(const int8_t* P, const int8_t* V, int32_t* O, int batch, int Tq, int Tk, int D,
+                     ivit_stream_t stream);
+
+/* ---- float <-> integer views at module edges (quant_utils.py:220; quant_modules.py:223,385-387) --
+ * z = round(x / s[c]) (mode 0) or trunc(x / s[c]) (mode 1, the `.to(int32)` of ivit_modules.py:38,107);
+ * y = float(z) * s[c].  n_s in {1, C}. */
+int ivit_f32_to_i32(const float* x, int64_t rows, int C, const float* s, int n_s, int mode, int32_t* z,
+                    ivit_stream_t stream);
+int ivit_i32_to_f32(const int32_t* z, int64_t rows, int C, const float* s, int n_s, float* y,
+                    ivit_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IVIT_HIP_H */

@@ -1,0 +1,105 @@
+"""GPU parity, whole model: the HIP engine against the golden vectors produced by the REFERENCE
+(tests/golden/*.npz: INT32 logits, top-1 and CRC32 of intermediate taps) and against the CPU oracle."""
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+ivit = pytest.importorskip("ivit_amd")
+from ivit_amd import synth  # noqa: E402
+from ivit_amd.checkpoint import load_synthetic_model  # noqa: E402
+from ivit_amd.engine import IntViTEngine  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def crc(a):
+    return zlib.crc32(np.ascontiguousarray(a, dtype=np.int32).tobytes())
+
+
+def build(tag, max_batch):
+    fs, ranges, cfg, meta, z = load_synthetic_model(tag)
+    eng = IntViTEngine(fs, ranges, cfg["embed_dim"], cfg["depth"], cfg["num_heads"], device=DEV, max_batch=max_batch)
+    return eng, fs, ranges, cfg, meta, z
+
+
+@pytest.mark.parametrize("tag", ["deit_tiny", "deit_small", "deit_base", "vit_base"])
+def test_golden_logits_and_taps(tag):
+    eng, fs, ranges, cfg, meta, z = build(tag, meta_batch(tag))
+    n = meta["n_images"]
+    imgs = torch.from_numpy(synth.make_images(n, meta["image_seed"])).to(DEV)
+    taps = {}
+    li, lf, t1 = eng.forward(imgs, taps)
+    torch.cuda.synchronize()
+    # every tap the reference recorded and the engine materialises, by CRC32
+    gold = dict(zip([str(x) for x in z["tap_names"]], z["tap_crc32"]))
+    checked = 0
+    for name, t in taps.items():
+        if name in gold:
+            assert crc(t.cpu().numpy().astype(np.int32)) == int(gold[name]), f"{tag}: tap {name} differs"
+            checked += 1
+    assert checked >= 8 * cfg["depth"] + 3
+    assert np.array_equal(li.cpu().numpy(), z["logits_int32"]), f"{tag}: INT32 logits differ"
+    assert np.array_equal(lf.cpu().numpy().view(np.int32), z["logits_f32_bits"])
+    assert np.array_equal(t1.cpu().numpy().astype(np.int64), z["top1"])
+
+
+def meta_batch(tag):
+    return {"deit_tiny": 8, "deit_small": 4, "deit_base": 4, "vit_base": 2}[tag]
+
+
+def test_full_taps_deit_tiny():
+    """the complete stage-by-stage tensors of image 0 stored in the fixture"""
+    eng, fs, ranges, cfg, meta, z = build("deit_tiny", 1)
+    imgs = torch.from_numpy(synth.make_images(1, meta["image_seed"])).to(DEV)
+    taps = {}
+    eng.forward(imgs, taps)
+    n = 0
+    for key in z.files:
+        if key.startswith("full/") and key[5:] in taps:
+            got = taps[key[5:]].cpu().numpy().astype(np.int32)
+            exp = z[key].astype(np.int32)
+            assert np.array_equal(got.reshape(exp.shape), exp), key
+            n += 1
+    assert n >= 10
+
+
+def test_batch_invariance_and_oracle_on_fresh_images():
+    """Config 2 shape (DeiT-S, batch 64): images the fixtures never saw, checked against the oracle on a
+    subset, and the size-independent property that an image's logits do not depend on its batch."""
+    eng, fs, ranges, cfg, meta, z = build("deit_small", 64)
+    imgs_np = synth.make_images(64, 4242)
+    imgs = torch.from_numpy(imgs_np).to(DEV)
+    li, lf, t1 = eng.forward(imgs)
+    li = li.cpu().numpy().copy()
+    om = orc.OracleViT(fs, ranges, cfg["embed_dim"], cfg["depth"], cfg["num_heads"])
+    sub = [0, 17, 63]
+    ref = om.forward(imgs_np[sub])
+    assert np.array_equal(li[sub], ref["logits_int32"])
+    perm = np.random.default_rng(0).permutation(64)
+    li2, _, _ = eng.forward(imgs[torch.from_numpy(perm).to(DEV)].contiguous())
+    assert np.array_equal(li2.cpu().numpy(), li[perm])
+    li3, _, _ = eng.forward(imgs[5:6].contiguous())
+    assert np.array_equal(li3.cpu().numpy(), li[5:6])
+
+
+def test_headline_batch_256_deit_base():
+    """Config 3 at full size: golden images embedded in a batch of 256 reproduce the golden logits."""
+    eng, fs, ranges, cfg, meta, z = build("deit_base", 256)
+    imgs_np = synth.make_images(256, 777)
+    gold = synth.make_images(meta["n_images"], meta["image_seed"])
+    pos = [0, 100, 200, 255][: meta["n_images"]]
+    for p, g in zip(pos, gold):
+        imgs_np[p] = g
+    li, lf, t1 = eng.forward(torch.from_numpy(imgs_np).to(DEV))
+    li = li.cpu().numpy()
+    assert np.array_equal(li[pos], z["logits_int32"])
+    assert np.array_equal(t1.cpu().numpy()[pos].astype(np.int64), z["top1"])
+    # determinism
+    li_b, _, _ = eng.forward(torch.from_numpy(imgs_np).to(DEV))
+    assert np.array_equal(li_b.cpu().numpy(), li)

@@ -1,0 +1,326 @@
+"""GPU parity, operator level: every HIP kernel (through the C ABI) against the CPU oracle and the
+reference-generated known-answer vectors.  Bit-exact: these are integer results."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+ivit = pytest.importorskip("ivit_amd")
+from ivit_amd import _lib  # noqa: E402
+from ivit_amd.prepare import dyadic  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def st():
+    return _lib.stream_ptr()
+
+
+def rand_me(rng, n, lo_exp=-12, hi_exp=-6):
+    """random requant ratios -> (m uint32, e int32) via the product's own dyadic()"""
+    pre = (rng.uniform(0.5, 1.0, size=n) * 2.0 ** rng.integers(lo_exp, hi_exp, size=n)).astype(np.float32)
+    m, e = dyadic(pre, np.float32(1.0))
+    return m, e
+
+
+def me_dev(m, e):
+    return dev(m.view(np.int32)), dev(e)
+
+
+@pytest.fixture(scope="module")
+def kat(golden_dir):
+    return np.load(os.path.join(golden_dir, "ops_kat.npz"))
+
+
+# ----------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 192, 192), (197 * 3, 768, 768), (1000, 384, 1536),
+                                   (64, 2304, 768), (129, 208, 128)])
+def test_gemm_requant(M, N, K):
+    rng = np.random.default_rng(M * 7 + N + K)
+    A = rng.integers(-128, 128, size=(M, K)).astype(np.int8)
+    W = rng.integers(-128, 128, size=(N, K)).astype(np.int8)
+    b = rng.integers(-50000, 50000, size=N).astype(np.int32)
+    m, e = rand_me(rng, N, -16, -9)
+    acc = orc.gemm_i8(A, W, b)
+    exp = orc.requant(acc, m.astype(np.float64), e, 8)
+    out = torch.empty(M, N, dtype=torch.int8, device=DEV)
+    md, ed = me_dev(m, e)
+    _lib.call("ivit_gemm_i8_requant", _lib.ptr(dev(A)), K, _lib.ptr(dev(W)), K, _lib.ptr(dev(b)), _lib.ptr(md),
+              _lib.ptr(ed), _lib.ptr(out), N, M, N, K, st())
+    got = out.cpu().numpy().astype(np.int32)
+    assert np.array_equal(got, exp), f"{(got != exp).sum()} of {got.size} differ"
+    assert np.abs(exp).max() > 10
+
+
+def test_gemm_i32_and_bias_none():
+    rng = np.random.default_rng(5)
+    M, N, K = 70, 1000, 192
+    A = rng.integers(-128, 128, size=(M, K)).astype(np.int8)
+    W = rng.integers(-128, 128, size=(N, K)).astype(np.int8)
+    b = rng.integers(-50000, 50000, size=N).astype(np.int32)
+    for bias in (b, None):
+        out = torch.empty(M, N, dtype=torch.int32, device=DEV)
+        _lib.call("ivit_gemm_i8_i32", _lib.ptr(dev(A)), K, _lib.ptr(dev(W)), K,
+                  None if bias is None else _lib.ptr(dev(bias)), _lib.ptr(out), N, M, N, K, st())
+        assert np.array_equal(out.cpu().numpy(), orc.gemm_i8(A, W, bias))
+
+
+def test_gemm_mfma_layout_identity():
+    """A = I-like selector with an asymmetric W catches any row/column swap of the MFMA maps."""
+    K = 128
+    A = np.zeros((128, K), np.int8)
+    A[np.arange(128), np.arange(128) % K] = 1
+    W = (np.arange(128)[:, None] * 3 + np.arange(K)[None, :] * 5) % 251 - 125
+    W = W.astype(np.int8)
+    out = torch.empty(128, 128, dtype=torch.int32, device=DEV)
+    _lib.call("ivit_gemm_i8_i32", _lib.ptr(dev(A)), K, _lib.ptr(dev(W)), K, None, _lib.ptr(out), 128, 128, 128, K, st())
+    assert np.array_equal(out.cpu().numpy(), orc.gemm_i8(A, W))
+
+
+def test_gemm_requant_residual():
+    rng = np.random.default_rng(11)
+    M, N, K = 333, 384, 384
+    A = rng.integers(-128, 128, size=(M, K)).astype(np.int8)
+    W = rng.integers(-128, 128, size=(N, K)).astype(np.int8)
+    b = rng.integers(-50000, 50000, size=N).astype(np.int32)
+    res = rng.integers(-128, 128, size=(M, N)).astype(np.int8)
+    m, e = rand_me(rng, N, -16, -9)
+    m1, e1 = dyadic(np.float32(0.7 * 2 ** -4), np.float32(2 ** -4))
+    m2, e2 = dyadic(np.float32(2 ** -5), np.float32(2 ** -4))
+    k3 = orc.requant(orc.gemm_i8(A, W, b), m.astype(np.float64), e, 8)
+    exp = orc.requant(k3, m1.astype(np.float64), e1, 8, z2=res.astype(np.int32), m2=m2.astype(np.float64), e2=e2)
+    out = torch.empty(M, N, dtype=torch.int8, device=DEV)
+    md, ed = me_dev(m, e)
+    _lib.call("ivit_gemm_i8_requant_residual", _lib.ptr(dev(A)), K, _lib.ptr(dev(W)), K, _lib.ptr(dev(b)),
+              _lib.ptr(md), _lib.ptr(ed), _lib.ptr(dev(res)), N, int(m1[0]), int(e1[0]), int(m2[0]), int(e2[0]),
+              _lib.ptr(out), N, M, N, K, st())
+    assert np.array_equal(out.cpu().numpy().astype(np.int32), exp)
+
+
+def test_gemm_requant_qkv_layout():
+    rng = np.random.default_rng(12)
+    B, T, H, hd = 3, 197, 3, 64
+    Cn = H * hd
+    M, N, K = B * T, 3 * Cn, Cn
+    A = rng.integers(-128, 128, size=(M, K)).astype(np.int8)
+    W = rng.integers(-128, 128, size=(N, K)).astype(np.int8)
+    b = rng.integers(-50000, 50000, size=N).astype(np.int32)
+    m, e = rand_me(rng, N, -16, -9)
+    exp = orc.requant(orc.gemm_i8(A, W, b), m.astype(np.float64), e, 8)
+    exp = exp.reshape(B, T, 3, H, hd).transpose(2, 0, 3, 1, 4)  # vit_quant.py:65-66
+    out = torch.empty(3 * M * Cn, dtype=torch.int8, device=DEV)
+    md, ed = me_dev(m, e)
+    _lib.call("ivit_gemm_i8_requant_qkv", _lib.ptr(dev(A)), K, _lib.ptr(dev(W)), K, _lib.ptr(dev(b)), _lib.ptr(md),
+              _lib.ptr(ed), _lib.ptr(out), T, H, hd, M, N, K, st())
+    assert np.array_equal(out.cpu().numpy().astype(np.int32).reshape(3, B, H, T, hd), exp)
+
+
+def test_gemm_rejects_bad_shapes():
+    a = torch.zeros(64, 100, dtype=torch.int8, device=DEV)
+    with pytest.raises(_lib.IvitError, match="multiple of 64"):
+        _lib.call("ivit_gemm_i8_i32", _lib.ptr(a), 100, _lib.ptr(a), 100, None, _lib.ptr(a), 64, 64, 64, 100, st())
+    with pytest.raises(_lib.IvitError, match="NULL"):
+        _lib.call("ivit_gemm_i8_i32", None, 64, _lib.ptr(a), 64, None, _lib.ptr(a), 64, 64, 64, 64, st())
+
+
+# ----------------------------------------------------------------------------------- attention
+@pytest.mark.parametrize("B,H,T,p_at", [(2, 3, 197, -2), (1, 6, 197, -3), (1, 2, 224, -1), (1, 1, 193, -2)])
+def test_attention_fused(B, H, T, p_at):
+    rng = np.random.default_rng(100 + B * H + T)
+    hd = 64
+    qkv = np.clip(np.rint(rng.normal(0, 40, size=(3, B, H, T, hd))), -128, 127).astype(np.int8)
+    s_a1 = np.float32(2.0 ** -4)
+    s_S = np.float32(np.float32(s_a1 * s_a1) * np.float32(0.125))
+    s_at = np.float32(2.0 ** p_at)
+    s_pv = np.float32(np.float32(1 / 128.0) * s_a1)
+    s_a2 = np.float32(2.0 ** -3)
+    ms, es = dyadic(s_S, s_at)
+    mo, eo = dyadic(s_pv, s_a2)
+    exp = np.empty((B, T, H * hd), np.int32)
+    for b in range(B):
+        for h in range(H):
+            S = orc.gemm_i8(qkv[0, b, h], qkv[1, b, h])
+            ka = orc.requant(S, ms.astype(np.float64), es, 8)
+            P = orc.shiftmax(ka, s_at)
+            assert P.max() <= 127
+            O = orc.gemm_i8(P.astype(np.int8), qkv[2, b, h], transB=False)
+            exp[b, :, h * hd:(h + 1) * hd] = orc.requant(O, mo.astype(np.float64), eo, 8)
+    out = torch.full((B * T, H * hd), 99, dtype=torch.int8, device=DEV)
+    _lib.call("ivit_attention_fused_i8", _lib.ptr(dev(qkv)), _lib.ptr(out), B, H, T, hd, int(ms[0]), int(es[0]),
+              float(s_at), int(mo[0]), int(eo[0]), st())
+    got = out.cpu().numpy().astype(np.int32).reshape(B, T, H * hd)
+    assert np.array_equal(got, exp), f"{(got != exp).sum()} of {got.size} differ"
+    assert np.abs(exp).max() > 20
+
+
+def test_attention_unsupported_geometry():
+    a = torch.zeros(1 << 16, dtype=torch.int8, device=DEV)
+    with pytest.raises(_lib.IvitError, match="unsupported geometry"):
+        _lib.call("ivit_attention_fused_i8", _lib.ptr(a), _lib.ptr(a), 1, 1, 49, 32, 1 << 30, 40, 0.25, 1 << 30, 40, st())
+
+
+# ----------------------------------------------------------------------------------- LayerNorm
+def _ln_host(gamma, beta, s_out):
+    from ivit_amd.prepare import LayerNormParams
+    return LayerNormParams(gamma, beta, s_out)
+
+
+def test_layernorm_kat(kat):
+    for ci in kat["ln_cases"][:3]:  # 8-bit inputs (the int8 kernel); case 3 is 16-bit -> i32 kernel
+        c = f"ln{ci}_"
+        k = kat[c + "k"]
+        lp = _ln_host(kat[c + "gamma"], kat[c + "beta"], kat[c + "q_sf"])
+        assert np.array_equal(lp.s_ln, kat[c + "sln"]) and np.array_equal(lp.bias_int, kat[c + "bias_int"])
+        rows, Cn = k.shape
+        out = torch.empty(rows, Cn, dtype=torch.int8, device=DEV)
+        md, ed = me_dev(lp.m, lp.e)
+        _lib.call("ivit_layernorm_i8", _lib.ptr(dev(k.astype(np.int8))), Cn, rows, Cn, _lib.ptr(dev(lp.bias_int)),
+                  _lib.ptr(dev(lp.s_ln)), _lib.ptr(md), _lib.ptr(ed), _lib.ptr(out), Cn, st())
+        got = out.cpu().numpy().astype(np.int32)
+        assert np.array_equal(got, kat[c + "q_out"]), (ci, (got != kat[c + "q_out"]).sum())
+
+
+def test_layernorm_f32_module_form_kat(kat):
+    for ci in kat["ln_cases"]:
+        c = f"ln{ci}_"
+        k = kat[c + "k"]
+        rows, Cn = k.shape
+        out = torch.empty(rows, Cn, dtype=torch.float32, device=DEV)
+        _lib.call("ivit_layernorm_i32_f32", _lib.ptr(dev(k)), Cn, rows, Cn, _lib.ptr(dev(kat[c + "bias_int"])),
+                  _lib.ptr(dev(kat[c + "sln"])), _lib.ptr(out), Cn, st())
+        assert np.array_equal(out.cpu().numpy().view(np.int32), kat[c + "y_bits"]), ci
+
+
+@pytest.mark.parametrize("rows,Cn", [(1000, 768), (513, 192), (64, 384), (7, 1024)])
+def test_layernorm_random_vs_oracle(rows, Cn):
+    rng = np.random.default_rng(rows + Cn)
+    k = np.clip(np.rint(rng.normal(rng.normal(0, 10, size=(rows, 1)), rng.uniform(1, 50, size=(rows, 1)),
+                                   size=(rows, Cn))), -128, 127).astype(np.int8)
+    gamma = rng.uniform(0.5, 1.5, size=Cn).astype(np.float32)
+    beta = rng.normal(0, 0.1, size=Cn).astype(np.float32)
+    y, s_ln, _ = orc.layernorm(k.astype(np.int32), gamma, beta)
+    s_out = np.float32(2.0 ** np.ceil(np.log2(np.abs(y * s_ln).max() / 127 * 0.8)))
+    m, e = orc.dyadic(s_ln, s_out)
+    exp = orc.requant(orc.roundtrip(y, s_ln), m, e, 8)
+    lp = _ln_host(gamma, beta, s_out)
+    out = torch.empty(rows, Cn, dtype=torch.int8, device=DEV)
+    md, ed = me_dev(lp.m, lp.e)
+    _lib.call("ivit_layernorm_i8", _lib.ptr(dev(k)), Cn, rows, Cn, _lib.ptr(dev(lp.bias_int)),
+              _lib.ptr(dev(lp.s_ln)), _lib.ptr(md), _lib.ptr(ed), _lib.ptr(out), Cn, st())
+    got = out.cpu().numpy().astype(np.int32)
+    assert np.array_equal(got, exp), f"{(got != exp).sum()} of {got.size} differ"
+
+
+# ----------------------------------------------------------------------------------- GELU
+def test_shiftgelu_kat_direct_and_lut(kat):
+    for ci in kat["gelu_cases"]:
+        c = f"gelu{ci}_"
+        k = kat[c + "k"].astype(np.int8)
+        s = float(kat[c + "s"])
+        rows, L = k.shape
+        out32 = torch.empty(rows, L, dtype=torch.int32, device=DEV)
+        _lib.call("ivit_shiftgelu_i8_i32", _lib.ptr(dev(k)), L, rows, L, s, _lib.ptr(out32), L, st())
+        assert np.array_equal(out32.cpu().numpy(), kat[c + "out"]), ci
+        # fused requant, direct and table forms
+        s_out = np.float32(2.0 ** np.ceil(np.log2(max(np.abs(kat[c + "out"]).max(), 1) * float(kat[c + "sout"]) / 127)))
+        m, e = dyadic(kat[c + "sout"], s_out)
+        exp = orc.requant(kat[c + "out"], m.astype(np.float64), e, 8)
+        out8 = torch.empty(rows, L, dtype=torch.int8, device=DEV)
+        _lib.call("ivit_shiftgelu_i8", _lib.ptr(dev(k)), L, rows, L, s, int(m[0]), int(e[0]), _lib.ptr(out8), L, st())
+        assert np.array_equal(out8.cpu().numpy().astype(np.int32), exp), ci
+        lut = torch.empty(65536, dtype=torch.int8, device=DEV)
+        _lib.call("ivit_shiftgelu_build_lut", s, int(m[0]), int(e[0]), _lib.ptr(lut), st())
+        out8b = torch.empty(rows, L, dtype=torch.int8, device=DEV)
+        _lib.call("ivit_shiftgelu_lut_i8", _lib.ptr(dev(k)), L, rows, L, _lib.ptr(lut), _lib.ptr(out8b), L, st())
+        assert np.array_equal(out8b.cpu().numpy().astype(np.int32), exp), ci
+
+
+def test_shiftgelu_all_row_maxima():
+    """every (row max, k) pair of the table against the oracle, incl. negative maxima (positive exp argument)"""
+    s = np.float32(2.0 ** -4)
+    rows = np.stack([np.minimum(np.arange(-128, 128), kmax) for kmax in range(-128, 128)]).astype(np.int8)
+    exp, s_go = orc.shiftgelu(rows.astype(np.int32), s)
+    m, e = dyadic(s_go, np.float32(2.0 ** -4))
+    exp8 = orc.requant(exp, m.astype(np.float64), e, 8)
+    out8 = torch.empty(256, 256, dtype=torch.int8, device=DEV)
+    lut = torch.empty(65536, dtype=torch.int8, device=DEV)
+    _lib.call("ivit_shiftgelu_build_lut", float(s), int(m[0]), int(e[0]), _lib.ptr(lut), st())
+    _lib.call("ivit_shiftgelu_lut_i8", _lib.ptr(dev(rows)), 256, 256, 256, _lib.ptr(lut), _lib.ptr(out8), 256, st())
+    assert np.array_equal(out8.cpu().numpy().astype(np.int32), exp8)
+    _lib.call("ivit_shiftgelu_i8", _lib.ptr(dev(rows)), 256, 256, 256, float(s), int(m[0]), int(e[0]),
+              _lib.ptr(out8), 256, st())
+    assert np.array_equal(out8.cpu().numpy().astype(np.int32), exp8)
+
+
+# ----------------------------------------------------------------------------------- Shiftmax
+def test_shiftmax_kat(kat):
+    for ci in kat["sm_cases"]:
+        c = f"sm{ci}_"
+        k = kat[c + "k"].astype(np.int8)
+        rows, L = k.shape
+        out = torch.empty(rows, L, dtype=torch.int8, device=DEV)
+        _lib.call("ivit_shiftmax_i8", _lib.ptr(dev(k)), L, rows, L, float(kat[c + "s"]), _lib.ptr(out), L, st())
+        assert np.array_equal(out.cpu().numpy().astype(np.int32), kat[c + "out"]), ci
+
+
+# ----------------------------------------------------------------------------------- element-wise
+def test_requant_generic_kat(kat):
+    for ci in kat["rq_cases"]:
+        c = f"rq{ci}_"
+        z = kat[c + "z"]
+        if np.abs(z).max() >= 2 ** 31:
+            continue
+        m, e = dyadic(kat[c + "pre"], kat[c + "zsf"])
+        assert np.array_equal(m.astype(np.float64), kat[c + "m"]) and np.array_equal(e, kat[c + "e"])
+        rows, Cn = z.shape
+        md, ed = me_dev(m, e)
+        z2p = m2d = e2d = None
+        n2 = 0
+        if c + "z2" in kat:
+            m2, e2 = dyadic(kat[c + "pre2"], kat[c + "zsf"])
+            m2d, e2d = me_dev(m2, e2)
+            z2p = dev(kat[c + "z2"])
+            n2 = 1
+        out = torch.empty(rows, Cn, dtype=torch.int32, device=DEV)
+        _lib.call("ivit_requant_i32", _lib.ptr(dev(z.astype(np.int32))), rows, Cn, _lib.ptr(md), _lib.ptr(ed), m.size,
+                  _lib.ptr(z2p), _lib.ptr(m2d), _lib.ptr(e2d), n2, int(kat[c + "bits"]), _lib.ptr(out), st())
+        assert np.array_equal(out.cpu().numpy(), kat[c + "out"]), ci
+
+
+def test_quantize_and_patchify(kat):
+    x = kat["qs_x"]
+    s = kat["qs_s"]
+    inv = float(np.float32(1.0) / s)
+    out = torch.empty(x.size, dtype=torch.int8, device=DEV)
+    _lib.call("ivit_quantize_input_f32_i8", _lib.ptr(dev(x)), _lib.ptr(out), x.size, inv, st())
+    assert np.array_equal(out.cpu().numpy().astype(np.int32).reshape(x.shape), kat["qs_out"])
+    rng = np.random.default_rng(3)
+    img = rng.normal(0, 1, size=(2, 3, 224, 224)).astype(np.float32)
+    A = torch.empty(2 * 196, 768, dtype=torch.int8, device=DEV)
+    _lib.call("ivit_quantize_patchify_f32_i8", _lib.ptr(dev(img)), _lib.ptr(A), 2, 3, 224, 16, inv, st())
+    k0 = orc.quant_sym(img, s, 8)
+    exp = k0.reshape(2, 3, 14, 16, 14, 16).transpose(0, 2, 4, 1, 3, 5).reshape(2 * 196, 768)
+    assert np.array_equal(A.cpu().numpy().astype(np.int32), exp)
+
+
+def test_head_argmax():
+    rng = np.random.default_rng(4)
+    acc = rng.integers(-100000, 100000, size=(9, 1000)).astype(np.int32)
+    acc[3, 17] = acc[3, 900] = 10 ** 6  # tie on the raw accumulator, broken by the per-class scale
+    s = rng.uniform(1e-6, 2e-6, size=1000).astype(np.float32)
+    lf = torch.empty(9, 1000, dtype=torch.float32, device=DEV)
+    t1 = torch.empty(9, dtype=torch.int32, device=DEV)
+    _lib.call("ivit_head_argmax", _lib.ptr(dev(acc)), _lib.ptr(dev(s)), 9, 1000, _lib.ptr(lf), _lib.ptr(t1), st())
+    exp = (acc.astype(np.float32) * s[None]).astype(np.float32)
+    assert np.array_equal(lf.cpu().numpy().view(np.int32), exp.view(np.int32))
+    assert np.array_equal(t1.cpu().numpy(), np.argmax(exp, axis=1))

@@ -1,0 +1,111 @@
+"""CPU tests of the product's host-side logic (i-vit_amd/prepare.py, synth.py, the C-ABI library's
+exports) against the oracle and the reference-generated fixtures.  No GPU compute."""
+import ctypes as C
+import hashlib
+import os
+import re
+
+import numpy as np
+import pytest
+
+import ivit_amd
+from ivit_amd import _lib, prepare, synth
+from ivit_amd.checkpoint import load_synthetic_model
+from oracle import oracle as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def kat(golden_dir):
+    return np.load(os.path.join(golden_dir, "ops_kat.npz"))
+
+
+def test_dyadic_matches_reference_batch_frexp(kat):
+    for ci in kat["rq_cases"]:
+        c = f"rq{ci}_"
+        m, e = prepare.dyadic(kat[c + "pre"], kat[c + "zsf"])
+        assert np.array_equal(m.astype(np.float64), kat[c + "m"])
+        assert np.array_equal(e, kat[c + "e"])
+
+
+def test_linear_params_match_reference_quantlinear(kat):
+    lp = prepare.LinearParams(kat["lin_W"], kat["lin_b"], kat["lin_sin"])
+    assert np.array_equal(lp.sw, kat["lin_sw"])
+    assert np.array_equal(lp.W8.astype(np.int32), kat["lin_wint"])
+    assert np.array_equal(lp.b32, kat["lin_bint"])
+    assert np.array_equal(lp.s_acc, kat["lin_sacc"])
+
+
+def test_layernorm_params_match_reference(kat):
+    for ci in kat["ln_cases"]:
+        c = f"ln{ci}_"
+        lp = prepare.LayerNormParams(kat[c + "gamma"], kat[c + "beta"], kat[c + "q_sf"])
+        assert np.array_equal(lp.s_ln, kat[c + "sln"])
+        assert np.array_equal(lp.bias_int, kat[c + "bias_int"])
+        mo, eo = orc.dyadic(kat[c + "sln"], kat[c + "q_sf"])
+        assert np.array_equal(lp.m.astype(np.float64), mo) and np.array_equal(lp.e, eo)
+
+
+def test_quant_sym_matches_reference(kat):
+    assert np.array_equal(prepare.quant_sym(kat["qs_x"], kat["qs_s"], 8), kat["qs_out"])
+    assert prepare.sym_scale(-3.0, 2.0) == orc.sym_scale(-3.0, 2.0)
+    assert prepare.sym_scale(0.0, 0.0) == np.finfo(np.float32).eps
+
+
+@pytest.mark.parametrize("tag", ["deit_tiny", "deit_small"])
+def test_synthetic_weights_reproduce_fixture_digests(tag):
+    """the synthetic generator + the product's weight quantisation give the integer weights the
+    reference derived when the fixtures were made (SHA-256 of weight_integer / bias_integer)"""
+    fs, ranges, cfg, meta, z = load_synthetic_model(tag)
+    sha = dict(zip([str(n) for n in z["wint_names"]], [str(d) for d in z["wint_sha"]]))
+
+    def scale(name):
+        lo, hi = ranges[name]
+        return prepare.sym_scale(lo, hi)
+
+    checks = {"patch_embed.proj": "qact_input", "blocks.0.attn.qkv": "blocks.0.qact1",
+              "blocks.3.mlp.fc1": "blocks.3.qact3", "blocks.11.mlp.fc2": "blocks.11.mlp.qact1", "head": "qact2"}
+    for lin, qa in checks.items():
+        lp = prepare.LinearParams(fs[lin + ".weight"], fs[lin + ".bias"], scale(qa))
+        w = lp.W8.astype(np.int32).reshape(fs[lin + ".weight"].shape)
+        assert hashlib.sha256(w.tobytes()).hexdigest()[:16] == sha[lin + ".weight_integer"], lin
+        assert hashlib.sha256(lp.b32.tobytes()).hexdigest()[:16] == sha[lin + ".bias_integer"], lin
+
+
+def test_qact_names_cover_fixture_ranges():
+    fs, ranges, cfg, meta, z = load_synthetic_model("deit_tiny")
+    assert list(ranges) == synth.qact_names(cfg["depth"])
+    assert len(ranges) == 137
+    for lo, hi in ranges.values():  # pow2-calibrated regime
+        p = np.log2(float(hi) / 127.0)
+        assert lo == -hi and p == round(p)
+
+
+def test_images_are_order_independent():
+    a = synth.make_images(3, 5)
+    b = synth.make_images(1, 5, start=2)
+    assert np.array_equal(a[2], b[0])
+
+
+def test_c_abi_library_exports_every_declared_symbol():
+    """include/ivit_hip.h <-> libivit_hip.so <-> the ctypes table agree (loads the library, calls nothing
+    that needs a GPU)."""
+    hdr = open(os.path.join(ROOT, "include", "ivit_hip.h")).read()
+    declared = set(re.findall(r"\b(?:int|const char\*)\s+(ivit_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_lib.SIGNATURES) | {"ivit_version", "ivit_last_error_string"}
+    L = _lib.lib()
+    for name in declared:
+        assert hasattr(L, name), name
+    assert L.ivit_version() >= 100
+    # argument validation happens before any HIP call: exercise the error path on CPU
+    with pytest.raises(_lib.IvitError, match="NULL"):
+        _lib.call("ivit_gemm_i8_i32", None, 64, None, 64, None, None, 64, 64, 64, 64, None)
+    assert b"NULL" in L.ivit_last_error_string()
+
+
+def test_engine_refuses_without_library(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.IvitError, match="no CPU / PyTorch fallback"):
+        _lib.lib()
