@@ -433,6 +433,7 @@ __global__ __launch_bounds__(NT) void requant_i32_kernel(const int32_t* z, int64
             int i2 = (n_me2 == 1) ? 0 : c;
             o = requant_double((double)z2[i], dyadic_mult(m2[i2], e2[i2])) + o;
         }
+        o = (double)(float)o;  // quant_utils.py:249 output.type(torch.float) precedes the clamp
         o = fmin(fmax(o, lo), hi);
         out[i] = (int32_t)o;
     }

@@ -131,6 +131,7 @@ class IntViTEngine:
         self.head_scale = dev(head.s_acc)
         self.int8_weight_bytes = sum(int(b[k]["W"].numel()) for b in self.blocks for k in ("qkv", "proj", "fc1", "fc2")) \
             + int(self.patch["W"].numel()) + int(self.head["W"].numel())
+        self.probe = None
         self._alloc(max_batch)
         torch.cuda.synchronize(self.dev)
 
@@ -160,9 +161,16 @@ class IntViTEngine:
 
     def _gemm_res(self, A, lda, lin, res, me4, out, M, st):
         C = self.C
+        probe = self.probe
+        if probe is not None:  # bench.py: HIP events around the dominant kernel, on the launch stream
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         _lib.call("ivit_gemm_i8_requant_residual", _lib.ptr(A), lda, _lib.ptr(lin["W"]), lin["K"],
                   _lib.ptr(lin["b"]), _lib.ptr(lin["m"]), _lib.ptr(lin["e"]), _lib.ptr(res), C,
                   me4[0], me4[1], me4[2], me4[3], _lib.ptr(out), C, M, lin["N"], lin["K"], st)
+        if probe is not None:
+            e1.record()
+            probe.append((e0, e1, M, lin["N"], lin["K"]))
 
     def _ln(self, x, ldx, rows, ln, out, st):
         C = self.C

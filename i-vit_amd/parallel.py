@@ -1,0 +1,34 @@
+"""Data-parallel driver: images are independent units, so each rank runs the whole integer forward on
+its own shard with replicated weights; the ONLY exchange is one all-gather of the per-image top-1
+indices (int32[B/rank]) per batch -- RCCL over xGMI on GPUs (torch.distributed backend "nccl"),
+gloo in the CPU tests.  SURVEY.md §8e.  (The reference has no distributed path at all: its NCCL
+helpers in /root/reference/utils/utils.py:215-237 are dead code.)"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n: int, world: int, rank: int):
+    """Contiguous shard [lo, hi) of n images for `rank` (sizes differ by at most one)."""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def gather_top1(local_top1: torch.Tensor, world: int) -> torch.Tensor:
+    """all-gather of equal-sized per-rank top-1 vectors -> [world * B_local] in rank order."""
+    if world == 1:
+        return local_top1
+    out = torch.empty(world * local_top1.numel(), dtype=local_top1.dtype, device=local_top1.device)
+    dist.all_gather_into_tensor(out, local_top1.contiguous())
+    return out
+
+
+class DataParallelTop1:
+    def __init__(self, engine, world: int):
+        self.engine, self.world = engine, world
+
+    def step(self, local_images: torch.Tensor) -> torch.Tensor:
+        _, _, top1 = self.engine(local_images)
+        return gather_top1(top1, self.world)

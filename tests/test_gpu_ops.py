@@ -18,8 +18,20 @@ from ivit_amd.prepare import dyadic  # noqa: E402
 DEV = "cuda:0"
 
 
+_KEEP = []  # device tensors whose raw pointers were handed to the C ABI stay alive for the whole test
+
+
 def dev(a):
-    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    _KEEP.append(t)
+    return t
+
+
+@pytest.fixture(autouse=True)
+def _release_device_tensors():
+    yield
+    torch.cuda.synchronize()
+    _KEEP.clear()
 
 
 def st():
