@@ -30,6 +30,8 @@ constexpr int SMEM_BYTES = 2 * STAGE_BYTES;  // 32 KiB >= 128 * 132
 
 enum { EPI_RQ = 0, EPI_RESID = 1, EPI_QKV = 2, EPI_I32 = 3 };
 
+bool g_force_small = false;  // tests: route every problem through the small-tile kernel
+
 struct GemmArgs {
     const int8_t* A;
     int64_t lda;
@@ -54,6 +56,90 @@ IVIT_DEV int swz(int r, int c) { return r * BK + ((c ^ ((r >> 2) & 3)) << 4); }
 IVIT_DEV int pack4_i8(int a, int b, int c, int d)
 {
     return (a & 0xff) | ((b & 0xff) << 8) | ((c & 0xff) << 16) | ((d & 0xff) << 24);
+}
+
+
+// ---- shared int8 epilogue --------------------------------------------------------------------
+// acc[TI][TJ]: TI channel sub-tiles x TJ token sub-tiles of 32x32 owned by this wave, channel origin
+// `wch`, token origin `wtok` inside a block tile of TOK tokens x 128 channels.
+// Phase 1: per-channel requant -> int8, 4 channels per dword -> LDS tile Cs[token][channel].
+// Phase 2: 16-byte row-contiguous chunks: optional residual QuantAct, optional head-major remap, store.
+template <int EPI, int TI, int TJ, int TOK>
+IVIT_DEV void epilogue_i8(v16i (&acc)[TI][TJ], const GemmArgs& g, char* smem, int m0, int n0, int wch, int wtok,
+                          int tid, int h, int l31)
+{
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int cl = wch + 32 * i + 8 * q + 4 * h;  // local channel of the quad
+            const int c0 = n0 + cl;
+            double Mc[4];
+            if (c0 < g.N) {
+                uint4 m4 = *reinterpret_cast<const uint4*>(g.m + c0);
+                int4 e4 = *reinterpret_cast<const int4*>(g.e + c0);
+                Mc[0] = dyadic_mult(m4.x, e4.x);
+                Mc[1] = dyadic_mult(m4.y, e4.y);
+                Mc[2] = dyadic_mult(m4.z, e4.z);
+                Mc[3] = dyadic_mult(m4.w, e4.w);
+            } else {
+                Mc[0] = Mc[1] = Mc[2] = Mc[3] = 0.0;
+            }
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                int b[4];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    // quant_utils.py:229-230: float64 product (53-bit rounding), /2^e, round-half-even
+                    double p = (double)acc[i][j][4 * q + jj] * Mc[jj];
+                    double t = p + IVIT_MAGIC;
+                    b[jj] = clamp_i32((int)(unsigned)__double_as_longlong(t), -128, 127);
+                }
+                const int tl = wtok + 32 * j + l31;
+                *reinterpret_cast<int*>(smem + tl * CS_STRIDE + cl) = pack4_i8(b[0], b[1], b[2], b[3]);
+            }
+        }
+    __syncthreads();
+
+    int8_t* out = reinterpret_cast<int8_t*>(g.out);
+    const int nthreads = blockDim.x;
+#pragma unroll 1
+    for (int q = tid; q < TOK * 8; q += nthreads) {
+        const int tl = q >> 3, cc = q & 7;
+        const int t = m0 + tl, cn = n0 + 16 * cc;
+        if (t >= g.M || cn >= g.N) continue;
+        const int* src = reinterpret_cast<const int*>(smem + tl * CS_STRIDE + 16 * cc);
+        int v[4] = {src[0], src[1], src[2], src[3]};
+        if constexpr (EPI == EPI_RESID) {
+            const int4 rv = *reinterpret_cast<const int4*>(g.res + (int64_t)t * g.ldr + cn);
+            const int rr[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                int o[4];
+#pragma unroll
+                for (int bb = 0; bb < 4; ++bb) {
+                    int k3 = (int)(int8_t)(v[d] >> (8 * bb));
+                    int xr = (int)(int8_t)(rr[d] >> (8 * bb));
+                    // quant_utils.py:229-245: two independently rounded products, then the sum
+                    int sres = requant_exact(k3, g.M_main) + requant_exact(xr, g.M_res);
+                    o[bb] = clamp_i32(sres, -128, 127);
+                }
+                v[d] = pack4_i8(o[0], o[1], o[2], o[3]);
+            }
+        }
+        int64_t off;
+        if constexpr (EPI == EPI_QKV) {
+            const int cdim = g.heads * g.head_dim;
+            const int which = cn / cdim, rem = cn - which * cdim;
+            const int hh = rem / g.head_dim, d0 = rem - hh * g.head_dim;
+            const int b = t / g.tokens, tok = t - b * g.tokens;
+            const int nb = g.M / g.tokens;
+            off = ((((int64_t)which * nb + b) * g.heads + hh) * g.tokens + tok) * g.head_dim + d0;
+        } else {
+            off = (int64_t)t * g.ldo + cn;
+        }
+        *reinterpret_cast<int4*>(out + off) = make_int4(v[0], v[1], v[2], v[3]);
+    }
 }
 
 template <int EPI>
@@ -171,80 +257,119 @@ __global__ __launch_bounds__(NT) void gemm_i8_kernel(GemmArgs g)
             }
         return;
     } else {
-        // requantise (per channel) -> int8, 4 channels per dword, into the LDS tile Cs[token][channel]
+        epilogue_i8<EPI, 2, 2, BM>(acc, g, smem, m0, n0, 64 * wn, 64 * wm, tid, h, l31);
+    }
+}
+
+
+// ================================================================================================
+// Large-problem kernel: block tile 256 tokens x 128 channels x 64 K-bytes, 4 waves (2 x 2, each
+// 64 channels x 128 tokens = 2 x 4 MFMA tiles, 128 accumulator registers), THREE LDS stages filled by
+// LDS-DMA (global_load_lds_dwordx4: no staging registers), one raw s_barrier per K step with a
+// counted vmcnt so the next stage's DMA stays in flight across it.  72 KiB LDS and <= 256 registers
+// give two workgroups per CU: one block's requant epilogue (VALU/float64 pipe) overlaps the other's
+// MFMA main loop.  LDS images are lane-linear per DMA instruction (16 rows x 64 B); the bank swizzle
+// is applied on the per-lane SOURCE address and again on the fragment read.
+// ================================================================================================
+constexpr int BTOK = 256, BCH = 128, BIG_NT = 256, BIG_STAGES = 3;
+constexpr int BIG_A_BYTES = BTOK * BK;                 // 16 KiB
+constexpr int BIG_STAGE = (BTOK + BCH) * BK;           // 24 KiB
+constexpr int BIG_SMEM = BIG_STAGES * BIG_STAGE;       // 72 KiB  (>= 256 * 132 epilogue tile)
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int EPI>
+__global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_big_kernel(GemmArgs g)
+{
+    __shared__ __attribute__((aligned(16))) char smem[BIG_SMEM];
+
+    const int nblk = g.tiles_m * g.tiles_n;
+    const int bid = blockIdx.x;
+    const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
+    const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int tm = lid / g.tiles_n, tn = lid - tm * g.tiles_n;
+    const int m0 = tm * BTOK, n0 = tn * BCH;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wc = wave >> 1, wt = wave & 1;
+    const int h = lane >> 5, l31 = lane & 31;
+
+    // ---- LDS-DMA sources: instruction q covers tile rows 16q..16q+15 (1 KiB); lane -> row 16q + lane/4,
+    // stored slot lane%4 holds global chunk (lane%4) ^ ((row>>2)&3)
+    const int8_t* asrc[4];
+    const int8_t* wsrc[2];
+    const int lrow = lane >> 2, lslot = lane & 3;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int row = 16 * (wave + 4 * i) + lrow;
+        int c = lslot ^ ((row >> 2) & 3);
+        asrc[i] = g.A + (int64_t)min(m0 + row, g.M - 1) * g.lda + 16 * c;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int row = 16 * (wave + 4 * i) + lrow;
+        int c = lslot ^ ((row >> 2) & 3);
+        wsrc[i] = g.W + (int64_t)min(n0 + row, g.N - 1) * g.ldw + 16 * c;
+    }
+
+    v16i acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int cn = n0 + 64 * wc + 32 * i + 8 * (r >> 2) + 4 * h + (r & 3);
+            int b = (g.bias != nullptr && cn < g.N) ? g.bias[cn] : 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j][r] = b;
+        }
+
+    const int nk = g.K / BK;
+    auto issue = [&](int kt) {
+        char* base = smem + (kt % BIG_STAGES) * BIG_STAGE;
+        const int koff = kt * BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(asrc[i] + koff), (lptr_t)(base + 1024 * (wave + 4 * i)), 16, 0, 0);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int cl = 64 * wn + 32 * i + 8 * q + 4 * h;  // local channel of the quad
-                const int c0 = n0 + cl;
-                double Mc[4];
-                if (c0 < g.N) {
-                    uint4 m4 = *reinterpret_cast<const uint4*>(g.m + c0);
-                    int4 e4 = *reinterpret_cast<const int4*>(g.e + c0);
-                    Mc[0] = dyadic_mult(m4.x, e4.x);
-                    Mc[1] = dyadic_mult(m4.y, e4.y);
-                    Mc[2] = dyadic_mult(m4.z, e4.z);
-                    Mc[3] = dyadic_mult(m4.w, e4.w);
-                } else {
-                    Mc[0] = Mc[1] = Mc[2] = Mc[3] = 0.0;
-                }
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    int b[4];
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) {
-                        // quant_utils.py:229-230: float64 product (53-bit rounding), /2^e, round-half-even
-                        double p = (double)acc[i][j][4 * q + jj] * Mc[jj];
-                        double t = p + IVIT_MAGIC;
-                        b[jj] = clamp_i32((int)(unsigned)__double_as_longlong(t), -128, 127);
-                    }
-                    const int tl = 64 * wm + 32 * j + l31;
-                    *reinterpret_cast<int*>(smem + tl * CS_STRIDE + cl) = pack4_i8(b[0], b[1], b[2], b[3]);
-                }
-            }
-        __syncthreads();
+            __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[i] + koff),
+                                             (lptr_t)(base + BIG_A_BYTES + 1024 * (wave + 4 * i)), 16, 0, 0);
+    };
 
-        int8_t* out = reinterpret_cast<int8_t*>(g.out);
+    // make sure the bias loads are retired before the DMA pipeline starts (the compiler's vmcnt
+    // bookkeeping must not meet an in-flight DMA at an ordinary load's use)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    issue(0);
+    if (nk > 1) issue(1);
+
+    const int wrow0 = 64 * wc + l31, arow0 = 128 * wt + l31;
+    for (int kt = 0; kt < nk; ++kt) {
+        // stage kt has landed for this wave's own DMAs once at most the 6 of stage kt+1 remain
+        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // ... and for everyone's; all reads of stage kt-1 are done
+        asm volatile("" ::: "memory");
+        if (kt + 2 < nk) issue(kt + 2);  // refills the buffer stage kt-1 used
+        const char* st = smem + (kt % BIG_STAGES) * BIG_STAGE;
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int q = tid + NT * it;
-            const int tl = q >> 3, cc = q & 7;
-            const int t = m0 + tl, cn = n0 + 16 * cc;
-            if (t >= g.M || cn >= g.N) continue;
-            const int* src = reinterpret_cast<const int*>(smem + tl * CS_STRIDE + 16 * cc);
-            int v[4] = {src[0], src[1], src[2], src[3]};
-            if constexpr (EPI == EPI_RESID) {
-                const int4 rv = *reinterpret_cast<const int4*>(g.res + (int64_t)t * g.ldr + cn);
-                const int rr[4] = {rv.x, rv.y, rv.z, rv.w};
+        for (int ks = 0; ks < 2; ++ks) {
+            v4i wf[2], af[4];
 #pragma unroll
-                for (int d = 0; d < 4; ++d) {
-                    int o[4];
+            for (int i = 0; i < 2; ++i)
+                wf[i] = *reinterpret_cast<const v4i*>(st + BIG_A_BYTES + swz(wrow0 + 32 * i, 2 * ks + h));
 #pragma unroll
-                    for (int bb = 0; bb < 4; ++bb) {
-                        int k3 = (int)(int8_t)(v[d] >> (8 * bb));
-                        int xr = (int)(int8_t)(rr[d] >> (8 * bb));
-                        // quant_utils.py:229-245: two independently rounded products, then the sum
-                        int s = requant_exact(k3, g.M_main) + requant_exact(xr, g.M_res);
-                        o[bb] = clamp_i32(s, -128, 127);
-                    }
-                    v[d] = pack4_i8(o[0], o[1], o[2], o[3]);
-                }
-            }
-            int64_t off;
-            if constexpr (EPI == EPI_QKV) {
-                const int cdim = g.heads * g.head_dim;
-                const int which = cn / cdim, rem = cn - which * cdim;
-                const int hh = rem / g.head_dim, d0 = rem - hh * g.head_dim;
-                const int b = t / g.tokens, tok = t - b * g.tokens;
-                const int nb = g.M / g.tokens;
-                off = ((((int64_t)which * nb + b) * g.heads + hh) * g.tokens + tok) * g.head_dim + d0;
-            } else {
-                off = (int64_t)t * g.ldo + cn;
-            }
-            *reinterpret_cast<int4*>(out + off) = make_int4(v[0], v[1], v[2], v[3]);
+            for (int j = 0; j < 4; ++j) af[j] = *reinterpret_cast<const v4i*>(st + swz(arow0 + 32 * j, 2 * ks + h));
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[i], af[j], acc[i][j], 0, 0, 0);
         }
     }
+    __syncthreads();  // every wave is done with the last stage before the tile is reused
+    epilogue_i8<EPI, 2, 4, BTOK>(acc, g, smem, m0, n0, 64 * wc, 128 * wt, tid, h, l31);
 }
 
 template <int EPI>
@@ -277,6 +402,15 @@ int launch_gemm(GemmArgs& g, const char* name, ivit_stream_t stream)
                      "%s: bad head geometry tokens=%d heads=%d head_dim=%d", name, g.tokens, g.heads, g.head_dim);
         IVIT_REQUIRE(g.N == 3 * g.heads * g.head_dim && g.M % g.tokens == 0,
                      "%s: N=%d != 3*heads*head_dim or M=%d %% tokens=%d != 0", name, g.N, g.M, g.tokens);
+    }
+    if constexpr (EPI != EPI_I32) {
+        if (g.M >= 2048 && g.N >= BCH && !g_force_small) {
+            g.tiles_m = (g.M + BTOK - 1) / BTOK;
+            g.tiles_n = (g.N + BCH - 1) / BCH;
+            hipLaunchKernelGGL(gemm_i8_big_kernel<EPI>, dim3(g.tiles_m * g.tiles_n), dim3(BIG_NT), 0,
+                               ivit_stream(stream), g);
+            IVIT_CHECK_LAUNCH(name);
+        }
     }
     g.tiles_m = (g.M + BM - 1) / BM;
     g.tiles_n = (g.N + BN - 1) / BN;
@@ -331,4 +465,11 @@ IVIT_EXPORT int ivit_gemm_i8_i32(const int8_t* A, int64_t lda, const int8_t* W, 
     g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias;
     g.out = out; g.ldo = ldo; g.M = M; g.N = N; g.K = K;
     return launch_gemm<EPI_I32>(g, "ivit_gemm_i8_i32", stream);
+}
+
+// test hook: 1 = always use the 128x128 register-staged kernel (so both kernels stay covered)
+IVIT_EXPORT int ivit_debug_force_small_gemm(int on)
+{
+    g_force_small = (on != 0);
+    return IVIT_OK;
 }

@@ -87,6 +87,11 @@ int ivit_gemm_i8_requant_qkv(const int8_t* A, int64_t lda, const int8_t* W, int6
 int ivit_gemm_i8_i32(const int8_t* A, int64_t lda, const int8_t* W, int64_t ldw, const int32_t* bias,
                      int32_t* out, int64_t ldo, int M, int N, int K, ivit_stream_t stream);
 
+/* Test hook: ivit_gemm_i8_* pick between two kernels by problem size (a 256x128-tile LDS-DMA kernel
+ * for M >= 2048, N >= 128; a 128x128-tile kernel otherwise).  on != 0 forces the small-tile kernel so
+ * tests can cover both on the same inputs.  Process-wide, not thread-safe; not for production use. */
+int ivit_debug_force_small_gemm(int on);
+
 /* ---- fused attention core -------------------------------------------------------------------
  * vit_quant.py:72-85: matmul_1 (q.k^T) -> qact_attn1 -> IVITIntSoftmax (Shiftmax,
  * ivit_modules.py:150-179) -> matmul_2 (P.v) -> qact2, per (image, head), never

@@ -56,7 +56,11 @@ def kat(golden_dir):
 
 # ----------------------------------------------------------------------------------- GEMM
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 192, 192), (197 * 3, 768, 768), (1000, 384, 1536),
-                                   (64, 2304, 768), (129, 208, 128)])
+                                   (64, 2304, 768), (129, 208, 128),
+                                   # M >= 2048 and N >= 128: the 256x128-tile LDS-DMA kernel (1, 2, 3 and many K steps,
+                                   # ragged token and channel tails)
+                                   (2048, 128, 64), (2304, 256, 128), (2500, 208, 192), (197 * 16, 768, 768),
+                                   (2100, 384, 3072)])
 def test_gemm_requant(M, N, K):
     rng = np.random.default_rng(M * 7 + N + K)
     A = rng.integers(-128, 128, size=(M, K)).astype(np.int8)
@@ -99,9 +103,9 @@ def test_gemm_mfma_layout_identity():
     assert np.array_equal(out.cpu().numpy(), orc.gemm_i8(A, W))
 
 
-def test_gemm_requant_residual():
-    rng = np.random.default_rng(11)
-    M, N, K = 333, 384, 384
+@pytest.mark.parametrize("M,N,K", [(333, 384, 384), (197 * 13, 768, 256), (2050, 192, 768)])
+def test_gemm_requant_residual(M, N, K):
+    rng = np.random.default_rng(11 + M)
     A = rng.integers(-128, 128, size=(M, K)).astype(np.int8)
     W = rng.integers(-128, 128, size=(N, K)).astype(np.int8)
     b = rng.integers(-50000, 50000, size=N).astype(np.int32)
@@ -119,9 +123,10 @@ def test_gemm_requant_residual():
     assert np.array_equal(out.cpu().numpy().astype(np.int32), exp)
 
 
-def test_gemm_requant_qkv_layout():
-    rng = np.random.default_rng(12)
-    B, T, H, hd = 3, 197, 3, 64
+@pytest.mark.parametrize("B,H", [(3, 3), (11, 6)])
+def test_gemm_requant_qkv_layout(B, H):
+    rng = np.random.default_rng(12 + B)
+    T, hd = 197, 64
     Cn = H * hd
     M, N, K = B * T, 3 * Cn, Cn
     A = rng.integers(-128, 128, size=(M, K)).astype(np.int8)
@@ -135,6 +140,28 @@ def test_gemm_requant_qkv_layout():
     _lib.call("ivit_gemm_i8_requant_qkv", _lib.ptr(dev(A)), K, _lib.ptr(dev(W)), K, _lib.ptr(dev(b)), _lib.ptr(md),
               _lib.ptr(ed), _lib.ptr(out), T, H, hd, M, N, K, st())
     assert np.array_equal(out.cpu().numpy().astype(np.int32).reshape(3, B, H, T, hd), exp)
+
+
+def test_gemm_both_kernels_agree():
+    """same large problem through the LDS-DMA kernel and (forced) through the small-tile kernel"""
+    rng = np.random.default_rng(77)
+    M, N, K = 2600, 384, 384
+    A = rng.integers(-128, 128, size=(M, K)).astype(np.int8)
+    W = rng.integers(-128, 128, size=(N, K)).astype(np.int8)
+    b = rng.integers(-50000, 50000, size=N).astype(np.int32)
+    m, e = rand_me(rng, N, -16, -9)
+    md, ed = me_dev(m, e)
+    dA, dW, db = dev(A), dev(W), dev(b)
+    outs = []
+    for force in (0, 1):
+        _lib.call("ivit_debug_force_small_gemm", force)
+        out = torch.empty(M, N, dtype=torch.int8, device=DEV)
+        _lib.call("ivit_gemm_i8_requant", _lib.ptr(dA), K, _lib.ptr(dW), K, _lib.ptr(db), _lib.ptr(md), _lib.ptr(ed),
+                  _lib.ptr(out), N, M, N, K, st())
+        outs.append(out.cpu().numpy())
+    _lib.call("ivit_debug_force_small_gemm", 0)
+    assert np.array_equal(outs[0], outs[1])
+    assert np.array_equal(outs[0].astype(np.int32), orc.requant(orc.gemm_i8(A, W, b), m.astype(np.float64), e, 8))
 
 
 def test_gemm_rejects_bad_shapes():
