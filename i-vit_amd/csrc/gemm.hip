@@ -15,6 +15,8 @@
 // int8 tile through LDS so that global stores (and the residual loads) are 16 B per lane, row
 // contiguous.  Block ids are remapped so that the 8 XCDs each walk a contiguous range of tiles
 // (token panel reuse in the XCD-private L2).
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -25,12 +27,13 @@ constexpr int BK = 64;   // K bytes per stage
 constexpr int NT = 256;
 constexpr int STAGE_BYTES = (BM + BN) * BK;  // 16 KiB
 constexpr int W_OFF = BM * BK;               // weight tile behind the token tile
-constexpr int CS_STRIDE = 132;               // epilogue tile row stride (33 dwords: conflict-free)
 constexpr int SMEM_BYTES = 2 * STAGE_BYTES;  // 32 KiB >= 128 * 132
 
 enum { EPI_RQ = 0, EPI_RESID = 1, EPI_QKV = 2, EPI_I32 = 3 };
 
+int g_kernel_choice = 0;      // 0 = automatic, 1 = never the 256x256 kernel (tests / A-B timing)
 bool g_force_small = false;  // tests: route every problem through the small-tile kernel
+int g_debug_flags = 0;       // perf ablations (scripts/gemm_ablate.py): 1 = skip DMA in the loop, 2 = skip MFMA, 4 = skip epilogue
 
 struct GemmArgs {
     const int8_t* A;
@@ -48,7 +51,11 @@ struct GemmArgs {
     int M, N, K;
     int tokens, heads, head_dim;
     int tiles_m, tiles_n;
+    int flags;
+    int stagger;  // number of first-generation blocks subject to the start stagger (0 = off)
 };
+
+IVIT_DEV int nk_of(const GemmArgs& g) { return g.K / 64; }
 
 // byte offset of 16-byte chunk c (0..3) of tile row r; rows are 64 B, four rows per 256-B bank row.
 IVIT_DEV int swz(int r, int c) { return r * BK + ((c ^ ((r >> 2) & 3)) << 4); }
@@ -64,67 +71,130 @@ IVIT_DEV int pack4_i8(int a, int b, int c, int d)
 // `wch`, token origin `wtok` inside a block tile of TOK tokens x 128 channels.
 // Phase 1: per-channel requant -> int8, 4 channels per dword -> LDS tile Cs[token][channel].
 // Phase 2: 16-byte row-contiguous chunks: optional residual QuantAct, optional head-major remap, store.
-template <int EPI, int TI, int TJ, int TOK>
-IVIT_DEV void epilogue_i8(v16i (&acc)[TI][TJ], const GemmArgs& g, char* smem, int m0, int n0, int wch, int wtok,
-                          int tid, int h, int l31)
+// Per-block table of the float32 neighbours (lo, hi) of each channel's requant multiplier, written once at
+// kernel start (one thread per channel); visible to the epilogue through the main loop's barriers.
+IVIT_DEV void fill_rq_table(const GemmArgs& g, char* rq_lds, int n0, int nch, int tid)
 {
+    if (tid < nch) {
+        float2 lh = make_float2(0.f, 0.f);
+        const int c = n0 + tid;
+        if (c < g.N) {
+            const double M = dyadic_mult(g.m[c], g.e[c]);
+            const float mf = (float)M;
+            const double back = (double)mf;
+            const int bits = __float_as_int(mf);
+            lh.x = (back > M) ? __int_as_float(bits - 1) : mf;  // largest float32 <= M
+            lh.y = (back < M) ? __int_as_float(bits + 1) : mf;  // smallest float32 >= M
+        }
+        reinterpret_cast<float2*>(rq_lds)[tid] = lh;
+    }
+}
+
+template <int EPI, int TI, int TJ, int TOK, int NTHREADS, int ABL = 0, int CH = 128>
+IVIT_DEV void epilogue_i8(v16i (&acc)[TI][TJ], const GemmArgs& g, char* smem, const char* rq_lds, int m0, int n0,
+                          int wch, int wtok, int tid, int h, int l31)
+{
+    constexpr int CSS = CH + 4;       // LDS row stride: (CH/4 + 1) dwords, odd -> conflict-free dword writes
+    constexpr int CPR = CH / 16;      // 16-byte chunks per row
+    // Phase 1.  out = clamp8(RNE(acc * M)), M = m * 2^-e, must equal the reference's float64
+    // evaluation (quant_utils.py:229-230) bit for bit.  Fast path on the ordinary float32 VALU (the
+    // float64 ops contend with the MFMA pipe): with lo <= M <= hi the two float32 neighbours of M,
+    //   t_lo = fma(acc, lo, 1.5*2^23), t_hi = fma(acc, hi, 1.5*2^23)
+    // are RNE(acc*lo) and RNE(acc*hi) exactly (one rounding, ulp 1), and RNE is monotone, so
+    // t_lo == t_hi certifies RNE(acc*M) -- including exact ties, which straddle and fail the test.
+    // Valid while acc is exact in float32 and |acc*hi| < 2^22 (M <= 1 is part of the contract), i.e.
+    // |acc| < 2^22; anything else, and any failed certificate, takes the float64 path for that quad.
+    const float2* rq = reinterpret_cast<const float2*>(rq_lds);
 #pragma unroll
-    for (int i = 0; i < TI; ++i)
+    for (int i = 0; i < TI; ++i) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int cl = wch + 32 * i + 8 * q + 4 * h;  // local channel of the quad
-            const int c0 = n0 + cl;
-            double Mc[4];
-            if (c0 < g.N) {
-                uint4 m4 = *reinterpret_cast<const uint4*>(g.m + c0);
-                int4 e4 = *reinterpret_cast<const int4*>(g.e + c0);
-                Mc[0] = dyadic_mult(m4.x, e4.x);
-                Mc[1] = dyadic_mult(m4.y, e4.y);
-                Mc[2] = dyadic_mult(m4.z, e4.z);
-                Mc[3] = dyadic_mult(m4.w, e4.w);
-            } else {
-                Mc[0] = Mc[1] = Mc[2] = Mc[3] = 0.0;
-            }
+            const float4 lh01 = *reinterpret_cast<const float4*>(rq + cl);      // lo0 hi0 lo1 hi1
+            const float4 lh23 = *reinterpret_cast<const float4*>(rq + cl + 2);  // lo2 hi2 lo3 hi3
+            const float lo[4] = {lh01.x, lh01.z, lh23.x, lh23.z};
+            const float hi[4] = {lh01.y, lh01.w, lh23.y, lh23.w};
 #pragma unroll
             for (int j = 0; j < TJ; ++j) {
                 int b[4];
+                bool unc = false;
+                float amax = 0.0f;
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
-                    // quant_utils.py:229-230: float64 product (53-bit rounding), /2^e, round-half-even
-                    double p = (double)acc[i][j][4 * q + jj] * Mc[jj];
-                    double t = p + IVIT_MAGIC;
-                    b[jj] = clamp_i32((int)(unsigned)__double_as_longlong(t), -128, 127);
+                    if constexpr (ABL & 8) {
+                        b[jj] = acc[i][j][4 * q + jj] + (int)lo[jj];
+                    } else {
+                        const float a = (float)acc[i][j][4 * q + jj];
+                        const int tl = __float_as_int(__builtin_fmaf(a, lo[jj], 12582912.0f));
+                        const int th = __float_as_int(__builtin_fmaf(a, hi[jj], 12582912.0f));
+                        unc |= (tl != th);
+                        amax = fmaxf(amax, fabsf(a));
+                        b[jj] = clamp_i32(tl, 0x4B400000 - 128, 0x4B400000 + 127);  // low byte = int8 result
+                    }
                 }
-                const int tl = wtok + 32 * j + l31;
-                *reinterpret_cast<int*>(smem + tl * CS_STRIDE + cl) = pack4_i8(b[0], b[1], b[2], b[3]);
+                if constexpr (!(ABL & 8)) {
+                    unc |= (amax >= 4194304.0f);
+                    if (__builtin_amdgcn_ballot_w64(unc) != 0) {  // rare: exact float64 evaluation
+                        const int c0 = min(n0 + cl, g.N - 4);
+                        const uint4 m4 = *reinterpret_cast<const uint4*>(g.m + c0);
+                        const int4 e4 = *reinterpret_cast<const int4*>(g.e + c0);
+                        const double Mc[4] = {dyadic_mult(m4.x, e4.x), dyadic_mult(m4.y, e4.y),
+                                              dyadic_mult(m4.z, e4.z), dyadic_mult(m4.w, e4.w)};
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) {
+                            // quant_utils.py:229-230: float64 product (53-bit rounding), /2^e, round-half-even
+                            double p = (double)acc[i][j][4 * q + jj] * Mc[jj];
+                            double t = p + IVIT_MAGIC;
+                            b[jj] = clamp_i32((int)(unsigned)__double_as_longlong(t), -128, 127);
+                        }
+                    }
+                }
+                const int tl_ = wtok + 32 * j + l31;
+                const unsigned w01 = __builtin_amdgcn_perm((unsigned)b[1], (unsigned)b[0], 0x0c0c0400u);
+                const unsigned w23 = __builtin_amdgcn_perm((unsigned)b[3], (unsigned)b[2], 0x04000c0cu);
+                *reinterpret_cast<unsigned*>(smem + tl_ * CSS + cl) = w01 | w23;
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
+    }
     __syncthreads();
+    if constexpr (ABL & 16) return;
 
     int8_t* out = reinterpret_cast<int8_t*>(g.out);
-    const int nthreads = blockDim.x;
-#pragma unroll 1
-    for (int q = tid; q < TOK * 8; q += nthreads) {
-        const int tl = q >> 3, cc = q & 7;
+    constexpr int NIT = TOK * CPR / NTHREADS;
+    int v[NIT][4];
+    int4 rv[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int q = tid + NTHREADS * it;
+        const int tl = q / CPR, cc = q % CPR;
+        const int* src = reinterpret_cast<const int*>(smem + tl * CSS + 16 * cc);
+        v[it][0] = src[0]; v[it][1] = src[1]; v[it][2] = src[2]; v[it][3] = src[3];
+        if constexpr (EPI == EPI_RESID) {
+            const int t = min(m0 + tl, g.M - 1), cn = min(n0 + 16 * cc, g.N - 16);
+            rv[it] = *reinterpret_cast<const int4*>(g.res + (int64_t)t * g.ldr + cn);
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int q = tid + NTHREADS * it;
+        const int tl = q / CPR, cc = q % CPR;
         const int t = m0 + tl, cn = n0 + 16 * cc;
         if (t >= g.M || cn >= g.N) continue;
-        const int* src = reinterpret_cast<const int*>(smem + tl * CS_STRIDE + 16 * cc);
-        int v[4] = {src[0], src[1], src[2], src[3]};
         if constexpr (EPI == EPI_RESID) {
-            const int4 rv = *reinterpret_cast<const int4*>(g.res + (int64_t)t * g.ldr + cn);
-            const int rr[4] = {rv.x, rv.y, rv.z, rv.w};
+            const int rr[4] = {rv[it].x, rv[it].y, rv[it].z, rv[it].w};
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
                 int o[4];
 #pragma unroll
                 for (int bb = 0; bb < 4; ++bb) {
-                    int k3 = (int)(int8_t)(v[d] >> (8 * bb));
+                    int k3 = (int)(int8_t)(v[it][d] >> (8 * bb));
                     int xr = (int)(int8_t)(rr[d] >> (8 * bb));
                     // quant_utils.py:229-245: two independently rounded products, then the sum
                     int sres = requant_exact(k3, g.M_main) + requant_exact(xr, g.M_res);
                     o[bb] = clamp_i32(sres, -128, 127);
                 }
-                v[d] = pack4_i8(o[0], o[1], o[2], o[3]);
+                v[it][d] = pack4_i8(o[0], o[1], o[2], o[3]);
             }
         }
         int64_t off;
@@ -138,14 +208,14 @@ IVIT_DEV void epilogue_i8(v16i (&acc)[TI][TJ], const GemmArgs& g, char* smem, in
         } else {
             off = (int64_t)t * g.ldo + cn;
         }
-        *reinterpret_cast<int4*>(out + off) = make_int4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<int4*>(out + off) = make_int4(v[it][0], v[it][1], v[it][2], v[it][3]);
     }
 }
 
 template <int EPI>
 __global__ __launch_bounds__(NT) void gemm_i8_kernel(GemmArgs g)
 {
-    __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
+    __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES + BN * 8];
 
     // ---- XCD-aware block -> tile map (bijective for any block count)
     const int nblk = g.tiles_m * g.tiles_n;
@@ -159,6 +229,7 @@ __global__ __launch_bounds__(NT) void gemm_i8_kernel(GemmArgs g)
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int h = lane >> 5, l31 = lane & 31;
+    if constexpr (EPI != EPI_I32) fill_rq_table(g, smem + SMEM_BYTES, n0, BN, tid);
 
     // ---- staging: thread moves chunks (row = tid/4 + 64 i, c = tid%4) of both tiles
     const int srow = tid >> 2, sc = tid & 3;
@@ -257,7 +328,7 @@ __global__ __launch_bounds__(NT) void gemm_i8_kernel(GemmArgs g)
             }
         return;
     } else {
-        epilogue_i8<EPI, 2, 2, BM>(acc, g, smem, m0, n0, 64 * wn, 64 * wm, tid, h, l31);
+        epilogue_i8<EPI, 2, 2, BM, NT>(acc, g, smem, smem + SMEM_BYTES, m0, n0, 64 * wn, 64 * wm, tid, h, l31);
     }
 }
 
@@ -279,10 +350,10 @@ constexpr int BIG_SMEM = BIG_STAGES * BIG_STAGE;       // 72 KiB  (>= 256 * 132 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <int EPI>
+template <int EPI, int ABL>
 __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_big_kernel(GemmArgs g)
 {
-    __shared__ __attribute__((aligned(16))) char smem[BIG_SMEM];
+    __shared__ __attribute__((aligned(16))) char smem[BIG_SMEM + BCH * 8];
 
     const int nblk = g.tiles_m * g.tiles_n;
     const int bid = blockIdx.x;
@@ -295,6 +366,7 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_big_kernel(GemmArgs g)
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wc = wave >> 1, wt = wave & 1;
     const int h = lane >> 5, l31 = lane & 31;
+    fill_rq_table(g, smem + BIG_SMEM, n0, BCH, tid);
 
     // ---- LDS-DMA sources: instruction q covers tile rows 16q..16q+15 (1 KiB); lane -> row 16q + lane/4,
     // stored slot lane%4 holds global chunk (lane%4) ^ ((row>>2)&3)
@@ -326,18 +398,32 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_big_kernel(GemmArgs g)
         }
 
     const int nk = g.K / BK;
-    auto issue = [&](int kt) {
+    // DMA piece `idx` (0..3: token tile, 4..5: weight tile) of K step kt
+    auto issue_one = [&](int kt, int idx) {
         char* base = smem + (kt % BIG_STAGES) * BIG_STAGE;
         const int koff = kt * BK;
+        if (idx < 4)
+            __builtin_amdgcn_global_load_lds((gptr_t)(asrc[idx] + koff), (lptr_t)(base + 1024 * (wave + 4 * idx)), 16, 0,
+                                             0);
+        else
+            __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[idx - 4] + koff),
+                                             (lptr_t)(base + BIG_A_BYTES + 1024 * (wave + 4 * (idx - 4))), 16, 0, 0);
+    };
+    auto issue = [&](int kt) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t)(asrc[i] + koff), (lptr_t)(base + 1024 * (wave + 4 * i)), 16, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[i] + koff),
-                                             (lptr_t)(base + BIG_A_BYTES + 1024 * (wave + 4 * i)), 16, 0, 0);
+        for (int idx = 0; idx < 6; ++idx) issue_one(kt, idx);
     };
 
+    // Two workgroups share a CU (one wave of each per SIMD).  Launched together they would run in
+    // lockstep -- both in the MFMA main loop, then both in the VALU/float64 epilogue -- and the two
+    // pipes would never overlap.  Stagger the first generation: the workgroup that landed in the odd
+    // wave slot of its SIMD sleeps for about half a main loop, so that from then on one workgroup's
+    // epilogue runs under the other's MFMAs.  Later generations inherit the phase shift.  (Speed only.)
+    if (g.stagger && blockIdx.x < (unsigned)g.stagger) {
+        const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1u;  // HW_ID.wave_id[0]
+        if (slot)
+            for (int it = 0; it < (nk_of(g) + 1) / 2; ++it) __builtin_amdgcn_s_sleep(64);
+    }
     // make sure the bias loads are retired before the DMA pipeline starts (the compiler's vmcnt
     // bookkeeping must not meet an in-flight DMA at an ordinary load's use)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -345,31 +431,263 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_big_kernel(GemmArgs g)
     if (nk > 1) issue(1);
 
     const int wrow0 = 64 * wc + l31, arow0 = 128 * wt + l31;
-    for (int kt = 0; kt < nk; ++kt) {
-        // stage kt has landed for this wave's own DMAs once at most the 6 of stage kt+1 remain
-        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();  // ... and for everyone's; all reads of stage kt-1 are done
-        asm volatile("" ::: "memory");
-        if (kt + 2 < nk) issue(kt + 2);  // refills the buffer stage kt-1 used
-        const char* st = smem + (kt % BIG_STAGES) * BIG_STAGE;
+    // fragment byte offsets inside a stage for k-sub-step 0 / 1 (the swizzle depends on the row only)
+    int woff[2][2], aoff[2][4];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            v4i wf[2], af[4];
+    for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-                wf[i] = *reinterpret_cast<const v4i*>(st + BIG_A_BYTES + swz(wrow0 + 32 * i, 2 * ks + h));
+        for (int i = 0; i < 2; ++i) woff[ks][i] = BIG_A_BYTES + swz(wrow0 + 32 * i, 2 * ks + h);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) af[j] = *reinterpret_cast<const v4i*>(st + swz(arow0 + 32 * j, 2 * ks + h));
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[i], af[j], acc[i][j], 0, 0, 0);
-        }
+        for (int j = 0; j < 4; ++j) aoff[ks][j] = swz(arow0 + 32 * j, 2 * ks + h);
     }
+    v4i wf0[2], af0[4], wf1[2], af1[4];
+    bool frags_once = false;
+    auto load_frags = [&](const char* st, int ks, v4i (&wf)[2], v4i (&af)[4]) {
+        if constexpr (ABL & 128) {
+            if (frags_once) return;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) wf[i] = *reinterpret_cast<const v4i*>(st + woff[ks][i]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) af[j] = *reinterpret_cast<const v4i*>(st + aoff[ks][j]);
+    };
+
+    // Pipeline (3 LDS stages, fragments double-buffered in registers):
+    //   iteration kt:  read frags(kt, ks=1) | MFMA on frags(kt, ks=0) interleaved with the DMA of stage kt+2
+    //                  wait own DMA of stage kt+1 + own LDS reads | barrier B_kt
+    //                  read frags(kt+1, ks=0) | MFMA on frags(kt, ks=1)
+    // RAW: stage kt+1 is read only after B_kt, which every wave reaches after its counted vmcnt.
+    // WAR: the DMA of stage kt+2 overwrites the buffer of stage kt-1; it is issued after B_{kt-1}, and
+    //      every wave waited lgkmcnt(0) (all its reads of stage kt-1 returned) before B_{kt-1}.
+    auto step = [&](int kt, auto dma_tag, auto last_tag) {
+        constexpr bool DMA = decltype(dma_tag)::value && !(ABL & 1);
+        constexpr bool LAST = decltype(last_tag)::value;
+        const char* st = smem + (kt % BIG_STAGES) * BIG_STAGE;
+        load_frags(st, 1, wf1, af1);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if constexpr (!(ABL & 2))
+                    acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf0[i], af0[j], acc[i][j], 0, 0, 0);
+                else
+                    asm volatile("" ::"v"(wf0[i]), "v"(af0[j]));
+                if constexpr (DMA)
+                    if (4 * i + j < 6) issue_one(kt + 2, 4 * i + j);
+            }
+        if constexpr (!(ABL & 256)) {
+            if constexpr (decltype(dma_tag)::value) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+        if constexpr (!LAST) load_frags(smem + ((kt + 1) % BIG_STAGES) * BIG_STAGE, 0, wf0, af0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if constexpr (!(ABL & 2))
+                    acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf1[i], af1[j], acc[i][j], 0, 0, 0);
+                else
+                    asm volatile("" ::"v"(wf1[i]), "v"(af1[j]));
+            }
+    };
+    using T = std::true_type;
+    using F = std::false_type;
+
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    load_frags(smem, 0, wf0, af0);
+    if constexpr (ABL & 128) {
+        load_frags(smem, 1, wf1, af1);
+        frags_once = true;
+    }
+    int kt = 0;
+    for (; kt + 2 < nk; ++kt) step(kt, T{}, F{});
+    if (kt + 1 < nk) { step(kt, F{}, F{}); ++kt; }
+    step(kt, F{}, T{});
     __syncthreads();  // every wave is done with the last stage before the tile is reused
-    epilogue_i8<EPI, 2, 4, BTOK>(acc, g, smem, m0, n0, 64 * wc, 128 * wt, tid, h, l31);
+    if constexpr (ABL & 4) {
+        int x = 0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) x ^= acc[i][j][r];
+        if (x == 0x7fffffff) reinterpret_cast<int*>(g.out)[tid] = x;
+        return;
+    }
+    epilogue_i8<EPI, 2, 4, BTOK, BIG_NT, ABL>(acc, g, smem, smem + BIG_SMEM, m0, n0, 64 * wc, 128 * wt, tid, h, l31);
+}
+
+
+// ================================================================================================
+// XL kernel: block tile 256 tokens x 256 channels x 64 K-bytes, 8 waves (4 channel groups x 2 token
+// groups, each 64 channels x 128 tokens = 2 x 4 MFMA tiles), FOUR LDS stages of 32 KiB filled by
+// LDS-DMA.  With int8 MFMAs the L2 -> LDS stream is the scarce resource and it is latency bound
+// (~1 us per piece under load): the tile moves the fewest bytes per MAC (0.0078 B) and the four-deep
+// ring keeps up to three stages (96 KiB per CU) in flight at all times.  One workgroup per CU.
+//   iteration kt:  read F(kt, ks=1) | MFMA F(kt, ks=0) interleaved with the 4 DMA pieces of stage kt+3
+//                  counted vmcnt: own pieces of stage kt+1 landed | lgkmcnt(0) | barrier B_kt
+//                  read F(kt+1, ks=0) | MFMA F(kt, ks=1)
+// RAW: stage kt+1 is read only after B_kt.  WAR: stage kt+3 reuses the buffer of stage kt-1, whose
+// reads every wave completed (lgkmcnt(0)) before B_{kt-1}; the DMA is issued after B_{kt-1}.
+// ================================================================================================
+constexpr int XTOK = 256, XCH = 256, XL_NT = 512, XL_STAGES = 4;
+constexpr int XL_A_BYTES = XTOK * BK;             // 16 KiB
+constexpr int XL_STAGE = (XTOK + XCH) * BK;       // 32 KiB
+constexpr int XL_SMEM = XL_STAGES * XL_STAGE;     // 128 KiB (>= 256 * 260 epilogue tile)
+
+template <int EPI, int ABL>
+__global__ __launch_bounds__(XL_NT, 2) void gemm_i8_xl_kernel(GemmArgs g)
+{
+    __shared__ __attribute__((aligned(16))) char smem[XL_SMEM + XCH * 8];
+
+    const int nblk = g.tiles_m * g.tiles_n;
+    const int bid = blockIdx.x;
+    const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
+    const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int tm = lid / g.tiles_n, tn = lid - tm * g.tiles_n;
+    const int m0 = tm * XTOK, n0 = tn * XCH;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wc = wave >> 1, wt = wave & 1;  // 4 x 2
+    const int h = lane >> 5, l31 = lane & 31;
+    fill_rq_table(g, smem + XL_SMEM, n0, XCH, tid);
+
+    // ---- LDS-DMA sources: piece q covers tile rows 16q..16q+15 (1 KiB); lane -> row 16q + lane/4, stored
+    // slot lane%4 holds global chunk (lane%4) ^ ((row>>2)&3).  Wave w owns pieces w and w + 8 of each tile.
+    const int8_t* asrc[2];
+    const int8_t* wsrc[2];
+    const int lrow = lane >> 2, lslot = lane & 3;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int row = 16 * (wave + 8 * i) + lrow;
+        int c = lslot ^ ((row >> 2) & 3);
+        asrc[i] = g.A + (int64_t)min(m0 + row, g.M - 1) * g.lda + 16 * c;
+        wsrc[i] = g.W + (int64_t)min(n0 + row, g.N - 1) * g.ldw + 16 * c;
+    }
+
+    v16i acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int cn = n0 + 64 * wc + 32 * i + 8 * (r >> 2) + 4 * h + (r & 3);
+            int b = (g.bias != nullptr && cn < g.N) ? g.bias[cn] : 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j][r] = b;
+        }
+
+    const int nk = g.K / BK;
+    auto issue_one = [&](int kt, int idx) {
+        char* base = smem + (kt % XL_STAGES) * XL_STAGE;
+        const int koff = kt * BK;
+        if (idx < 2)
+            __builtin_amdgcn_global_load_lds((gptr_t)(asrc[idx] + koff), (lptr_t)(base + 1024 * (wave + 8 * idx)), 16, 0,
+                                             0);
+        else
+            __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[idx - 2] + koff),
+                                             (lptr_t)(base + XL_A_BYTES + 1024 * (wave + 8 * (idx - 2))), 16, 0, 0);
+    };
+    auto issue = [&](int kt) {
+        if constexpr (!(ABL & 1)) {
+#pragma unroll
+            for (int idx = 0; idx < 4; ++idx) issue_one(kt, idx);
+        }
+    };
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // bias / table loads retired before the DMA pipeline starts
+    issue(0);
+    if (nk > 1) issue(1);
+    if (nk > 2) issue(2);
+
+    const int wrow0 = 64 * wc + l31, arow0 = 128 * wt + l31;
+    int woff[2][2], aoff[2][4];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) woff[ks][i] = XL_A_BYTES + swz(wrow0 + 32 * i, 2 * ks + h);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) aoff[ks][j] = swz(arow0 + 32 * j, 2 * ks + h);
+    }
+    v4i wf0[2], af0[4], wf1[2], af1[4];
+    auto load_frags = [&](const char* st, int ks, v4i (&wf)[2], v4i (&af)[4]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) wf[i] = *reinterpret_cast<const v4i*>(st + woff[ks][i]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) af[j] = *reinterpret_cast<const v4i*>(st + aoff[ks][j]);
+    };
+    // VM = number of this wave's DMA pieces allowed to stay in flight at the barrier (the stages after kt+1)
+    auto step = [&](int kt, auto dma_tag, auto vm_tag, auto last_tag) {
+        constexpr bool DMA = decltype(dma_tag)::value && !(ABL & 1);
+        constexpr int VM = decltype(vm_tag)::value;
+        constexpr bool LAST = decltype(last_tag)::value;
+        const char* st = smem + (kt % XL_STAGES) * XL_STAGE;
+        load_frags(st, 1, wf1, af1);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if constexpr (!(ABL & 2))
+                    acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf0[i], af0[j], acc[i][j], 0, 0, 0);
+                else
+                    asm volatile("" ::"v"(wf0[i]), "v"(af0[j]));
+                if constexpr (DMA)
+                    if (((4 * i + j) & 1) == 0 && (4 * i + j) < 8) issue_one(kt + 3, (4 * i + j) >> 1);
+            }
+        if constexpr (VM == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        else if constexpr (VM == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if constexpr (!LAST) load_frags(smem + ((kt + 1) % XL_STAGES) * XL_STAGE, 0, wf0, af0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if constexpr (!(ABL & 2))
+                    acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf1[i], af1[j], acc[i][j], 0, 0, 0);
+                else
+                    asm volatile("" ::"v"(wf1[i]), "v"(af1[j]));
+            }
+    };
+    using T = std::true_type;
+    using F = std::false_type;
+    using V8 = std::integral_constant<int, 8>;
+    using V4 = std::integral_constant<int, 4>;
+    using V0 = std::integral_constant<int, 0>;
+
+    // stage 0 landed: everything issued after it may stay in flight
+    if (nk > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    load_frags(smem, 0, wf0, af0);
+    int kt = 0;
+    for (; kt + 3 < nk; ++kt) step(kt, T{}, V8{}, F{});
+    if (kt + 2 < nk) { step(kt, F{}, V4{}, F{}); ++kt; }
+    if (kt + 1 < nk) { step(kt, F{}, V0{}, F{}); ++kt; }
+    step(kt, F{}, V0{}, T{});
+
+    __syncthreads();
+    if constexpr (ABL & 4) {
+        int x = 0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) x ^= acc[i][j][r];
+        if (x == 0x7fffffff) reinterpret_cast<int*>(g.out)[tid] = x;
+        return;
+    }
+    epilogue_i8<EPI, 2, 4, XTOK, XL_NT, ABL, XCH>(acc, g, smem, smem + XL_SMEM, m0, n0, 64 * wc, 128 * wt, tid, h, l31);
 }
 
 template <int EPI>
@@ -403,12 +721,58 @@ int launch_gemm(GemmArgs& g, const char* name, ivit_stream_t stream)
         IVIT_REQUIRE(g.N == 3 * g.heads * g.head_dim && g.M % g.tokens == 0,
                      "%s: N=%d != 3*heads*head_dim or M=%d %% tokens=%d != 0", name, g.N, g.M, g.tokens);
     }
+    g.flags = g_debug_flags & (31 | 128 | 256);
     if constexpr (EPI != EPI_I32) {
+        if (g.M >= 2048 && g.N % XCH == 0 && !g_force_small && g_kernel_choice != 1 &&
+            (g_debug_flags & 32)) {
+            g.tiles_m = (g.M + XTOK - 1) / XTOK;
+            g.tiles_n = g.N / XCH;
+            dim3 grid(g.tiles_m * g.tiles_n), blk(XL_NT);
+            hipStream_t st = ivit_stream(stream);
+            if (EPI == EPI_RQ && g.flags != 0) {
+                switch (g.flags) {
+                    case 1: hipLaunchKernelGGL((gemm_i8_xl_kernel<EPI_RQ, 1>), grid, blk, 0, st, g); break;
+                    case 2: hipLaunchKernelGGL((gemm_i8_xl_kernel<EPI_RQ, 2>), grid, blk, 0, st, g); break;
+                    case 4: hipLaunchKernelGGL((gemm_i8_xl_kernel<EPI_RQ, 4>), grid, blk, 0, st, g); break;
+                    case 5: hipLaunchKernelGGL((gemm_i8_xl_kernel<EPI_RQ, 5>), grid, blk, 0, st, g); break;
+                    case 6: hipLaunchKernelGGL((gemm_i8_xl_kernel<EPI_RQ, 6>), grid, blk, 0, st, g); break;
+                    case 7: hipLaunchKernelGGL((gemm_i8_xl_kernel<EPI_RQ, 7>), grid, blk, 0, st, g); break;
+                    case 8: hipLaunchKernelGGL((gemm_i8_xl_kernel<EPI_RQ, 8>), grid, blk, 0, st, g); break;
+                    case 16: hipLaunchKernelGGL((gemm_i8_xl_kernel<EPI_RQ, 16>), grid, blk, 0, st, g); break;
+                    default: hipLaunchKernelGGL((gemm_i8_xl_kernel<EPI_RQ, 3>), grid, blk, 0, st, g); break;
+                }
+            } else {
+                hipLaunchKernelGGL((gemm_i8_xl_kernel<EPI, 0>), grid, blk, 0, st, g);
+            }
+            IVIT_CHECK_LAUNCH(name);
+        }
         if (g.M >= 2048 && g.N >= BCH && !g_force_small) {
+            g.stagger = (g_debug_flags & 64) ? 0 : 512;  // 2 workgroups x 256 CUs
             g.tiles_m = (g.M + BTOK - 1) / BTOK;
             g.tiles_n = (g.N + BCH - 1) / BCH;
-            hipLaunchKernelGGL(gemm_i8_big_kernel<EPI>, dim3(g.tiles_m * g.tiles_n), dim3(BIG_NT), 0,
-                               ivit_stream(stream), g);
+            dim3 grid(g.tiles_m * g.tiles_n), blk(BIG_NT);
+            hipStream_t st = ivit_stream(stream);
+            if (EPI == EPI_RQ && g.flags != 0) {  // perf ablations (scripts/gemm_ablate.py), EPI_RQ only
+                switch (g.flags) {
+                    case 1: hipLaunchKernelGGL((gemm_i8_big_kernel<EPI_RQ, 1>), grid, blk, 0, st, g); break;
+                    case 2: hipLaunchKernelGGL((gemm_i8_big_kernel<EPI_RQ, 2>), grid, blk, 0, st, g); break;
+                    case 3: hipLaunchKernelGGL((gemm_i8_big_kernel<EPI_RQ, 3>), grid, blk, 0, st, g); break;
+                    case 4: hipLaunchKernelGGL((gemm_i8_big_kernel<EPI_RQ, 4>), grid, blk, 0, st, g); break;
+                    case 5: hipLaunchKernelGGL((gemm_i8_big_kernel<EPI_RQ, 5>), grid, blk, 0, st, g); break;
+                    case 6: hipLaunchKernelGGL((gemm_i8_big_kernel<EPI_RQ, 6>), grid, blk, 0, st, g); break;
+                    case 7: hipLaunchKernelGGL((gemm_i8_big_kernel<EPI_RQ, 7>), grid, blk, 0, st, g); break;
+                    case 8: hipLaunchKernelGGL((gemm_i8_big_kernel<EPI_RQ, 8>), grid, blk, 0, st, g); break;
+                    case 16: hipLaunchKernelGGL((gemm_i8_big_kernel<EPI_RQ, 16>), grid, blk, 0, st, g); break;
+                    case 24: hipLaunchKernelGGL((gemm_i8_big_kernel<EPI_RQ, 24>), grid, blk, 0, st, g); break;
+                    case 11: hipLaunchKernelGGL((gemm_i8_big_kernel<EPI_RQ, 11>), grid, blk, 0, st, g); break;
+                    case 19: hipLaunchKernelGGL((gemm_i8_big_kernel<EPI_RQ, 19>), grid, blk, 0, st, g); break;
+                    case 133: hipLaunchKernelGGL((gemm_i8_big_kernel<EPI_RQ, 133>), grid, blk, 0, st, g); break;
+                    case 389: hipLaunchKernelGGL((gemm_i8_big_kernel<EPI_RQ, 389>), grid, blk, 0, st, g); break;
+                    default: hipLaunchKernelGGL((gemm_i8_big_kernel<EPI_RQ, 3>), grid, blk, 0, st, g); break;
+                }
+            } else {
+                hipLaunchKernelGGL((gemm_i8_big_kernel<EPI, 0>), grid, blk, 0, st, g);
+            }
             IVIT_CHECK_LAUNCH(name);
         }
     }
@@ -470,6 +834,13 @@ IVIT_EXPORT int ivit_gemm_i8_i32(const int8_t* A, int64_t lda, const int8_t* W, 
 // test hook: 1 = always use the 128x128 register-staged kernel (so both kernels stay covered)
 IVIT_EXPORT int ivit_debug_force_small_gemm(int on)
 {
-    g_force_small = (on != 0);
+    g_force_small = (on == 1);   // 1: 128x128 register-staged kernel only
+    g_kernel_choice = (on == 2); // 2: at most the 256x128 LDS-DMA kernel
+    return IVIT_OK;
+}
+
+IVIT_EXPORT int ivit_debug_set_gemm_flags(int flags)
+{
+    g_debug_flags = flags;
     return IVIT_OK;
 }

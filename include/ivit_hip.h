@@ -91,6 +91,9 @@ int ivit_gemm_i8_i32(const int8_t* A, int64_t lda, const int8_t* W, int64_t ldw,
  * for M >= 2048, N >= 128; a 128x128-tile kernel otherwise).  on != 0 forces the small-tile kernel so
  * tests can cover both on the same inputs.  Process-wide, not thread-safe; not for production use. */
 int ivit_debug_force_small_gemm(int on);
+/* Perf-ablation hook for scripts/gemm_ablate.py (bit 0: skip the in-loop DMA, bit 1: skip the MFMAs,
+ * bit 2: skip the epilogue); results are WRONG whenever flags != 0. */
+int ivit_debug_set_gemm_flags(int flags);
 
 /* ---- fused attention core -------------------------------------------------------------------
  * vit_quant.py:72-85: matmul_1 (q.k^T) -> qact_attn1 -> IVITIntSoftmax (Shiftmax,

@@ -60,7 +60,10 @@ def kat(golden_dir):
                                    # M >= 2048 and N >= 128: the 256x128-tile LDS-DMA kernel (1, 2, 3 and many K steps,
                                    # ragged token and channel tails)
                                    (2048, 128, 64), (2304, 256, 128), (2500, 208, 192), (197 * 16, 768, 768),
-                                   (2100, 384, 3072)])
+                                   (2100, 384, 3072),
+                                   # N % 256 == 0 and K % 128 == 0: the 256x256x128 kernel (1, 2, 3, many K steps)
+                                   (2048, 256, 128), (2300, 512, 256), (197 * 12, 768, 384), (2100, 768, 3072),
+                                   (197 * 11, 2304, 768)])
 def test_gemm_requant(M, N, K):
     rng = np.random.default_rng(M * 7 + N + K)
     A = rng.integers(-128, 128, size=(M, K)).astype(np.int8)
@@ -76,6 +79,36 @@ def test_gemm_requant(M, N, K):
     got = out.cpu().numpy().astype(np.int32)
     assert np.array_equal(got, exp), f"{(got != exp).sum()} of {got.size} differ"
     assert np.abs(exp).max() > 10
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 128, 64), (2304, 256, 128), (2304, 128, 192)])
+def test_gemm_requant_ties_and_exact_fallback(M, N, K):
+    """(a) multipliers that are exact float32 values (1/16, 3/32): one accumulator in 16 is an exact tie and must
+    round half to even on the float32 fast path; (b) accumulators beyond 2^22 (huge bias) and multipliers with 31
+    significant bits: the float64 fallback of the epilogue."""
+    rng = np.random.default_rng(M + N + K)
+    A = rng.integers(-128, 128, size=(M, K)).astype(np.int8)
+    W = rng.integers(-20, 21, size=(N, K)).astype(np.int8)
+    b = rng.integers(-500, 500, size=N).astype(np.int32)
+    m = np.full(N, 1 << 30, np.uint32)
+    e = np.full(N, 34, np.int32)            # M = 2^30 / 2^34 = 1/16
+    m[1::2] = 3 << 29                       # M = 3/32
+    e[1::2] = 35
+    b[5::16] = 30_000_000                   # |acc| > 2^22 -> exact path; tiny multiplier keeps it in range
+    m[5::16] = (1 << 30) + 12345
+    e[5::16] = 30 + 25
+    b[6::16] = -2_000_000_000               # near the int32 limit
+    m[6::16] = (1 << 31) - 1
+    e[6::16] = 31 + 24
+    acc = orc.gemm_i8(A, W, b)
+    assert (np.abs(acc[:, 0::2] % 16) == 8).any(), "no exact ties generated"
+    exp = orc.requant(acc, m.astype(np.float64), e, 8)
+    out = torch.empty(M, N, dtype=torch.int8, device=DEV)
+    md, ed = me_dev(m, e)
+    _lib.call("ivit_gemm_i8_requant", _lib.ptr(dev(A)), K, _lib.ptr(dev(W)), K, _lib.ptr(dev(b)), _lib.ptr(md),
+              _lib.ptr(ed), _lib.ptr(out), N, M, N, K, st())
+    got = out.cpu().numpy().astype(np.int32)
+    assert np.array_equal(got, exp), f"{(got != exp).sum()} of {got.size} differ"
 
 
 def test_gemm_i32_and_bias_none():
@@ -103,7 +136,7 @@ def test_gemm_mfma_layout_identity():
     assert np.array_equal(out.cpu().numpy(), orc.gemm_i8(A, W))
 
 
-@pytest.mark.parametrize("M,N,K", [(333, 384, 384), (197 * 13, 768, 256), (2050, 192, 768)])
+@pytest.mark.parametrize("M,N,K", [(333, 384, 384), (197 * 13, 768, 256), (2050, 192, 768), (2050, 768, 192)])
 def test_gemm_requant_residual(M, N, K):
     rng = np.random.default_rng(11 + M)
     A = rng.integers(-128, 128, size=(M, K)).astype(np.int8)
@@ -145,7 +178,7 @@ def test_gemm_requant_qkv_layout(B, H):
 def test_gemm_both_kernels_agree():
     """same large problem through the LDS-DMA kernel and (forced) through the small-tile kernel"""
     rng = np.random.default_rng(77)
-    M, N, K = 2600, 384, 384
+    M, N, K = 2600, 512, 384
     A = rng.integers(-128, 128, size=(M, K)).astype(np.int8)
     W = rng.integers(-128, 128, size=(N, K)).astype(np.int8)
     b = rng.integers(-50000, 50000, size=N).astype(np.int32)
@@ -153,14 +186,14 @@ def test_gemm_both_kernels_agree():
     md, ed = me_dev(m, e)
     dA, dW, db = dev(A), dev(W), dev(b)
     outs = []
-    for force in (0, 1):
+    for force in (0, 1, 2):
         _lib.call("ivit_debug_force_small_gemm", force)
         out = torch.empty(M, N, dtype=torch.int8, device=DEV)
         _lib.call("ivit_gemm_i8_requant", _lib.ptr(dA), K, _lib.ptr(dW), K, _lib.ptr(db), _lib.ptr(md), _lib.ptr(ed),
                   _lib.ptr(out), N, M, N, K, st())
         outs.append(out.cpu().numpy())
     _lib.call("ivit_debug_force_small_gemm", 0)
-    assert np.array_equal(outs[0], outs[1])
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
     assert np.array_equal(outs[0].astype(np.int32), orc.requant(orc.gemm_i8(A, W, b), m.astype(np.float64), e, 8))
 
 
