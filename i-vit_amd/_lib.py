@@ -44,6 +44,7 @@ SIGNATURES = {
     "ivit_bgemm_pv_i8": [vp, vp, vp, ci, ci, ci, ci, vp],
     "ivit_f32_to_i32": [vp, i64, ci, vp, ci, ci, vp, vp],
     "ivit_i32_to_f32": [vp, i64, ci, vp, ci, vp, vp],
+    "ivit_narrow_i32_i8": [vp, vp, i64, vp, vp],
 }
 
 

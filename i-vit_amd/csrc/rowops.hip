@@ -466,6 +466,17 @@ __global__ __launch_bounds__(NT) void i32_to_f32_kernel(const int32_t* z, int64_
         y[i] = (float)z[i] * s[n_s == 1 ? 0 : (int)(i % C)];
 }
 
+__global__ __launch_bounds__(NT) void narrow_i32_i8_kernel(const int32_t* z, int8_t* out, int64_t n, int* overflow)
+{
+    bool bad = false;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+        int v = z[i];
+        bad |= (v < -128 || v > 127);
+        out[i] = (int8_t)clamp_i32(v, -128, 127);
+    }
+    if (bad && overflow) atomicOr(overflow, 1);
+}
+
 // module-level QuantMatMul: small batched products, one output element per thread (not the hot path:
 // the engine uses the fused MFMA attention kernel)
 template <bool PV>
@@ -717,4 +728,13 @@ IVIT_EXPORT int ivit_i32_to_f32(const int32_t* z, int64_t rows, int C, const flo
     hipLaunchKernelGGL(i32_to_f32_kernel, dim3(ew_grid(rows * C)), dim3(NT), 0, ivit_stream(stream), z, rows, C, s, n_s,
                        y);
     IVIT_CHECK_LAUNCH("ivit_i32_to_f32");
+}
+
+IVIT_EXPORT int ivit_narrow_i32_i8(const int32_t* z, int8_t* out, int64_t n, int32_t* overflow_flag,
+                                   ivit_stream_t stream)
+{
+    IVIT_REQUIRE(z && out && n > 0, "ivit_narrow_i32_i8: bad operand");
+    hipLaunchKernelGGL(narrow_i32_i8_kernel, dim3(ew_grid(n)), dim3(NT), 0, ivit_stream(stream), z, out, n,
+                       overflow_flag);
+    IVIT_CHECK_LAUNCH("ivit_narrow_i32_i8");
 }

@@ -1,0 +1,99 @@
+"""I-ViT non-linear operators behind the reference's module API
+(/root/reference/models/quantization_utils/ivit_modules.py:10-179), backed by the HIP kernels."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import _lib
+from ..prepare import LayerNormParams, f32
+from .quant_modules import _dev_table, _st, narrow_i8, to_float, to_int32
+
+
+class IVITIntLayerNorm(nn.LayerNorm):
+    """I-LayerNorm, ivit_modules.py:10-65."""
+
+    def __init__(self, normalized_shape, eps=1e-6, elementwise_affine=True):
+        super().__init__(normalized_shape, eps, elementwise_affine)
+        self.dim_sqrt = None
+        self.register_buffer("norm_scaling_factor", torch.zeros(normalized_shape))
+        self.register_buffer("bias_integer", torch.zeros_like(self.bias))
+        self._cache = None
+
+    def fix(self):
+        pass
+
+    def unfix(self):
+        pass
+
+    def forward(self, x, scaling_factor=None):
+        C = x.shape[-1]
+        key = (self.weight._version, self.bias._version, x.device)
+        if self._cache is None or self._cache[0] != key:
+            lp = LayerNormParams(self.weight.detach().cpu().numpy(), self.bias.detach().cpu().numpy(), f32(1.0))
+            self._cache = (key, _dev_table(lp.bias_int, x.device), _dev_table(lp.s_ln, x.device))
+            self.dim_sqrt = torch.sqrt(torch.tensor(float(C)))
+        _, bias_int, s_ln = self._cache
+        k = to_int32(x, scaling_factor, trunc=True)            # :36-38 x / scaling_factor, .to(int32)
+        out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+        _lib.call("ivit_layernorm_i32_f32", _lib.ptr(k), C, k.numel() // C, C, _lib.ptr(bias_int), _lib.ptr(s_ln),
+                  _lib.ptr(out), C, _st())
+        self.bias_integer = bias_int                            # :59
+        self.norm_scaling_factor = s_ln                         # :64
+        return out, s_ln
+
+
+class IVITIntGELU(nn.Module):
+    """ShiftGELU, ivit_modules.py:68-126."""
+
+    def __init__(self, output_bit=8, n=23):
+        super().__init__()
+        if output_bit != 8 or n != 23:
+            raise NotImplementedError("the HIP ShiftGELU implements output_bit=8, n=23 (the reference defaults)")
+        self.output_bit, self.n = output_bit, n
+        self.register_buffer("act_scaling_factor", torch.zeros(1))
+
+    def fix(self):
+        pass
+
+    def unfix(self):
+        pass
+
+    def forward(self, x, scaling_factor=None):
+        L = x.shape[-1]
+        k8 = narrow_i8(to_int32(x, scaling_factor, trunc=True), "IVITIntGELU input")   # :106-107
+        out = torch.empty(x.shape, dtype=torch.int32, device=x.device)
+        _lib.call("ivit_shiftgelu_i8_i32", _lib.ptr(k8), L, k8.numel() // L, L, float(scaling_factor.reshape(-1)[0]),
+                  _lib.ptr(out), L, _st())
+        s = (scaling_factor.reshape(-1)[:1].float() * torch.tensor([1 / 2 ** (self.output_bit - 1)],
+                                                                  device=x.device)).float()  # :121,124
+        self.act_scaling_factor = s
+        return to_float(out, s), s
+
+
+class IVITIntSoftmax(nn.Module):
+    """Shiftmax, ivit_modules.py:129-179."""
+
+    def __init__(self, output_bit=8):
+        super().__init__()
+        if output_bit != 8:
+            raise NotImplementedError("the HIP Shiftmax implements output_bit=8 (the reference default)")
+        self.output_bit, self.n = output_bit, 15
+        self.register_buffer("act_scaling_factor", torch.zeros(1))
+
+    def fix(self):
+        pass
+
+    def unfix(self):
+        pass
+
+    def forward(self, x, scaling_factor):
+        L = x.shape[-1]
+        k8 = narrow_i8(to_int32(x, scaling_factor), "IVITIntSoftmax input")
+        out8 = torch.empty(x.shape, dtype=torch.int8, device=x.device)
+        _lib.call("ivit_shiftmax_i8", _lib.ptr(k8), L, k8.numel() // L, L, float(scaling_factor.reshape(-1)[0]),
+                  _lib.ptr(out8), L, _st())
+        s = torch.tensor([1 / 2 ** (self.output_bit - 1)], dtype=torch.float32, device=x.device)  # :176
+        self.act_scaling_factor = s
+        return to_float(out8.to(torch.int32), s), s

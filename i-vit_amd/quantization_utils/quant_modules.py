@@ -1,0 +1,289 @@
+"""nn.Module mirror of the reference's fake-quant operators, backed by the HIP kernels.
+
+Same class names, constructor arguments, registered buffers (state_dict keys),
+``fix()/unfix()`` protocol and ``forward(x, scale, ...) -> (y, scale)`` contract as
+/root/reference/models/quantization_utils/quant_modules.py:131-511, so the reference's model
+files and checkpoints apply unchanged.  Tensors crossing a module boundary are the reference's
+float32 ``value = integer * scale`` views; inside, each module converts to integers, runs the
+integer kernel through the C ABI (``ivit_*`` in include/ivit_hip.h) and converts back.  This is the
+compatibility path (one launch per conversion); ``VisionTransformer.forward`` of a frozen model
+takes the fused int8 engine (engine.py) instead.
+
+Scales are read back to the host to derive the dyadic (m, e) pairs exactly as batch_frexp does
+(quant_utils.py:151-175); that is what the reference itself does on every call (numpy + Decimal).
+Valid in the regime the parity contract covers (power-of-two activation scales).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import _lib
+from ..prepare import LinearParams, dyadic, f32, sym_scale
+
+
+# ----------------------------------------------------------------------------- device helpers
+def _st():
+    return _lib.stream_ptr()
+
+
+def _dev_table(a, device):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(device)
+
+
+def to_int32(x: torch.Tensor, scale: torch.Tensor, trunc: bool = False) -> torch.Tensor:
+    """z = round(x / scale) (quant_utils.py:220) or trunc (the `.to(int32)` of ivit_modules.py:38,107);
+    scale has 1 or x.shape[-1] entries."""
+    x = x.contiguous().float()
+    s = scale.reshape(-1).contiguous().float()
+    C = x.shape[-1]
+    assert s.numel() in (1, C), "scale must be per tensor or per last-dim channel"
+    z = torch.empty(x.shape, dtype=torch.int32, device=x.device)
+    _lib.call("ivit_f32_to_i32", _lib.ptr(x), x.numel() // C, C, _lib.ptr(s), s.numel(), int(trunc), _lib.ptr(z), _st())
+    return z
+
+
+def to_float(z: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
+    z = z.contiguous()
+    s = scale.reshape(-1).contiguous().float()
+    C = z.shape[-1]
+    assert s.numel() in (1, C)
+    y = torch.empty(z.shape, dtype=torch.float32, device=z.device)
+    _lib.call("ivit_i32_to_f32", _lib.ptr(z), z.numel() // C, C, _lib.ptr(s), s.numel(), _lib.ptr(y), _st())
+    return y
+
+
+def narrow_i8(z: torch.Tensor, what: str) -> torch.Tensor:
+    out = torch.empty(z.shape, dtype=torch.int8, device=z.device)
+    flag = torch.zeros(1, dtype=torch.int32, device=z.device)
+    _lib.call("ivit_narrow_i32_i8", _lib.ptr(z), _lib.ptr(out), z.numel(), _lib.ptr(flag), _st())
+    if int(flag.item()) != 0:
+        raise _lib.IvitError(f"{what}: integer activations exceed 8 bits; the int8 MFMA kernels cannot represent them")
+    return out
+
+
+def _me_tables(pre_sf: torch.Tensor, z_sf, device):
+    m, e = dyadic(pre_sf.detach().reshape(-1).cpu().numpy(), f32(z_sf))
+    return _dev_table(m.view(np.int32), device), _dev_table(e, device), m.size
+
+
+# ----------------------------------------------------------------------------- QuantLinear
+class QuantLinear(nn.Linear):
+    """quant_modules.py:131-226."""
+
+    def __init__(self, in_features, out_features, bias=True, weight_bit=8, bias_bit=32, per_channel=True,
+                 quant_mode="symmetric"):
+        super().__init__(in_features, out_features, bias)
+        if quant_mode != "symmetric":
+            raise ValueError(f"unknown quant mode: {quant_mode}")
+        if weight_bit != 8 or not per_channel:
+            raise NotImplementedError("the HIP path implements 8-bit per-channel weights (the reference default)")
+        self.weight_bit, self.bias_bit, self.per_channel, self.quant_mode = weight_bit, bias_bit, per_channel, quant_mode
+        self.quantize_bias = bias_bit is not None
+        self.register_buffer("fc_scaling_factor", torch.zeros(self.out_features))
+        self.register_buffer("weight_integer", torch.zeros_like(self.weight))
+        if self.bias is not None:
+            self.register_buffer("bias_integer", torch.zeros_like(self.bias))
+        self._cache = None
+
+    def __repr__(self):
+        return "(" + super().__repr__() + f" weight_bit={self.weight_bit}, quant_mode={self.quant_mode})"
+
+    def fix(self):
+        pass
+
+    def unfix(self):
+        pass
+
+    def _params(self, s_in: float):
+        key = (self.weight._version, None if self.bias is None else self.bias._version, s_in, self.weight.device)
+        if self._cache is None or self._cache[0] != key:
+            lp = LinearParams(self.weight.detach().cpu().numpy(),
+                              None if self.bias is None else self.bias.detach().cpu().numpy(), s_in)
+            dev = self.weight.device
+            W8 = _dev_table(lp.W8, dev)
+            b32 = None if lp.b32 is None else _dev_table(lp.b32, dev)
+            s_acc = _dev_table(lp.s_acc, dev)
+            # buffers the reference overwrites on every call (quant_modules.py:211-220)
+            self.fc_scaling_factor = _dev_table(lp.sw, dev)
+            self.weight_integer = W8.float().reshape(self.weight.shape)
+            if b32 is not None:
+                self.bias_integer = b32.float()
+            self._cache = (key, W8, b32, s_acc)
+        return self._cache[1:]
+
+    def forward(self, x, prev_act_scaling_factor=None):
+        assert prev_act_scaling_factor is not None and prev_act_scaling_factor.shape == (1,)
+        W8, b32, s_acc = self._params(float(prev_act_scaling_factor.item()))
+        K, N = self.in_features, self.out_features
+        if K % 64 != 0 or N % 4 != 0:
+            raise NotImplementedError("ivit_gemm_i8_i32 needs in_features % 64 == 0 and out_features % 4 == 0")
+        a8 = narrow_i8(to_int32(x, prev_act_scaling_factor), "QuantLinear input")
+        M = a8.numel() // K
+        acc = torch.empty((*x.shape[:-1], N), dtype=torch.int32, device=x.device)
+        _lib.call("ivit_gemm_i8_i32", _lib.ptr(a8), K, _lib.ptr(W8), K, _lib.ptr(b32), _lib.ptr(acc), N, M, N, K, _st())
+        return to_float(acc, s_acc), s_acc
+
+
+# ----------------------------------------------------------------------------- QuantAct
+class QuantAct(nn.Module):
+    """quant_modules.py:229-387 (fixedpoint_mul quant_utils.py:193-253; input mode :79-97)."""
+
+    def __init__(self, activation_bit=8, act_range_momentum=0.95, running_stat=True, per_channel=False,
+                 channel_len=None, quant_mode="symmetric"):
+        super().__init__()
+        if quant_mode != "symmetric":
+            raise ValueError(f"unknown quant mode: {quant_mode}")
+        if per_channel:
+            raise NotImplementedError("per-channel activation ranges are not used by the ViT path")
+        self.activation_bit, self.act_range_momentum = activation_bit, act_range_momentum
+        self.running_stat, self.quant_mode, self.per_channel = running_stat, quant_mode, per_channel
+        self.percentile = None
+        self.register_buffer("x_min", torch.zeros(1))
+        self.register_buffer("x_max", torch.zeros(1))
+        self.register_buffer("act_scaling_factor", torch.zeros(1))
+
+    def __repr__(self):
+        return (f"{self.__class__.__name__}(activation_bit={self.activation_bit}, quant_mode: {self.quant_mode}, "
+                f"Act_min: {self.x_min.item():.2f}, Act_max: {self.x_max.item():.2f})")
+
+    def fix(self):
+        self.running_stat = False
+
+    def unfix(self):
+        self.running_stat = True
+
+    def _observe(self, x_act):
+        """calibration statistics (quant_modules.py:310-360); torch reductions, not a hot path"""
+        x_min, x_max = x_act.detach().min(), x_act.detach().max()
+        if torch.eq(self.x_min, self.x_max).all():
+            self.x_min = self.x_min + x_min
+            self.x_max = self.x_max + x_max
+        elif self.act_range_momentum == -1:
+            self.x_min = torch.min(self.x_min, x_min)
+            self.x_max = torch.max(self.x_max, x_max)
+        else:
+            mo = self.act_range_momentum
+            self.x_min = self.x_min * mo + x_min * (1 - mo)
+            self.x_max = self.x_max * mo + x_max * (1 - mo)
+
+    def forward(self, x, pre_act_scaling_factor=None, identity=None, identity_scaling_factor=None,
+                specified_min=None, specified_max=None):
+        if self.running_stat:
+            self._observe(x if identity is None else identity + x)
+        x_min = self.x_min if specified_min is None else specified_min
+        x_max = self.x_max if specified_max is None else specified_max
+        s_out = sym_scale(float(x_min.reshape(-1)[0]), float(x_max.reshape(-1)[0]), self.activation_bit)
+        self.act_scaling_factor = torch.full((1,), float(s_out), dtype=torch.float32, device=x.device)
+        bits = self.activation_bit
+        if pre_act_scaling_factor is None:
+            # input mode: clamp(round(1/s * x))  (SymmetricQuantFunction)
+            if bits != 8:
+                raise NotImplementedError("input-mode QuantAct is 8 bit on the HIP path")
+            xin = x.contiguous().float()
+            q8 = torch.empty(xin.shape, dtype=torch.int8, device=x.device)
+            _lib.call("ivit_quantize_input_f32_i8", _lib.ptr(xin), _lib.ptr(q8), xin.numel(),
+                      float(f32(1.0) / s_out), _st())
+            q = q8.to(torch.int32)
+        else:
+            z = to_int32(x, pre_act_scaling_factor)
+            C = x.shape[-1]
+            m, e, n_me = _me_tables(pre_act_scaling_factor, s_out, x.device)
+            z2 = m2 = e2 = None
+            n2 = 0
+            if identity is not None:
+                if identity.shape != x.shape:  # e.g. pos_embed [1,T,C] against [B,T,C] (vit_quant.py:296)
+                    identity = identity.expand_as(x)
+                z2 = to_int32(identity, identity_scaling_factor)
+                m2, e2, n2 = _me_tables(identity_scaling_factor, s_out, x.device)
+            q = torch.empty(z.shape, dtype=torch.int32, device=x.device)
+            _lib.call("ivit_requant_i32", _lib.ptr(z), z.numel() // C, C, _lib.ptr(m), _lib.ptr(e), n_me,
+                      _lib.ptr(z2), _lib.ptr(m2), _lib.ptr(e2), n2, bits, _lib.ptr(q), _st())
+        return to_float(q, self.act_scaling_factor), self.act_scaling_factor
+
+
+# ----------------------------------------------------------------------------- QuantMatMul
+class QuantMatMul(nn.Module):
+    """quant_modules.py:390-409: (A/sA) @ (B/sB) with scale sA*sB."""
+
+    def __init__(self):
+        super().__init__()
+        self.register_buffer("act_scaling_factor", torch.zeros(1))
+
+    def fix(self):
+        pass
+
+    def unfix(self):
+        pass
+
+    def forward(self, A, pre_act_scaling_factor_A, B, pre_act_scaling_factor_B):
+        a8 = narrow_i8(to_int32(A, pre_act_scaling_factor_A), "QuantMatMul A")
+        b8 = narrow_i8(to_int32(B, pre_act_scaling_factor_B), "QuantMatMul B")  # to_int32 makes B contiguous [.., K, N]
+        Tq, Kd = A.shape[-2], A.shape[-1]
+        N = B.shape[-1]
+        assert B.shape[-2] == Kd and A.shape[:-2] == B.shape[:-2]
+        batch = a8.numel() // (Tq * Kd)
+        out = torch.empty((*A.shape[:-1], N), dtype=torch.int32, device=A.device)
+        _lib.call("ivit_bgemm_pv_i8", _lib.ptr(a8), _lib.ptr(b8), _lib.ptr(out), batch, Tq, Kd, N, _st())
+        s = (pre_act_scaling_factor_A * pre_act_scaling_factor_B).float()
+        self.act_scaling_factor = s
+        return to_float(out, s), s
+
+
+# ----------------------------------------------------------------------------- QuantConv2d
+class QuantConv2d(nn.Conv2d):
+    """quant_modules.py:412-511, for the patch-embedding geometry (kernel == stride, no padding)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
+                 weight_bit=8, bias_bit=32, quant_mode="symmetric", per_channel=True, weight_percentile=0):
+        super().__init__(in_channels, out_channels, kernel_size, stride=stride, padding=padding, dilation=dilation,
+                         groups=groups, bias=bias)
+        if quant_mode != "symmetric" or not per_channel or weight_bit != 8:
+            raise NotImplementedError("the HIP path implements symmetric 8-bit per-channel conv weights")
+        self.weight_bit, self.bias_bit, self.quant_mode, self.per_channel = weight_bit, bias_bit, quant_mode, per_channel
+        self.weight_percentile = weight_percentile
+        self.quantize_bias = bias_bit is not None
+        self.register_buffer("conv_scaling_factor", torch.zeros(self.out_channels))
+        self.register_buffer("weight_integer", torch.zeros_like(self.weight))
+        self.register_buffer("bias_integer", torch.zeros_like(self.bias))
+        self._cache = None
+
+    def __repr__(self):
+        return "(" + super().__repr__() + f" weight_bit={self.weight_bit}, quant_mode={self.quant_mode})"
+
+    def fix(self):
+        pass
+
+    def unfix(self):
+        pass
+
+    def forward(self, x, pre_act_scaling_factor=None):
+        kh, kw = self.kernel_size
+        if not (kh == kw == self.stride[0] == self.stride[1] and self.padding == (0, 0) and self.groups == 1
+                and self.dilation == (1, 1)):
+            raise NotImplementedError("QuantConv2d on the HIP path is the non-overlapping patch convolution")
+        B, Cin, H, Wd = x.shape
+        assert H == Wd and H % kh == 0
+        s_in = float(pre_act_scaling_factor.reshape(-1)[0])
+        key = (self.weight._version, self.bias._version, s_in, self.weight.device)
+        if self._cache is None or self._cache[0] != key:
+            lp = LinearParams(self.weight.detach().cpu().numpy(), self.bias.detach().cpu().numpy(), s_in)
+            dev = x.device
+            self._cache = (key, _dev_table(lp.W8, dev), _dev_table(lp.b32, dev), _dev_table(lp.s_acc, dev))
+            self.conv_scaling_factor = _dev_table(lp.sw, dev)
+            self.weight_integer = self._cache[1].float().reshape(self.weight.shape)
+            self.bias_integer = self._cache[2].float()
+        _, W8, b32, s_acc = self._cache
+        g = H // kh
+        K = Cin * kh * kw
+        A = torch.empty(B * g * g, K, dtype=torch.int8, device=x.device)
+        xin = x.contiguous().float()
+        _lib.call("ivit_quantize_patchify_f32_i8", _lib.ptr(xin), _lib.ptr(A), B, Cin, H, kh, float(f32(1.0) / f32(s_in)),
+                  _st())
+        N = self.out_channels
+        acc = torch.empty(B * g * g, N, dtype=torch.int32, device=x.device)
+        _lib.call("ivit_gemm_i8_i32", _lib.ptr(A), K, _lib.ptr(W8), K, _lib.ptr(b32), _lib.ptr(acc), N, B * g * g, N, K,
+                  _st())
+        y = to_float(acc, s_acc).reshape(B, g, g, N).permute(0, 3, 1, 2).contiguous()
+        return y, s_acc.view(1, -1, 1, 1)

@@ -1,0 +1,192 @@
+"""DeiT / ViT assembly with the reference's module tree and checkpoint keys
+(/root/reference/models/vit_quant.py:23-406), running on the MI355X integer kernels.
+
+Two execution paths give bit-identical results:
+  * a frozen model (every QuantAct fixed, `freeze_model`) forwards through the fused int8 engine
+    (engine.IntViTEngine): int8 activations end to end, ~100 kernel launches per batch;
+  * otherwise (calibration, debugging, module-level tests) the modules are called one by one exactly as the
+    reference's forward does, each converting float <-> integer views around its HIP kernel.
+"""
+from __future__ import annotations
+
+from functools import partial
+
+import torch
+from torch import nn
+
+from .layers_quant import DropPath, Mlp, PatchEmbed, trunc_normal_
+from .quantization_utils import (QuantAct, QuantLinear, QuantMatMul, get_gelu, get_layernorm, get_softmax)
+
+__all__ = ["deit_tiny_patch16_224", "deit_small_patch16_224", "deit_base_patch16_224", "vit_base_patch16_224",
+           "vit_large_patch16_224", "VisionTransformer"]
+
+
+class Attention(nn.Module):
+    def __init__(self, dim, num_heads=8, qkv_bias=False, qk_scale=None, attn_drop=0.0, proj_drop=0.0, bitwidth_out=8,
+                 bitwidth_softmax=8, softmax_cls=nn.Softmax):
+        super().__init__()
+        self.num_heads = num_heads
+        self.scale = qk_scale or (dim // num_heads) ** -0.5
+        self.qkv = QuantLinear(dim, dim * 3, bias=qkv_bias)
+        self.qact1 = QuantAct()
+        self.qact_attn1 = QuantAct()
+        self.qact2 = QuantAct()
+        self.proj = QuantLinear(dim, dim)
+        self.qact3 = QuantAct(bitwidth_out)
+        self.attn_drop = nn.Dropout(attn_drop)
+        self.proj_drop = nn.Dropout(proj_drop)
+        self.int_softmax = softmax_cls(bitwidth_softmax)
+        self.matmul_1 = QuantMatMul()
+        self.matmul_2 = QuantMatMul()
+
+    def forward(self, x, act_scaling_factor):
+        B, N, C = x.shape
+        x, s = self.qkv(x, act_scaling_factor)
+        x, s_qkv = self.qact1(x, s)
+        q, k, v = x.reshape(B, N, 3, self.num_heads, C // self.num_heads).permute(2, 0, 3, 1, 4).unbind(0)
+        attn, s = self.matmul_1(q, s_qkv, k.transpose(-2, -1), s_qkv)
+        attn, s = self.qact_attn1(attn * self.scale, s * self.scale)
+        attn, s = self.int_softmax(attn, s)
+        x, s = self.matmul_2(self.attn_drop(attn), s, v, s_qkv)
+        x, s = self.qact2(x.transpose(1, 2).reshape(B, N, C), s)
+        x, s = self.proj(x, s)
+        x, s = self.qact3(x, s)
+        return self.proj_drop(x), s
+
+
+class Block(nn.Module):
+    def __init__(self, dim, num_heads, softmax_cls, mlp_ratio=4.0, qkv_bias=False, qk_scale=None, drop=0.0,
+                 attn_drop=0.0, drop_path=0.0, act_layer=nn.GELU, norm_layer=nn.LayerNorm, attention_out_bw=8,
+                 softmax_bw=8, mlp_out_bw=8, norm2_in_bw=8, att_block_out_bw=8):
+        super().__init__()
+        self.norm1 = norm_layer(dim)
+        self.qact1 = QuantAct()
+        self.attn = Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias, qk_scale=qk_scale, attn_drop=attn_drop,
+                              proj_drop=drop, bitwidth_out=attention_out_bw, bitwidth_softmax=softmax_bw,
+                              softmax_cls=softmax_cls)
+        self.drop_path = DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
+        self.qact2 = QuantAct(norm2_in_bw)
+        self.norm2 = norm_layer(dim)
+        self.qact3 = QuantAct()
+        self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop,
+                       bitwidth_out=mlp_out_bw)
+        self.qact4 = QuantAct(att_block_out_bw)
+
+    def forward(self, x_1, s_1):
+        x, s = self.norm1(x_1, s_1)
+        x, s = self.qact1(x, s)
+        x, s = self.attn(x, s)
+        x_2, s_2 = self.qact2(self.drop_path(x), s, x_1, s_1)      # residual 1
+        x, s = self.norm2(x_2, s_2)
+        x, s = self.qact3(x, s)
+        x, s = self.mlp(x, s)
+        return self.qact4(self.drop_path(x), s, x_2, s_2)          # residual 2
+
+
+class VisionTransformer(nn.Module):
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, num_classes=1000, embed_dim=768, depth=12,
+                 num_heads=12, mlp_ratio=4.0, qkv_bias=True, qk_scale=None, representation_size=None, drop_rate=0.0,
+                 attn_drop_rate=0.0, drop_path_rate=0.0, patch_embed_bw=8, pos_encoding_bw=8, block_input_bw=8,
+                 attention_out_bw=8, softmax_bw=8, mlp_out_bw=8, norm2_in_bw=8, att_block_out_bw=8,
+                 gelu_type="ivit", softmax_type="ivit", layernorm_type="ivit"):
+        super().__init__()
+        if representation_size:
+            raise NotImplementedError("pre_logits representation layers are not part of the integer path")
+        self.num_classes = num_classes
+        self.num_features = self.embed_dim = embed_dim
+        self.depth, self.num_heads = depth, num_heads
+        gelu_layer, softmax_cls, norm_layer = get_gelu(gelu_type), get_softmax(softmax_type), get_layernorm(layernorm_type)
+
+        self.qact_input = QuantAct()
+        self.patch_embed = PatchEmbed(img_size=img_size, patch_size=patch_size, in_chans=in_chans, embed_dim=embed_dim,
+                                      bitwidth_out=patch_embed_bw)
+        num_patches = self.patch_embed.num_patches
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.pos_embed = nn.Parameter(torch.zeros(1, num_patches + 1, embed_dim))
+        self.pos_drop = nn.Dropout(p=drop_rate)
+        self.qact_pos = QuantAct(pos_encoding_bw)
+        self.qact1 = QuantAct(block_input_bw)
+        dpr = [x.item() for x in torch.linspace(0, drop_path_rate, depth)]
+        self.blocks = nn.ModuleList([
+            Block(dim=embed_dim, num_heads=num_heads, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, qk_scale=qk_scale,
+                  drop=drop_rate, attn_drop=attn_drop_rate, drop_path=dpr[i], act_layer=gelu_layer,
+                  norm_layer=norm_layer, softmax_cls=softmax_cls, attention_out_bw=attention_out_bw,
+                  softmax_bw=softmax_bw, mlp_out_bw=mlp_out_bw, norm2_in_bw=norm2_in_bw,
+                  att_block_out_bw=att_block_out_bw) for i in range(depth)])
+        self.norm = norm_layer(embed_dim)
+        self.qact2 = QuantAct()
+        self.pre_logits = nn.Identity()
+        self.head = QuantLinear(self.num_features, num_classes) if num_classes > 0 else nn.Identity()
+        trunc_normal_(self.pos_embed, std=0.02)
+        trunc_normal_(self.cls_token, std=0.02)
+        self.apply(self._init_weights)
+        self._engine = None
+        self.use_engine = True   # frozen models take the fused int8 engine
+
+    @staticmethod
+    def _init_weights(m):
+        if isinstance(m, nn.Linear):
+            trunc_normal_(m.weight, std=0.02)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+    # ---------------------------------------------------------------- module-by-module path
+    def forward_features(self, x):
+        B = x.shape[0]
+        x, s = self.qact_input(x)
+        x, s = self.patch_embed(x, s)
+        x = torch.cat((self.cls_token.expand(B, -1, -1), x), dim=1)   # raw float cls row shares the patch scale
+        x_pos, s_pos = self.qact_pos(self.pos_embed)
+        x, s = self.qact1(x, s, x_pos, s_pos)
+        x = self.pos_drop(x)
+        for blk in self.blocks:
+            x, s = blk(x, s)
+        x, s = self.norm(x, s)
+        x, s = self.qact2(x[:, 0], s)
+        return self.pre_logits(x), s
+
+    # ---------------------------------------------------------------- fused engine path
+    def is_frozen(self):
+        return all(not m.running_stat for m in self.modules() if isinstance(m, QuantAct))
+
+    def engine(self, max_batch):
+        """Build (once) the int8 engine from this model's float parameters and QuantAct ranges."""
+        from .engine import IntViTEngine
+        key = (max_batch, next(self.parameters()).device)
+        if self._engine is None or self._engine[0] != key or self._engine[1].max_batch < max_batch:
+            float_state = {k: v for k, v in self.state_dict().items()}
+            ranges = {n: (float(m.x_min.reshape(-1)[0]), float(m.x_max.reshape(-1)[0]))
+                      for n, m in self.named_modules() if isinstance(m, QuantAct)}
+            eng = IntViTEngine(float_state, ranges, self.embed_dim, self.depth, self.num_heads,
+                               device=key[1], max_batch=max_batch)
+            self._engine = (key, eng)
+        return self._engine[1]
+
+    def forward(self, x):
+        if self.use_engine and not self.training and self.is_frozen() and x.is_cuda and self.embed_dim // self.num_heads == 64:
+            _, logits_f32, _ = self.engine(x.shape[0])(x.contiguous().float())
+            return logits_f32.clone()
+        x, s = self.forward_features(x)
+        x, _ = self.head(x, s)
+        return x
+
+
+def _factory(embed_dim, depth, num_heads, name):
+    def make(pretrained=False, **kwargs):
+        if pretrained:
+            raise RuntimeError(f"{name}(pretrained=True) downloads weights (vit_quant.py:325-331); there is no network "
+                               "here -- load a state_dict instead")
+        return VisionTransformer(patch_size=16, embed_dim=embed_dim, depth=depth, num_heads=num_heads, mlp_ratio=4,
+                                 qkv_bias=True, **kwargs)
+    make.__name__ = name
+    return make
+
+
+deit_tiny_patch16_224 = _factory(192, 12, 3, "deit_tiny_patch16_224")
+deit_small_patch16_224 = _factory(384, 12, 6, "deit_small_patch16_224")
+deit_base_patch16_224 = _factory(768, 12, 12, "deit_base_patch16_224")
+vit_base_patch16_224 = _factory(768, 12, 12, "vit_base_patch16_224")
+vit_large_patch16_224 = _factory(1024, 24, 16, "vit_large_patch16_224")

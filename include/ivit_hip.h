@@ -184,6 +184,10 @@ int ivit_f32_to_i32(const float* x, int64_t rows, int C, const float* s, int n_s
 int ivit_i32_to_f32(const int32_t* z, int64_t rows, int C, const float* s, int n_s, float* y,
                     ivit_stream_t stream);
 
+/* int32 integer view -> int8 operand of the GEMM / matmul kernels (module-level path).  Values outside
+ * [-128, 127] saturate and set *overflow_flag (device int32, may be NULL) to 1. */
+int ivit_narrow_i32_i8(const int32_t* z, int8_t* out, int64_t n, int32_t* overflow_flag, ivit_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -336,11 +336,25 @@ def gen_model(tag):
     print(f"[{tag}] wrote fixtures; top1 = {top1.tolist()}")
 
 
+def gen_schema():
+    """state_dict keys and shapes of the reference's DeiT models (the on-disk checkpoint format)"""
+    out = {}
+    for factory in ("deit_tiny_patch16_224", "deit_small_patch16_224", "deit_base_patch16_224"):
+        model = getattr(ref_models, factory)(pretrained=False, gelu_type="ivit", softmax_type="ivit",
+                                             layernorm_type="ivit")
+        out[factory] = {k: list(v.shape) for k, v in model.state_dict().items()}
+    with open(os.path.join(GOLD, "state_dict_schema.json"), "w") as f:
+        json.dump(out, f)
+    print("state_dict_schema.json written:", {k: len(v) for k, v in out.items()})
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    what = sys.argv[1:] or ["ops", "deit_tiny", "deit_small", "deit_base", "vit_base"]
+    what = sys.argv[1:] or ["ops", "schema", "deit_tiny", "deit_small", "deit_base", "vit_base"]
     for w in what:
         if w == "ops":
             gen_ops()
+        elif w == "schema":
+            gen_schema()
         else:
             gen_model(w)

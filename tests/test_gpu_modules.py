@@ -1,0 +1,211 @@
+"""The nn.Module mirror of the reference's operator API (i-vit_amd/quantization_utils, vit_quant.py) on the GPU:
+module outputs are the reference's float32 `integer * scale` tensors, compared BITWISE with vectors the reference's
+own modules produced (tests/golden/ops_kat.npz) and with the whole-model goldens."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ivit = pytest.importorskip("ivit_amd")
+from ivit_amd import synth  # noqa: E402
+from ivit_amd.checkpoint import load_synthetic_model  # noqa: E402
+import ivit_amd.quantization_utils as q  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def bits(x):
+    return x.detach().cpu().numpy().view(np.int32)
+
+
+@pytest.fixture(scope="module")
+def kat(golden_dir):
+    return np.load(os.path.join(golden_dir, "ops_kat.npz"))
+
+
+def frozen_qact(bits_, s_out):
+    qa = q.QuantAct(bits_).to(DEV)
+    n = 2 ** (bits_ - 1) - 1
+    qa.x_max.fill_(float(s_out) * n)
+    qa.x_min.fill_(-float(s_out) * n)
+    qa.fix()
+    return qa
+
+
+def test_quantact_kat(kat):
+    for ci in kat["rq_cases"]:
+        c = f"rq{ci}_"
+        z, pre = kat[c + "z"], kat[c + "pre"]
+        if np.abs(z).max() >= 2 ** 31 or kat[c + "zsf"] < np.finfo(np.float32).eps:
+            continue  # (QuantAct clamps its scale to float32 eps; that vector drives fixedpoint_mul directly)
+        qa = frozen_qact(int(kat[c + "bits"]), kat[c + "zsf"])
+        x = (t(z.astype(np.float32)) * t(pre)).unsqueeze(0)           # the producer's float view
+        kw = {}
+        if c + "z2" in kat:
+            kw = dict(identity=(t(kat[c + "z2"].astype(np.float32)) * float(kat[c + "pre2"])).unsqueeze(0),
+                      identity_scaling_factor=t(np.array([kat[c + "pre2"]], np.float32)))
+        y, s = qa(x, t(pre), **kw)
+        assert float(s) == float(kat[c + "zsf"])
+        exp = (kat[c + "out"].astype(np.float32) * kat[c + "zsf"]).astype(np.float32)
+        assert np.array_equal(bits(y)[0], exp.view(np.int32)), ci
+
+
+def test_quantact_input_mode(kat):
+    qa = q.QuantAct().to(DEV)
+    qa.x_max.fill_(4.0)
+    qa.x_min.fill_(-4.0)
+    qa.fix()
+    y, s = qa(t(kat["qs_x"]))
+    assert float(s) == float(kat["qs_s"])
+    assert np.array_equal(bits(y), (kat["qs_out"].astype(np.float32) * kat["qs_s"]).astype(np.float32).view(np.int32))
+
+
+def test_quantlinear_kat(kat):
+    lin = q.QuantLinear(80, 24)
+    pad = q.QuantLinear(128, 24)     # the HIP GEMM wants K % 64 == 0: zero-pad K (no effect on the products)
+    W = np.zeros((24, 128), np.float32)
+    W[:, :80] = kat["lin_W"]
+    pad.weight.data = torch.from_numpy(W)
+    pad.bias.data = torch.from_numpy(kat["lin_b"])
+    pad.to(DEV)
+    x = np.zeros((1, 10, 128), np.float32)
+    x[0, :, :80] = kat["lin_x"]
+    s_in = kat["lin_sin"]
+    y, s = pad(t(x) * float(s_in), t(np.array([s_in], np.float32)))
+    assert np.array_equal(s.cpu().numpy(), kat["lin_sacc"])
+    assert np.array_equal(pad.weight_integer.cpu().numpy()[:, :80].astype(np.int32), kat["lin_wint"])
+    assert np.array_equal(pad.bias_integer.cpu().numpy().astype(np.int32), kat["lin_bint"])
+    exp = (kat["lin_acc"].astype(np.float32) * kat["lin_sacc"][None]).astype(np.float32)
+    assert np.array_equal(bits(y)[0], exp.view(np.int32))
+    assert lin.state_dict().keys() == pad.state_dict().keys()
+
+
+def test_quantconv_kat(kat):
+    conv = q.QuantConv2d(3, 8, kernel_size=16, stride=16)
+    conv.weight.data = torch.from_numpy(kat["conv_W"])
+    conv.bias.data = torch.from_numpy(kat["conv_b"])
+    conv.to(DEV)
+    s_in = kat["conv_sin"]
+    y, s = conv(t(kat["conv_x"].astype(np.float32)) * float(s_in), t(np.array([s_in], np.float32)))
+    assert s.shape == (1, 8, 1, 1) and np.array_equal(s.reshape(-1).cpu().numpy(), kat["conv_sacc"])
+    exp = (kat["conv_acc"].astype(np.float32) * kat["conv_sacc"].reshape(1, 8, 1, 1)).astype(np.float32)
+    assert np.array_equal(bits(y), exp.view(np.int32))
+
+
+def test_quantmatmul_kat(kat):
+    mm = q.QuantMatMul().to(DEV)
+    sa = 2.0 ** -4
+    s1 = t(np.array([sa], np.float32))
+    y, s = mm(t(kat["mm_a"].astype(np.float32)) * sa, s1, t(kat["mm_b"].astype(np.float32)) * sa, s1)
+    assert np.array_equal(s.cpu().numpy(), kat["mm_s"])
+    exp = (kat["mm_out"].astype(np.float32) * kat["mm_s"]).astype(np.float32)
+    assert np.array_equal(bits(y), exp.view(np.int32))
+    # the q.k^T call pattern of vit_quant.py:72-73 (transposed, non-contiguous second operand)
+    kT = (t(kat["mm_b"].astype(np.float32)) * sa).transpose(-2, -1).contiguous().transpose(-2, -1)
+    y2, _ = mm(t(kat["mm_a"].astype(np.float32)) * sa, s1, kT, s1)
+    assert np.array_equal(bits(y2), exp.view(np.int32))
+
+
+def test_layernorm_module_kat(kat):
+    for ci in kat["ln_cases"]:
+        c = f"ln{ci}_"
+        k = kat[c + "k"]
+        ln = q.IVITIntLayerNorm(k.shape[1])
+        ln.weight.data = torch.from_numpy(kat[c + "gamma"])
+        ln.bias.data = torch.from_numpy(kat[c + "beta"])
+        ln.to(DEV)
+        s = float(kat[c + "s"])
+        y, sln = ln((t(k.astype(np.float32)) * s).unsqueeze(0), t(np.array([s], np.float32)))
+        assert np.array_equal(sln.cpu().numpy(), kat[c + "sln"])
+        assert np.array_equal(bits(y)[0], kat[c + "y_bits"]), ci
+        assert np.array_equal(ln.bias_integer.cpu().numpy(), kat[c + "bias_int"])
+        if ci < 3:  # followed by the 8-bit QuantAct, as in Block.forward
+            qa = frozen_qact(8, kat[c + "q_sf"])
+            yq, sq = qa(y, sln)
+            exp = (kat[c + "q_out"].astype(np.float32) * kat[c + "q_sf"]).astype(np.float32)
+            assert np.array_equal(bits(yq)[0], exp.view(np.int32)), ci
+
+
+def test_gelu_softmax_modules_kat(kat):
+    for ci in kat["gelu_cases"]:
+        c = f"gelu{ci}_"
+        g = q.IVITIntGELU().to(DEV)
+        s = float(kat[c + "s"])
+        y, so = g((t(kat[c + "k"].astype(np.float32)) * s).unsqueeze(0), t(np.array([s], np.float32)))
+        assert float(so) == float(kat[c + "sout"])
+        exp = (kat[c + "out"].astype(np.float32) * kat[c + "sout"]).astype(np.float32)
+        assert np.array_equal(bits(y)[0], exp.view(np.int32)), ci
+    for ci in kat["sm_cases"]:
+        c = f"sm{ci}_"
+        sm = q.IVITIntSoftmax().to(DEV)
+        s = float(kat[c + "s"])
+        y, so = sm((t(kat[c + "k"].astype(np.float32)) * s).reshape(1, 1, *kat[c + "k"].shape),
+                   t(np.array([s], np.float32)))
+        assert float(so) == 1 / 128
+        exp = (kat[c + "out"].astype(np.float32) / 128).astype(np.float32)
+        assert np.array_equal(bits(y)[0, 0], exp.view(np.int32)), ci
+
+
+def test_registry_and_aliases():
+    assert q.get_gelu("ivit") is q.IVITIntGELU and q.get_softmax("ivit") is q.IVITIntSoftmax
+    assert q.get_layernorm("ivit") is q.IVITIntLayerNorm and q.IntGELU is q.IVITIntGELU
+    with pytest.raises(KeyError, match="only"):
+        q.get_gelu("ibert")
+
+
+def load_model(tag):
+    fs, ranges, cfg, meta, z = load_synthetic_model(tag)
+    model = getattr(ivit, meta["factory"])()
+    missing, unexpected = model.load_state_dict({k: torch.from_numpy(v) for k, v in fs.items()}, strict=False)
+    assert not unexpected
+    for name, mod in model.named_modules():
+        if isinstance(mod, q.QuantAct):
+            mod.x_min.fill_(float(ranges[name][0]))
+            mod.x_max.fill_(float(ranges[name][1]))
+    model.to(DEV)
+    ivit.freeze_model(model)
+    return model, meta, z
+
+
+def test_model_module_path_matches_reference_golden():
+    """DeiT-T through the module-by-module path (reference call protocol), 2 golden images: float logits bitwise."""
+    model, meta, z = load_model("deit_tiny")
+    model.use_engine = False
+    imgs = torch.from_numpy(synth.make_images(2, meta["image_seed"])).to(DEV)
+    with torch.no_grad():
+        y = model(imgs)
+    assert np.array_equal(bits(y), z["logits_f32_bits"][:2])
+    # buffers the reference leaves in the state_dict after a forward (Appendix D) are populated
+    sd = model.state_dict()
+    assert sd["blocks.0.attn.qkv.weight_integer"].abs().max() > 0 and sd["blocks.3.qact1.act_scaling_factor"].item() > 0
+
+
+def test_model_engine_path_matches_reference_golden():
+    """the same frozen nn.Module, default path = fused int8 engine"""
+    model, meta, z = load_model("deit_small")
+    imgs = torch.from_numpy(synth.make_images(meta["n_images"], meta["image_seed"])).to(DEV)
+    with torch.no_grad():
+        y = model(imgs)
+    assert np.array_equal(bits(y), z["logits_f32_bits"])
+    assert np.array_equal(y.argmax(dim=1).cpu().numpy(), z["top1"])
+
+
+def test_calibration_then_freeze_runs():
+    """running-stat mode (calibration forward) followed by freeze: the protocol of scripts/inference.py:33-91,223"""
+    fs, ranges, cfg, meta, z = load_synthetic_model("deit_tiny")
+    model = ivit.deit_tiny_patch16_224().to(DEV)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in fs.items()}, strict=False)
+    model.eval()
+    imgs = torch.from_numpy(synth.make_images(2, 7)).to(DEV)
+    with torch.no_grad():
+        model(imgs)                       # calibration: initialises every x_min / x_max
+    assert all(float(m.x_max) > 0 for m in model.modules() if isinstance(m, q.QuantAct))
+    ivit.freeze_model(model)
+    assert model.is_frozen()

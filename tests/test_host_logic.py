@@ -109,3 +109,15 @@ def test_engine_refuses_without_library(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(_lib.IvitError, match="no CPU / PyTorch fallback"):
         _lib.lib()
+
+
+def test_module_tree_matches_reference_state_dict_schema(golden_dir):
+    """keys AND shapes of the nn.Module mirror equal the reference's checkpoints (fixture from the reference)"""
+    import json
+    sch = json.load(open(os.path.join(golden_dir, "state_dict_schema.json")))
+    for name, ref in sch.items():
+        mine = {k: list(v.shape) for k, v in getattr(ivit_amd, name)().state_dict().items()}
+        assert list(mine) == list(ref), name
+        assert mine == ref, name
+    with pytest.raises(RuntimeError, match="no network"):
+        ivit_amd.deit_tiny_patch16_224(pretrained=True)
