@@ -26,6 +26,20 @@ MAC_PER_IMAGE = 17.5638e9          # SURVEY.md Appendix C (GEMM + attention + pa
 INT8_PEAK_TOPS = 5033.0            # 256 CU x 4 SIMD x 1024 MAC/clk x 2.4 GHz x 2 ops (MI355X_MICROARCH.md)
 
 
+def pmc_traffic(kernel_key):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary (FETCH_SIZE / WRITE_SIZE
+    passes, corrected as MI355X_MICROARCH.md prescribes; scripts/summarize_profiles.py).  None if no summary."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json")))
+    if not files:
+        return None, None
+    try:
+        d = json.load(open(files[-1]))
+        return d["pmc"][kernel_key]["hbm_bytes_per_launch_corrected"], os.path.basename(files[-1])
+    except (KeyError, ValueError):
+        return None, None
+
+
 def cpu_baseline(fs, ranges, cfg):
     """The CPU oracle (port of the reference's integer algorithm, oracle/ivit_oracle.c) timed on this
     host's cores on a bounded sample of the same workload."""
@@ -102,9 +116,10 @@ def main():
         macs = [float(M) * N * K for _, _, M, N, K in probe]
         avg_ms = sum(ms) / len(ms)
         achieved = 2.0 * sum(macs) / (sum(ms) * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": "gemm_i8_kernel<EPI_RESID> (attn.proj + mlp.fc2, residual QuantAct fused)",
+        traffic, traffic_src = pmc_traffic("gemm_i8_big_kernel<1, 0>")
+        roof = {"bound": "mfma", "kernel": "gemm_i8_big_kernel<EPI_RESID> (attn.proj + mlp.fc2, residual QuantAct fused)",
                 "achieved": round(achieved, 1), "peak": INT8_PEAK_TOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / INT8_PEAK_TOPS, 4), "traffic": None,
+                "frac": round(achieved / INT8_PEAK_TOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "launches": len(ms), "avg_launch_ms": round(avg_ms, 4),
                 "algorithmic_ops_per_launch": 2.0 * sum(macs) / len(macs)}
         out = {"metric": "images/sec DeiT-B INT8 @batch256, 1→8 MI355X; % INT8 MFMA peak",
