@@ -4,30 +4,32 @@
 //   -> IVITIntSoftmax (Shiftmax, ivit_modules.py:150-179) -> matmul_2 -> qact2
 // without materialising the [B,H,T,T] score tensor.
 //
-// MFMA formulation (v_mfma_i32_32x32x32_i8, 64-lane waves):
-//   S^T tile = K_tile . Q_tile^T : keys are the "A" rows, queries the "B" columns, so a lane owns ONE
-//   query (col = lane&31) and 16 of the tile's 32 keys in its registers
-//   (key = 32kt + (r&3) + 8(r>>2) + 4(lane>>5)); the other 16 live in lane^32.  A whole softmax row
-//   (<= 224 keys) is therefore 7x16 registers in two lanes: the row max / row sum are register
-//   reductions plus ONE cross-lane exchange.
-//   O^T tile = Vt . P^T : the packed int8 probabilities are used directly as the "B" operand (byte
-//   4(r>>2)+(r&3) of k-step kt); V is transposed once per workgroup into LDS with its keys stored in
-//   exactly that byte order, so the "A" fragment is a single ds_read_b128.
-// Shiftmax's integer exponential depends only on (row max - k) in [0,255]: it is tabulated once per
-// workgroup in LDS (256 x u32) with the reference's arithmetic (shiftexp_int), the row sum is an
-// exact u32 sum rounded once to float32 (= the reference's float32 sum whenever that is exact).
+// MFMA formulation (v_mfma_i32_16x16x64_i8: the whole head dimension is ONE instruction deep):
+//   S^T tile (16 keys x 16 queries) = K_tile . Q_tile^T: keys are the "A" rows, queries the "B" columns, so a
+//   lane owns ONE query (col = lane&15) and 4 keys of each 16-key tile (key = 16kt + 4(lane>>4) + r); the lanes
+//   l, l^16, l^32, l^48 share a query.  A whole Shiftmax row (<= 208 keys) is 13 x 4 registers in four lanes:
+//   row max / row sum are register reductions plus two cross-lane exchanges.  ~110 VGPRs, so several
+//   workgroups share a CU and one wave's Shiftmax arithmetic (VALU) runs under another's MFMAs.
+//   O^T tile (16 d x 16 queries) = Vt . P^T over key steps of 64: the packed int8 probabilities of four
+//   consecutive key tiles ARE the "B" fragment (byte 4t + r of step s = key 64s + 16t + 4g + r); V is transposed
+//   once per workgroup into LDS with its keys stored in exactly that byte order, so the "A" fragment is a single
+//   ds_read_b128.  Both LDS images are swizzled for conflict-free 16-lane-group reads.
+// Shiftmax's integer exponential depends only on (row max - k) in [0,255]: tabulated once per workgroup in LDS
+// (256 x u32) with the reference's arithmetic (shiftexp_int); the row sum is an exact u32 sum rounded once to
+// float32 (= the reference's float32 sum whenever that is exact).
 #include "common.h"
 
 namespace {
 
 constexpr int NT = 256;
-constexpr int HD = 64;              // head dim
-constexpr int NKT = 7;              // key tiles of 32 (tokens <= 224)
-constexpr int KPAD = NKT * 32;      // 224
-constexpr int VT_STRIDE = KPAD + 16;  // 240: ds_read_b128 of 16 lanes with distinct d hit 16 distinct slots
-constexpr int K_BYTES = KPAD * HD;          // 14336
-constexpr int VT_BYTES = HD * VT_STRIDE;    // 15360
-constexpr int LUT_OFF = K_BYTES + VT_BYTES; // 29696
+constexpr int HD = 64;                 // head dim = one 16x16x64 MFMA deep
+constexpr int NKT = 13;                // key tiles of 16 (tokens <= 208)
+constexpr int KP = NKT * 16;           // 208 K rows in LDS
+constexpr int NKS = 4;                 // key steps of 64 for P.V (256 key slots; P = 0 beyond T)
+constexpr int VT_ROW = NKS * 64;       // 256 B per d row: one bank row, chunk j stored at j ^ (d & 15)
+constexpr int K_BYTES = KP * HD;       // 13312
+constexpr int VT_BYTES = HD * VT_ROW;  // 16384
+constexpr int LUT_OFF = K_BYTES + VT_BYTES;
 constexpr int SMEM_BYTES = LUT_OFF + 256 * 4;
 
 struct AttnArgs {
@@ -35,19 +37,23 @@ struct AttnArgs {
     int8_t* out;
     int batch, heads, tokens;
     double Ms, Mo;
-    int x0;  // floor(-1/s_attn)
+    int x0;    // floor(-1/s_attn)
+    int ksat;  // first table index whose argument is clamped at n*x0: every later entry is identical
 };
 
-IVIT_DEV int kswz(int r, int c) { return r * HD + ((c ^ ((r >> 2) & 3)) << 4); }
+// K image: 64-byte rows; 16-byte chunk c of row r at slot (c + 2*((r>>2)&1)) & 3.  A 16x16x64 fragment read has
+// lanes 0-15 on rows 0-15 chunk 0, lanes 16-31 chunk 1, ...; with this rotation every ds_read_b128 lane group
+// ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ...) touches 16 distinct 16-byte slots of the 256-byte bank row.
+IVIT_DEV int kswz(int r, int c) { return r * HD + (((c + 2 * ((r >> 2) & 1)) & 3) << 4); }
 
-__global__ __launch_bounds__(NT) void attention_kernel(AttnArgs a)
+__global__ __launch_bounds__(NT, 3) void attention_kernel(AttnArgs a)
 {
     __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
     const int T = a.tokens;
     const int bh = blockIdx.x;
     const int b = bh / a.heads, hh = bh - b * a.heads;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int h = lane >> 5, l31 = lane & 31;
+    const int g = lane >> 4, l15 = lane & 15;
     const int64_t plane = (int64_t)a.batch * a.heads * T * HD;
     const int8_t* qg = a.qkv + (int64_t)bh * T * HD;
     const int8_t* kg = qg + plane;
@@ -56,61 +62,72 @@ __global__ __launch_bounds__(NT) void attention_kernel(AttnArgs a)
     // ---- Shiftmax exponent table: lut[i] = int_exp_shift(-i), i = kmax - k in [0,255]
     reinterpret_cast<unsigned*>(smem + LUT_OFF)[tid] = shiftexp_int(-tid, a.x0, 15);
 
-    // ---- K tile [key][64] (swizzled 16-byte chunks); rows >= T are never consumed unmasked
+    // ---- K tile [key][64]; rows >= T are never consumed unmasked
     for (int q = tid; q < T * 4; q += NT) {
         int r = q >> 2, c = q & 3;
         v4i v = *reinterpret_cast<const v4i*>(kg + (int64_t)r * HD + 16 * c);
         *reinterpret_cast<v4i*>(smem + kswz(r, c)) = v;
     }
-    // ---- V transposed: Vt[d][32kt + 16h' + 4g + j] = V[key = 32kt + 8g + 4h' + j][d]
-    for (int q = tid; q < T * 4; q += NT) {
-        int key = q >> 2, c = q & 3;
-        v4i v = *reinterpret_cast<const v4i*>(vg + (int64_t)key * HD + 16 * c);
-        int kap = key & 31;
-        int pos = (key & ~31) + 16 * ((kap >> 2) & 1) + 4 * (kap >> 3) + (kap & 3);
-        char* dst = smem + K_BYTES + (16 * c) * VT_STRIDE + pos;
+    // ---- V transposed: Vt[d][chunk j = 4s + g'][byte 4t + r] = V[key = 64s + 16t + 4g' + r][d], chunk j of row d
+    //      stored at position j ^ (d & 15).  One work item = 4 consecutive keys x 16 d: the 4x4 byte blocks are
+    //      transposed in registers (v_perm_b32), so every LDS write is a whole dword (4 keys of one d).
+    for (int q = tid; q < ((T + 3) >> 2) * 4; q += NT) {
+        const int kg4 = q >> 2, c = q & 3;      // keys 4*kg4 .. 4*kg4+3, d = 16c .. 16c+15
+        v4i v[4];
 #pragma unroll
-        for (int w = 0; w < 4; ++w)
+        for (int r = 0; r < 4; ++r)
+            v[r] = *reinterpret_cast<const v4i*>(vg + (int64_t)min(4 * kg4 + r, T - 1) * HD + 16 * c);
+        const int key0 = 4 * kg4;
+        const int j = 4 * (key0 >> 6) + ((key0 >> 2) & 3);
+        const int boff = 4 * ((key0 >> 4) & 3);
 #pragma unroll
-            for (int bb = 0; bb < 4; ++bb) dst[(4 * w + bb) * VT_STRIDE] = (char)(v[w] >> (8 * bb));
+        for (int w = 0; w < 4; ++w) {
+            // rows = keys r (v[r][w] holds d = 16c+4w .. +3 in its bytes) -> columns: dword bb = 4 keys of d = 16c+4w+bb
+            const unsigned a0 = (unsigned)v[0][w], a1 = (unsigned)v[1][w], a2 = (unsigned)v[2][w], a3 = (unsigned)v[3][w];
+            const unsigned lo01 = __builtin_amdgcn_perm(a1, a0, 0x05010400u);  // a0.b0 a1.b0 a0.b1 a1.b1
+            const unsigned hi01 = __builtin_amdgcn_perm(a1, a0, 0x07030602u);  // a0.b2 a1.b2 a0.b3 a1.b3
+            const unsigned lo23 = __builtin_amdgcn_perm(a3, a2, 0x05010400u);
+            const unsigned hi23 = __builtin_amdgcn_perm(a3, a2, 0x07030602u);
+            const unsigned t[4] = {__builtin_amdgcn_perm(lo23, lo01, 0x05040100u),   // d+0: a0.b0 a1.b0 a2.b0 a3.b0
+                                   __builtin_amdgcn_perm(lo23, lo01, 0x07060302u),   // d+1
+                                   __builtin_amdgcn_perm(hi23, hi01, 0x05040100u),   // d+2
+                                   __builtin_amdgcn_perm(hi23, hi01, 0x07060302u)};  // d+3
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) {
+                const int d = 16 * c + 4 * w + bb;
+                *reinterpret_cast<unsigned*>(smem + K_BYTES + d * VT_ROW + ((j ^ (d & 15)) << 4) + boff) = t[bb];
+            }
+        }
     }
     __syncthreads();
 
     const unsigned* lut = reinterpret_cast<const unsigned*>(smem + LUT_OFF);
-    const int nqt = (T + 31) >> 5;
+    const int nqt = (T + 15) >> 4;
 
     for (int qt = wave; qt < nqt; qt += 4) {
-        const int qrow = qt * 32 + l31;           // this lane's query
+        const int qrow = qt * 16 + l15;  // this lane's query
         const int qld = min(qrow, T - 1);
-        v4i qf[2];
-        qf[0] = *reinterpret_cast<const v4i*>(qg + (int64_t)qld * HD + 16 * h);
-        qf[1] = *reinterpret_cast<const v4i*>(qg + (int64_t)qld * HD + 32 + 16 * h);
+        const v4i qf = *reinterpret_cast<const v4i*>(qg + (int64_t)qld * HD + 16 * g);
 
         // ---- S^T = K . Q^T, requantised to the 8-bit Shiftmax input (qact_attn1)
-        int s[NKT][16];
+        int s[NKT][4];
         int rmax = -1000;
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
-            v16i acc;
+            const v4i kf = *reinterpret_cast<const v4i*>(smem + kswz(16 * kt + l15, g));
+            v4i acc = {0, 0, 0, 0};
+            acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(kf, qf, acc, 0, 0, 0);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                v4i kf = *reinterpret_cast<const v4i*>(smem + kswz(32 * kt + l31, 2 * ks + h));
-                acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(kf, qf[ks], acc, 0, 0, 0);
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
+            for (int r = 0; r < 4; ++r) {
                 // |S| <= 64*128*128 = 2^20, m < 2^32: the product is exact in float64
                 int ka = clamp_i32(requant_exact(acc[r], a.Ms), -128, 127);
-                if (kt == NKT - 1) {
-                    int key = 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    ka = (key < T) ? ka : -1000;
-                }
+                if (kt == NKT - 1) ka = (16 * kt + 4 * g + r < T) ? ka : -1000;
                 s[kt][r] = ka;
                 rmax = max(rmax, ka);
             }
+            if ((kt & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // at most 4 K fragments in flight (registers)
         }
+        rmax = max(rmax, __shfl_xor(rmax, 16));
         rmax = max(rmax, __shfl_xor(rmax, 32));
 
         // ---- Shiftmax (ivit_modules.py:164-175): e = exp_int(k - max), sum, factor, e*factor >> 24
@@ -118,56 +135,56 @@ __global__ __launch_bounds__(NT) void attention_kernel(AttnArgs a)
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                unsigned e = lut[(rmax - s[kt][r]) & 255];
+            for (int r = 0; r < 4; ++r) {
+                unsigned e = lut[min(rmax - s[kt][r], a.ksat) & 255];
                 if (kt == NKT - 1) e = (s[kt][r] == -1000) ? 0u : e;
                 s[kt][r] = (int)e;
                 esum += e;
             }
+        esum += __shfl_xor(esum, 16);
         esum += __shfl_xor(esum, 32);
-        float S = (float)esum;                            // exp_int.sum (:171)
-        S = fminf(S, 2147483648.0f);                      // clamp_max_(2**31-1) in float32 (:173)
-        const float factor = floorf((1.0f / S) * 2147483648.0f);  // (:174)
+        float S = (float)esum;                                     // exp_int.sum (:171)
+        S = fminf(S, 2147483648.0f);                               // clamp_max_(2**31-1) in float32 (:173)
+        const float factor = floorf((1.0f / S) * 2147483648.0f);   // (:174)
 
-        v4i pk[NKT];
+        // packed probabilities: dword t of key step ks = bytes r = 0..3 of key tile 4ks + t
+        v4i pk[NKS];
 #pragma unroll
-        for (int kt = 0; kt < NKT; ++kt)
+        for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
+            for (int t = 0; t < 4; ++t) {
                 unsigned w = 0;
+                if (4 * ks + t < NKT) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float pr = (float)(unsigned)s[kt][4 * g4 + j] * factor;  // float32 product (:175)
-                    unsigned p = ((unsigned)pr) >> 24;                        // floor(. / 2^24)
-                    w |= (p & 0xffu) << (8 * j);
+                    for (int r = 0; r < 4; ++r) {
+                        float pr = (float)(unsigned)s[4 * ks + t][r] * factor;  // float32 product (:175)
+                        unsigned p = ((unsigned)pr) >> 24;                       // floor(. / 2^24)
+                        w |= (p & 0xffu) << (8 * r);
+                    }
                 }
-                pk[kt][g4] = (int)w;
+                pk[ks][t] = (int)w;
             }
 
         // ---- O^T = Vt . P^T, requantised (attn.qact2), 4 consecutive d per dword
+        int8_t* orow = a.out + ((int64_t)b * T + qrow) * ((int64_t)a.heads * HD) + hh * HD + 4 * g;
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-            v16i acc;
+        for (int dt = 0; dt < 4; ++dt) {
+            v4i acc = {0, 0, 0, 0};
+            const int d = 16 * dt + l15;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0;
-#pragma unroll
-            for (int kt = 0; kt < NKT; ++kt) {
-                v4i vf = *reinterpret_cast<const v4i*>(smem + K_BYTES + (32 * dt + l31) * VT_STRIDE + 32 * kt + 16 * h);
-                acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(vf, pk[kt], acc, 0, 0, 0);
+            for (int ks = 0; ks < NKS; ++ks) {
+                const v4i vf = *reinterpret_cast<const v4i*>(smem + K_BYTES + d * VT_ROW + (((4 * ks + g) ^ (d & 15)) << 4));
+                acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(vf, pk[ks], acc, 0, 0, 0);
             }
             if (qrow < T) {
-                int8_t* orow = a.out + ((int64_t)b * T + qrow) * ((int64_t)a.heads * HD) + hh * HD + 32 * dt + 4 * h;
+                unsigned w = 0;
 #pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    unsigned w = 0;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        // |O| <= 224*127*128 < 2^22: exact float64 product
-                        int o = clamp_i32(requant_exact(acc[4 * g4 + j], a.Mo), -128, 127);
-                        w |= ((unsigned)o & 0xffu) << (8 * j);
-                    }
-                    *reinterpret_cast<unsigned*>(orow + 8 * g4) = w;
+                for (int r = 0; r < 4; ++r) {
+                    // |O| <= 208*127*128 < 2^22: exact float64 product
+                    int o = clamp_i32(requant_exact(acc[r], a.Mo), -128, 127);
+                    w |= ((unsigned)o & 0xffu) << (8 * r);
                 }
+                *reinterpret_cast<unsigned*>(orow + 16 * dt) = w;
             }
         }
     }
@@ -181,8 +198,8 @@ IVIT_EXPORT int ivit_attention_fused_i8(const int8_t* qkv, int8_t* out, int batc
 {
     IVIT_REQUIRE(qkv && out, "ivit_attention_fused_i8: NULL operand");
     IVIT_REQUIRE(batch > 0 && heads > 0, "ivit_attention_fused_i8: empty batch");
-    if (head_dim != HD || tokens <= 32 * (NKT - 1) || tokens > KPAD) {
-        ivit_set_error("ivit_attention_fused_i8: unsupported geometry head_dim=%d tokens=%d (need 64, 193..224)",
+    if (head_dim != HD || tokens <= 16 * (NKT - 1) || tokens > KP) {
+        ivit_set_error("ivit_attention_fused_i8: unsupported geometry head_dim=%d tokens=%d (need 64, 193..208)",
                        head_dim, tokens);
         return IVIT_ERR_UNSUPPORTED;
     }
@@ -200,6 +217,12 @@ IVIT_EXPORT int ivit_attention_fused_i8(const int8_t* qkv, int8_t* out, int batc
     IVIT_REQUIRE((double)tokens * (double)(-a.x0) * 32768.0 < 4294967296.0,
                  "ivit_attention_fused_i8: Shiftmax row sum could overflow 32 bits (x0=%d)", a.x0);
     IVIT_REQUIRE(a.Ms < 2048.0 && a.Mo < 512.0, "ivit_attention_fused_i8: requant multiplier too large");
+    a.ksat = 255;
+    for (int i = 0; i < 256; ++i) {
+        const int d = -i;
+        const int x = d + (d >> 1) - (d >> 4);  // ivit_modules.py:151 (arithmetic shifts = floor)
+        if (x <= 15 * a.x0) { a.ksat = i; break; }
+    }
     hipLaunchKernelGGL(attention_kernel, dim3(batch * heads), dim3(NT), 0, ivit_stream(stream), a);
     IVIT_CHECK_LAUNCH("ivit_attention_fused_i8");
 }

@@ -33,6 +33,7 @@ enum { EPI_RQ = 0, EPI_RESID = 1, EPI_QKV = 2, EPI_I32 = 3 };
 
 int g_kernel_choice = 0;      // 0 = automatic, 1 = never the 256x256 kernel (tests / A-B timing)
 bool g_force_small = false;  // tests: route every problem through the small-tile kernel
+void* g_stamp_buf = nullptr;
 int g_debug_flags = 0;       // perf ablations (scripts/gemm_ablate.py): 1 = skip DMA in the loop, 2 = skip MFMA, 4 = skip epilogue
 
 struct GemmArgs {
@@ -94,6 +95,9 @@ template <int EPI, int TI, int TJ, int TOK, int NTHREADS, int ABL = 0, int CH = 
 IVIT_DEV void epilogue_i8(v16i (&acc)[TI][TJ], const GemmArgs& g, char* smem, const char* rq_lds, int m0, int n0,
                           int wch, int wtok, int tid, int h, int l31)
 {
+    // The epilogue is a short VALU burst next to the co-resident workgroup's MFMA stream: give it issue priority
+    // so its dependent chains do not wait behind queued MFMAs (which run in the matrix pipe once issued).
+    __builtin_amdgcn_s_setprio(2);
     constexpr int CSS = CH + 4;       // LDS row stride: (CH/4 + 1) dwords, odd -> conflict-free dword writes
     constexpr int CPR = CH / 16;      // 16-byte chunks per row
     // Phase 1.  out = clamp8(RNE(acc * M)), M = m * 2^-e, must equal the reference's float64
@@ -114,50 +118,66 @@ IVIT_DEV void epilogue_i8(v16i (&acc)[TI][TJ], const GemmArgs& g, char* smem, co
             const float4 lh23 = *reinterpret_cast<const float4*>(rq + cl + 2);  // lo2 hi2 lo3 hi3
             const float lo[4] = {lh01.x, lh01.z, lh23.x, lh23.z};
             const float hi[4] = {lh01.y, lh01.w, lh23.y, lh23.w};
+            // one branch-free batch of TJ*4 independent chains (instruction-level parallelism: the wave that
+            // runs this shares its SIMD with a main-loop wave, so there is no second VALU wave to hide latency)
+            int b[TJ][4];
+            unsigned unc = 0;      // OR of (t_lo ^ t_hi): non-zero <=> some certificate failed
+            float amax = 0.0f;
 #pragma unroll
-            for (int j = 0; j < TJ; ++j) {
-                int b[4];
-                bool unc = false;
-                float amax = 0.0f;
+            for (int j = 0; j < TJ; ++j)
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
                     if constexpr (ABL & 8) {
-                        b[jj] = acc[i][j][4 * q + jj] + (int)lo[jj];
+                        b[j][jj] = acc[i][j][4 * q + jj] + (int)lo[jj];
                     } else {
                         const float a = (float)acc[i][j][4 * q + jj];
                         const int tl = __float_as_int(__builtin_fmaf(a, lo[jj], 12582912.0f));
                         const int th = __float_as_int(__builtin_fmaf(a, hi[jj], 12582912.0f));
-                        unc |= (tl != th);
+                        unc |= (unsigned)(tl ^ th);
+                        asm volatile("" : "+v"(unc));  // keep the xor/or form (no per-element compare + select)
                         amax = fmaxf(amax, fabsf(a));
-                        b[jj] = clamp_i32(tl, 0x4B400000 - 128, 0x4B400000 + 127);  // low byte = int8 result
+                        b[j][jj] = clamp_i32(tl, 0x4B400000 - 128, 0x4B400000 + 127);  // low byte = int8 result
                     }
                 }
-                if constexpr (!(ABL & 8)) {
-                    unc |= (amax >= 4194304.0f);
-                    if (__builtin_amdgcn_ballot_w64(unc) != 0) {  // rare: exact float64 evaluation
-                        const int c0 = min(n0 + cl, g.N - 4);
-                        const uint4 m4 = *reinterpret_cast<const uint4*>(g.m + c0);
-                        const int4 e4 = *reinterpret_cast<const int4*>(g.e + c0);
-                        const double Mc[4] = {dyadic_mult(m4.x, e4.x), dyadic_mult(m4.y, e4.y),
-                                              dyadic_mult(m4.z, e4.z), dyadic_mult(m4.w, e4.w)};
+            if constexpr (!(ABL & 8)) {
+                const bool bad = (unc != 0) | (amax >= 4194304.0f);
+                if (__builtin_amdgcn_ballot_w64(bad) != 0) {  // rare: exact float64 evaluation of the batch
+                    const int c0 = min(n0 + cl, g.N - 4);
+                    const uint4 m4 = *reinterpret_cast<const uint4*>(g.m + c0);
+                    const int4 e4 = *reinterpret_cast<const int4*>(g.e + c0);
+                    const double Mc[4] = {dyadic_mult(m4.x, e4.x), dyadic_mult(m4.y, e4.y), dyadic_mult(m4.z, e4.z),
+                                          dyadic_mult(m4.w, e4.w)};
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j)
 #pragma unroll
                         for (int jj = 0; jj < 4; ++jj) {
                             // quant_utils.py:229-230: float64 product (53-bit rounding), /2^e, round-half-even
                             double p = (double)acc[i][j][4 * q + jj] * Mc[jj];
                             double t = p + IVIT_MAGIC;
-                            b[jj] = clamp_i32((int)(unsigned)__double_as_longlong(t), -128, 127);
+                            b[j][jj] = clamp_i32((int)(unsigned)__double_as_longlong(t), -128, 127);
                         }
-                    }
                 }
+            }
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
                 const int tl_ = wtok + 32 * j + l31;
-                const unsigned w01 = __builtin_amdgcn_perm((unsigned)b[1], (unsigned)b[0], 0x0c0c0400u);
-                const unsigned w23 = __builtin_amdgcn_perm((unsigned)b[3], (unsigned)b[2], 0x04000c0cu);
+                const unsigned w01 = __builtin_amdgcn_perm((unsigned)b[j][1], (unsigned)b[j][0], 0x0c0c0400u);
+                const unsigned w23 = __builtin_amdgcn_perm((unsigned)b[j][3], (unsigned)b[j][2], 0x04000c0cu);
                 *reinterpret_cast<unsigned*>(smem + tl_ * CSS + cl) = w01 | w23;
             }
         }
         __builtin_amdgcn_sched_barrier(0);
     }
+    unsigned long long t_p1 = 0, t_sync = 0;
+    if constexpr (ABL & 512) t_p1 = __builtin_amdgcn_s_memtime();
     __syncthreads();
+    if constexpr (ABL & 512) {
+        t_sync = __builtin_amdgcn_s_memtime();
+        if (tid == 0 && g.res != nullptr) {
+            unsigned long long* d = reinterpret_cast<unsigned long long*>(const_cast<int8_t*>(g.res)) + 8ull * blockIdx.x;
+            d[4] = t_p1; d[5] = t_sync;
+        }
+    }
     if constexpr (ABL & 16) return;
 
     int8_t* out = reinterpret_cast<int8_t*>(g.out);
@@ -354,6 +374,11 @@ template <int EPI, int ABL>
 __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_big_kernel(GemmArgs g)
 {
     __shared__ __attribute__((aligned(16))) char smem[BIG_SMEM + BCH * 8];
+    unsigned long long t_start = 0, t_loop = 0, t_epi = 0, r_start = 0;
+    if constexpr (ABL & 512) {
+        t_start = __builtin_amdgcn_s_memtime();
+        r_start = __builtin_amdgcn_s_memrealtime();
+    }
 
     const int nblk = g.tiles_m * g.tiles_n;
     const int bid = blockIdx.x;
@@ -366,7 +391,6 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_big_kernel(GemmArgs g)
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wc = wave >> 1, wt = wave & 1;
     const int h = lane >> 5, l31 = lane & 31;
-    fill_rq_table(g, smem + BIG_SMEM, n0, BCH, tid);
 
     // ---- LDS-DMA sources: instruction q covers tile rows 16q..16q+15 (1 KiB); lane -> row 16q + lane/4,
     // stored slot lane%4 holds global chunk (lane%4) ^ ((row>>2)&3)
@@ -385,17 +409,6 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_big_kernel(GemmArgs g)
         int c = lslot ^ ((row >> 2) & 3);
         wsrc[i] = g.W + (int64_t)min(n0 + row, g.N - 1) * g.ldw + 16 * c;
     }
-
-    v16i acc[2][4];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            int cn = n0 + 64 * wc + 32 * i + 8 * (r >> 2) + 4 * h + (r & 3);
-            int b = (g.bias != nullptr && cn < g.N) ? g.bias[cn] : 0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j][r] = b;
-        }
 
     const int nk = g.K / BK;
     // DMA piece `idx` (0..3: token tile, 4..5: weight tile) of K step kt
@@ -424,11 +437,29 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_big_kernel(GemmArgs g)
         if (slot)
             for (int it = 0; it < (nk_of(g) + 1) / 2; ++it) __builtin_amdgcn_s_sleep(64);
     }
-    // make sure the bias loads are retired before the DMA pipeline starts (the compiler's vmcnt
-    // bookkeeping must not meet an in-flight DMA at an ordinary load's use)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // Start the DMA ring first, then fetch the bias / requant tables under its latency.  The ordinary loads'
+    // results are consumed right here, where a full vmcnt(0) drain (which also retires both stages) is wanted
+    // anyway; no ordinary load remains in flight once the main loop starts.
     issue(0);
     if (nk > 1) issue(1);
+    fill_rq_table(g, smem + BIG_SMEM, n0, BCH, tid);
+    v16i acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c0 = n0 + 64 * wc + 32 * i + 8 * q + 4 * h;   // 4 consecutive channels of this register quad
+            int4 b4 = make_int4(0, 0, 0, 0);
+            if (g.bias != nullptr && c0 < g.N) b4 = *reinterpret_cast<const int4*>(g.bias + c0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[i][j][4 * q + 0] = b4.x;
+                acc[i][j][4 * q + 1] = b4.y;
+                acc[i][j][4 * q + 2] = b4.z;
+                acc[i][j][4 * q + 3] = b4.w;
+            }
+        }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     const int wrow0 = 64 * wc + l31, arow0 = 128 * wt + l31;
     // fragment byte offsets inside a stage for k-sub-step 0 / 1 (the swizzle depends on the row only)
@@ -495,8 +526,6 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_big_kernel(GemmArgs g)
     using T = std::true_type;
     using F = std::false_type;
 
-    if (nk > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     load_frags(smem, 0, wf0, af0);
@@ -509,6 +538,7 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_big_kernel(GemmArgs g)
     if (kt + 1 < nk) { step(kt, F{}, F{}); ++kt; }
     step(kt, F{}, T{});
     __syncthreads();  // every wave is done with the last stage before the tile is reused
+    if constexpr (ABL & 512) t_loop = __builtin_amdgcn_s_memtime();
     if constexpr (ABL & 4) {
         int x = 0;
 #pragma unroll
@@ -521,6 +551,15 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_big_kernel(GemmArgs g)
         return;
     }
     epilogue_i8<EPI, 2, 4, BTOK, BIG_NT, ABL>(acc, g, smem, smem + BIG_SMEM, m0, n0, 64 * wc, 128 * wt, tid, h, l31);
+    if constexpr (ABL & 512) {   // diagnostic build only: per-workgroup timeline into a buffer nothing else reads
+        t_epi = __builtin_amdgcn_s_memtime();
+        if (tid == 0 && g.res != nullptr) {
+            unsigned long long* d = reinterpret_cast<unsigned long long*>(const_cast<int8_t*>(g.res)) + 8ull * blockIdx.x;
+            d[0] = __builtin_amdgcn_s_getreg((15 << 11) | (0 << 6) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) << 32);
+            d[1] = t_start; d[2] = t_loop; d[3] = t_epi;
+            d[6] = r_start; d[7] = __builtin_amdgcn_s_memrealtime();
+        }
+    }
 }
 
 
@@ -705,6 +744,7 @@ int launch_gemm(GemmArgs& g, const char* name, ivit_stream_t stream)
                      g.N, (long long)g.ldo);
     } else {
         IVIT_REQUIRE(g.m && g.e, "%s: NULL requantiser table", name);
+        IVIT_REQUIRE(((uintptr_t)g.bias % 16 == 0), "%s: bias must be 16-byte aligned", name);
         IVIT_REQUIRE(g.N % 16 == 0, "%s: N=%d must be a multiple of 16", name, g.N);
         IVIT_REQUIRE(((uintptr_t)g.m % 16 == 0) && ((uintptr_t)g.e % 16 == 0), "%s: m/e tables must be 16-byte aligned",
                      name);
@@ -721,7 +761,7 @@ int launch_gemm(GemmArgs& g, const char* name, ivit_stream_t stream)
         IVIT_REQUIRE(g.N == 3 * g.heads * g.head_dim && g.M % g.tokens == 0,
                      "%s: N=%d != 3*heads*head_dim or M=%d %% tokens=%d != 0", name, g.N, g.M, g.tokens);
     }
-    g.flags = g_debug_flags & (31 | 128 | 256);
+    g.flags = g_debug_flags & (31 | 128 | 256 | 512);
     if constexpr (EPI != EPI_I32) {
         if (g.M >= 2048 && g.N % XCH == 0 && !g_force_small && g_kernel_choice != 1 &&
             (g_debug_flags & 32)) {
@@ -768,6 +808,12 @@ int launch_gemm(GemmArgs& g, const char* name, ivit_stream_t stream)
                     case 19: hipLaunchKernelGGL((gemm_i8_big_kernel<EPI_RQ, 19>), grid, blk, 0, st, g); break;
                     case 133: hipLaunchKernelGGL((gemm_i8_big_kernel<EPI_RQ, 133>), grid, blk, 0, st, g); break;
                     case 389: hipLaunchKernelGGL((gemm_i8_big_kernel<EPI_RQ, 389>), grid, blk, 0, st, g); break;
+                    case 512: g.res = (const int8_t*)g_stamp_buf; hipLaunchKernelGGL((gemm_i8_big_kernel<EPI_RQ, 512>), grid, blk, 0, st, g); break;
+                    case 515: g.res = (const int8_t*)g_stamp_buf; hipLaunchKernelGGL((gemm_i8_big_kernel<EPI_RQ, 515>), grid, blk, 0, st, g); break;
+                    case 516: g.res = (const int8_t*)g_stamp_buf; hipLaunchKernelGGL((gemm_i8_big_kernel<EPI_RQ, 516>), grid, blk, 0, st, g); break;
+                    case 517: g.res = (const int8_t*)g_stamp_buf; hipLaunchKernelGGL((gemm_i8_big_kernel<EPI_RQ, 517>), grid, blk, 0, st, g); break;
+                    case 518: g.res = (const int8_t*)g_stamp_buf; hipLaunchKernelGGL((gemm_i8_big_kernel<EPI_RQ, 518>), grid, blk, 0, st, g); break;
+                    case 513: g.res = (const int8_t*)g_stamp_buf; hipLaunchKernelGGL((gemm_i8_big_kernel<EPI_RQ, 513>), grid, blk, 0, st, g); break;
                     default: hipLaunchKernelGGL((gemm_i8_big_kernel<EPI_RQ, 3>), grid, blk, 0, st, g); break;
                 }
             } else {
@@ -842,5 +888,13 @@ IVIT_EXPORT int ivit_debug_force_small_gemm(int on)
 IVIT_EXPORT int ivit_debug_set_gemm_flags(int flags)
 {
     g_debug_flags = flags;
+    return IVIT_OK;
+}
+
+// diagnostic: device buffer (8 x uint64 per workgroup) receiving {HW_ID | XCC_ID<<32, t_start, t_loop_end, t_end}
+// from the stamped build selected by ivit_debug_set_gemm_flags(512)
+IVIT_EXPORT int ivit_debug_set_stamp_buffer(void* buf)
+{
+    g_stamp_buf = buf;
     return IVIT_OK;
 }

@@ -58,6 +58,7 @@ int ivit_quantize_patchify_f32_i8(const float* img, int8_t* A, int batch, int ch
  * quant_utils.py:193-253).
  *   acc[t][n] = sum_k A[t][k] * W[n][k] + bias[n]          (exact int32)
  * A [M, K] int8 (lda), W [N, K] int8 (ldw), bias [N] int32 or NULL.  K % 64 == 0.
+ * Contract for the requantising forms: e[n] >= 31 (multiplier <= 1: int32 accumulators -> 8 bits).
  */
 
 /* out[t][n] = clamp8(RNE(acc * m[n] / 2^e[n]));  N % 16 == 0 */
@@ -94,6 +95,8 @@ int ivit_debug_force_small_gemm(int on);
 /* Perf-ablation hook for scripts/gemm_ablate.py (bit 0: skip the in-loop DMA, bit 1: skip the MFMAs,
  * bit 2: skip the epilogue); results are WRONG whenever flags != 0. */
 int ivit_debug_set_gemm_flags(int flags);
+/* Diagnostic timeline buffer (8 x uint64 per workgroup) for the stamped build (flags = 512); scripts/gemm_timeline.py */
+int ivit_debug_set_stamp_buffer(void* buf);
 
 /* ---- fused attention core -------------------------------------------------------------------
  * vit_quant.py:72-85: matmul_1 (q.k^T) -> qact_attn1 -> IVITIntSoftmax (Shiftmax,
@@ -104,7 +107,7 @@ int ivit_debug_set_gemm_flags(int flags);
  *   (m_s, e_s): requantiser of q.k^T into the Shiftmax input (8 bit)
  *   s_attn: float32 scale of the Shiftmax input (x0 = floor(-1/s_attn), n = 15)
  *   (m_o, e_o): requantiser of P.v into the 8-bit output.
- * Supported: head_dim 64, 160 < tokens <= 224. */
+ * Supported: head_dim 64, 193 <= tokens <= 208 (13 key tiles of 16). */
 int ivit_attention_fused_i8(const int8_t* qkv, int8_t* out, int batch, int heads, int tokens, int head_dim,
                             uint32_t m_s, int32_t e_s, float s_attn, uint32_t m_o, int32_t e_o,
                             ivit_stream_t stream);
@@ -113,7 +116,8 @@ int ivit_attention_fused_i8(const int8_t* qkv, int8_t* out, int batch, int heads
  * IVITIntLayerNorm.forward (ivit_modules.py:30-65) then QuantAct (fixedpoint_mul).
  *   x [rows, C] int8 (ldx), per channel: bias_int[c] = floor((beta/gamma)/(sqrt(C)/2^30)),
  *   s_ln[c] = (sqrt(C)/2^30)*gamma[c] (both float32, prepared by the caller as the reference
- *   computes them, :53-62), (m[c], e[c]) requantiser s_ln[c] -> output scale.
+ *   computes them, :53-62), (m[c], e[c]) requantiser s_ln[c] -> output scale; contract e[c] >= 40
+ *   (multiplier <= 2^-9: I-LayerNorm outputs are ~30-bit integers requantised to 8 bits).
  *   out [rows, C] int8 (ldo).  C % 4 == 0, C <= 4096. */
 int ivit_layernorm_i8(const int8_t* x, int64_t ldx, int rows, int C, const float* bias_int, const float* s_ln,
                       const uint32_t* m, const int32_t* e, int8_t* out, int64_t ldo, ivit_stream_t stream);
