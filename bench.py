@@ -111,13 +111,15 @@ def main():
 
     if rank == 0:
         value = world * BATCH * args.steps / dt
-        # dominant kernel: gemm_i8_kernel<EPI_RESID> (attn.proj and mlp.fc2 with the fused residual QuantAct)
+        # dominant kernel: gemm_i8_pers_kernel<EPI_RESID> (attn.proj and mlp.fc2 with the fused residual QuantAct)
         ms = [e0.elapsed_time(e1) for e0, e1, *_ in probe]
         macs = [float(M) * N * K for _, _, M, N, K in probe]
         avg_ms = sum(ms) / len(ms)
         achieved = 2.0 * sum(macs) / (sum(ms) * 1e-3) / 1e12
-        traffic, traffic_src = pmc_traffic("gemm_i8_big_kernel<1, 0>")
-        roof = {"bound": "mfma", "kernel": "gemm_i8_big_kernel<EPI_RESID> (attn.proj + mlp.fc2, residual QuantAct fused)",
+        traffic, traffic_src = pmc_traffic("gemm_i8_pers_kernel<1>")
+        if traffic is None:
+            traffic, traffic_src = pmc_traffic("gemm_i8_big_kernel<1, 0>")
+        roof = {"bound": "mfma", "kernel": "gemm_i8_pers_kernel<EPI_RESID> (attn.proj + mlp.fc2, residual QuantAct fused)",
                 "achieved": round(achieved, 1), "peak": INT8_PEAK_TOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / INT8_PEAK_TOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "launches": len(ms), "avg_launch_ms": round(avg_ms, 4),

@@ -91,9 +91,14 @@ IVIT_DEV void fill_rq_table(const GemmArgs& g, char* rq_lds, int n0, int nch, in
     }
 }
 
-template <int EPI, int TI, int TJ, int TOK, int NTHREADS, int ABL = 0, int CH = 128>
+struct NoHook {
+    IVIT_DEV void issue() const {}
+    IVIT_DEV void consume() const {}
+};
+
+template <int EPI, int TI, int TJ, int TOK, int NTHREADS, int ABL = 0, int CH = 128, typename Hook = NoHook>
 IVIT_DEV void epilogue_i8(v16i (&acc)[TI][TJ], const GemmArgs& g, char* smem, const char* rq_lds, int m0, int n0,
-                          int wch, int wtok, int tid, int h, int l31)
+                          int wch, int wtok, int tid, int h, int l31, const Hook& hook = Hook())
 {
     // The epilogue is a short VALU burst next to the co-resident workgroup's MFMA stream: give it issue priority
     // so its dependent chains do not wait behind queued MFMAs (which run in the matrix pipe once issued).
@@ -184,6 +189,7 @@ IVIT_DEV void epilogue_i8(v16i (&acc)[TI][TJ], const GemmArgs& g, char* smem, co
     constexpr int NIT = TOK * CPR / NTHREADS;
     int v[NIT][4];
     int4 rv[NIT];
+    hook.issue();    // persistent kernel: next tile's table loads go out before this tile's stores
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int q = tid + NTHREADS * it;
@@ -195,6 +201,7 @@ IVIT_DEV void epilogue_i8(v16i (&acc)[TI][TJ], const GemmArgs& g, char* smem, co
             rv[it] = *reinterpret_cast<const int4*>(g.res + (int64_t)t * g.ldr + cn);
         }
     }
+    hook.consume();
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int q = tid + NTHREADS * it;
@@ -729,6 +736,225 @@ __global__ __launch_bounds__(XL_NT, 2) void gemm_i8_xl_kernel(GemmArgs g)
     epilogue_i8<EPI, 2, 4, XTOK, XL_NT, ABL, XCH>(acc, g, smem, smem + XL_SMEM, m0, n0, 64 * wc, 128 * wt, tid, h, l31);
 }
 
+
+// ================================================================================================
+// Persistent form of the 256 x 128 kernel: 2 workgroups per CU loop over tiles (tile = block + k * grid).
+// What a relaunch per tile costs -- workgroup dispatch, the cold start of the DMA ring, table loads --
+// is hidden: stage 0 of the NEXT tile is prefetched into LDS buffer 0 while this tile's epilogue runs
+// (its int8 staging tile lives in buffers 1-2), and the next tile's bias / requant table is fetched
+// inside the epilogue, before this tile's stores are issued, into the other half of a double-buffered
+// LDS table, so the next main loop starts without a vmcnt(0) drain behind those stores.
+// ================================================================================================
+constexpr int PT_OFF = BIG_SMEM;          // tables: 2 x { float2 lohi[128]; int bias[128] }
+constexpr int PT_BYTES = BCH * 12;
+constexpr int PERS_SMEM = BIG_SMEM + 2 * PT_BYTES;
+
+struct PersTile {
+    int m0, n0;
+};
+
+IVIT_DEV PersTile pers_tile(const GemmArgs& g, int t)
+{
+    const int nblk = g.tiles_m * g.tiles_n;
+    const int q8 = nblk >> 3, r8 = nblk & 7, xcd = t & 7;
+    const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (t >> 3);
+    const int tm = lid / g.tiles_n, tn = lid - tm * g.tiles_n;
+    return PersTile{tm * BTOK, tn * BCH};
+}
+
+// loads of one channel's table entry (issued early, consumed later)
+struct PersTableLoad {
+    unsigned m;
+    int e, bias;
+    bool valid;
+};
+
+IVIT_DEV PersTableLoad pers_table_issue(const GemmArgs& g, int n0, int tid)
+{
+    PersTableLoad r{0u, 0, 0, false};
+    const int c = n0 + tid;
+    if (tid < BCH && c < g.N) {
+        r.m = g.m[c];
+        r.e = g.e[c];
+        r.bias = g.bias ? g.bias[c] : 0;
+        r.valid = true;
+    }
+    return r;
+}
+
+IVIT_DEV void pers_table_write(const PersTableLoad& r, char* tab, int tid)
+{
+    if (tid < BCH) {
+        float2 lh = make_float2(0.f, 0.f);
+        if (r.valid) {
+            const double M = dyadic_mult(r.m, r.e);
+            const float mf = (float)M;
+            const int bits = __float_as_int(mf);
+            lh.x = ((double)mf > M) ? __int_as_float(bits - 1) : mf;
+            lh.y = ((double)mf < M) ? __int_as_float(bits + 1) : mf;
+        }
+        reinterpret_cast<float2*>(tab)[tid] = lh;
+        reinterpret_cast<int*>(tab + BCH * 8)[tid] = r.bias;
+    }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_pers_kernel(GemmArgs g)
+{
+    __shared__ __attribute__((aligned(16))) char smem[PERS_SMEM];
+    const int ntiles = g.tiles_m * g.tiles_n;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wc = wave >> 1, wt = wave & 1;
+    const int h = lane >> 5, l31 = lane & 31;
+    const int lrow = lane >> 2, lslot = lane & 3;
+    const int nk = g.K / BK;
+
+    const int8_t* asrc[4];
+    const int8_t* wsrc[2];
+    auto set_sources = [&](const PersTile& t) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int row = 16 * (wave + 4 * i) + lrow;
+            int c = lslot ^ ((row >> 2) & 3);
+            asrc[i] = g.A + (int64_t)min(t.m0 + row, g.M - 1) * g.lda + 16 * c;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int row = 16 * (wave + 4 * i) + lrow;
+            int c = lslot ^ ((row >> 2) & 3);
+            wsrc[i] = g.W + (int64_t)min(t.n0 + row, g.N - 1) * g.ldw + 16 * c;
+        }
+    };
+    auto issue_one = [&](int kt, int idx) {
+        char* base = smem + (kt % BIG_STAGES) * BIG_STAGE;
+        const int koff = kt * BK;
+        if (idx < 4)
+            __builtin_amdgcn_global_load_lds((gptr_t)(asrc[idx] + koff), (lptr_t)(base + 1024 * (wave + 4 * idx)), 16, 0,
+                                             0);
+        else
+            __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[idx - 4] + koff),
+                                             (lptr_t)(base + BIG_A_BYTES + 1024 * (wave + 4 * (idx - 4))), 16, 0, 0);
+    };
+    auto issue = [&](int kt) {
+#pragma unroll
+        for (int idx = 0; idx < 6; ++idx) issue_one(kt, idx);
+    };
+
+    const int wrow0 = 64 * wc + l31, arow0 = 128 * wt + l31;
+    int woff[2][2], aoff[2][4];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) woff[ks][i] = BIG_A_BYTES + swz(wrow0 + 32 * i, 2 * ks + h);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) aoff[ks][j] = swz(arow0 + 32 * j, 2 * ks + h);
+    }
+    v4i wf0[2], af0[4], wf1[2], af1[4];
+    auto load_frags = [&](const char* st, int ks, v4i (&wf)[2], v4i (&af)[4]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) wf[i] = *reinterpret_cast<const v4i*>(st + woff[ks][i]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) af[j] = *reinterpret_cast<const v4i*>(st + aoff[ks][j]);
+    };
+    v16i acc[2][4];
+    auto step = [&](int kt, auto dma_tag, auto last_tag) {
+        constexpr bool DMA = decltype(dma_tag)::value;
+        constexpr bool LAST = decltype(last_tag)::value;
+        const char* st = smem + (kt % BIG_STAGES) * BIG_STAGE;
+        load_frags(st, 1, wf1, af1);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf0[i], af0[j], acc[i][j], 0, 0, 0);
+                if constexpr (DMA)
+                    if (4 * i + j < 6) issue_one(kt + 2, 4 * i + j);
+            }
+        if constexpr (DMA) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if constexpr (!LAST) load_frags(smem + ((kt + 1) % BIG_STAGES) * BIG_STAGE, 0, wf0, af0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf1[i], af1[j], acc[i][j], 0, 0, 0);
+    };
+    using T = std::true_type;
+    using F = std::false_type;
+
+    // ---- first tile: table + stage 0
+    int tile = blockIdx.x;
+    PersTile cur = pers_tile(g, tile);
+    {
+        PersTableLoad tl = pers_table_issue(g, cur.n0, tid);
+        pers_table_write(tl, smem + PT_OFF, tid);
+    }
+    set_sources(cur);
+    if (g.stagger && blockIdx.x < (unsigned)g.stagger) {   // see gemm_i8_big_kernel: de-phase the two co-resident groups
+        const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1u;
+        if (slot)
+            for (int it = 0; it < (nk + 1) / 2; ++it) __builtin_amdgcn_s_sleep(64);
+    }
+    issue(0);
+
+    for (int it = 0; tile < ntiles; ++it, tile += gridDim.x) {
+        char* tab = smem + PT_OFF + (it & 1) * PT_BYTES;
+        char* tab_next = smem + PT_OFF + ((it + 1) & 1) * PT_BYTES;
+        // stage 0 of this tile is in flight (or landed); the table was written during the previous epilogue
+        if (nk > 1) issue(1);
+        if (nk > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // own pieces of stage 0 (and everything older)
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                     // everyone's stage 0; table visible
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int4 b4 = *reinterpret_cast<const int4*>(tab + BCH * 8 + 4 * (64 * wc + 32 * i + 8 * q + 4 * h));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[i][j][4 * q + 0] = b4.x;
+                    acc[i][j][4 * q + 1] = b4.y;
+                    acc[i][j][4 * q + 2] = b4.z;
+                    acc[i][j][4 * q + 3] = b4.w;
+                }
+            }
+        load_frags(smem, 0, wf0, af0);
+        int kt = 0;
+        for (; kt + 2 < nk; ++kt) step(kt, T{}, F{});
+        if (kt + 1 < nk) { step(kt, F{}, F{}); ++kt; }
+        step(kt, F{}, T{});
+        __syncthreads();   // all waves are done with every stage: buffers free
+
+        // ---- prefetch stage 0 of the next tile, then this tile's epilogue (staging in buffers 1-2)
+        const int next = tile + gridDim.x;
+        const bool more = next < ntiles;   // uniform
+        PersTile nxt = cur;
+        if (more) {
+            nxt = pers_tile(g, next);
+            set_sources(nxt);
+            issue(0);
+        }
+        struct Hook {
+            const GemmArgs& g;
+            int n0, tid;
+            char* dst;
+            bool more;
+            mutable PersTableLoad ld;
+            IVIT_DEV void issue() const { if (more) ld = pers_table_issue(g, n0, tid); }
+            IVIT_DEV void consume() const { if (more) pers_table_write(ld, dst, tid); }
+        };
+        Hook hook{g, nxt.n0, tid, tab_next, more, PersTableLoad{0u, 0, 0, false}};
+        epilogue_i8<EPI, 2, 4, BTOK, BIG_NT, 0, BCH, Hook>(acc, g, smem + BIG_STAGE, tab, cur.m0, cur.n0, 64 * wc, 128 * wt,
+                                                          tid, h, l31, hook);
+        cur = nxt;
+        __syncthreads();   // staging reads done before the next tile's stage 1 DMA overwrites buffer 1
+    }
+}
+
 template <int EPI>
 int launch_gemm(GemmArgs& g, const char* name, ivit_stream_t stream)
 {
@@ -784,6 +1010,15 @@ int launch_gemm(GemmArgs& g, const char* name, ivit_stream_t stream)
             } else {
                 hipLaunchKernelGGL((gemm_i8_xl_kernel<EPI, 0>), grid, blk, 0, st, g);
             }
+            IVIT_CHECK_LAUNCH(name);
+        }
+        if (g.M >= 2048 && g.N >= BCH && !g_force_small && g.flags == 0 && !(g_debug_flags & 1024)) {
+            g.stagger = (g_debug_flags & 64) ? 0 : 512;  // 2 workgroups x 256 CUs
+            g.tiles_m = (g.M + BTOK - 1) / BTOK;
+            g.tiles_n = (g.N + BCH - 1) / BCH;
+            const int ntiles = g.tiles_m * g.tiles_n;
+            const int grid = ntiles < 512 ? ntiles : 512;
+            hipLaunchKernelGGL((gemm_i8_pers_kernel<EPI>), dim3(grid), dim3(BIG_NT), 0, ivit_stream(stream), g);
             IVIT_CHECK_LAUNCH(name);
         }
         if (g.M >= 2048 && g.N >= BCH && !g_force_small) {
