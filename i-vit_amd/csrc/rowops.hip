@@ -23,9 +23,9 @@ IVIT_DEV int pack4(int a, int b, int c, int d)
     return (a & 0xff) | ((b & 0xff) << 8) | ((c & 0xff) << 16) | ((d & 0xff) << 24);
 }
 
-static inline int grid_for_rows(int64_t rows)
+static inline int grid_for_rows(int64_t rows, int rows_per_wave = 1)
 {
-    int64_t blocks = (rows + WPB - 1) / WPB;
+    int64_t blocks = (rows + WPB * rows_per_wave - 1) / (WPB * rows_per_wave);
     return (int)(blocks < 4096 ? blocks : 4096);
 }
 
@@ -95,53 +95,84 @@ __global__ __launch_bounds__(NT) void layernorm_i8_kernel(LnArgs a)
     }
     const int8_t* xin = reinterpret_cast<const int8_t*>(a.x);
     int8_t* out = reinterpret_cast<int8_t*>(a.out);
-    for (int row = blockIdx.x * WPB + wave; row < a.rows; row += gridDim.x * WPB) {
-        const int* xr = reinterpret_cast<const int*>(xin + (int64_t)row * a.ldx);
-        int w[NJ];
-        int sum = 0;
+    // G rows per wave and iteration.  The per-row statistics (mean division, ten Newton steps, reciprocal) are scalar
+    // work that a one-row-per-wave kernel repeats in all 64 lanes; here lane r evaluates them for row r of the group
+    // (G rows in parallel across lanes) and the results come back as wave-uniform values through v_readlane.
+    constexpr int G = (NJ <= 4) ? 4 : 1;
+    for (int row0 = (blockIdx.x * WPB + wave) * G; row0 < a.rows; row0 += gridDim.x * WPB * G) {
+        int w[G][NJ], sum[G], var[G];
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            int d = lane + 64 * j;
-            w[j] = (d < nd) ? xr[d] : 0;
-            sum += sx8(w[j], 0) + sx8(w[j], 1) + sx8(w[j], 2) + sx8(w[j], 3);
+        for (int rr = 0; rr < G; ++rr) {
+            const int row = min(row0 + rr, a.rows - 1);
+            const int* xr = reinterpret_cast<const int*>(xin + (int64_t)row * a.ldx);
+            sum[rr] = 0;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                int d = lane + 64 * j;
+                w[rr][j] = (d < nd) ? xr[d] : 0;
+                sum[rr] += sx8(w[rr][j], 0) + sx8(w[rr][j], 1) + sx8(w[rr][j], 2) + sx8(w[rr][j], 3);
+            }
         }
-        sum = wave_reduce_sum_i32(sum);
-        int mean_int;
-        ln_mean(sum, C, mean_int);
-        int var = 0;  // <= 4096 * 255^2 < 2^31
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            if (lane + 64 * j < nd) {
+        for (int o = 32; o > 0; o >>= 1)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    int dlt = sx8(w[j], c) - mean_int;
-                    var += dlt * dlt;
+            for (int rr = 0; rr < G; ++rr) sum[rr] += __shfl_xor(sum[rr], o);
+        // lane rr: mean of row rr (:37), computed once
+        int my_sum = sum[0];
+#pragma unroll
+        for (int rr = 1; rr < G; ++rr) my_sum = (lane == rr) ? sum[rr] : my_sum;
+        int my_mean;
+        ln_mean(my_sum, C, my_mean);
+        int mean_int[G];
+#pragma unroll
+        for (int rr = 0; rr < G; ++rr) {
+            mean_int[rr] = __builtin_amdgcn_readlane(my_mean, rr);
+            var[rr] = 0;  // <= 4096 * 255^2 < 2^31
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                if (lane + 64 * j < nd) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        int dlt = sx8(w[rr][j], c) - mean_int[rr];
+                        var[rr] += dlt * dlt;
+                    }
                 }
             }
         }
-        var = wave_reduce_sum_i32(var);
-        const float factor = ln_factor((long long)var);
-        int* orow = reinterpret_cast<int*>(out + (int64_t)row * a.ldo);
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            int d = lane + 64 * j;
-            if (d < nd) {
-                int o[4];
+        for (int o = 32; o > 0; o >>= 1)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    float dl = (float)(sx8(w[j], c) - mean_int);
-                    float v = floorf((dl * factor) * 0.5f);          // :52  float32 product, /2, floor
-                    float y = v + bias[j][c];                          // :61  float32 add
-                    float x = y * sln[j][c];                           // :63  float32 product
-                    // quant_utils.py:220  z = round(x / s): the correctly rounded float32 quotient,
-                    // obtained as RN24(RN53(x * RN53(1/s))) (no midpoint can lie within 2^-52 of x/s)
-                    float qf = (float)((double)x * rs[j][c]);
-                    float z = rintf(qf);
-                    double p = (double)z * Mq[j][c];                   // :229 float64 product
-                    double t = p + IVIT_MAGIC;                         // :230 round half to even
-                    o[c] = clamp_i32((int)(unsigned)__double_as_longlong(t), -128, 127);
+            for (int rr = 0; rr < G; ++rr) var[rr] += __shfl_xor(var[rr], o);
+        int my_var = var[0];
+#pragma unroll
+        for (int rr = 1; rr < G; ++rr) my_var = (lane == rr) ? var[rr] : my_var;
+        const float my_factor = ln_factor((long long)my_var);   // :45-51, lane rr <-> row rr
+#pragma unroll
+        for (int rr = 0; rr < G; ++rr) {
+            if (row0 + rr >= a.rows) continue;
+            const float factor = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_factor), rr));
+            int* orow = reinterpret_cast<int*>(out + (int64_t)(row0 + rr) * a.ldo);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                int d = lane + 64 * j;
+                if (d < nd) {
+                    int o[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        float dl = (float)(sx8(w[rr][j], c) - mean_int[rr]);
+                        float v = floorf((dl * factor) * 0.5f);          // :52  float32 product, /2, floor
+                        float y = v + bias[j][c];                          // :61  float32 add
+                        float x = y * sln[j][c];                           // :63  float32 product
+                        // quant_utils.py:220  z = round(x / s): the correctly rounded float32 quotient,
+                        // obtained as RN24(RN53(x * RN53(1/s))) (no midpoint can lie within 2^-52 of x/s)
+                        float qf = (float)((double)x * rs[j][c]);
+                        float z = rintf(qf);
+                        double p = (double)z * Mq[j][c];                   // :229 float64 product
+                        double t = p + IVIT_MAGIC;                         // :230 round half to even
+                        o[c] = clamp_i32((int)(unsigned)__double_as_longlong(t), -128, 127);
+                    }
+                    orow[d] = pack4(o[0], o[1], o[2], o[3]);
                 }
-                orow[d] = pack4(o[0], o[1], o[2], o[3]);
             }
         }
     }
@@ -252,30 +283,83 @@ __global__ __launch_bounds__(NT) void shiftgelu_lut_kernel(GeluArgs a)
     reinterpret_cast<int8_t*>(a.out)[idx] = r;
 }
 
-// table form: row max by wave reduction, the row's 256-byte table slice staged in LDS, byte gather
+// table form: row max by wave reduction, the row's 256-byte table slice staged in LDS, byte gather.
+// NJ dwords per lane stay in registers between the max pass and the gather (one HBM read per byte); two rows per
+// wave and iteration keep twice the loads in flight (the kernel is HBM-latency bound).  NJ = 0: generic re-read form.
+template <int NJ>
 __global__ __launch_bounds__(NT) void shiftgelu_lut_apply_kernel(GeluArgs a)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char tab[WPB][256];
+    constexpr int RW = 2;
+    constexpr int NJR = NJ > 0 ? NJ : 1;
+    __shared__ __attribute__((aligned(16))) unsigned char tab[WPB][RW][256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nd = a.L >> 2;
-    for (int row = blockIdx.x * WPB + wave; row < a.rows; row += gridDim.x * WPB) {
-        const int* xr = reinterpret_cast<const int*>(a.x + (int64_t)row * a.ldx);
-        int* orow = reinterpret_cast<int*>(reinterpret_cast<int8_t*>(a.out) + (int64_t)row * a.ldo);
-        int kmax = -128;
-        for (int d = lane; d < nd; d += 64) {
-            int w = xr[d];
-            kmax = max(max(kmax, sx8(w, 0)), max(sx8(w, 1), max(sx8(w, 2), sx8(w, 3))));
+    for (int row0 = (blockIdx.x * WPB + wave) * RW; row0 < a.rows; row0 += gridDim.x * WPB * RW) {
+        const int* xr[RW];
+        int kmax[RW];
+        int w[RW][NJR];
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            xr[r] = reinterpret_cast<const int*>(a.x + (int64_t)min(row0 + r, a.rows - 1) * a.ldx);
+            kmax[r] = -128;
         }
-        kmax = wave_reduce_max_i32(kmax);
-        reinterpret_cast<int*>(tab[wave])[lane] =
-            reinterpret_cast<const int*>(a.lut + (int64_t)(kmax + 128) * 256)[lane];
+        if constexpr (NJ > 0) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int r = 0; r < RW; ++r) {
+                    const int d = lane + 64 * j;
+                    w[r][j] = (d < nd) ? xr[r][d] : (int)0x80808080;
+                }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int r = 0; r < RW; ++r)
+                    kmax[r] = max(max(kmax[r], sx8(w[r][j], 0)), max(sx8(w[r][j], 1), max(sx8(w[r][j], 2), sx8(w[r][j], 3))));
+        } else {
+            for (int d = lane; d < nd; d += 64) {
+#pragma unroll
+                for (int r = 0; r < RW; ++r) {
+                    int v = xr[r][d];
+                    kmax[r] = max(max(kmax[r], sx8(v, 0)), max(sx8(v, 1), max(sx8(v, 2), sx8(v, 3))));
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+            for (int r = 0; r < RW; ++r) kmax[r] = max(kmax[r], __shfl_xor(kmax[r], o));
+#pragma unroll
+        for (int r = 0; r < RW; ++r)
+            reinterpret_cast<int*>(tab[wave][r])[lane] =
+                reinterpret_cast<const int*>(a.lut + (int64_t)(kmax[r] + 128) * 256)[lane];
         __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the table slice is in LDS
-        for (int d = lane; d < nd; d += 64) {
-            unsigned w = (unsigned)xr[d] ^ 0x80808080u;  // k + 128 per byte
-            unsigned r = (unsigned)tab[wave][w & 255] | ((unsigned)tab[wave][(w >> 8) & 255] << 8) |
-                         ((unsigned)tab[wave][(w >> 16) & 255] << 16) | ((unsigned)tab[wave][w >> 24] << 24);
-            orow[d] = (int)r;
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the table slices are in LDS
+        auto map4 = [&](int r, unsigned v) {
+            v ^= 0x80808080u;  // k + 128 per byte
+            const unsigned char* tb = tab[wave][r];
+            return (unsigned)tb[v & 255] | ((unsigned)tb[(v >> 8) & 255] << 8) | ((unsigned)tb[(v >> 16) & 255] << 16) |
+                   ((unsigned)tb[v >> 24] << 24);
+        };
+        if constexpr (NJ > 0) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int r = 0; r < RW; ++r) {
+                    const int d = lane + 64 * j;
+                    if (d < nd && row0 + r < a.rows)
+                        reinterpret_cast<int*>(reinterpret_cast<int8_t*>(a.out) + (int64_t)(row0 + r) * a.ldo)[d] =
+                            (int)map4(r, (unsigned)w[r][j]);
+                }
+        } else {
+            for (int d = lane; d < nd; d += 64) {
+#pragma unroll
+                for (int r = 0; r < RW; ++r) {
+                    if (row0 + r >= a.rows) continue;
+                    reinterpret_cast<int*>(reinterpret_cast<int8_t*>(a.out) + (int64_t)(row0 + r) * a.ldo)[d] =
+                        (int)map4(r, (unsigned)xr[r][d]);
+                }
+            }
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -536,7 +620,7 @@ IVIT_EXPORT int ivit_layernorm_i8(const int8_t* x, int64_t ldx, int rows, int C,
                  "ivit_layernorm_i8: per-channel tables must be 16-byte aligned");
     LnArgs a{x, ldx, rows, C, bias_int, s_ln, m, e, out, ldo};
     const int nj = (C / 4 + 63) / 64;
-    const int grid = grid_for_rows(rows);
+    const int grid = grid_for_rows(rows, nj <= 4 ? 4 : 1);
     hipStream_t st = ivit_stream(stream);
     if (nj <= 1) hipLaunchKernelGGL(layernorm_i8_kernel<1>, dim3(grid), dim3(NT), 0, st, a);
     else if (nj <= 2) hipLaunchKernelGGL(layernorm_i8_kernel<2>, dim3(grid), dim3(NT), 0, st, a);
@@ -605,7 +689,13 @@ IVIT_EXPORT int ivit_shiftgelu_lut_i8(const int8_t* x, int64_t ldx, int rows, in
                  "ivit_shiftgelu_lut_i8: rows=%d L=%d must be 4-byte aligned rows", rows, L);
     GeluArgs a{};
     a.x = x; a.ldx = ldx; a.rows = rows; a.L = L; a.lut = lut; a.out = out; a.ldo = ldo;
-    hipLaunchKernelGGL(shiftgelu_lut_apply_kernel, dim3(grid_for_rows(rows)), dim3(NT), 0, ivit_stream(stream), a);
+    const dim3 grid(grid_for_rows(rows, 2)), blk(NT);
+    hipStream_t st = ivit_stream(stream);
+    const int nj = (L / 4 + 63) / 64;
+    if (nj <= 3) hipLaunchKernelGGL(shiftgelu_lut_apply_kernel<3>, grid, blk, 0, st, a);
+    else if (nj <= 6) hipLaunchKernelGGL(shiftgelu_lut_apply_kernel<6>, grid, blk, 0, st, a);
+    else if (nj <= 12) hipLaunchKernelGGL(shiftgelu_lut_apply_kernel<12>, grid, blk, 0, st, a);
+    else hipLaunchKernelGGL(shiftgelu_lut_apply_kernel<0>, grid, blk, 0, st, a);
     IVIT_CHECK_LAUNCH("ivit_shiftgelu_lut_i8");
 }
 
