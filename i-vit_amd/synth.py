@@ -116,3 +116,67 @@ def qact_names(depth: int = 12):
                   p + "qact2", p + "qact3", p + "mlp.qact_gelu", p + "mlp.qact1", p + "mlp.qact2", p + "qact4"]
     names += ["qact2"]
     return names
+
+
+# ------------------------------------------------------------------------------------------------ Swin
+# (/root/reference/models/swin_quant.py:567-585): patch 4, window 7, embed 96, depths (2,2,6,2), heads (3,6,12,24)
+SWIN_CONFIGS = {
+    "swin_tiny_patch4_window7_224": dict(embed_dim=96, depths=(2, 2, 6, 2), num_heads=(3, 6, 12, 24), window=7),
+}
+REL_POS_STD = 0.5   # reference init is 0.02 (swin_quant.py:112); widened so the bias path is exercised
+
+
+def make_swin_float_state(model: str, seed: int = 0) -> "OrderedDict[str, np.ndarray]":
+    """Float32 parameters with the reference's Swin state_dict names."""
+    cfg = SWIN_CONFIGS[model]
+    C0, depths, heads, ws = cfg["embed_dim"], cfg["depths"], cfg["num_heads"], cfg["window"]
+    sd: "OrderedDict[str, np.ndarray]" = OrderedDict()
+
+    def lin(prefix, out_f, in_f, gain=1.0, bias=True):
+        sd[prefix + ".weight"] = _trunc_normal(seed, prefix + ".weight", (out_f, in_f)) * np.float32(gain)
+        if bias:
+            sd[prefix + ".bias"] = _normal(seed, prefix + ".bias", (out_f,), 0.02)
+
+    def ln(prefix, n):
+        sd[prefix + ".weight"] = _uniform(seed, prefix + ".weight", (n,), 0.5, 1.5)
+        sd[prefix + ".bias"] = _normal(seed, prefix + ".bias", (n,), 0.1)
+
+    sd["patch_embed.proj.weight"] = _trunc_normal(seed, "patch_embed.proj.weight", (C0, 3, 4, 4), std=0.1)
+    sd["patch_embed.proj.bias"] = _normal(seed, "patch_embed.proj.bias", (C0,), 0.02)
+    ln("patch_embed.norm", C0)
+    for li, (depth, nh) in enumerate(zip(depths, heads)):
+        C = C0 * 2 ** li
+        for bi in range(depth):
+            p = f"layers.{li}.blocks.{bi}."
+            ln(p + "norm1", C)
+            sd[p + "attn.relative_position_bias_table"] = _normal(seed, p + "attn.relative_position_bias_table",
+                                                                  ((2 * ws - 1) ** 2, nh), REL_POS_STD)
+            lin(p + "attn.qkv", 3 * C, C, gain=QKV_GAIN)
+            lin(p + "attn.proj", C, C)
+            ln(p + "norm2", C)
+            lin(p + "mlp.fc1", 4 * C, C)
+            lin(p + "mlp.fc2", C, 4 * C)
+        if li < len(depths) - 1:
+            p = f"layers.{li}.downsample."
+            ln(p + "norm", 4 * C)
+            lin(p + "reduction", 2 * C, 4 * C, bias=False)
+    Cl = C0 * 2 ** (len(depths) - 1)
+    ln("norm", Cl)
+    lin("head", NUM_CLASSES, Cl)
+    return sd
+
+
+def swin_qact_names(depths=(2, 2, 6, 2)):
+    """Every QuantAct of the reference's SwinTransformer that its forward calls, in module order
+    (swin_quant.py:459-518; `act_out` is constructed but never called, :518,563)."""
+    names = ["qact_input", "patch_embed.qact_before_norm", "patch_embed.qact", "qact1"]
+    for li, depth in enumerate(depths):
+        for bi in range(depth):
+            p = f"layers.{li}.blocks.{bi}."
+            names += [p + "qact1", p + "attn.qact1", p + "attn.qact_attn1", p + "attn.qact_table", p + "attn.qact2",
+                      p + "attn.qact3", p + "attn.qact4", p + "qact2", p + "qact3", p + "mlp.qact_gelu", p + "mlp.qact1",
+                      p + "mlp.qact2", p + "qact4"]
+        if li < len(depths) - 1:
+            names += [f"layers.{li}.downsample.qact1", f"layers.{li}.downsample.qact2"]
+    names += ["qact2", "qact3"]
+    return names

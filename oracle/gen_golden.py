@@ -336,6 +336,92 @@ def gen_model(tag):
     print(f"[{tag}] wrote fixtures; top1 = {top1.tolist()}")
 
 
+def gen_swin(tag="swin_tiny"):
+    """Swin-T (config 5).  The fork's swin_quant.py is dead code (SURVEY finding 6); it runs with the three extra
+    harness-side shims of SURVEY Appendix E (tkinter stub, Int* aliases, bias-free QuantLinear weight_function) --
+    reference files untouched."""
+    import types
+    sys.modules.setdefault("tkinter", types.SimpleNamespace(X=None))                      # shim 2
+    rq.IntLayerNorm, rq.IntSoftmax, rq.IntGELU = rq.IVITIntLayerNorm, rq.IVITIntSoftmax, rq.IVITIntGELU  # shim 3
+    import models.swin_quant as sq
+    factory, wseed, cseed, cb, iseed, nimg = "swin_tiny_patch4_window7_224", 21, 201, 2, 2001, 3
+    cfg = synth.SWIN_CONFIGS[factory]
+    t0 = time.time()
+    model = getattr(sq, factory)(pretrained=False)
+    for mod in model.modules():                                                            # shim 4
+        if isinstance(mod, rq.QuantLinear) and mod.bias is None:
+            mod.weight_function = lambda x, *a: None if x is None else SymmetricQuantFunction.apply(x, *a)
+    fs = synth.make_swin_float_state(factory, wseed)
+    missing, unexpected = model.load_state_dict({k: torch.from_numpy(v) for k, v in fs.items()}, strict=False)
+    assert not unexpected, unexpected
+    model.eval()
+    model(torch.from_numpy(synth.make_images(cb, cseed)))
+    ranges, bitsof = {}, {}
+    for name, mod in model.named_modules():
+        if isinstance(mod, rq.QuantAct):
+            mx = float(torch.max(-mod.x_min, mod.x_max))
+            if mx == 0.0:
+                continue  # act_out: never called (swin_quant.py:518,563)
+            q = 2 ** (mod.activation_bit - 1) - 1
+            p = int(np.ceil(np.log2(mx / q)))
+            mod.x_max.fill_(q * 2.0 ** p)
+            mod.x_min.fill_(-q * 2.0 ** p)
+            ranges[name] = (np.float32(mod.x_min.item()), np.float32(mod.x_max.item()))
+            bitsof[name] = mod.activation_bit
+    assert list(ranges) == synth.swin_qact_names(cfg["depths"]), "QuantAct order drifted"
+    ref_models.freeze_model(model)
+    taps = {}
+
+    def hook(name):
+        def fn(mod, inp, outp):
+            y, s = outp
+            taps[name] = to_int(y, s)
+        return fn
+
+    for name, mod in model.named_modules():
+        if isinstance(mod, (rq.QuantAct, rq.IVITIntSoftmax, rq.IVITIntGELU)) and name != "act_out":
+            mod.register_forward_hook(hook(name))
+    imgs = synth.make_images(nimg, iseed)
+    y = model(torch.from_numpy(imgs))
+    s_head = (model.head.fc_scaling_factor * model.qact3.act_scaling_factor).float()
+    logits_int = torch.round(y / s_head).to(torch.int64).numpy().astype(np.int32)
+    logits_f32 = y.numpy().astype(np.float32)
+    top1 = y.argmax(dim=1).numpy().astype(np.int64)
+    t_ref = time.time() - t0
+
+    t1 = time.time()
+    om = orc.OracleSwin(fs, ranges, cfg["embed_dim"], cfg["depths"], cfg["num_heads"], cfg["window"])
+    otaps = {}
+    res = om.forward(imgs, otaps)
+    miss = [n for n in taps if n not in otaps]
+    bad = [n for n in taps if n in otaps and not np.array_equal(taps[n].reshape(-1), otaps[n].reshape(-1))]
+    print(f"[{tag}] reference {t_ref:.1f}s, oracle {time.time()-t1:.1f}s; taps {len(taps)}, missing in oracle {miss[:4]}, "
+          f"differing {bad[:6]} ({len(bad)})")
+    assert not miss and not bad
+    assert np.array_equal(res["logits_int32"], logits_int), "INT32 logits differ"
+    assert np.array_equal(res["logits_f32"].view(np.int32), logits_f32.view(np.int32))
+    print(f"[{tag}] all taps + logits bit-equal; max|acc|={om.max_acc}, softmax rows sum>=2^24: "
+          f"{om.softmax_inexact_rows}, LN rows |sum|>=2^24: {om.ln_big_sum_rows}")
+    assert om.max_acc < 2 ** 24
+    names = sorted(taps)
+    out = {
+        "meta": np.array(json.dumps(dict(tag=tag, factory=factory, weight_seed=wseed, calib_seed=cseed, calib_batch=cb,
+                                         image_seed=iseed, n_images=nimg, qkv_gain=synth.QKV_GAIN,
+                                         max_abs_acc=om.max_acc, softmax_inexact_rows=om.softmax_inexact_rows,
+                                         ln_big_sum_rows=om.ln_big_sum_rows, torch=torch.__version__,
+                                         numpy=np.__version__))),
+        "range_names": np.array(list(ranges)),
+        "range_bits": np.array([bitsof[n] for n in ranges], np.int32),
+        "x_min": np.array([v[0] for v in ranges.values()], np.float32),
+        "x_max": np.array([v[1] for v in ranges.values()], np.float32),
+        "logits_int32": logits_int, "logits_f32_bits": logits_f32.view(np.int32), "top1": top1,
+        "tap_names": np.array(names), "tap_crc32": np.array([crc(taps[n]) for n in names], np.uint32),
+        "tap_absmax": np.array([int(np.abs(taps[n]).max()) for n in names], np.int64),
+    }
+    np.savez_compressed(os.path.join(GOLD, f"{tag}.npz"), **out)
+    print(f"[{tag}] wrote fixtures; top1 = {top1.tolist()}")
+
+
 def gen_schema():
     """state_dict keys and shapes of the reference's DeiT models (the on-disk checkpoint format)"""
     out = {}
@@ -356,5 +442,7 @@ if __name__ == "__main__":
             gen_ops()
         elif w == "schema":
             gen_schema()
+        elif w.startswith("swin"):
+            gen_swin(w)
         else:
             gen_model(w)
