@@ -427,13 +427,12 @@ __global__ __launch_bounds__(NT) void quantize_kernel(const float* x, int8_t* ou
 }
 
 // img [B, chans, hw, hw] -> A [B*gh*gw, chans*patch*patch]; one thread quantises 4 consecutive kw
-__global__ __launch_bounds__(NT) void patchify_kernel(const float* img, int8_t* A, int batch, int chans, int hw,
-                                                      int patch, float inv_scale)
+__global__ __launch_bounds__(NT) void patchify_kernel(const float* img, int8_t* A, int64_t lda, int batch, int chans,
+                                                      int hw, int patch, float inv_scale)
 {
     const int g = hw / patch;
     const int pw4 = patch >> 2;
     const int64_t total = (int64_t)batch * chans * hw * (hw >> 2);  // groups of 4 pixels
-    const int K = chans * patch * patch;
     for (int64_t q = (int64_t)blockIdx.x * NT + threadIdx.x; q < total; q += (int64_t)gridDim.x * NT) {
         // source order (coalesced float4 reads): b, c, y, x4
         int x4 = (int)(q % (hw >> 2));
@@ -447,8 +446,8 @@ __global__ __launch_bounds__(NT) void patchify_kernel(const float* img, int8_t* 
         int py = y / patch, kh = y - py * patch;
         int64_t row = ((int64_t)b * g + py) * g + px;
         int col = (c * patch + kh) * patch + kw;
-        *reinterpret_cast<int*>(A + row * K + col) = pack4(quant_sym_i8(v.x, inv_scale), quant_sym_i8(v.y, inv_scale),
-                                                           quant_sym_i8(v.z, inv_scale), quant_sym_i8(v.w, inv_scale));
+        *reinterpret_cast<int*>(A + row * lda + col) = pack4(quant_sym_i8(v.x, inv_scale), quant_sym_i8(v.y, inv_scale),
+                                                             quant_sym_i8(v.z, inv_scale), quant_sym_i8(v.w, inv_scale));
     }
 }
 
@@ -721,17 +720,31 @@ IVIT_EXPORT int ivit_quantize_input_f32_i8(const float* x, int8_t* out, int64_t 
     IVIT_CHECK_LAUNCH("ivit_quantize_input_f32_i8");
 }
 
+static int launch_patchify(const char* who, const float* img, int8_t* A, int64_t lda, int batch, int chans, int hw, int patch,
+                           float inv_scale, ivit_stream_t stream)
+{
+    IVIT_REQUIRE(img && A && batch > 0 && chans > 0, "%s: bad operand", who);
+    IVIT_REQUIRE(patch > 0 && patch % 4 == 0 && hw % patch == 0, "%s: hw=%d patch=%d", who, hw, patch);
+    IVIT_REQUIRE(lda >= (int64_t)chans * patch * patch && lda % 4 == 0, "%s: lda=%lld too small or not a multiple of 4", who,
+                 (long long)lda);
+    IVIT_REQUIRE(((uintptr_t)img % 16 == 0) && ((uintptr_t)A % 4 == 0), "%s: misaligned", who);
+    const int64_t total = (int64_t)batch * chans * hw * (hw / 4);
+    hipLaunchKernelGGL(patchify_kernel, dim3(ew_grid(total)), dim3(NT), 0, ivit_stream(stream), img, A, lda, batch, chans,
+                       hw, patch, inv_scale);
+    IVIT_CHECK_LAUNCH(who);
+}
+
 IVIT_EXPORT int ivit_quantize_patchify_f32_i8(const float* img, int8_t* A, int batch, int chans, int hw, int patch,
                                               float inv_scale, ivit_stream_t stream)
 {
-    IVIT_REQUIRE(img && A && batch > 0 && chans > 0, "ivit_quantize_patchify_f32_i8: bad operand");
-    IVIT_REQUIRE(patch > 0 && patch % 4 == 0 && hw % patch == 0, "ivit_quantize_patchify_f32_i8: hw=%d patch=%d", hw,
-                 patch);
-    IVIT_REQUIRE(((uintptr_t)img % 16 == 0) && ((uintptr_t)A % 4 == 0), "ivit_quantize_patchify_f32_i8: misaligned");
-    const int64_t total = (int64_t)batch * chans * hw * (hw / 4);
-    hipLaunchKernelGGL(patchify_kernel, dim3(ew_grid(total)), dim3(NT), 0, ivit_stream(stream), img, A, batch, chans,
-                       hw, patch, inv_scale);
-    IVIT_CHECK_LAUNCH("ivit_quantize_patchify_f32_i8");
+    return launch_patchify("ivit_quantize_patchify_f32_i8", img, A, (int64_t)chans * patch * patch, batch, chans, hw, patch,
+                           inv_scale, stream);
+}
+
+IVIT_EXPORT int ivit_quantize_patchify_ld_f32_i8(const float* img, int8_t* A, int64_t lda, int batch, int chans, int hw,
+                                                 int patch, float inv_scale, ivit_stream_t stream)
+{
+    return launch_patchify("ivit_quantize_patchify_ld_f32_i8", img, A, lda, batch, chans, hw, patch, inv_scale, stream);
 }
 
 IVIT_EXPORT int ivit_embed_assemble_i8(const int8_t* patch, const int16_t* pos_add, const int8_t* cls_row, uint32_t m,

@@ -1,0 +1,472 @@
+// swin.hip -- the additional integer kernels of the Swin path (config 5): 16-bit residual stream, windowed
+// attention with relative-position bias and shift mask, patch merging, token average pooling.
+// Reference: /root/reference/models/swin_quant.py (WindowAttention :121-169, SwinTransformerBlock :251-301,
+// PatchMerging :328-349, SwinTransformer.forward_features :539-558); operators as in rowops.hip / attention.hip.
+// The fork's swin_quant.py does not run as shipped (SURVEY.md finding 6); semantics are SURVEY Appendix A.8, pinned by
+// tests/golden/swin_tiny.npz (generated from the reference with harness-side shims).
+#include "common.h"
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int WPB = NT / 64;
+
+static inline int ew_grid(int64_t n)
+{
+    int64_t b = (n + NT - 1) / NT;
+    return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+
+static inline int grid_for_rows(int64_t rows, int rpw = 1)
+{
+    int64_t blocks = (rows + WPB * rpw - 1) / (WPB * rpw);
+    return (int)(blocks < 4096 ? blocks : 4096);
+}
+
+IVIT_DEV int pack4(int a, int b, int c, int d)
+{
+    return (a & 0xff) | ((b & 0xff) << 8) | ((c & 0xff) << 16) | ((d & 0xff) << 24);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Row maps: the window partition / cyclic shift of SwinTransformerBlock.forward (swin_quant.py:258-271, 278-289) are
+// pure row permutations of a [B, H*W, C] tensor.  win_row(r) = index, in window-major order
+// (image, window row, window col, row in window, col in window), of token r = (b, y, x) after rolling by -shift.
+// ------------------------------------------------------------------------------------------------
+struct WinMap {
+    int H, W, ws, shift;  // ws == 0: identity
+};
+
+IVIT_DEV int64_t win_row(const WinMap& m, int64_t r)
+{
+    if (m.ws == 0) return r;
+    const int L = m.H * m.W;
+    const int b = (int)(r / L);
+    const int t = (int)(r - (int64_t)b * L);
+    int y = t / m.W, x = t - y * m.W;
+    // shifted_x[y'] = x[(y' + shift) mod H]  =>  token (y, x) lands at y' = (y - shift) mod H
+    y = y - m.shift; if (y < 0) y += m.H;
+    x = x - m.shift; if (x < 0) x += m.W;
+    const int wy = y / m.ws, iy = y - wy * m.ws, wx = x / m.ws, ix = x - wx * m.ws;
+    const int nwx = m.W / m.ws;
+    return ((int64_t)b * (m.H / m.ws) * nwx + (int64_t)wy * nwx + wx) * (m.ws * m.ws) + iy * m.ws + ix;
+}
+
+// ------------------------------------------------------------------------------------------------
+// 8 -> 16 bit QuantAct (SwinTransformer.qact1, swin_quant.py:546; also used as an exact int8 -> int16 widening)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void requant_i8_i16_kernel(const int8_t* x, double Mq, int16_t* out, int64_t n)
+{
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT)
+        out[i] = (int16_t)clamp_i32(requant_exact((int)x[i], Mq), -32768, 32767);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Two-operand 16-bit QuantAct of the residual connections (swin_quant.py:293, 299; quant_utils.py:232-245):
+//   out[r] = clamp16(RNE(a[map(r)] * Ma) + RNE(res[r] * Mr));  a is int16 (attn.qact4) or int8 (mlp.qact2)
+// ------------------------------------------------------------------------------------------------
+template <typename TA>
+__global__ __launch_bounds__(NT) void residual_i16_kernel(const TA* a, const uint32_t* m_pre, const int32_t* e_pre, double Ma,
+                                                          const int16_t* res, double Mr, int16_t* out, int64_t rows, int C,
+                                                          WinMap map)
+{
+    const int c4 = C >> 2;
+    const int64_t total = rows * c4;
+    for (int64_t q = (int64_t)blockIdx.x * NT + threadIdx.x; q < total; q += (int64_t)gridDim.x * NT) {
+        const int64_t r = q / c4;
+        const int c = (int)(q - r * c4) * 4;
+        const int64_t ra = win_row(map, r);
+        int av[4];
+        if (sizeof(TA) == 1) {
+            const int w = *reinterpret_cast<const int*>(reinterpret_cast<const int8_t*>(a) + ra * C + c);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) av[i] = (int)(int8_t)(w >> (8 * i));
+        } else if (sizeof(TA) == 2) {
+            const int2 w = *reinterpret_cast<const int2*>(reinterpret_cast<const int16_t*>(a) + ra * C + c);
+            av[0] = (int)(int16_t)w.x; av[1] = w.x >> 16; av[2] = (int)(int16_t)w.y; av[3] = w.y >> 16;
+        } else {  // raw GEMM accumulators: the 16-bit QuantAct behind the projection first (attn.qact4, swin_quant.py:166)
+            const v4i w = *reinterpret_cast<const v4i*>(reinterpret_cast<const int32_t*>(a) + ra * C + c);
+            const v4i mm = *reinterpret_cast<const v4i*>(m_pre + c);
+            const v4i ee = *reinterpret_cast<const v4i*>(e_pre + c);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                av[i] = clamp_i32(requant_exact(w[i], dyadic_mult((uint32_t)mm[i], ee[i])), -32768, 32767);
+        }
+        const int2 rw = *reinterpret_cast<const int2*>(res + r * C + c);
+        const int rv[4] = {(int)(int16_t)rw.x, rw.x >> 16, (int)(int16_t)rw.y, rw.y >> 16};
+        int o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = clamp_i32(requant_exact(av[i], Ma) + requant_exact(rv[i], Mr), -32768, 32767);
+        int2 ow;
+        ow.x = (o[0] & 0xffff) | (o[1] << 16);
+        ow.y = (o[2] & 0xffff) | (o[3] << 16);
+        *reinterpret_cast<int2*>(out + r * C + c) = ow;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// I-LayerNorm on the 16-bit stream + QuantAct(8) (+ optional row map on the OUTPUT: window partition)
+// ivit_modules.py:30-65 with 16-bit inputs: var up to ~3.5e10 -> the Newton iteration runs on RN24(var) in float32
+// with correctly rounded divisions, exactly as the reference does.
+// ------------------------------------------------------------------------------------------------
+struct Ln16Args {
+    const int16_t* x;
+    int rows, C;
+    const float* bias_int;
+    const float* s_ln;
+    const uint32_t* m;
+    const int32_t* e;
+    int8_t* out;
+    int64_t ldo;
+    WinMap map;
+};
+
+__global__ __launch_bounds__(NT) void layernorm_i16_i8_kernel(Ln16Args a)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int C = a.C;
+    for (int row = blockIdx.x * WPB + wave; row < a.rows; row += gridDim.x * WPB) {
+        const int16_t* xr = a.x + (int64_t)row * C;
+        int sum = 0;  // |sum| < 2^31 for C <= 4096
+        for (int c = lane; c < C; c += 64) sum += xr[c];
+        sum = wave_reduce_sum_i32(sum);
+        const float mean = (float)sum / (float)C;                    // :37 (RN24 of the exact sum, / C)
+        const int mean_int = (int)rintf(mean);
+        long long var = 0;
+        for (int c = lane; c < C; c += 64) {
+            long long d = (long long)xr[c] - mean_int;
+            var += d * d;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            int vlo = __shfl_xor((int)(var & 0xffffffffll), o);
+            int vhi = __shfl_xor((int)(var >> 32), o);
+            var += ((long long)vhi << 32) | (unsigned)vlo;
+        }
+        float varf = (float)var, t = 65536.0f;                       // :45-49
+#pragma unroll 1
+        for (int it = 0; it < 10; ++it) t = floorf((t + floorf(varf / t)) * 0.5f);
+        const float factor = floorf((1.0f / t) * 2147483648.0f);     // :51
+        int8_t* orow = a.out + win_row(a.map, row) * a.ldo;
+        for (int c = lane; c < C; c += 64) {
+            float dl = (float)(xr[c] - mean_int);
+            float v = floorf((dl * factor) * 0.5f);                   // :52
+            float y = v + a.bias_int[c];                              // :61
+            float s = a.s_ln[c];
+            float x = y * s;                                          // :63
+            float z = rintf(x / s);                                   // quant_utils.py:220 (correctly rounded quotient)
+            double p = (double)z * dyadic_mult(a.m[c], a.e[c]);       // :229
+            double tt = p + IVIT_MAGIC;                               // :230
+            orow[c] = (int8_t)clamp_i32((int)(unsigned)__double_as_longlong(tt), -128, 127);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// PatchMerging gather (swin_quant.py:337-344): [B, H*W, C] int16 -> [B, H/2*W/2, 4C], channel blocks
+// (0::2,0::2), (1::2,0::2), (0::2,1::2), (1::2,1::2)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void patch_merge_kernel(const int16_t* x, int16_t* out, int B, int H, int W, int C)
+{
+    const int c4 = C >> 2;
+    const int H2 = H >> 1, W2 = W >> 1;
+    const int64_t total = (int64_t)B * H2 * W2 * 4 * c4;
+    for (int64_t q = (int64_t)blockIdx.x * NT + threadIdx.x; q < total; q += (int64_t)gridDim.x * NT) {
+        int cc = (int)(q % c4);
+        int64_t r = q / c4;
+        int blk = (int)(r & 3);
+        r >>= 2;
+        int x2 = (int)(r % W2);
+        r /= W2;
+        int y2 = (int)(r % H2);
+        int b = (int)(r / H2);
+        const int dy = blk & 1, dx = blk >> 1;
+        const int2 v = *reinterpret_cast<const int2*>(x + (((int64_t)b * H + 2 * y2 + dy) * W + 2 * x2 + dx) * C + 4 * cc);
+        *reinterpret_cast<int2*>(out + (((int64_t)b * H2 + y2) * W2 + x2) * (4 * C) + blk * C + 4 * cc) = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Token average pooling + QuantAct (swin_quant.py:554-555): z = round(fl32(sum_t k[t][c] / T)), requant -> int8
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void avgpool_kernel(const int8_t* x, int8_t* out, int B, int T, int C, double Mq)
+{
+    const int64_t total = (int64_t)B * C;
+    for (int64_t q = (int64_t)blockIdx.x * NT + threadIdx.x; q < total; q += (int64_t)gridDim.x * NT) {
+        const int b = (int)(q / C), c = (int)(q - (int64_t)b * C);
+        int sum = 0;
+        for (int t = 0; t < T; ++t) sum += x[((int64_t)b * T + t) * C + c];
+        const float z = rintf((float)sum / (float)T);
+        out[q] = (int8_t)clamp_i32(requant_exact((int)z, Mq), -128, 127);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Windowed attention: one wave per (window, head); T = ws*ws <= 64 tokens, head_dim 32.
+//   S^T = K . Q^T on v_mfma_i32_16x16x32_i8 (the head dimension is one instruction deep), qact_attn1 (8 bit),
+//   + relative position bias through the two-operand qact2 (the bias operand RNE(k_tab * m / 2^e) is a load-time
+//   constant table [nH, T, T] int16), + shift mask (integer -100/s, table [nW, T, T] int16, added after the clamp,
+//   swin_quant.py:149-155), Shiftmax, O^T = Vt . P^T on v_mfma_i32_16x16x64_i8 (all 64 key slots in one step), qact3.
+// ------------------------------------------------------------------------------------------------
+struct WinAttnArgs {
+    const int8_t* qkv;      // [3][B_][nH][T][32]
+    int8_t* out;            // [B_*T, nH*32] with row stride ldo
+    int64_t ldo;
+    const int16_t* bias;    // [nH][T][T]
+    const int16_t* mask;    // [nW][T][T] or NULL
+    int nwin, heads, T, nW;
+    double Ms, Mb, Mo;      // qact_attn1; qact2 main operand; qact3
+    int x0, ksat;
+};
+
+constexpr int WHD = 32;
+constexpr int WVT_ROW = 64;                      // Vt row: 64 key slots
+constexpr int WVT_BYTES = WHD * WVT_ROW;         // 2 KiB per wave
+constexpr int WLUT_OFF = WPB * WVT_BYTES;
+
+__global__ __launch_bounds__(NT) void window_attention_kernel(WinAttnArgs a)
+{
+    __shared__ __attribute__((aligned(16))) char smem[WLUT_OFF + 256 * 4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, l15 = lane & 15;
+    const int T = a.T;
+    reinterpret_cast<unsigned*>(smem + WLUT_OFF)[tid] = shiftexp_int(-tid, a.x0, 15);
+    __syncthreads();
+    const unsigned* lut = reinterpret_cast<const unsigned*>(smem + WLUT_OFF);
+    char* vt = smem + wave * WVT_BYTES;
+    const int64_t plane = (int64_t)a.nwin * a.heads * T * WHD;
+    const int npairs = a.nwin * a.heads;
+
+    for (int pair = blockIdx.x * WPB + wave; pair < npairs; pair += gridDim.x * WPB) {
+        const int win = pair / a.heads, hh = pair - win * a.heads;
+        const int8_t* qg = a.qkv + (int64_t)pair * T * WHD;
+        const int8_t* kg = qg + plane;
+        const int8_t* vg = qg + 2 * plane;
+        // ---- V transposed into this wave's LDS tile: Vt[d][chunk g'][byte 4t + r] = V[key 16t + 4g' + r][d];
+        //      chunk j of row d at slot (j + 2*((d>>2)&1)) & 3.  Work item = 4 keys x 16 d (13 x 2 items).
+        __builtin_amdgcn_wave_barrier();
+        if (lane < ((T + 3) >> 2) * 2) {
+            const int kg4 = lane >> 1, c = lane & 1;
+            v4i v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = *reinterpret_cast<const v4i*>(vg + (int64_t)min(4 * kg4 + r, T - 1) * WHD + 16 * c);
+            const int key0 = 4 * kg4;
+            const int j = (key0 >> 2) & 3, boff = 4 * ((key0 >> 4) & 3);
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const unsigned a0 = (unsigned)v[0][w], a1 = (unsigned)v[1][w], a2 = (unsigned)v[2][w], a3 = (unsigned)v[3][w];
+                const unsigned lo01 = __builtin_amdgcn_perm(a1, a0, 0x05010400u), hi01 = __builtin_amdgcn_perm(a1, a0, 0x07030602u);
+                const unsigned lo23 = __builtin_amdgcn_perm(a3, a2, 0x05010400u), hi23 = __builtin_amdgcn_perm(a3, a2, 0x07030602u);
+                const unsigned t4[4] = {__builtin_amdgcn_perm(lo23, lo01, 0x05040100u), __builtin_amdgcn_perm(lo23, lo01, 0x07060302u),
+                                        __builtin_amdgcn_perm(hi23, hi01, 0x05040100u), __builtin_amdgcn_perm(hi23, hi01, 0x07060302u)};
+#pragma unroll
+                for (int bb = 0; bb < 4; ++bb) {
+                    const int d = 16 * c + 4 * w + bb;
+                    *reinterpret_cast<unsigned*>(vt + d * WVT_ROW + (((j + 2 * ((d >> 2) & 1)) & 3) << 4) + boff) = t4[bb];
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+
+        // K fragments of the 4 key tiles: lane (key 16kt + l15, 8 bytes at 8g)
+        long kf[4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+            kf[kt] = *reinterpret_cast<const long*>(kg + (int64_t)min(16 * kt + l15, T - 1) * WHD + 8 * g);
+
+        const int wmask = a.mask ? (win % a.nW) : 0;
+        for (int qt = 0; qt < 4; ++qt) {
+            const int qrow = 16 * qt + l15;
+            if (16 * qt >= T) break;  // uniform
+            const int qld = min(qrow, T - 1);
+            const long qf = *reinterpret_cast<const long*>(qg + (int64_t)qld * WHD + 8 * g);
+            const int16_t* brow = a.bias + ((int64_t)hh * T + qld) * T;
+            const int16_t* mrow = a.mask ? a.mask + ((int64_t)wmask * T + qld) * T : nullptr;
+            int s[4][4];
+            int rmax = -100000;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                v4i acc = {0, 0, 0, 0};
+                acc = __builtin_amdgcn_mfma_i32_16x16x32_i8(kf[kt], qf, acc, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = 16 * kt + 4 * g + r;
+                    int ka = -100000;
+                    if (key < T) {
+                        const int kS = clamp_i32(requant_exact(acc[r], a.Ms), -128, 127);        // qact_attn1
+                        ka = clamp_i32(requant_exact(kS, a.Mb) + (int)brow[key], -128, 127);     // qact2 (two operands)
+                        if (mrow) ka += (int)mrow[key];                                          // shift mask, after the clamp
+                    }
+                    s[kt][r] = ka;
+                    rmax = max(rmax, ka);
+                }
+            }
+            rmax = max(rmax, __shfl_xor(rmax, 16));
+            rmax = max(rmax, __shfl_xor(rmax, 32));
+            unsigned esum = 0;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    unsigned e = (s[kt][r] == -100000) ? 0u : lut[min(rmax - s[kt][r], a.ksat) & 255];
+                    s[kt][r] = (int)e;
+                    esum += e;
+                }
+            esum += __shfl_xor(esum, 16);
+            esum += __shfl_xor(esum, 32);
+            float S = fminf((float)esum, 2147483648.0f);                 // ivit_modules.py:171-173
+            const float factor = floorf((1.0f / S) * 2147483648.0f);     // :174
+            v4i pk;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                unsigned w = 0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float pr = (float)(unsigned)s[t][r] * factor;       // :175
+                    w |= ((((unsigned)pr) >> 24) & 0xffu) << (8 * r);
+                }
+                pk[t] = (int)w;
+            }
+            int8_t* orow = a.out + ((int64_t)win * T + qrow) * a.ldo + hh * WHD + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const int d = 16 * dt + l15;
+                const v4i vf = *reinterpret_cast<const v4i*>(vt + d * WVT_ROW + (((g + 2 * ((d >> 2) & 1)) & 3) << 4));
+                v4i acc = {0, 0, 0, 0};
+                acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(vf, pk, acc, 0, 0, 0);
+                if (qrow < T) {
+                    unsigned w = 0;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        w |= ((unsigned)clamp_i32(requant_exact(acc[r], a.Mo), -128, 127) & 0xffu) << (8 * r);
+                    *reinterpret_cast<unsigned*>(orow + 16 * dt) = w;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// ================================================================================================
+IVIT_EXPORT int ivit_requant_i8_i16(const int8_t* x, uint32_t m, int32_t e, int16_t* out, int64_t n, ivit_stream_t stream)
+{
+    IVIT_REQUIRE(x && out && n > 0, "ivit_requant_i8_i16: bad operand");
+    const double Mq = ivit_dyadic_to_double(m, e);
+    IVIT_REQUIRE(Mq < 8388608.0, "ivit_requant_i8_i16: multiplier too large");
+    hipLaunchKernelGGL(requant_i8_i16_kernel, dim3(ew_grid(n)), dim3(NT), 0, ivit_stream(stream), x, Mq, out, n);
+    IVIT_CHECK_LAUNCH("ivit_requant_i8_i16");
+}
+
+static int check_map(const char* who, int64_t rows, int H, int W, int ws, int shift)
+{
+    if (ws == 0) return IVIT_OK;
+    IVIT_REQUIRE(H > 0 && W > 0 && ws > 0 && H % ws == 0 && W % ws == 0 && shift >= 0 && shift < ws && rows % ((int64_t)H * W) == 0,
+                 "%s: bad window map H=%d W=%d ws=%d shift=%d rows=%lld", who, H, W, ws, shift, (long long)rows);
+    return IVIT_OK;
+}
+
+IVIT_EXPORT int ivit_residual_requant_i16(const void* a, int a_bits, const uint32_t* m_pre, const int32_t* e_pre,
+                                          uint32_t m_a, int32_t e_a, const int16_t* res, uint32_t m_r, int32_t e_r,
+                                          int16_t* out, int64_t rows, int C, int H, int W, int ws, int shift,
+                                          ivit_stream_t stream)
+{
+    IVIT_REQUIRE(a && res && out && rows > 0 && C > 0 && C % 4 == 0, "ivit_residual_requant_i16: bad operand");
+    IVIT_REQUIRE(a_bits == 8 || a_bits == 16 || a_bits == 32, "ivit_residual_requant_i16: a_bits must be 8, 16 or 32");
+    IVIT_REQUIRE((a_bits == 32) == (m_pre != nullptr && e_pre != nullptr),
+                 "ivit_residual_requant_i16: (m_pre, e_pre) are required for, and only for, int32 accumulators");
+    IVIT_REQUIRE(((uintptr_t)a % 16 == 0) && ((uintptr_t)res % 8 == 0) && ((uintptr_t)out % 8 == 0) &&
+                     ((uintptr_t)m_pre % 16 == 0) && ((uintptr_t)e_pre % 16 == 0),
+                 "ivit_residual_requant_i16: misaligned operand");
+    int rc = check_map("ivit_residual_requant_i16", rows, H, W, ws, shift);
+    if (rc) return rc;
+    const double Ma = ivit_dyadic_to_double(m_a, e_a), Mr = ivit_dyadic_to_double(m_r, e_r);
+    IVIT_REQUIRE(Ma < 32768.0 && Mr < 32768.0, "ivit_residual_requant_i16: multiplier too large");
+    WinMap map{H, W, ws, shift};
+    const int grid = ew_grid(rows * (C / 4));
+    hipStream_t st = ivit_stream(stream);
+    if (a_bits == 8)
+        hipLaunchKernelGGL(residual_i16_kernel<int8_t>, dim3(grid), dim3(NT), 0, st, reinterpret_cast<const int8_t*>(a),
+                           m_pre, e_pre, Ma, res, Mr, out, rows, C, map);
+    else if (a_bits == 16)
+        hipLaunchKernelGGL(residual_i16_kernel<int16_t>, dim3(grid), dim3(NT), 0, st, reinterpret_cast<const int16_t*>(a),
+                           m_pre, e_pre, Ma, res, Mr, out, rows, C, map);
+    else
+        hipLaunchKernelGGL(residual_i16_kernel<int32_t>, dim3(grid), dim3(NT), 0, st, reinterpret_cast<const int32_t*>(a),
+                           m_pre, e_pre, Ma, res, Mr, out, rows, C, map);
+    IVIT_CHECK_LAUNCH("ivit_residual_requant_i16");
+}
+
+IVIT_EXPORT int ivit_layernorm_i16_i8(const int16_t* x, int rows, int C, const float* bias_int, const float* s_ln,
+                                      const uint32_t* m, const int32_t* e, int8_t* out, int64_t ldo, int H, int W, int ws,
+                                      int shift, ivit_stream_t stream)
+{
+    IVIT_REQUIRE(x && out && bias_int && s_ln && m && e && rows > 0 && C > 0 && C <= 4096 && ldo >= C,
+                 "ivit_layernorm_i16_i8: bad operand");
+    int rc = check_map("ivit_layernorm_i16_i8", rows, H, W, ws, shift);
+    if (rc) return rc;
+    Ln16Args a{x, rows, C, bias_int, s_ln, m, e, out, ldo, WinMap{H, W, ws, shift}};
+    hipLaunchKernelGGL(layernorm_i16_i8_kernel, dim3(grid_for_rows(rows)), dim3(NT), 0, ivit_stream(stream), a);
+    IVIT_CHECK_LAUNCH("ivit_layernorm_i16_i8");
+}
+
+IVIT_EXPORT int ivit_patch_merge_i16(const int16_t* x, int16_t* out, int batch, int H, int W, int C, ivit_stream_t stream)
+{
+    IVIT_REQUIRE(x && out && batch > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C % 4 == 0,
+                 "ivit_patch_merge_i16: bad operand");
+    IVIT_REQUIRE(((uintptr_t)x % 8 == 0) && ((uintptr_t)out % 8 == 0), "ivit_patch_merge_i16: misaligned operand");
+    const int64_t total = (int64_t)batch * (H / 2) * (W / 2) * C;
+    hipLaunchKernelGGL(patch_merge_kernel, dim3(ew_grid(total)), dim3(NT), 0, ivit_stream(stream), x, out, batch, H, W, C);
+    IVIT_CHECK_LAUNCH("ivit_patch_merge_i16");
+}
+
+IVIT_EXPORT int ivit_avgpool_requant_i8(const int8_t* x, int8_t* out, int batch, int tokens, int C, uint32_t m, int32_t e,
+                                        ivit_stream_t stream)
+{
+    IVIT_REQUIRE(x && out && batch > 0 && tokens > 0 && C > 0, "ivit_avgpool_requant_i8: bad operand");
+    const double Mq = ivit_dyadic_to_double(m, e);
+    IVIT_REQUIRE(Mq < 1048576.0, "ivit_avgpool_requant_i8: multiplier too large");
+    hipLaunchKernelGGL(avgpool_kernel, dim3(ew_grid((int64_t)batch * C)), dim3(NT), 0, ivit_stream(stream), x, out, batch,
+                       tokens, C, Mq);
+    IVIT_CHECK_LAUNCH("ivit_avgpool_requant_i8");
+}
+
+IVIT_EXPORT int ivit_window_attention_i8(const int8_t* qkv, int8_t* out, int64_t ldo, const int16_t* bias_add, const int16_t* mask_add,
+                                         int windows, int windows_per_image, int heads, int tokens, int head_dim,
+                                         uint32_t m_s, int32_t e_s, uint32_t m_b, int32_t e_b, float s_attn, uint32_t m_o,
+                                         int32_t e_o, ivit_stream_t stream)
+{
+    IVIT_REQUIRE(qkv && out && bias_add, "ivit_window_attention_i8: NULL operand");
+    IVIT_REQUIRE(windows > 0 && heads > 0 && windows_per_image > 0 && windows % windows_per_image == 0,
+                 "ivit_window_attention_i8: bad window counts");
+    if (head_dim != WHD || tokens < 2 || tokens > 64) {
+        ivit_set_error("ivit_window_attention_i8: unsupported geometry head_dim=%d tokens=%d (need 32, 2..64)", head_dim, tokens);
+        return IVIT_ERR_UNSUPPORTED;
+    }
+    IVIT_REQUIRE(((uintptr_t)qkv % 16 == 0) && ((uintptr_t)out % 4 == 0) && ldo % 4 == 0 && ldo >= (int64_t)heads * head_dim,
+                 "ivit_window_attention_i8: misaligned operand or ldo too small");
+    IVIT_REQUIRE(s_attn > 0.0f, "ivit_window_attention_i8: scale must be positive");
+    WinAttnArgs a;
+    a.qkv = qkv; a.out = out; a.ldo = ldo; a.bias = bias_add; a.mask = mask_add;
+    a.nwin = windows; a.heads = heads; a.T = tokens; a.nW = windows_per_image;
+    a.Ms = ivit_dyadic_to_double(m_s, e_s);
+    a.Mb = ivit_dyadic_to_double(m_b, e_b);
+    a.Mo = ivit_dyadic_to_double(m_o, e_o);
+    IVIT_REQUIRE(a.Ms < 2048.0 && a.Mb < 1048576.0 && a.Mo < 512.0, "ivit_window_attention_i8: requant multiplier too large");
+    const float x0f = __builtin_floorf((1.0f / s_attn) * -1.0f);
+    IVIT_REQUIRE(x0f <= -1.0f && x0f >= -4096.0f, "ivit_window_attention_i8: x0=%g outside [-4096,-1]", (double)x0f);
+    a.x0 = (int)x0f;
+    // exact u32 row sum: tokens * |x0| * 2^15 must stay below 2^32
+    IVIT_REQUIRE((double)tokens * (double)(-a.x0) * 32768.0 < 4294967296.0,
+                 "ivit_window_attention_i8: Shiftmax row sum could overflow 32 bits (x0=%d)", a.x0);
+    a.ksat = 255;
+    for (int i = 0; i < 256; ++i) {
+        const int d = -i;
+        if (d + (d >> 1) - (d >> 4) <= 15 * a.x0) { a.ksat = i; break; }
+    }
+    const int npairs = windows * heads;
+    const int grid = (npairs + WPB - 1) / WPB;
+    hipLaunchKernelGGL(window_attention_kernel, dim3(grid < 8192 ? grid : 8192), dim3(NT), 0, ivit_stream(stream), a);
+    IVIT_CHECK_LAUNCH("ivit_window_attention_i8");
+}

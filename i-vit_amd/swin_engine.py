@@ -1,0 +1,344 @@
+"""Integer-only Swin forward on MI355X (config 5): int8 GEMM operands, int16 residual stream, every operator a
+hand-written HIP kernel reached through the C ABI (include/ivit_hip.h, second half).
+
+Dataflow = the reference's frozen-model forward (/root/reference/models/swin_quant.py:539-564; WindowAttention
+:121-169; SwinTransformerBlock :251-301; PatchMerging :328-349; PatchEmbed with norm, layers_quant.py:191-203):
+
+  images f32 --quantize+im2col(4x4)--> int8 [B*3136, 48|64] --GEMM+requant--> qact_before_norm int8
+    --I-LayerNorm+requant--> patch_embed.qact int8 --requant 8->16--> x int16 [B*3136, 96]
+  per block { LN16->8 written in window order (partition + cyclic shift are a row map inside the kernel)
+              -> GEMM qkv (+requant, head-major per window) -> window attention (bias, mask, Shiftmax, P.V)
+              -> GEMM proj (int32) -> qact4(16) + window reverse + residual QuantAct(16) in one pass
+              -> LN16->8 -> GEMM fc1 -> ShiftGELU table -> GEMM fc2 (+requant) -> residual QuantAct(16) }
+  per stage end { 2x2 patch-merge gather int16 -> LN16->8 -> GEMM reduction (+requant) -> widen to int16 }
+  LN16->8 -> token average pool + requant -> GEMM head -> INT32 logits -> scale + argmax
+
+There is no fallback path: a missing libivit_hip.so or a kernel error raises.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _lib
+from .prepare import LayerNormParams, LinearParams, dyadic, f32, quant_sym, requant_host, sym_scale
+from .synth import IMG_SIZE, NUM_CLASSES
+
+PATCH = 4
+HEAD_DIM = 32
+IDENT = (1 << 30, 30)  # dyadic 1.0
+
+
+def _np(v):
+    if isinstance(v, torch.Tensor):
+        return v.detach().cpu().numpy()
+    return np.asarray(v)
+
+
+def _pad64(k):
+    return (k + 63) // 64 * 64
+
+
+def rel_position_index(ws: int) -> np.ndarray:
+    """relative_position_index of WindowAttention (swin_quant.py:73-88): [ws*ws, ws*ws] into the (2ws-1)^2 table."""
+    yy, xx = np.divmod(np.arange(ws * ws), ws)
+    dy = yy[:, None] - yy[None, :] + (ws - 1)
+    dx = xx[:, None] - xx[None, :] + (ws - 1)
+    return dy * (2 * ws - 1) + dx
+
+
+def shift_mask_regions(H: int, W: int, ws: int, shift: int) -> np.ndarray:
+    """Region id of every window token of a shifted block (swin_quant.py:223-243): [nW, ws*ws]."""
+    def band(n):
+        b = np.zeros(n, np.int64)
+        b[n - ws:n - shift] = 1
+        b[n - shift:] = 2
+        return b
+    img = band(H)[:, None] * 3 + band(W)[None, :]
+    return img.reshape(H // ws, ws, W // ws, ws).transpose(0, 2, 1, 3).reshape(-1, ws * ws)
+
+
+def window_row_map(B: int, H: int, W: int, ws: int, shift: int) -> np.ndarray:
+    """Host restatement of the kernels' win_row (csrc/swin.hip): destination row, in window order, of token (b,y,x)."""
+    y, x = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    ys, xs = (y - shift) % H, (x - shift) % W
+    idx = ((ys // ws) * (W // ws) + xs // ws) * (ws * ws) + (ys % ws) * ws + xs % ws
+    return (np.arange(B)[:, None] * (H * W) + idx.reshape(-1)[None, :]).reshape(-1)
+
+
+class IntSwinEngine:
+    def __init__(self, float_state, ranges, embed_dim=96, depths=(2, 2, 6, 2), num_heads=(3, 6, 12, 24), window=7,
+                 device="cuda:0", max_batch: int = 64):
+        self.C0, self.depths, self.heads, self.window = embed_dim, tuple(depths), tuple(num_heads), window
+        self.dev = torch.device(device)
+        self.max_batch = max_batch
+        _lib.lib()  # fail loudly now if the HIP library is absent
+        P = {k: _np(v).astype(np.float32) for k, v in float_state.items()}
+        R = ranges
+
+        def s(name, bits=8):
+            lo, hi = R[name]
+            return sym_scale(lo, hi, bits)
+
+        def dev(a, dtype=None):
+            t = torch.from_numpy(np.ascontiguousarray(a))
+            if dtype is not None:
+                t = t.to(dtype)
+            return t.to(self.dev)
+
+        def lin_host(name, s_in):
+            lp = LinearParams(P[name + ".weight"], P.get(name + ".bias"), s_in)
+            Kp = _pad64(lp.K)
+            W = np.zeros((lp.W8.shape[0], Kp), np.int8)   # zero K-padding: the operand's pad columns never contribute
+            W[:, :lp.K] = lp.W8
+            d = dict(W=dev(W), b=None if lp.b32 is None else dev(lp.b32), K=Kp, N=W.shape[0])
+            return lp, d
+
+        def lin_dev(name, s_in, s_out):
+            lp, d = lin_host(name, s_in)
+            m, e = lp.requant_to(s_out)
+            d.update(m=dev(m.view(np.int32)), e=dev(e))
+            return d
+
+        def ln_dev(prefix, s_out):
+            lp = LayerNormParams(P[prefix + ".weight"], P[prefix + ".bias"], s_out)
+            return dict(bias=dev(lp.bias_int), s=dev(lp.s_ln), m=dev(lp.m.view(np.int32)), e=dev(lp.e))
+
+        def sme(pre, z):
+            m, e = dyadic(pre, z)
+            return int(m[0]), int(e[0])
+
+        # ---- stem (layers_quant.py:191-203 with norm_layer; swin_quant.py:541-546)
+        s0 = s("qact_input")
+        self.inv_s0 = float(f32(1.0) / s0)
+        s_bn = s("patch_embed.qact_before_norm")
+        self.patch = lin_dev("patch_embed.proj", s0, s_bn)
+        s_pq = s("patch_embed.qact")
+        self.patch_ln = ln_dev("patch_embed.norm", s_pq)
+        s_x = s("qact1", 16)
+        self.stem_me = sme(s_pq, s_x)
+
+        # ---- stages
+        self.stages = []
+        G = IMG_SIZE // PATCH
+        H = W = G
+        C = embed_dim
+        for li, (depth, nH) in enumerate(zip(self.depths, self.heads)):
+            if C // nH != HEAD_DIM:
+                raise ValueError("window attention kernel supports head_dim 32 only")
+            st = dict(H=H, W=W, C=C, nH=nH, blocks=[], down=None)
+            for bi in range(depth):
+                p = f"layers.{li}.blocks.{bi}."
+                win = min(window, H)
+                shift = 0 if (bi % 2 == 0 or min(H, W) <= window) else window // 2
+                N = win * win
+                blk = dict(win=win, shift=shift)
+                s_q1 = s(p + "qact1")
+                blk["ln1"] = ln_dev(p + "norm1", s_q1)
+                s_a1 = s(p + "attn.qact1")
+                blk["qkv"] = lin_dev(p + "attn.qkv", s_q1, s_a1)
+                s_S = f32(f32(s_a1 * s_a1) * f32(HEAD_DIM ** -0.5))            # swin_quant.py:139-141
+                s_at = s(p + "attn.qact_attn1")
+                s_tab = s(p + "attn.qact_table")
+                s_A = s(p + "attn.qact2")
+                ktab = quant_sym(P[p + "attn.relative_position_bias_table"], s_tab, 8)   # [(2ws-1)^2, nH]
+                m2, e2 = dyadic(s_tab, s_A)
+                bias = ktab[rel_position_index(win).reshape(-1)].reshape(N, N, nH).transpose(2, 0, 1)
+                bias_add = requant_host(bias, m2[0], e2[0])                    # identity operand of qact2, :143-147
+                assert np.abs(bias_add).max() < 32768
+                mask_add = None
+                if shift:
+                    reg = shift_mask_regions(H, W, win, shift)
+                    mval = f32(-100.0) / s_A                                    # :149-155: (k*s + (-100)) / s
+                    if mval != np.rint(mval) or abs(mval) >= 32768:
+                        raise ValueError("shift mask / attention scale is not a 16-bit integer (outside the pow2 regime)")
+                    mask_add = np.where(reg[:, :, None] != reg[:, None, :], int(mval), 0).astype(np.int16)
+                s_pv = f32(f32(1.0 / 128.0) * s_a1)
+                s_a3 = s(p + "attn.qact3")
+                blk["attn"] = dict(ms=sme(s_S, s_at), mb=sme(s_at, s_A), s_attn=float(s_A), mo=sme(s_pv, s_a3),
+                                   bias=dev(bias_add.astype(np.int16)), mask=None if mask_add is None else dev(mask_add),
+                                   nW=(H // win) * (W // win))
+                lp, d = lin_host(p + "attn.proj", s_a3)
+                s_a4 = s(p + "attn.qact4", 16)
+                mp, ep = dyadic(lp.s_acc, s_a4)
+                d.update(m=dev(mp.view(np.int32)), e=dev(ep))
+                blk["proj"] = d
+                s_b2 = s(p + "qact2", 16)
+                blk["res1"] = sme(s_a4, s_b2) + sme(s_x, s_b2)
+                s_b3 = s(p + "qact3")
+                blk["ln2"] = ln_dev(p + "norm2", s_b3)
+                s_g = s(p + "mlp.qact_gelu")
+                blk["fc1"] = lin_dev(p + "mlp.fc1", s_b3, s_g)
+                s_go = f32(s_g * f32(1.0 / 128.0))
+                s_m1 = s(p + "mlp.qact1")
+                mg, eg = sme(s_go, s_m1)
+                lut = torch.empty(65536, dtype=torch.int8, device=self.dev)
+                _lib.call("ivit_shiftgelu_build_lut", float(s_g), mg, eg, _lib.ptr(lut), self._stream())
+                blk["gelu_lut"] = lut
+                s_m2 = s(p + "mlp.qact2")
+                blk["fc2"] = lin_dev(p + "mlp.fc2", s_m1, s_m2)
+                s_b4 = s(p + "qact4", 16)
+                blk["res2"] = sme(s_m2, s_b4) + sme(s_b2, s_b4)
+                s_x = s_b4
+                st["blocks"].append(blk)
+            if li < len(self.depths) - 1:
+                p = f"layers.{li}.downsample."
+                s_d1 = s(p + "qact1")
+                s_d2 = s(p + "qact2")
+                st["down"] = dict(ln=ln_dev(p + "norm", s_d1), red=lin_dev(p + "reduction", s_d1, s_d2))
+                s_x = s_d2
+            self.stages.append(st)
+            if st["down"] is not None:
+                H, W, C = H // 2, W // 2, 2 * C
+        self.C_last, self.T_last = C, H * W
+
+        # ---- tail (swin_quant.py:552-563)
+        s_q2 = s("qact2")
+        self.ln_f = ln_dev("norm", s_q2)
+        s_q3 = s("qact3")
+        self.pool_me = sme(s_q2, s_q3)
+        lp, d = lin_host("head", s_q3)
+        self.head = d
+        self.head_scale = dev(lp.s_acc)
+        self._alloc(max_batch)
+        torch.cuda.synchronize(self.dev)
+
+    # ------------------------------------------------------------------ plumbing
+    def _stream(self):
+        return _lib.stream_ptr()
+
+    def _alloc(self, B):
+        C0 = self.C0
+        M0 = B * (IMG_SIZE // PATCH) ** 2
+        ld0 = _pad64(C0)
+        i8 = dict(dtype=torch.int8, device=self.dev)
+        i16 = dict(dtype=torch.int16, device=self.dev)
+        slack = 256  # GEMM K-padding reads up to ld - C bytes past the last row of a C-strided operand
+        self.ws = dict(
+            a0=torch.zeros(M0 * 64 + slack, **i8),
+            pe=torch.empty(M0 * C0, **i8), pn=torch.empty(M0 * C0, **i8),
+            x=torch.empty(M0 * C0, **i16), x2=torch.empty(M0 * C0, **i16),
+            h=torch.zeros(M0 * ld0 + slack, **i8), ao=torch.zeros(M0 * ld0 + slack, **i8),
+            qkv=torch.empty(3 * M0 * C0, **i8),
+            acc=torch.empty(M0 * C0, dtype=torch.int32, device=self.dev),
+            f1=torch.empty(M0 * 4 * C0, **i8), g=torch.empty(M0 * 4 * C0, **i8), f2=torch.empty(M0 * C0, **i8),
+            xm=torch.empty(M0 * C0, **i16), hm=torch.empty(M0 * C0, **i8), red=torch.empty(M0 * C0 // 2, **i8),
+            hN=torch.empty(B * self.T_last * self.C_last, **i8), pooled=torch.empty(B * self.C_last, **i8),
+            logits=torch.empty(B, NUM_CLASSES, dtype=torch.int32, device=self.dev),
+            logits_f=torch.empty(B, NUM_CLASSES, dtype=torch.float32, device=self.dev),
+            top1=torch.empty(B, dtype=torch.int32, device=self.dev),
+        )
+
+    def _gemm(self, A, lda, lin, out, ldo, M, st):
+        _lib.call("ivit_gemm_i8_requant", _lib.ptr(A), lda, _lib.ptr(lin["W"]), lin["K"], _lib.ptr(lin["b"]),
+                  _lib.ptr(lin["m"]), _lib.ptr(lin["e"]), _lib.ptr(out), ldo, M, lin["N"], lin["K"], st)
+
+    def _ln16(self, x, rows, C, ln, out, ldo, st, H=0, W=0, ws=0, shift=0):
+        _lib.call("ivit_layernorm_i16_i8", _lib.ptr(x), rows, C, _lib.ptr(ln["bias"]), _lib.ptr(ln["s"]),
+                  _lib.ptr(ln["m"]), _lib.ptr(ln["e"]), _lib.ptr(out), ldo, H, W, ws, shift, st)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, images: torch.Tensor, taps: dict | None = None):
+        """images: float32 [B,3,224,224] on the engine's device.  Returns (logits_int32 [B,1000], logits_f32, top1)
+        -- views of the engine's workspace, valid until the next call.  `taps` (tests) receives clones of the
+        intermediate integer tensors in the reference's layouts."""
+        assert images.is_cuda and images.dtype == torch.float32 and images.is_contiguous()
+        B = images.shape[0]
+        assert images.shape[1:] == (3, IMG_SIZE, IMG_SIZE) and 0 < B <= self.max_batch
+        ws = self.ws
+        st = self._stream()
+        G = IMG_SIZE // PATCH
+        C0 = self.C0
+        M = B * G * G
+
+        def tap(name, t, rows, C, ld=None, perm=None):
+            if taps is None:
+                return
+            ld = C if ld is None else ld
+            v = t[: rows * ld].view(rows, ld)[:, :C]
+            if perm is not None:
+                v = v[perm]
+            taps[name] = v.clone()
+
+        _lib.call("ivit_quantize_patchify_ld_f32_i8", _lib.ptr(images), _lib.ptr(ws["a0"]), 64, B, 3, IMG_SIZE, PATCH,
+                  self.inv_s0, st)
+        self._gemm(ws["a0"], 64, self.patch, ws["pe"], C0, M, st)
+        tap("patch_embed.qact_before_norm", ws["pe"], M, C0)
+        ln = self.patch_ln
+        _lib.call("ivit_layernorm_i8", _lib.ptr(ws["pe"]), C0, M, C0, _lib.ptr(ln["bias"]), _lib.ptr(ln["s"]),
+                  _lib.ptr(ln["m"]), _lib.ptr(ln["e"]), _lib.ptr(ws["pn"]), C0, st)
+        tap("patch_embed.qact", ws["pn"], M, C0)
+        x, x2 = ws["x"], ws["x2"]
+        _lib.call("ivit_requant_i8_i16", _lib.ptr(ws["pn"]), self.stem_me[0], self.stem_me[1], _lib.ptr(x), M * C0, st)
+        tap("qact1", x, M, C0)
+
+        for li, stg in enumerate(self.stages):
+            H, W, C, nH = stg["H"], stg["W"], stg["C"], stg["nH"]
+            M = B * H * W
+            ld = _pad64(C)
+            for bi, blk in enumerate(stg["blocks"]):
+                p = f"layers.{li}.blocks.{bi}."
+                win, shift = blk["win"], blk["shift"]
+                N = win * win
+                nwin = M // N
+                perm = None
+                if taps is not None:
+                    perm = torch.from_numpy(window_row_map(B, H, W, win, shift)).to(self.dev)
+                self._ln16(x, M, C, blk["ln1"], ws["h"], ld, st, H, W, win, shift)
+                tap(p + "qact1", ws["h"], M, C, ld, perm)
+                q = blk["qkv"]
+                _lib.call("ivit_gemm_i8_requant_qkv", _lib.ptr(ws["h"]), ld, _lib.ptr(q["W"]), q["K"], _lib.ptr(q["b"]),
+                          _lib.ptr(q["m"]), _lib.ptr(q["e"]), _lib.ptr(ws["qkv"]), N, nH, HEAD_DIM, M, 3 * C, q["K"], st)
+                if taps is not None:   # reference layout [B_, N, 3C] (swin_quant.py:131-133)
+                    hm = ws["qkv"][: 3 * M * C].view(3, nwin, nH, N, HEAD_DIM)
+                    taps[p + "attn.qact1"] = hm.permute(1, 3, 0, 2, 4).reshape(nwin, N, 3 * C).clone()
+                a = blk["attn"]
+                _lib.call("ivit_window_attention_i8", _lib.ptr(ws["qkv"]), _lib.ptr(ws["ao"]), ld, _lib.ptr(a["bias"]),
+                          _lib.ptr(a["mask"]), nwin, a["nW"], nH, N, HEAD_DIM, a["ms"][0], a["ms"][1], a["mb"][0],
+                          a["mb"][1], a["s_attn"], a["mo"][0], a["mo"][1], st)
+                tap(p + "attn.qact3", ws["ao"], M, C, ld)
+                pj = blk["proj"]
+                _lib.call("ivit_gemm_i8_i32", _lib.ptr(ws["ao"]), ld, _lib.ptr(pj["W"]), pj["K"], _lib.ptr(pj["b"]),
+                          _lib.ptr(ws["acc"]), C, M, C, pj["K"], st)
+                r = blk["res1"]
+                _lib.call("ivit_residual_requant_i16", _lib.ptr(ws["acc"]), 32, _lib.ptr(pj["m"]), _lib.ptr(pj["e"]),
+                          r[0], r[1], _lib.ptr(x), r[2], r[3], _lib.ptr(x2), M, C, H, W, win, shift, st)
+                tap(p + "qact2", x2, M, C)
+                self._ln16(x2, M, C, blk["ln2"], ws["h"], ld, st)
+                tap(p + "qact3", ws["h"], M, C, ld)
+                self._gemm(ws["h"], ld, blk["fc1"], ws["f1"], 4 * C, M, st)
+                tap(p + "mlp.qact_gelu", ws["f1"], M, 4 * C)
+                _lib.call("ivit_shiftgelu_lut_i8", _lib.ptr(ws["f1"]), 4 * C, M, 4 * C, _lib.ptr(blk["gelu_lut"]),
+                          _lib.ptr(ws["g"]), 4 * C, st)
+                tap(p + "mlp.qact1", ws["g"], M, 4 * C)
+                self._gemm(ws["g"], 4 * C, blk["fc2"], ws["f2"], C, M, st)
+                tap(p + "mlp.qact2", ws["f2"], M, C)
+                r = blk["res2"]
+                _lib.call("ivit_residual_requant_i16", _lib.ptr(ws["f2"]), 8, None, None, r[0], r[1], _lib.ptr(x2), r[2],
+                          r[3], _lib.ptr(x), M, C, 0, 0, 0, 0, st)
+                tap(p + "qact4", x, M, C)
+            dn = stg["down"]
+            if dn is not None:
+                p = f"layers.{li}.downsample."
+                _lib.call("ivit_patch_merge_i16", _lib.ptr(x), _lib.ptr(ws["xm"]), B, H, W, C, st)
+                M4 = M // 4
+                self._ln16(ws["xm"], M4, 4 * C, dn["ln"], ws["hm"], 4 * C, st)
+                tap(p + "qact1", ws["hm"], M4, 4 * C)
+                self._gemm(ws["hm"], 4 * C, dn["red"], ws["red"], 2 * C, M4, st)
+                tap(p + "qact2", ws["red"], M4, 2 * C)
+                _lib.call("ivit_requant_i8_i16", _lib.ptr(ws["red"]), IDENT[0], IDENT[1], _lib.ptr(x), M4 * 2 * C, st)
+
+        C, T = self.C_last, self.T_last
+        self._ln16(x, B * T, C, self.ln_f, ws["hN"], C, st)
+        tap("qact2", ws["hN"], B * T, C)
+        _lib.call("ivit_avgpool_requant_i8", _lib.ptr(ws["hN"]), _lib.ptr(ws["pooled"]), B, T, C, self.pool_me[0],
+                  self.pool_me[1], st)
+        tap("qact3", ws["pooled"], B, C)
+        hd = self.head
+        _lib.call("ivit_gemm_i8_i32", _lib.ptr(ws["pooled"]), C, _lib.ptr(hd["W"]), hd["K"], _lib.ptr(hd["b"]),
+                  _lib.ptr(ws["logits"]), NUM_CLASSES, B, NUM_CLASSES, hd["K"], st)
+        _lib.call("ivit_head_argmax", _lib.ptr(ws["logits"]), _lib.ptr(self.head_scale), B, NUM_CLASSES,
+                  _lib.ptr(ws["logits_f"]), _lib.ptr(ws["top1"]), st)
+        return ws["logits"][:B], ws["logits_f"][:B], ws["top1"][:B]
+
+    __call__ = forward

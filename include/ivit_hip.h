@@ -51,6 +51,10 @@ int ivit_quantize_input_f32_i8(const float* x, int8_t* out, int64_t n, float inv
  *   column order (c, kh, kw) = the flattening of the conv weight [out, c, kh, kw]. */
 int ivit_quantize_patchify_f32_i8(const float* img, int8_t* A, int batch, int chans, int hw, int patch,
                                   float inv_scale, ivit_stream_t stream);
+/* as above with an explicit row stride lda >= chans*patch*patch (Swin: patch 4 -> K = 48, padded to the GEMM's
+ * K granularity of 64); columns [K, lda) are not written: the caller zero-fills them once. */
+int ivit_quantize_patchify_ld_f32_i8(const float* img, int8_t* A, int64_t lda, int batch, int chans, int hw, int patch,
+                                     float inv_scale, ivit_stream_t stream);
 
 /* ---- INT8 GEMM on v_mfma_i32_32x32x32_i8 with fused epilogues -------------------------------
  * QuantLinear.forward / QuantConv2d.forward (quant_modules.py:186-226, 478-511) followed by
@@ -191,6 +195,62 @@ int ivit_i32_to_f32(const int32_t* z, int64_t rows, int C, const float* s, int n
 /* int32 integer view -> int8 operand of the GEMM / matmul kernels (module-level path).  Values outside
  * [-128, 127] saturate and set *overflow_flag (device int32, may be NULL) to 1. */
 int ivit_narrow_i32_i8(const int32_t* z, int8_t* out, int64_t n, int32_t* overflow_flag, ivit_stream_t stream);
+
+/* =================================================================================================
+ * Swin (models/swin_quant.py): 16-bit residual stream, windowed attention, patch merging, pooling.
+ * The window partition, cyclic shift and their inverses (swin_quant.py:18-50, 258-271, 278-289) are row
+ * permutations of a [B, H*W, C] tensor; kernels that take (H, W, ws, shift) apply
+ *   win_row(b, y, x) = window-major index of token (b, (y - shift) mod H, (x - shift) mod W)
+ * on the fly (ws == 0: identity), so no partitioned copy of the activations is ever materialised.
+ * ================================================================================================= */
+
+/* 8 -> 16 bit QuantAct (SwinTransformer.qact1, swin_quant.py:546): out = clamp16(RNE(x * m / 2^e)).
+ * With (m, e) = (2^30, 30) it is the exact int8 -> int16 widening used behind PatchMerging. */
+int ivit_requant_i8_i16(const int8_t* x, uint32_t m, int32_t e, int16_t* out, int64_t n, ivit_stream_t stream);
+
+/* Two-operand 16-bit QuantAct of the residual connections (SwinTransformerBlock.qact2 / qact4,
+ * swin_quant.py:293,299; quant_utils.py:232-245):
+ *   out[r][c] = clamp16(RNE(k[win_row(r)][c] * m_a / 2^e_a) + RNE(res[r][c] * m_r / 2^e_r))
+ * a_bits = 8 / 16: k = a (int8 / int16 [rows, C]);
+ * a_bits = 32: a holds raw int32 accumulators of attn.proj and k = clamp16(RNE(a * m_pre[c] / 2^e_pre[c]))
+ *   is the 16-bit attn.qact4 (swin_quant.py:166) fused in; (m_pre, e_pre) must be NULL otherwise.
+ * The window map applies to `a` only (window_reverse + un-shift, swin_quant.py:278-289). C % 4 == 0. */
+int ivit_residual_requant_i16(const void* a, int a_bits, const uint32_t* m_pre, const int32_t* e_pre, uint32_t m_a,
+                              int32_t e_a, const int16_t* res, uint32_t m_r, int32_t e_r, int16_t* out, int64_t rows,
+                              int C, int H, int W, int ws, int shift, ivit_stream_t stream);
+
+/* I-LayerNorm on the 16-bit stream + 8-bit QuantAct (ivit_modules.py:30-65 with the Newton iteration on
+ * float32(var), as the reference runs it); row r of x is written to row win_row(r) of out (stride ldo >= C):
+ * norm1 writes straight into window order (swin_quant.py:258-271).  Same constants and contract as
+ * ivit_layernorm_i8. */
+int ivit_layernorm_i16_i8(const int16_t* x, int rows, int C, const float* bias_int, const float* s_ln,
+                          const uint32_t* m, const int32_t* e, int8_t* out, int64_t ldo, int H, int W, int ws, int shift,
+                          ivit_stream_t stream);
+
+/* PatchMerging gather (swin_quant.py:337-344): x [B, H*W, C] int16 -> out [B, (H/2)*(W/2), 4C],
+ * channel blocks (even y, even x), (odd y, even x), (even y, odd x), (odd y, odd x). */
+int ivit_patch_merge_i16(const int16_t* x, int16_t* out, int batch, int H, int W, int C, ivit_stream_t stream);
+
+/* AdaptiveAvgPool1d over the tokens + qact3 (swin_quant.py:554-555):
+ *   out[b][c] = clamp8(RNE(round(fl32(sum_t x[b][t][c] / tokens)) * m / 2^e)) */
+int ivit_avgpool_requant_i8(const int8_t* x, int8_t* out, int batch, int tokens, int C, uint32_t m, int32_t e,
+                            ivit_stream_t stream);
+
+/* WindowAttention core (swin_quant.py:137-161): matmul_1 -> qact_attn1 -> + relative position bias through the
+ * two-operand qact2 -> + shift mask -> Shiftmax -> matmul_2 -> qact3, one wave per (window, head).
+ *   qkv      [3][windows][heads][tokens][32] int8 (ivit_gemm_i8_requant_qkv on window-ordered rows)
+ *   out      [windows*tokens, ldo] int8, column h*32 + d
+ *   bias_add [heads][tokens][tokens] int16 = RNE(qact_table(table)[index] * m2 / 2^e2): the identity operand of
+ *            qact2, a load-time constant
+ *   mask_add [windows_per_image][tokens][tokens] int16 in {0, -100/s_attn} or NULL (un-shifted block); added after
+ *            qact2's clamp, as the reference adds the float mask to the fake-quantised scores (:149-155)
+ *   (m_s,e_s): q.k^T -> qact_attn1;  (m_b,e_b): qact_attn1 -> qact2;  s_attn: scale of qact2 (Shiftmax input);
+ *   (m_o,e_o): P.v -> qact3.
+ * Supported: head_dim 32, 2 <= tokens <= 64. */
+int ivit_window_attention_i8(const int8_t* qkv, int8_t* out, int64_t ldo, const int16_t* bias_add,
+                             const int16_t* mask_add, int windows, int windows_per_image, int heads, int tokens,
+                             int head_dim, uint32_t m_s, int32_t e_s, uint32_t m_b, int32_t e_b, float s_attn,
+                             uint32_t m_o, int32_t e_o, ivit_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,309 @@
+"""GPU parity for the Swin path (config 5): the extra HIP kernels against the CPU oracle, and the whole
+IntSwinEngine against tests/golden/swin_tiny.npz (INT32 logits, top-1, CRC32 of the reference's taps)."""
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+ivit = pytest.importorskip("ivit_amd")
+from ivit_amd import _lib, synth  # noqa: E402
+from ivit_amd.checkpoint import load_fixture  # noqa: E402
+from ivit_amd.prepare import LayerNormParams, dyadic  # noqa: E402
+from ivit_amd.swin_engine import IntSwinEngine  # noqa: E402
+
+DEV = "cuda:0"
+_KEEP = []
+
+
+def dev(a):
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    _KEEP.append(t)
+    return t
+
+
+@pytest.fixture(autouse=True)
+def _release_device_tensors():
+    yield
+    torch.cuda.synchronize()
+    _KEEP.clear()
+
+
+def st():
+    return _lib.stream_ptr()
+
+
+def crc(a):
+    return zlib.crc32(np.ascontiguousarray(a, dtype=np.int32).tobytes())
+
+
+def sme(pre, z):
+    m, e = dyadic(np.float32(pre), np.float32(z))
+    return int(m[0]), int(e[0])
+
+
+def ome(pre, z):
+    return orc.dyadic(np.float32(pre), np.float32(z))
+
+
+# ----------------------------------------------------------------------------------- elementwise kernels
+def test_requant_i8_i16():
+    rng = np.random.default_rng(1)
+    x = rng.integers(-128, 128, size=100003, dtype=np.int8)
+    for pre, z in ((0.031, 0.00011), (1.0, 1.0), (0.5, 3.0)):
+        m, e = sme(pre, z)
+        out = torch.empty(x.size, dtype=torch.int16, device=DEV)
+        _lib.call("ivit_requant_i8_i16", _lib.ptr(dev(x)), m, e, _lib.ptr(out), x.size, st())
+        om, oe = ome(pre, z)
+        ref = orc.requant(x.astype(np.int32).reshape(1, -1), om, oe, 16).reshape(-1)
+        assert np.array_equal(out.cpu().numpy().astype(np.int32), ref)
+    m, e = 1 << 30, 30
+    out = torch.empty(x.size, dtype=torch.int16, device=DEV)
+    _lib.call("ivit_requant_i8_i16", _lib.ptr(dev(x)), m, e, _lib.ptr(out), x.size, st())
+    assert np.array_equal(out.cpu().numpy(), x.astype(np.int16))
+
+
+@pytest.mark.parametrize("a_bits", [8, 16, 32])
+@pytest.mark.parametrize("B,H,ws,shift,C", [(2, 14, 7, 3, 96), (3, 8, 4, 0, 64), (1, 7, 7, 0, 768), (2, 8, 4, 2, 36)])
+def test_residual_requant_i16(a_bits, B, H, ws, shift, C):
+    rng = np.random.default_rng(a_bits * 100 + H)
+    rows = B * H * H
+    res = rng.integers(-32768, 32768, size=(rows, C)).astype(np.int16)
+    ma, mr = sme(0.013, 0.02), sme(0.0171, 0.02)
+    oma, omr = ome(0.013, 0.02), ome(0.0171, 0.02)
+    mp = ep = None
+    if a_bits == 8:
+        a = rng.integers(-128, 128, size=(rows, C)).astype(np.int8)
+        k = a.astype(np.int32)
+    elif a_bits == 16:
+        a = rng.integers(-32768, 32768, size=(rows, C)).astype(np.int16)
+        k = a.astype(np.int32)
+    else:
+        a = rng.integers(-200000, 200000, size=(rows, C)).astype(np.int32)
+        pre = (rng.uniform(0.5, 1.0, size=C) * 2.0 ** rng.integers(-4, 1, size=C)).astype(np.float32)
+        mpre, epre = dyadic(pre, np.float32(1.0))
+        om, oe = orc.dyadic(pre, np.float32(1.0))
+        k = orc.requant(a, om, oe, 16)
+        mp, ep = dev(mpre.view(np.int32)), dev(epre)
+    # reference: window_reverse + roll back of the window-ordered `k`, then the two-operand QuantAct
+    kk = orc._win_reverse(k.reshape(-1, ws, ws, C), ws, H, H)
+    if shift:
+        kk = np.roll(kk, (shift, shift), axis=(1, 2))
+    ref = orc.requant(np.ascontiguousarray(kk.reshape(rows, C)), oma[0], oma[1], 16, z2=res.astype(np.int32), m2=omr[0],
+                      e2=omr[1])
+    out = torch.empty(rows, C, dtype=torch.int16, device=DEV)
+    _lib.call("ivit_residual_requant_i16", _lib.ptr(dev(a)), a_bits, _lib.ptr(mp), _lib.ptr(ep), ma[0], ma[1],
+              _lib.ptr(dev(res)), mr[0], mr[1], _lib.ptr(out), rows, C, H, H, ws, shift, st())
+    assert np.array_equal(out.cpu().numpy().astype(np.int32), ref)
+    # identity map
+    out2 = torch.empty(rows, C, dtype=torch.int16, device=DEV)
+    _lib.call("ivit_residual_requant_i16", _lib.ptr(dev(a)), a_bits, _lib.ptr(mp), _lib.ptr(ep), ma[0], ma[1],
+              _lib.ptr(dev(res)), mr[0], mr[1], _lib.ptr(out2), rows, C, 0, 0, 0, 0, st())
+    ref2 = orc.requant(np.ascontiguousarray(k), oma[0], oma[1], 16, z2=res.astype(np.int32), m2=omr[0], e2=omr[1])
+    assert np.array_equal(out2.cpu().numpy().astype(np.int32), ref2)
+
+
+def test_residual_requant_i16_rejects_bad_arguments():
+    a = dev(np.zeros((49, 8), np.int8))
+    r = dev(np.zeros((49, 8), np.int16))
+    o = torch.empty(49, 8, dtype=torch.int16, device=DEV)
+    with pytest.raises(_lib.IvitError):   # H not a multiple of the window
+        _lib.call("ivit_residual_requant_i16", _lib.ptr(a), 8, None, None, 1 << 30, 30, _lib.ptr(r), 1 << 30, 30,
+                  _lib.ptr(o), 49, 8, 7, 7, 4, 0, st())
+    with pytest.raises(_lib.IvitError):   # int32 accumulators without their requantiser table
+        _lib.call("ivit_residual_requant_i16", _lib.ptr(a), 32, None, None, 1 << 30, 30, _lib.ptr(r), 1 << 30, 30,
+                  _lib.ptr(o), 49, 8, 0, 0, 0, 0, st())
+
+
+@pytest.mark.parametrize("rows,C,amp", [(300, 96, 30000), (64, 384, 3000), (50, 768, 32767), (33, 1536, 200), (7, 100, 5)])
+def test_layernorm_i16_i8(rows, C, amp):
+    rng = np.random.default_rng(C + amp)
+    x = rng.integers(-amp, amp + 1, size=(rows, C)).astype(np.int16)
+    x[0] = 0  # constant row: var = 0
+    x[1] = amp
+    gamma = rng.uniform(0.5, 1.5, size=C).astype(np.float32)
+    beta = (rng.standard_normal(C) * 0.1).astype(np.float32)
+    s_out = np.float32(4.0 / 127.0)
+    lp = LayerNormParams(gamma, beta, s_out)
+    y, s_ln, _ = orc.layernorm(x.astype(np.int32), gamma, beta)
+    z = orc.roundtrip(y, s_ln)
+    om, oe = orc.dyadic(s_ln, s_out)
+    ref = orc.requant(z, om, oe, 8)
+    out = torch.zeros(rows, C + 16, dtype=torch.int8, device=DEV)
+    _lib.call("ivit_layernorm_i16_i8", _lib.ptr(dev(x)), rows, C, _lib.ptr(dev(lp.bias_int)), _lib.ptr(dev(lp.s_ln)),
+              _lib.ptr(dev(lp.m.view(np.int32))), _lib.ptr(dev(lp.e)), _lib.ptr(out), C + 16, 0, 0, 0, 0, st())
+    got = out.cpu().numpy()
+    assert np.array_equal(got[:, :C].astype(np.int32), ref)
+    assert not got[:, C:].any()
+
+
+def test_layernorm_i16_i8_window_order():
+    rng = np.random.default_rng(5)
+    B, H, ws, shift, C = 2, 14, 7, 3, 96
+    rows = B * H * H
+    x = rng.integers(-20000, 20000, size=(rows, C)).astype(np.int16)
+    gamma = rng.uniform(0.5, 1.5, size=C).astype(np.float32)
+    beta = (rng.standard_normal(C) * 0.1).astype(np.float32)
+    lp = LayerNormParams(gamma, beta, np.float32(4.0 / 127.0))
+    args = (_lib.ptr(dev(lp.bias_int)), _lib.ptr(dev(lp.s_ln)), _lib.ptr(dev(lp.m.view(np.int32))), _lib.ptr(dev(lp.e)))
+    plain = torch.empty(rows, C, dtype=torch.int8, device=DEV)
+    _lib.call("ivit_layernorm_i16_i8", _lib.ptr(dev(x)), rows, C, *args, _lib.ptr(plain), C, 0, 0, 0, 0, st())
+    wino = torch.empty(rows, C, dtype=torch.int8, device=DEV)
+    _lib.call("ivit_layernorm_i16_i8", _lib.ptr(dev(x)), rows, C, *args, _lib.ptr(wino), C, H, H, ws, shift, st())
+    p = plain.cpu().numpy().reshape(B, H, H, C)
+    exp = orc._win_partition(np.roll(p, (-shift, -shift), axis=(1, 2)), ws).reshape(rows, C)
+    assert np.array_equal(wino.cpu().numpy(), exp)
+
+
+def test_patch_merge_i16():
+    rng = np.random.default_rng(9)
+    B, H, W, C = 3, 8, 6, 20
+    x = rng.integers(-32768, 32768, size=(B, H, W, C)).astype(np.int16)
+    ref = np.concatenate([x[:, 0::2, 0::2], x[:, 1::2, 0::2], x[:, 0::2, 1::2], x[:, 1::2, 1::2]], -1)
+    out = torch.empty(B * H * W * C, dtype=torch.int16, device=DEV)
+    _lib.call("ivit_patch_merge_i16", _lib.ptr(dev(x)), _lib.ptr(out), B, H, W, C, st())
+    assert np.array_equal(out.cpu().numpy().reshape(ref.shape), ref)
+
+
+def test_avgpool_requant_i8():
+    rng = np.random.default_rng(11)
+    B, T, C = 5, 49, 768
+    x = rng.integers(-128, 128, size=(B, T, C)).astype(np.int8)
+    m, e = sme(0.031, 0.027)
+    om, oe = ome(0.031, 0.027)
+    mean_f = (x.astype(np.int32).sum(axis=1).astype(np.float32) / np.float32(T)).astype(np.float32)
+    ref = orc.requant(np.rint(mean_f).astype(np.float32), om, oe, 8)
+    out = torch.empty(B, C, dtype=torch.int8, device=DEV)
+    _lib.call("ivit_avgpool_requant_i8", _lib.ptr(dev(x)), _lib.ptr(out), B, T, C, m, e, st())
+    assert np.array_equal(out.cpu().numpy().astype(np.int32), ref)
+
+
+def test_patchify_ld():
+    rng = np.random.default_rng(13)
+    B, hw, patch = 2, 32, 4
+    img = rng.standard_normal((B, 3, hw, hw)).astype(np.float32)
+    s0 = np.float32(4.0 / 127.0)
+    inv = float(np.float32(1.0) / s0)
+    g = hw // patch
+    A = torch.full((B * g * g, 64), 77, dtype=torch.int8, device=DEV)
+    _lib.call("ivit_quantize_patchify_ld_f32_i8", _lib.ptr(dev(img)), _lib.ptr(A), 64, B, 3, hw, patch, inv, st())
+    k0 = orc.quant_sym(img, s0, 8)
+    ref = k0.reshape(B, 3, g, patch, g, patch).transpose(0, 2, 4, 1, 3, 5).reshape(B * g * g, 48)
+    got = A.cpu().numpy()
+    assert np.array_equal(got[:, :48].astype(np.int32), ref)
+    assert (got[:, 48:] == 77).all()
+
+
+# ----------------------------------------------------------------------------------- window attention
+def window_attention_ref(q8, k8, v8, bias_add, mask_add, nW, me_s, me_b, s_attn, me_o):
+    """oracle composition of swin_quant.py:137-161 on integers; q8/k8/v8 [B_, nH, N, hd]"""
+    B_, nH, N, hd = q8.shape
+    S = np.einsum("bhqd,bhkd->bhqk", q8.astype(np.int64), k8.astype(np.int64)).astype(np.int32)
+    kS = orc.requant(S.reshape(-1, N), me_s[0], me_s[1], 8).reshape(B_, nH, N, N)
+    lin = orc.requant(kS.reshape(-1, N), me_b[0], me_b[1], 32).reshape(B_, nH, N, N)   # RNE(kS * Mb), no clamp yet
+    kA = np.clip(lin + bias_add[None].astype(np.int32), -128, 127)
+    if mask_add is not None:
+        kA = (kA.reshape(B_ // nW, nW, nH, N, N) + mask_add[None, :, None].astype(np.int32)).reshape(B_, nH, N, N)
+    Pm = orc.shiftmax(kA, s_attn)
+    O = np.einsum("bhqk,bhkd->bqhd", Pm.astype(np.int64), v8.astype(np.int64)).astype(np.int32)
+    return orc.requant(O.reshape(-1, hd), me_o[0], me_o[1], 8).reshape(B_, N, nH * hd), kA, Pm
+
+
+@pytest.mark.parametrize("B_,nW,nH,N,s_attn,masked", [(8, 4, 3, 49, 0.25, True), (6, 1, 6, 49, 0.5, False),
+                                                      (4, 4, 2, 16, 1.0, True), (3, 1, 24, 49, 2.0, False),
+                                                      (5, 1, 1, 64, 0.125, False), (2, 2, 2, 9, 0.0625, True)])
+def test_window_attention(B_, nW, nH, N, s_attn, masked):
+    rng = np.random.default_rng(B_ * 1000 + N)
+    hd = 32
+    qkv = rng.integers(-128, 128, size=(3, B_, nH, N, hd)).astype(np.int8)
+    qkv[0, 0, 0, 0] = 127   # saturating scores
+    qkv[1, 0, 0] = 127
+    s_S = np.float32(2.0 ** -9 * 0.9)
+    s_at = np.float32(s_attn)
+    ms, omS = sme(s_S, s_at), ome(s_S, s_at)
+    mb, omB = sme(s_at, s_at * np.float32(1.0)), ome(s_at, s_at)
+    if N == 49:  # a non-trivial qact_attn1 -> qact2 ratio too
+        mb, omB = sme(s_at * np.float32(0.75), s_at), ome(s_at * np.float32(0.75), s_at)
+    mo, omO = sme(np.float32(2.0 ** -7 * 0.05), 0.043), ome(np.float32(2.0 ** -7 * 0.05), 0.043)
+    bias_add = rng.integers(-60, 61, size=(nH, N, N)).astype(np.int16)
+    mask_add = None
+    if masked:
+        mval = int(np.float32(-100.0) / s_at)
+        mask_add = np.where(rng.random((nW, N, N)) < 0.3, mval, 0).astype(np.int16)
+        for w in range(nW):
+            np.fill_diagonal(mask_add[w], 0)
+    ref, kA, Pm = window_attention_ref(qkv[0], qkv[1], qkv[2], bias_add, mask_add, nW, omS, omB, s_at, omO)
+    ld = nH * hd + 32
+    out = torch.zeros(B_ * N, ld, dtype=torch.int8, device=DEV)
+    _lib.call("ivit_window_attention_i8", _lib.ptr(dev(qkv)), _lib.ptr(out), ld, _lib.ptr(dev(bias_add)),
+              _lib.ptr(None if mask_add is None else dev(mask_add)), B_, nW, nH, N, hd, ms[0], ms[1], mb[0], mb[1],
+              float(s_at), mo[0], mo[1], st())
+    got = out.cpu().numpy()
+    assert np.array_equal(got[:, : nH * hd].astype(np.int32).reshape(B_, N, nH * hd), ref)
+    assert not got[:, nH * hd:].any()
+    assert Pm.max() > 0
+
+
+def test_window_attention_rejects_unsupported_geometry():
+    q = dev(np.zeros(3 * 49 * 64, np.int8))
+    o = torch.empty(49 * 64, dtype=torch.int8, device=DEV)
+    b = dev(np.zeros(49 * 49, np.int16))
+    with pytest.raises(_lib.IvitError):
+        _lib.call("ivit_window_attention_i8", _lib.ptr(q), _lib.ptr(o), 64, _lib.ptr(b), None, 1, 1, 1, 49, 64,
+                  1 << 30, 40, 1 << 30, 31, 0.25, 1 << 30, 40, st())
+    with pytest.raises(_lib.IvitError):
+        _lib.call("ivit_window_attention_i8", _lib.ptr(q), _lib.ptr(o), 32, _lib.ptr(b), None, 1, 1, 1, 65, 32,
+                  1 << 30, 40, 1 << 30, 31, 0.25, 1 << 30, 40, st())
+
+
+# ----------------------------------------------------------------------------------- whole model
+def build_swin(max_batch):
+    z, meta, ranges = load_fixture("swin_tiny")
+    cfg = synth.SWIN_CONFIGS[meta["factory"]]
+    fs = synth.make_swin_float_state(meta["factory"], meta["weight_seed"])
+    eng = IntSwinEngine(fs, ranges, cfg["embed_dim"], cfg["depths"], cfg["num_heads"], cfg["window"], device=DEV,
+                        max_batch=max_batch)
+    return eng, fs, ranges, cfg, meta, z
+
+
+def test_swin_golden_logits_and_taps():
+    eng, fs, ranges, cfg, meta, z = build_swin(4)
+    n = meta["n_images"]
+    imgs = torch.from_numpy(synth.make_images(n, meta["image_seed"])).to(DEV)
+    taps = {}
+    li, lf, t1 = eng.forward(imgs, taps)
+    torch.cuda.synchronize()
+    gold = dict(zip([str(x) for x in z["tap_names"]], z["tap_crc32"]))
+    checked, bad = 0, []
+    for name, t in taps.items():
+        assert name in gold, name
+        if crc(t.cpu().numpy().astype(np.int32)) != int(gold[name]):
+            bad.append(name)
+        checked += 1
+    assert not bad, f"first differing taps: {bad[:6]}"
+    nblk = sum(cfg["depths"])
+    assert checked == 9 * nblk + 2 * (len(cfg["depths"]) - 1) + 5
+    assert np.array_equal(li.cpu().numpy(), z["logits_int32"])
+    assert np.array_equal(lf.cpu().numpy().view(np.int32), z["logits_f32_bits"])
+    assert np.array_equal(t1.cpu().numpy().astype(np.int64), z["top1"])
+
+
+def test_swin_batch_invariance_and_oracle_on_fresh_images():
+    eng, fs, ranges, cfg, meta, z = build_swin(16)
+    imgs_np = synth.make_images(16, 5151)
+    imgs = torch.from_numpy(imgs_np).to(DEV)
+    li, lf, t1 = eng.forward(imgs)
+    li = li.cpu().numpy().copy()
+    om = orc.OracleSwin(fs, ranges, cfg["embed_dim"], cfg["depths"], cfg["num_heads"], cfg["window"])
+    sub = [0, 15]
+    ref = om.forward(imgs_np[sub])
+    assert np.array_equal(li[sub], ref["logits_int32"])
+    perm = np.random.default_rng(0).permutation(16)
+    li2, _, _ = eng.forward(imgs[torch.from_numpy(perm).to(DEV)].contiguous())
+    assert np.array_equal(li2.cpu().numpy(), li[perm])
+    li3, _, _ = eng.forward(imgs[5:6].contiguous())
+    assert np.array_equal(li3.cpu().numpy(), li[5:6])
