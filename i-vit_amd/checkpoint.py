@@ -20,7 +20,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 
 TAGS = {"deit_tiny": "deit_tiny_patch16_224", "deit_small": "deit_small_patch16_224",
-        "deit_base": "deit_base_patch16_224", "vit_base": "vit_base_patch16_224"}
+        "deit_base": "deit_base_patch16_224", "vit_base": "vit_base_patch16_224",
+        "swin_tiny": "swin_tiny_patch4_window7_224"}
 
 
 def load_fixture(tag: str):
@@ -33,6 +34,10 @@ def load_fixture(tag: str):
 def load_synthetic_model(tag: str):
     """-> (float_state, ranges, cfg, meta, fixture) for one of the committed synthetic models."""
     z, meta, ranges = load_fixture(tag)
-    cfg = synth.MODEL_CONFIGS[meta["factory"]]
-    fs = synth.make_float_state(meta["factory"], meta["weight_seed"])
+    if meta["factory"] in synth.SWIN_CONFIGS:
+        cfg = synth.SWIN_CONFIGS[meta["factory"]]
+        fs = synth.make_swin_float_state(meta["factory"], meta["weight_seed"])
+    else:
+        cfg = synth.MODEL_CONFIGS[meta["factory"]]
+        fs = synth.make_float_state(meta["factory"], meta["weight_seed"])
     return fs, ranges, cfg, meta, z

@@ -9,6 +9,8 @@
 // rounds (24-bit products, correctly rounded quotients, the float64 requant product); each such
 // site is a single IEEE operation on exactly representable operands, compiled with
 // -ffp-contract=off, and is listed in DESIGN.md.
+#include <limits.h>
+
 #include "common.h"
 
 namespace {
@@ -368,20 +370,22 @@ __global__ __launch_bounds__(NT) void shiftgelu_lut_apply_kernel(GeluArgs a)
 // ------------------------------------------------------------------------------------------------
 // stand-alone Shiftmax (module-level)
 // ------------------------------------------------------------------------------------------------
+template <typename TX>
 struct SmArgs {
-    const int8_t* x;
+    const TX* x;
     int64_t ldx;
     int rows, L, x0;
     int8_t* out;
     int64_t ldo;
 };
 
-__global__ __launch_bounds__(NT) void shiftmax_kernel(SmArgs a)
+template <typename TX>
+__global__ __launch_bounds__(NT) void shiftmax_kernel(SmArgs<TX> a)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int row = blockIdx.x * WPB + wave; row < a.rows; row += gridDim.x * WPB) {
-        const int8_t* xr = a.x + (int64_t)row * a.ldx;
-        int kmax = -128;
+        const TX* xr = a.x + (int64_t)row * a.ldx;
+        int kmax = INT_MIN;
         for (int i = lane; i < a.L; i += 64) kmax = max(kmax, (int)xr[i]);
         kmax = wave_reduce_max_i32(kmax);
         unsigned long long sum = 0;
@@ -698,16 +702,29 @@ IVIT_EXPORT int ivit_shiftgelu_lut_i8(const int8_t* x, int64_t ldx, int rows, in
     IVIT_CHECK_LAUNCH("ivit_shiftgelu_lut_i8");
 }
 
+template <typename TX>
+static int launch_shiftmax(const char* who, const TX* x, int64_t ldx, int rows, int L, float s, int8_t* out, int64_t ldo,
+                           ivit_stream_t stream)
+{
+    IVIT_REQUIRE(x && out && rows > 0 && L > 1 && ldx >= L && ldo >= L, "%s: bad operand (L must be > 1)", who);
+    IVIT_REQUIRE(s > 0.0f, "%s: scale must be positive", who);
+    const float x0f = __builtin_floorf((1.0f / s) * -1.0f);
+    IVIT_REQUIRE(x0f <= -1.0f && x0f >= -65535.0f, "%s: x0=%g outside [-65535,-1]", who, (double)x0f);
+    SmArgs<TX> a{x, ldx, rows, L, (int)x0f, out, ldo};
+    hipLaunchKernelGGL(shiftmax_kernel<TX>, dim3(grid_for_rows(rows)), dim3(NT), 0, ivit_stream(stream), a);
+    IVIT_CHECK_LAUNCH(who);
+}
+
 IVIT_EXPORT int ivit_shiftmax_i8(const int8_t* x, int64_t ldx, int rows, int L, float s, int8_t* out, int64_t ldo,
                                  ivit_stream_t stream)
 {
-    IVIT_REQUIRE(x && out && rows > 0 && L > 1 && ldx >= L && ldo >= L, "ivit_shiftmax_i8: bad operand (L must be > 1)");
-    IVIT_REQUIRE(s > 0.0f, "ivit_shiftmax_i8: scale must be positive");
-    const float x0f = __builtin_floorf((1.0f / s) * -1.0f);
-    IVIT_REQUIRE(x0f <= -1.0f && x0f >= -65535.0f, "ivit_shiftmax_i8: x0=%g outside [-65535,-1]", (double)x0f);
-    SmArgs a{x, ldx, rows, L, (int)x0f, out, ldo};
-    hipLaunchKernelGGL(shiftmax_kernel, dim3(grid_for_rows(rows)), dim3(NT), 0, ivit_stream(stream), a);
-    IVIT_CHECK_LAUNCH("ivit_shiftmax_i8");
+    return launch_shiftmax<int8_t>("ivit_shiftmax_i8", x, ldx, rows, L, s, out, ldo, stream);
+}
+
+IVIT_EXPORT int ivit_shiftmax_i32_i8(const int32_t* x, int64_t ldx, int rows, int L, float s, int8_t* out, int64_t ldo,
+                                     ivit_stream_t stream)
+{
+    return launch_shiftmax<int32_t>("ivit_shiftmax_i32_i8", x, ldx, rows, L, s, out, ldo, stream);
 }
 
 IVIT_EXPORT int ivit_quantize_input_f32_i8(const float* x, int8_t* out, int64_t n, float inv_scale,

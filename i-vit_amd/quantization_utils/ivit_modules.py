@@ -90,9 +90,9 @@ class IVITIntSoftmax(nn.Module):
 
     def forward(self, x, scaling_factor):
         L = x.shape[-1]
-        k8 = narrow_i8(to_int32(x, scaling_factor), "IVITIntSoftmax input")
+        k = to_int32(x, scaling_factor)   # int32: Swin's masked scores (swin_quant.py:151-156) exceed 8 bits
         out8 = torch.empty(x.shape, dtype=torch.int8, device=x.device)
-        _lib.call("ivit_shiftmax_i8", _lib.ptr(k8), L, k8.numel() // L, L, float(scaling_factor.reshape(-1)[0]),
+        _lib.call("ivit_shiftmax_i32_i8", _lib.ptr(k), L, k.numel() // L, L, float(scaling_factor.reshape(-1)[0]),
                   _lib.ptr(out8), L, _st())
         s = torch.tensor([1 / 2 ** (self.output_bit - 1)], dtype=torch.float32, device=x.device)  # :176
         self.act_scaling_factor = s

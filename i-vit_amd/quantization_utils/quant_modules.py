@@ -63,6 +63,19 @@ def narrow_i8(z: torch.Tensor, what: str) -> torch.Tensor:
     return out
 
 
+def _pad_k(k: int) -> int:
+    """the GEMM kernels step K in 64-byte slabs; operands are zero-padded up to it (Swin: K = 96, 48)"""
+    return (k + 63) // 64 * 64
+
+
+def _pad_cols(a: np.ndarray, kp: int) -> np.ndarray:
+    if a.shape[1] == kp:
+        return a
+    out = np.zeros((a.shape[0], kp), a.dtype)
+    out[:, :a.shape[1]] = a
+    return out
+
+
 def _me_tables(pre_sf: torch.Tensor, z_sf, device):
     m, e = dyadic(pre_sf.detach().reshape(-1).cpu().numpy(), f32(z_sf))
     return _dev_table(m.view(np.int32), device), _dev_table(e, device), m.size
@@ -102,12 +115,12 @@ class QuantLinear(nn.Linear):
             lp = LinearParams(self.weight.detach().cpu().numpy(),
                               None if self.bias is None else self.bias.detach().cpu().numpy(), s_in)
             dev = self.weight.device
-            W8 = _dev_table(lp.W8, dev)
+            W8 = _dev_table(_pad_cols(lp.W8, _pad_k(lp.K)), dev)
             b32 = None if lp.b32 is None else _dev_table(lp.b32, dev)
             s_acc = _dev_table(lp.s_acc, dev)
             # buffers the reference overwrites on every call (quant_modules.py:211-220)
             self.fc_scaling_factor = _dev_table(lp.sw, dev)
-            self.weight_integer = W8.float().reshape(self.weight.shape)
+            self.weight_integer = _dev_table(lp.W8, dev).float().reshape(self.weight.shape)
             if b32 is not None:
                 self.bias_integer = b32.float()
             self._cache = (key, W8, b32, s_acc)
@@ -117,12 +130,17 @@ class QuantLinear(nn.Linear):
         assert prev_act_scaling_factor is not None and prev_act_scaling_factor.shape == (1,)
         W8, b32, s_acc = self._params(float(prev_act_scaling_factor.item()))
         K, N = self.in_features, self.out_features
-        if K % 64 != 0 or N % 4 != 0:
-            raise NotImplementedError("ivit_gemm_i8_i32 needs in_features % 64 == 0 and out_features % 4 == 0")
+        if K % 16 != 0 or N % 4 != 0:
+            raise NotImplementedError("ivit_gemm_i8_i32 needs in_features % 16 == 0 and out_features % 4 == 0")
         a8 = narrow_i8(to_int32(x, prev_act_scaling_factor), "QuantLinear input")
         M = a8.numel() // K
+        Kp = _pad_k(K)
+        if Kp != K:
+            a8p = torch.zeros(M, Kp, dtype=torch.int8, device=x.device)
+            a8p[:, :K] = a8.reshape(M, K)
+            a8 = a8p
         acc = torch.empty((*x.shape[:-1], N), dtype=torch.int32, device=x.device)
-        _lib.call("ivit_gemm_i8_i32", _lib.ptr(a8), K, _lib.ptr(W8), K, _lib.ptr(b32), _lib.ptr(acc), N, M, N, K, _st())
+        _lib.call("ivit_gemm_i8_i32", _lib.ptr(a8), Kp, _lib.ptr(W8), Kp, _lib.ptr(b32), _lib.ptr(acc), N, M, N, Kp, _st())
         return to_float(acc, s_acc), s_acc
 
 
@@ -270,17 +288,18 @@ class QuantConv2d(nn.Conv2d):
         if self._cache is None or self._cache[0] != key:
             lp = LinearParams(self.weight.detach().cpu().numpy(), self.bias.detach().cpu().numpy(), s_in)
             dev = x.device
-            self._cache = (key, _dev_table(lp.W8, dev), _dev_table(lp.b32, dev), _dev_table(lp.s_acc, dev))
+            self._cache = (key, _dev_table(_pad_cols(lp.W8, _pad_k(lp.K)), dev), _dev_table(lp.b32, dev),
+                           _dev_table(lp.s_acc, dev))
             self.conv_scaling_factor = _dev_table(lp.sw, dev)
-            self.weight_integer = self._cache[1].float().reshape(self.weight.shape)
+            self.weight_integer = _dev_table(lp.W8, dev).float().reshape(self.weight.shape)
             self.bias_integer = self._cache[2].float()
         _, W8, b32, s_acc = self._cache
         g = H // kh
-        K = Cin * kh * kw
-        A = torch.empty(B * g * g, K, dtype=torch.int8, device=x.device)
+        K = _pad_k(Cin * kh * kw)
+        A = torch.zeros(B * g * g, K, dtype=torch.int8, device=x.device)
         xin = x.contiguous().float()
-        _lib.call("ivit_quantize_patchify_f32_i8", _lib.ptr(xin), _lib.ptr(A), B, Cin, H, kh, float(f32(1.0) / f32(s_in)),
-                  _st())
+        _lib.call("ivit_quantize_patchify_ld_f32_i8", _lib.ptr(xin), _lib.ptr(A), K, B, Cin, H, kh,
+                  float(f32(1.0) / f32(s_in)), _st())
         N = self.out_channels
         acc = torch.empty(B * g * g, N, dtype=torch.int32, device=x.device)
         _lib.call("ivit_gemm_i8_i32", _lib.ptr(A), K, _lib.ptr(W8), K, _lib.ptr(b32), _lib.ptr(acc), N, B * g * g, N, K,

@@ -1,0 +1,327 @@
+"""Swin assembly with the reference's module tree and checkpoint keys
+(/root/reference/models/swin_quant.py:18-640), running on the MI355X integer kernels.
+
+As in vit_quant.py two execution paths give bit-identical results:
+  * a frozen model forwards through the fused engine (swin_engine.IntSwinEngine): int8 GEMM operands, int16
+    residual stream, window partition / shift folded into the kernels' row maps;
+  * otherwise (calibration, debugging, module-level tests) the modules run one by one as the reference's forward
+    does, with the reshapes / rolls / mask addition between them done on the float views.
+
+The fork's own swin_quant.py cannot be imported or run as shipped (SURVEY.md finding 6: missing aliases, a
+bias-free QuantLinear crash); this mirror implements the behaviour the file specifies, pinned by
+tests/golden/swin_tiny.npz (generated from the reference with harness-side shims only).
+"""
+from __future__ import annotations
+
+from functools import partial
+from typing import Optional
+
+import torch
+from torch import nn
+
+from .layers_quant import DropPath, Mlp, PatchEmbed, to_2tuple, trunc_normal_
+from .quantization_utils import IntGELU, IntLayerNorm, IntSoftmax, QuantAct, QuantLinear, QuantMatMul
+
+__all__ = ["swin_tiny_patch4_window7_224", "swin_small_patch4_window7_224", "swin_base_patch4_window7_224",
+           "SwinTransformer", "window_partition", "window_reverse"]
+
+
+def window_partition(x, window_size: int):
+    """[B, H, W, C] -> [B * nW, ws, ws, C] (swin_quant.py:18-31)."""
+    B, H, W, C = x.shape
+    x = x.reshape(B, H // window_size, window_size, W // window_size, window_size, C)
+    return x.permute(0, 1, 3, 2, 4, 5).reshape(-1, window_size, window_size, C)
+
+
+def window_reverse(windows, window_size: int, H: int, W: int):
+    """inverse of window_partition (swin_quant.py:34-50)."""
+    B = windows.shape[0] // ((H // window_size) * (W // window_size))
+    x = windows.reshape(B, H // window_size, W // window_size, window_size, window_size, -1)
+    return x.permute(0, 1, 3, 2, 4, 5).reshape(B, H, W, -1)
+
+
+class WindowAttention(nn.Module):
+    """W-MSA / SW-MSA with relative position bias (swin_quant.py:52-169)."""
+
+    def __init__(self, dim, window_size, num_heads, qkv_bias=True, attn_drop=0.0, proj_drop=0.0):
+        super().__init__()
+        self.dim, self.window_size, self.num_heads = dim, window_size, num_heads
+        self.scale = (dim // num_heads) ** -0.5
+        wh, ww = window_size
+        self.relative_position_bias_table = nn.Parameter(torch.zeros((2 * wh - 1) * (2 * ww - 1), num_heads))
+        ys, xs = torch.arange(wh * ww) // ww, torch.arange(wh * ww) % ww
+        index = (ys[:, None] - ys[None, :] + wh - 1) * (2 * ww - 1) + (xs[:, None] - xs[None, :] + ww - 1)
+        self.register_buffer("relative_position_index", index)
+        self.qkv = QuantLinear(dim, dim * 3, bias=qkv_bias)
+        self.qact1 = QuantAct()
+        self.qact_attn1 = QuantAct()
+        self.qact_table = QuantAct()
+        self.qact2 = QuantAct()
+        self.attn_drop = nn.Dropout(attn_drop)
+        self.log_int_softmax = IntSoftmax()
+        self.qact3 = QuantAct()
+        self.qact4 = QuantAct(16)
+        self.proj = QuantLinear(dim, dim)
+        self.proj_drop = nn.Dropout(proj_drop)
+        trunc_normal_(self.relative_position_bias_table, std=0.02)
+        self.matmul_1 = QuantMatMul()
+        self.matmul_2 = QuantMatMul()
+
+    def forward(self, x, act_scaling_factor, mask: Optional[torch.Tensor] = None):
+        B_, N, C = x.shape
+        nH = self.num_heads
+        x, s = self.qkv(x, act_scaling_factor)
+        x, s_qkv = self.qact1(x, s)
+        q, k, v = x.reshape(B_, N, 3, nH, C // nH).permute(2, 0, 3, 1, 4).unbind(0)
+        attn, s = self.matmul_1(q, s_qkv, k.transpose(-2, -1), s_qkv)
+        attn, s = self.qact_attn1(attn * self.scale, s * self.scale)
+        table, s_table = self.qact_table(self.relative_position_bias_table)
+        bias = table[self.relative_position_index.reshape(-1)].reshape(N, N, nH).permute(2, 0, 1).contiguous()
+        attn, s = self.qact2(attn, s, bias.unsqueeze(0), s_table)
+        if mask is not None:
+            nW = mask.shape[0]
+            attn = (attn.reshape(B_ // nW, nW, nH, N, N) + mask.unsqueeze(1).unsqueeze(0)).reshape(-1, nH, N, N)
+        attn, s = self.log_int_softmax(attn, s)
+        x, s = self.matmul_2(self.attn_drop(attn), s, v, s_qkv)
+        x, s = self.qact3(x.transpose(1, 2).reshape(B_, N, C), s)
+        x, s = self.proj(x, s)
+        x, s = self.qact4(x, s)
+        return self.proj_drop(x), s
+
+
+class SwinTransformerBlock(nn.Module):
+    """swin_quant.py:172-301."""
+
+    def __init__(self, dim, input_resolution, num_heads, window_size=7, shift_size=0, mlp_ratio=4.0, qkv_bias=True,
+                 drop=0.0, attn_drop=0.0, drop_path=0.0, act_layer=nn.GELU, norm_layer=nn.LayerNorm):
+        super().__init__()
+        self.dim, self.input_resolution, self.num_heads = dim, input_resolution, num_heads
+        self.window_size, self.shift_size, self.mlp_ratio = window_size, shift_size, mlp_ratio
+        if min(input_resolution) <= window_size:   # a single window covers the map: no partition, no shift
+            self.shift_size = 0
+            self.window_size = min(input_resolution)
+        assert 0 <= self.shift_size < self.window_size, "shift_size must in 0-window_size"
+        self.norm1 = norm_layer(dim)
+        self.qact1 = QuantAct()
+        self.attn = WindowAttention(dim, window_size=to_2tuple(self.window_size), num_heads=num_heads,
+                                    qkv_bias=qkv_bias, attn_drop=attn_drop, proj_drop=drop)
+        self.drop_path = DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
+        self.qact2 = QuantAct(16)
+        self.norm2 = norm_layer(dim)
+        self.qact3 = QuantAct()
+        self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
+        self.qact4 = QuantAct(16)
+        attn_mask = None
+        if self.shift_size > 0:
+            H, W = input_resolution
+            ws, sh = self.window_size, self.shift_size
+
+            def band(n):
+                b = torch.zeros(n)
+                b[n - ws:n - sh] = 1
+                b[n - sh:] = 2
+                return b
+            region = (band(H)[:, None] * 3 + band(W)[None, :]).reshape(1, H, W, 1)
+            reg = window_partition(region, ws).reshape(-1, ws * ws)
+            attn_mask = torch.where(reg[:, None, :] != reg[:, :, None], torch.tensor(-100.0), torch.tensor(0.0))
+        self.register_buffer("attn_mask", attn_mask)
+
+    def forward(self, x_1, s_1):
+        H, W = self.input_resolution
+        B, L, C = x_1.shape
+        assert L == H * W, "input feature has wrong size"
+        ws, sh = self.window_size, self.shift_size
+        x, s = self.norm1(x_1, s_1)
+        x, s = self.qact1(x, s)
+        x = x.reshape(B, H, W, C)
+        if sh > 0:
+            x = torch.roll(x, shifts=(-sh, -sh), dims=(1, 2))
+        x, s = self.attn(window_partition(x, ws).reshape(-1, ws * ws, C), s, mask=self.attn_mask)
+        x = window_reverse(x.reshape(-1, ws, ws, C), ws, H, W)
+        if sh > 0:
+            x = torch.roll(x, shifts=(sh, sh), dims=(1, 2))
+        x = self.drop_path(x.reshape(B, H * W, C))
+        x_2, s_2 = self.qact2(x, s, x_1, s_1)                       # residual 1 (16 bit)
+        x, s = self.norm2(x_2, s_2)
+        x, s = self.qact3(x, s)
+        x, s = self.mlp(x, s)
+        return self.qact4(self.drop_path(x), s, x_2, s_2)           # residual 2 (16 bit)
+
+
+class PatchMerging(nn.Module):
+    """swin_quant.py:304-360."""
+
+    def __init__(self, input_resolution, dim, norm_layer=nn.LayerNorm):
+        super().__init__()
+        self.input_resolution, self.dim = input_resolution, dim
+        self.norm = norm_layer(4 * dim)
+        self.qact1 = QuantAct()
+        self.reduction = QuantLinear(4 * dim, 2 * dim, bias=False)
+        self.qact2 = QuantAct()
+
+    def forward(self, x, act_scaling_factor):
+        H, W = self.input_resolution
+        B, L, C = x.shape
+        assert L == H * W, "input feature has wrong size"
+        assert H % 2 == 0 and W % 2 == 0, f"x size ({H}*{W}) are not even."
+        x = x.reshape(B, H, W, C)
+        x = torch.cat([x[:, 0::2, 0::2], x[:, 1::2, 0::2], x[:, 0::2, 1::2], x[:, 1::2, 1::2]], -1)
+        x, s = self.norm(x.reshape(B, -1, 4 * C), act_scaling_factor)
+        x, s = self.qact1(x, s)
+        x, s = self.reduction(x, s)
+        return self.qact2(x, s)
+
+    def extra_repr(self) -> str:
+        return f"input_resolution={self.input_resolution}, dim={self.dim}"
+
+
+class BasicLayer(nn.Module):
+    """One stage (swin_quant.py:363-421)."""
+
+    def __init__(self, dim, input_resolution, depth, num_heads, window_size, mlp_ratio=4.0, qkv_bias=True, drop=0.0,
+                 attn_drop=0.0, drop_path=0.0, norm_layer=nn.LayerNorm, downsample=None, use_checkpoint=False):
+        super().__init__()
+        if use_checkpoint:
+            raise NotImplementedError("activation checkpointing is a training feature; the integer path is inference")
+        self.dim, self.input_resolution, self.depth, self.use_checkpoint = dim, input_resolution, depth, use_checkpoint
+        self.blocks = nn.ModuleList([
+            SwinTransformerBlock(dim=dim, input_resolution=input_resolution, num_heads=num_heads,
+                                 window_size=window_size, shift_size=0 if i % 2 == 0 else window_size // 2,
+                                 mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, drop=drop, attn_drop=attn_drop,
+                                 drop_path=drop_path[i] if isinstance(drop_path, list) else drop_path,
+                                 act_layer=IntGELU, norm_layer=norm_layer) for i in range(depth)])
+        self.downsample = downsample(input_resolution, dim=dim, norm_layer=norm_layer) if downsample is not None else None
+
+    def forward(self, x, act_scaling_factor):
+        for blk in self.blocks:
+            x, act_scaling_factor = blk(x, act_scaling_factor)
+        if self.downsample is not None:
+            x, act_scaling_factor = self.downsample(x, act_scaling_factor)
+        return x, act_scaling_factor
+
+    def extra_repr(self) -> str:
+        return f"dim={self.dim}, input_resolution={self.input_resolution}, depth={self.depth}"
+
+
+class SwinTransformer(nn.Module):
+    """swin_quant.py:424-564."""
+
+    def __init__(self, img_size=224, patch_size=4, in_chans=3, num_classes=1000, embed_dim=96, depths=(2, 2, 6, 2),
+                 num_heads=(3, 6, 12, 24), window_size=7, mlp_ratio=4.0, qkv_bias=True, drop_rate=0.0,
+                 attn_drop_rate=0.0, drop_path_rate=0.1, norm_layer=nn.LayerNorm, ape=False, patch_norm=True,
+                 use_checkpoint=False, **kwargs):
+        super().__init__()
+        self.num_classes, self.num_layers, self.embed_dim = num_classes, len(depths), embed_dim
+        self.depths, self.num_heads, self.window_size = tuple(depths), tuple(num_heads), window_size
+        self.ape, self.patch_norm, self.mlp_ratio = ape, patch_norm, mlp_ratio
+        self.num_features = int(embed_dim * 2 ** (self.num_layers - 1))
+        self.qact_input = QuantAct()
+        self.patch_embed = PatchEmbed(img_size=img_size, patch_size=patch_size, in_chans=in_chans, embed_dim=embed_dim,
+                                      norm_layer=norm_layer if patch_norm else None)
+        self.patch_grid = self.patch_embed.grid_size
+        if ape:
+            self.absolute_pos_embed = nn.Parameter(torch.zeros(1, self.patch_embed.num_patches, embed_dim))
+            trunc_normal_(self.absolute_pos_embed, std=0.02)
+            self.qact_pos = QuantAct(16)
+        else:
+            self.absolute_pos_embed = None
+        self.qact1 = QuantAct(16)
+        self.pos_drop = nn.Dropout(p=drop_rate)
+        dpr = [x.item() for x in torch.linspace(0, drop_path_rate, sum(depths))]
+        self.layers = nn.Sequential(*[
+            BasicLayer(dim=int(embed_dim * 2 ** i), input_resolution=(self.patch_grid[0] // 2 ** i, self.patch_grid[1] // 2 ** i),
+                       depth=depths[i], num_heads=num_heads[i], window_size=window_size, mlp_ratio=mlp_ratio,
+                       qkv_bias=qkv_bias, drop=drop_rate, attn_drop=attn_drop_rate,
+                       drop_path=dpr[sum(depths[:i]):sum(depths[:i + 1])], norm_layer=norm_layer,
+                       downsample=PatchMerging if i < self.num_layers - 1 else None, use_checkpoint=use_checkpoint)
+            for i in range(self.num_layers)])
+        self.norm = norm_layer(self.num_features)
+        self.qact2 = QuantAct()
+        self.avgpool = nn.AdaptiveAvgPool1d(1)
+        self.qact3 = QuantAct()
+        self.head = QuantLinear(self.num_features, num_classes) if num_classes > 0 else nn.Identity()
+        self.act_out = QuantAct()
+        self.apply(self._init_weights)
+        self._engine = None
+        self.use_engine = True   # frozen models take the fused engine
+
+    @staticmethod
+    def _init_weights(m):
+        if isinstance(m, nn.Linear):
+            trunc_normal_(m.weight, std=0.02)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+    @torch.jit.ignore
+    def no_weight_decay(self):
+        return {"absolute_pos_embed"}
+
+    @torch.jit.ignore
+    def no_weight_decay_keywords(self):
+        return {"relative_position_bias_table"}
+
+    # ---------------------------------------------------------------- module-by-module path
+    def forward_features(self, x):
+        x, s = self.qact_input(x)
+        x, s = self.patch_embed(x, s)
+        if self.absolute_pos_embed is not None:
+            x_pos, s_pos = self.qact_pos(self.absolute_pos_embed)
+            x, s = self.qact1(x, s, x_pos, s_pos)
+        else:
+            x, s = self.qact1(x, s)
+        x = self.pos_drop(x)
+        for layer in self.layers:
+            x, s = layer(x, s)
+        x, s = self.norm(x, s)
+        x, s = self.qact2(x, s)
+        x = self.avgpool(x.transpose(1, 2))                       # [B, C, 1] float mean over the tokens
+        x, s = self.qact3(x.transpose(1, 2), s)                   # channels last for the per-tensor requant kernel
+        return torch.flatten(x, 1), s
+
+    # ---------------------------------------------------------------- fused engine path
+    def is_frozen(self):
+        return all(not m.running_stat for n, m in self.named_modules() if isinstance(m, QuantAct) and n != "act_out")
+
+    def engine_supported(self):
+        return (not self.ape and self.patch_norm and self.num_classes > 0
+                and all(int(self.embed_dim * 2 ** i) // h == 32 for i, h in enumerate(self.num_heads)))
+
+    def engine(self, max_batch):
+        """Build (once) the integer engine from this model's float parameters and QuantAct ranges."""
+        from .swin_engine import IntSwinEngine
+        key = (max_batch, next(self.parameters()).device)
+        if self._engine is None or self._engine[0] != key or self._engine[1].max_batch < max_batch:
+            float_state = {k: v for k, v in self.state_dict().items()}
+            ranges = {n: (float(m.x_min.reshape(-1)[0]), float(m.x_max.reshape(-1)[0]))
+                      for n, m in self.named_modules() if isinstance(m, QuantAct)}
+            eng = IntSwinEngine(float_state, ranges, self.embed_dim, self.depths, self.num_heads, self.window_size,
+                                device=key[1], max_batch=max_batch)
+            self._engine = (key, eng)
+        return self._engine[1]
+
+    def forward(self, x):
+        if self.use_engine and not self.training and self.is_frozen() and x.is_cuda and self.engine_supported():
+            _, logits_f32, _ = self.engine(x.shape[0])(x.contiguous().float())
+            return logits_f32.clone()
+        x, s = self.forward_features(x)
+        x, _ = self.head(x, s)
+        return x
+
+
+def _factory(embed_dim, depths, num_heads, name):
+    def make(pretrained=False, quant=False, calibrate=False, cfg=None, **kwargs):
+        if pretrained:
+            raise RuntimeError(f"{name}(pretrained=True) downloads weights (swin_quant.py:579-584); there is no network "
+                               "here -- load a state_dict instead")
+        return SwinTransformer(patch_size=4, window_size=7, embed_dim=embed_dim, depths=depths, num_heads=num_heads,
+                               norm_layer=partial(IntLayerNorm, eps=1e-6), **kwargs)
+    make.__name__ = name
+    return make
+
+
+swin_tiny_patch4_window7_224 = _factory(96, (2, 2, 6, 2), (3, 6, 12, 24), "swin_tiny_patch4_window7_224")
+swin_small_patch4_window7_224 = _factory(96, (2, 2, 18, 2), (3, 6, 12, 24), "swin_small_patch4_window7_224")
+swin_base_patch4_window7_224 = _factory(128, (2, 2, 18, 2), (4, 8, 16, 32), "swin_base_patch4_window7_224")

@@ -150,6 +150,10 @@ int ivit_shiftgelu_lut_i8(const int8_t* x, int64_t ldx, int rows, int L, const i
  * x [rows, L] int8 with scale s -> out [rows, L] int8 in [0, 127] (scale 2^-7). L <= 1024. */
 int ivit_shiftmax_i8(const int8_t* x, int64_t ldx, int rows, int L, float s, int8_t* out, int64_t ldo,
                      ivit_stream_t stream);
+/* the same on int32 inputs, |x| < 2^28: Swin adds the shift mask (-100/s, beyond 8 bits) to the scores in front of
+ * the softmax (swin_quant.py:151-156) */
+int ivit_shiftmax_i32_i8(const int32_t* x, int64_t ldx, int rows, int L, float s, int8_t* out, int64_t ldo,
+                         ivit_stream_t stream);
 
 /* ---- generic QuantAct on integers (fixedpoint_mul, quant_utils.py:193-253) ---------------------
  * z [rows, C] int32; (m,e) per channel (n_me == C) or per tensor (n_me == 1); optional identity

@@ -336,14 +336,19 @@ def gen_model(tag):
     print(f"[{tag}] wrote fixtures; top1 = {top1.tolist()}")
 
 
-def gen_swin(tag="swin_tiny"):
-    """Swin-T (config 5).  The fork's swin_quant.py is dead code (SURVEY finding 6); it runs with the three extra
-    harness-side shims of SURVEY Appendix E (tkinter stub, Int* aliases, bias-free QuantLinear weight_function) --
-    reference files untouched."""
+def _import_swin():
     import types
     sys.modules.setdefault("tkinter", types.SimpleNamespace(X=None))                      # shim 2
     rq.IntLayerNorm, rq.IntSoftmax, rq.IntGELU = rq.IVITIntLayerNorm, rq.IVITIntSoftmax, rq.IVITIntGELU  # shim 3
     import models.swin_quant as sq
+    return sq
+
+
+def gen_swin(tag="swin_tiny"):
+    """Swin-T (config 5).  The fork's swin_quant.py is dead code (SURVEY finding 6); it runs with the three extra
+    harness-side shims of SURVEY Appendix E (tkinter stub, Int* aliases, bias-free QuantLinear weight_function) --
+    reference files untouched."""
+    sq = _import_swin()
     factory, wseed, cseed, cb, iseed, nimg = "swin_tiny_patch4_window7_224", 21, 201, 2, 2001, 3
     cfg = synth.SWIN_CONFIGS[factory]
     t0 = time.time()
@@ -423,12 +428,15 @@ def gen_swin(tag="swin_tiny"):
 
 
 def gen_schema():
-    """state_dict keys and shapes of the reference's DeiT models (the on-disk checkpoint format)"""
+    """state_dict keys and shapes of the reference's DeiT and Swin models (the on-disk checkpoint format)"""
     out = {}
     for factory in ("deit_tiny_patch16_224", "deit_small_patch16_224", "deit_base_patch16_224"):
         model = getattr(ref_models, factory)(pretrained=False, gelu_type="ivit", softmax_type="ivit",
                                              layernorm_type="ivit")
         out[factory] = {k: list(v.shape) for k, v in model.state_dict().items()}
+    sq = _import_swin()
+    for factory in ("swin_tiny_patch4_window7_224",):
+        out[factory] = {k: list(v.shape) for k, v in getattr(sq, factory)(pretrained=False).state_dict().items()}
     with open(os.path.join(GOLD, "state_dict_schema.json"), "w") as f:
         json.dump(out, f)
     print("state_dict_schema.json written:", {k: len(v) for k, v in out.items()})

@@ -166,7 +166,7 @@ def load_model(tag):
     missing, unexpected = model.load_state_dict({k: torch.from_numpy(v) for k, v in fs.items()}, strict=False)
     assert not unexpected
     for name, mod in model.named_modules():
-        if isinstance(mod, q.QuantAct):
+        if isinstance(mod, q.QuantAct) and name in ranges:   # Swin's act_out is never called and has no range
             mod.x_min.fill_(float(ranges[name][0]))
             mod.x_max.fill_(float(ranges[name][1]))
     model.to(DEV)
@@ -207,5 +207,45 @@ def test_calibration_then_freeze_runs():
     with torch.no_grad():
         model(imgs)                       # calibration: initialises every x_min / x_max
     assert all(float(m.x_max) > 0 for m in model.modules() if isinstance(m, q.QuantAct))
+    ivit.freeze_model(model)
+    assert model.is_frozen()
+
+
+# ----------------------------------------------------------------------------------- Swin module mirror
+def test_swin_module_path_matches_reference_golden():
+    """Swin-T through the module-by-module path (reference call protocol: float views, torch roll / partition /
+    mask-add between the HIP-backed modules), 1 golden image: float logits bitwise."""
+    model, meta, z = load_model("swin_tiny")
+    model.use_engine = False
+    imgs = torch.from_numpy(synth.make_images(1, meta["image_seed"])).to(DEV)
+    with torch.no_grad():
+        y = model(imgs)
+    assert np.array_equal(bits(y), z["logits_f32_bits"][:1])
+    sd = model.state_dict()
+    assert sd["layers.0.downsample.reduction.weight_integer"].abs().max() > 0
+    assert "layers.0.downsample.reduction.bias_integer" not in sd
+    assert sd["layers.1.blocks.1.attn.qact4.act_scaling_factor"].item() > 0
+
+
+def test_swin_engine_path_matches_reference_golden():
+    """the same frozen nn.Module, default path = fused integer engine"""
+    model, meta, z = load_model("swin_tiny")
+    imgs = torch.from_numpy(synth.make_images(meta["n_images"], meta["image_seed"])).to(DEV)
+    with torch.no_grad():
+        y = model(imgs)
+    assert np.array_equal(bits(y), z["logits_f32_bits"])
+    assert np.array_equal(y.argmax(dim=1).cpu().numpy(), z["top1"])
+
+
+def test_swin_calibration_then_freeze_runs():
+    fs, ranges, cfg, meta, z = load_synthetic_model("swin_tiny")
+    model = ivit.swin_tiny_patch4_window7_224().to(DEV)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in fs.items()}, strict=False)
+    model.eval()
+    imgs = torch.from_numpy(synth.make_images(1, 7)).to(DEV)
+    with torch.no_grad():
+        model(imgs)
+    called = [n for n, m in model.named_modules() if isinstance(m, q.QuantAct) and float(m.x_max) > 0]
+    assert called == synth.swin_qact_names(cfg["depths"])      # act_out is constructed but never called
     ivit.freeze_model(model)
     assert model.is_frozen()
