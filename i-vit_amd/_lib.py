@@ -54,7 +54,7 @@ SIGNATURES = {
     "ivit_layernorm_i16_i8": [vp, ci, ci, vp, vp, vp, vp, vp, i64, ci, ci, ci, ci, vp],
     "ivit_patch_merge_i16": [vp, vp, ci, ci, ci, ci, vp],
     "ivit_avgpool_requant_i8": [vp, vp, ci, ci, ci, u32, i32, vp],
-    "ivit_window_attention_i8": [vp, vp, i64, vp, vp, ci, ci, ci, ci, ci, u32, i32, u32, i32, f32, u32, i32, vp],
+    "ivit_window_attention_i8": [vp, vp, i64, vp, vp, ci, ci, ci, ci, ci, ci, u32, i32, u32, i32, f32, u32, i32, vp],
 }
 
 

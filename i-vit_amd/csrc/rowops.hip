@@ -623,7 +623,11 @@ IVIT_EXPORT int ivit_layernorm_i8(const int8_t* x, int64_t ldx, int rows, int C,
                  "ivit_layernorm_i8: per-channel tables must be 16-byte aligned");
     LnArgs a{x, ldx, rows, C, bias_int, s_ln, m, e, out, ldo};
     const int nj = (C / 4 + 63) / 64;
-    const int grid = grid_for_rows(rows, nj <= 4 ? 4 : 1);
+    // each wave sets up its per-channel constants (4*NJ f64 reciprocals per lane) once: launch no more workgroups than
+    // stay resident (256 CUs x waves/SIMD at the kernel's register count) and let them stride over the rows
+    const int resident = 256 * (nj <= 1 ? 8 : nj <= 2 ? 4 : nj <= 3 ? 3 : nj <= 8 ? 2 : 1);
+    int grid = grid_for_rows(rows, nj <= 4 ? 4 : 1);
+    if (grid > resident) grid = resident;
     hipStream_t st = ivit_stream(stream);
     if (nj <= 1) hipLaunchKernelGGL(layernorm_i8_kernel<1>, dim3(grid), dim3(NT), 0, st, a);
     else if (nj <= 2) hipLaunchKernelGGL(layernorm_i8_kernel<2>, dim3(grid), dim3(NT), 0, st, a);

@@ -162,6 +162,119 @@ __global__ __launch_bounds__(NT) void layernorm_i16_i8_kernel(Ln16Args a)
     }
 }
 
+// Sub-wave tiling of the same computation for C % 8 == 0, C <= 1536: LPR lanes share a row (64 / LPR rows per wave and
+// iteration), each lane owns NJ chunks of 8 channels (one 16-byte load each) and keeps their per-channel constants in
+// registers for the whole kernel.  The per-row scalar work (mean division, Newton steps) is evaluated once per
+// wave-iteration for all rows of the wave in parallel; with LPR = C / 24 every lane is busy (C = 96 * 2^k: NJ = 3).
+template <int LPR, int NJ>
+__global__ __launch_bounds__(NT) void layernorm_i16_i8_tiled_kernel(Ln16Args a)
+{
+    constexpr int RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane & (LPR - 1), grp = lane / LPR;
+    const int C = a.C, nd = C >> 3;
+    float bias[NJ][8], sln[NJ][8];
+    double rs[NJ][8], Mq[NJ][8];
+    {
+        // all table loads first (vector loads, independent), then the arithmetic: the waves of this kernel have little
+        // else in flight to hide a chain of dependent global-load latencies behind
+        float4 bq[NJ][2], sq[NJ][2];
+        uint4 mq[NJ][2];
+        int4 eq[NJ][2];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int d = min(sub + LPR * j, nd - 1);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                bq[j][h] = *reinterpret_cast<const float4*>(a.bias_int + 8 * d + 4 * h);
+                sq[j][h] = *reinterpret_cast<const float4*>(a.s_ln + 8 * d + 4 * h);
+                mq[j][h] = *reinterpret_cast<const uint4*>(a.m + 8 * d + 4 * h);
+                eq[j][h] = *reinterpret_cast<const int4*>(a.e + 8 * d + 4 * h);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float bb[4] = {bq[j][h].x, bq[j][h].y, bq[j][h].z, bq[j][h].w};
+                const float ss[4] = {sq[j][h].x, sq[j][h].y, sq[j][h].z, sq[j][h].w};
+                const unsigned mm[4] = {mq[j][h].x, mq[j][h].y, mq[j][h].z, mq[j][h].w};
+                const int ee[4] = {eq[j][h].x, eq[j][h].y, eq[j][h].z, eq[j][h].w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    bias[j][4 * h + c] = bb[c];
+                    sln[j][4 * h + c] = ss[c];
+                    rs[j][4 * h + c] = 1.0 / (double)ss[c];
+                    Mq[j][4 * h + c] = dyadic_mult(mm[c], ee[c]);
+                }
+            }
+    }
+    const float fC = (float)C;
+    for (int row0 = (blockIdx.x * WPB + wave) * RPW; row0 < a.rows; row0 += gridDim.x * WPB * RPW) {
+        const int row = row0 + grp;
+        const bool live = row < a.rows;
+        const int16_t* xr = a.x + (int64_t)min(row, a.rows - 1) * C;
+        v4i w[NJ];
+        int sum = 0;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int d = sub + LPR * j;
+            w[j] = (d < nd) ? *reinterpret_cast<const v4i*>(xr + 8 * d) : v4i{0, 0, 0, 0};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sum += (int)(int16_t)w[j][q] + (w[j][q] >> 16);
+        }
+#pragma unroll
+        for (int o = LPR / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        const int mean_int = (int)rintf((float)sum / fC);                       // :37
+        unsigned long long var = 0;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            if (sub + LPR * j < nd) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned d0 = (unsigned)abs((int)(int16_t)w[j][q] - mean_int);
+                    const unsigned d1 = (unsigned)abs((w[j][q] >> 16) - mean_int);
+                    var += (unsigned long long)d0 * d0;
+                    var += (unsigned long long)d1 * d1;
+                }
+            }
+        }
+#pragma unroll
+        for (int o = LPR / 2; o > 0; o >>= 1) {
+            const unsigned vlo = (unsigned)__shfl_xor((int)(unsigned)var, o);
+            const unsigned vhi = (unsigned)__shfl_xor((int)(var >> 32), o);
+            var += ((unsigned long long)vhi << 32) | vlo;
+        }
+        float varf = (float)var, t = 65536.0f;                                  // :45-49
+#pragma unroll 1
+        for (int it = 0; it < 10; ++it) t = floorf((t + floorf(varf / t)) * 0.5f);
+        const float hfactor = floorf((1.0f / t) * 2147483648.0f) * 0.5f;        // :51; the /2 of :52 commutes (exact scaling)
+        int8_t* orow = a.out + win_row(a.map, min(row, a.rows - 1)) * a.ldo;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int d = sub + LPR * j;
+            int o[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int xv = (c & 1) ? (w[j][c >> 1] >> 16) : (int)(int16_t)w[j][c >> 1];
+                const float dl = (float)(xv - mean_int);
+                const float v = floorf(dl * hfactor);                           // :52
+                const float y = v + bias[j][c];                                 // :61
+                const float x = y * sln[j][c];                                  // :63
+                const float z = rintf((float)((double)x * rs[j][c]));           // quant_utils.py:220, see layernorm_i8_kernel
+                const double tt = (double)z * Mq[j][c] + IVIT_MAGIC;            // :229-230
+                o[c] = clamp_i32((int)(unsigned)__double_as_longlong(tt), -128, 127);
+            }
+            if (live && d < nd) {
+                int2 pk;
+                pk.x = pack4(o[0], o[1], o[2], o[3]);
+                pk.y = pack4(o[4], o[5], o[6], o[7]);
+                *reinterpret_cast<int2*>(orow + 8 * d) = pk;
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // PatchMerging gather (swin_quant.py:337-344): [B, H*W, C] int16 -> [B, H/2*W/2, 4C], channel blocks
 // (0::2,0::2), (1::2,0::2), (0::2,1::2), (1::2,1::2)
@@ -205,15 +318,16 @@ __global__ __launch_bounds__(NT) void avgpool_kernel(const int8_t* x, int8_t* ou
 // Windowed attention: one wave per (window, head); T = ws*ws <= 64 tokens, head_dim 32.
 //   S^T = K . Q^T on v_mfma_i32_16x16x32_i8 (the head dimension is one instruction deep), qact_attn1 (8 bit),
 //   + relative position bias through the two-operand qact2 (the bias operand RNE(k_tab * m / 2^e) is a load-time
-//   constant table [nH, T, T] int16), + shift mask (integer -100/s, table [nW, T, T] int16, added after the clamp,
-//   swin_quant.py:149-155), Shiftmax, O^T = Vt . P^T on v_mfma_i32_16x16x64_i8 (all 64 key slots in one step), qact3.
+//   constant table [nH, T, 64] int16, keys padded to 64), + shift mask (the integer -100/s wherever the region ids of
+//   query and key differ, added after the clamp, swin_quant.py:149-155), Shiftmax, O^T = Vt . P^T on v_mfma_i32_16x16x64_i8 (all 64 key slots in one step), qact3.
 // ------------------------------------------------------------------------------------------------
 struct WinAttnArgs {
     const int8_t* qkv;      // [3][B_][nH][T][32]
     int8_t* out;            // [B_*T, nH*32] with row stride ldo
     int64_t ldo;
-    const int16_t* bias;    // [nH][T][T]
-    const int16_t* mask;    // [nW][T][T] or NULL
+    const int16_t* bias;    // [nH][T][64]
+    const uint8_t* region;  // [nW][64] or NULL
+    int mask_value;
     int nwin, heads, T, nW;
     double Ms, Mb, Mo;      // qact_attn1; qact2 main operand; qact3
     int x0, ksat;
@@ -275,28 +389,36 @@ __global__ __launch_bounds__(NT) void window_attention_kernel(WinAttnArgs a)
         for (int kt = 0; kt < 4; ++kt)
             kf[kt] = *reinterpret_cast<const long*>(kg + (int64_t)min(16 * kt + l15, T - 1) * WHD + 8 * g);
 
-        const int wmask = a.mask ? (win % a.nW) : 0;
+        // shift mask (swin_quant.py:223-249): tokens of different regions of the rolled image do not attend to each other
+        unsigned kreg[4] = {0u, 0u, 0u, 0u};
+        const uint8_t* regrow = a.region ? a.region + (win % a.nW) * 64 : nullptr;
+        if (regrow) {
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) kreg[kt] = *reinterpret_cast<const unsigned*>(regrow + 16 * kt + 4 * g);
+        }
         for (int qt = 0; qt < 4; ++qt) {
             const int qrow = 16 * qt + l15;
             if (16 * qt >= T) break;  // uniform
             const int qld = min(qrow, T - 1);
             const long qf = *reinterpret_cast<const long*>(qg + (int64_t)qld * WHD + 8 * g);
-            const int16_t* brow = a.bias + ((int64_t)hh * T + qld) * T;
-            const int16_t* mrow = a.mask ? a.mask + ((int64_t)wmask * T + qld) * T : nullptr;
+            const int16_t* brow = a.bias + ((int64_t)hh * T + qld) * 64 + 4 * g;
+            const unsigned qreg = regrow ? regrow[qld] : 0u;
             int s[4][4];
             int rmax = -100000;
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
                 v4i acc = {0, 0, 0, 0};
                 acc = __builtin_amdgcn_mfma_i32_16x16x32_i8(kf[kt], qf, acc, 0, 0, 0);
+                const int2 bw = *reinterpret_cast<const int2*>(brow + 16 * kt);
+                const int bv[4] = {(int)(int16_t)bw.x, bw.x >> 16, (int)(int16_t)bw.y, bw.y >> 16};
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int key = 16 * kt + 4 * g + r;
                     int ka = -100000;
                     if (key < T) {
                         const int kS = clamp_i32(requant_exact(acc[r], a.Ms), -128, 127);        // qact_attn1
-                        ka = clamp_i32(requant_exact(kS, a.Mb) + (int)brow[key], -128, 127);     // qact2 (two operands)
-                        if (mrow) ka += (int)mrow[key];                                          // shift mask, after the clamp
+                        ka = clamp_i32(requant_exact(kS, a.Mb) + bv[r], -128, 127);              // qact2 (two operands)
+                        if (((kreg[kt] >> (8 * r)) & 0xffu) != qreg) ka += a.mask_value;         // shift mask, after the clamp
                     }
                     s[kt][r] = ka;
                     rmax = max(rmax, ka);
@@ -407,7 +529,31 @@ IVIT_EXPORT int ivit_layernorm_i16_i8(const int16_t* x, int rows, int C, const f
     int rc = check_map("ivit_layernorm_i16_i8", rows, H, W, ws, shift);
     if (rc) return rc;
     Ln16Args a{x, rows, C, bias_int, s_ln, m, e, out, ldo, WinMap{H, W, ws, shift}};
-    hipLaunchKernelGGL(layernorm_i16_i8_kernel, dim3(grid_for_rows(rows)), dim3(NT), 0, ivit_stream(stream), a);
+    hipStream_t st = ivit_stream(stream);
+    const bool tiled = C % 8 == 0 && C <= 1536 && ldo % 8 == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)out % 8 == 0) &&
+                       ((uintptr_t)bias_int % 16 == 0) && ((uintptr_t)s_ln % 16 == 0) && ((uintptr_t)m % 16 == 0) &&
+                       ((uintptr_t)e % 16 == 0);
+    if (!tiled) {
+        hipLaunchKernelGGL(layernorm_i16_i8_kernel, dim3(grid_for_rows(rows)), dim3(NT), 0, st, a);
+        IVIT_CHECK_LAUNCH("ivit_layernorm_i16_i8");
+    }
+    const int nd = C / 8;
+    int lpr = 4;
+    while ((nd + lpr - 1) / lpr > 3) lpr *= 2;   // smallest group of lanes that covers a row with <= 3 chunks per lane
+    const int nj = (nd + lpr - 1) / lpr;
+    // persistent-style launch: the per-channel constants (24 f64 reciprocals per lane) are set up once per wave, so keep
+    // the grid at the number of resident workgroups (2 per CU at ~195 VGPRs) and let each wave stride over many rows
+    int nblk = grid_for_rows(rows, 64 / lpr);
+    if (nblk > 512) nblk = 512;
+    const dim3 grid(nblk), blk(NT);
+#define LN16_CASE(L, J) \
+    if (lpr == L && nj == J) hipLaunchKernelGGL((layernorm_i16_i8_tiled_kernel<L, J>), grid, blk, 0, st, a)
+    LN16_CASE(4, 1); LN16_CASE(4, 2); LN16_CASE(4, 3);
+    LN16_CASE(8, 2); LN16_CASE(8, 3);
+    LN16_CASE(16, 2); LN16_CASE(16, 3);
+    LN16_CASE(32, 2); LN16_CASE(32, 3);
+    LN16_CASE(64, 2); LN16_CASE(64, 3);
+#undef LN16_CASE
     IVIT_CHECK_LAUNCH("ivit_layernorm_i16_i8");
 }
 
@@ -432,10 +578,10 @@ IVIT_EXPORT int ivit_avgpool_requant_i8(const int8_t* x, int8_t* out, int batch,
     IVIT_CHECK_LAUNCH("ivit_avgpool_requant_i8");
 }
 
-IVIT_EXPORT int ivit_window_attention_i8(const int8_t* qkv, int8_t* out, int64_t ldo, const int16_t* bias_add, const int16_t* mask_add,
-                                         int windows, int windows_per_image, int heads, int tokens, int head_dim,
-                                         uint32_t m_s, int32_t e_s, uint32_t m_b, int32_t e_b, float s_attn, uint32_t m_o,
-                                         int32_t e_o, ivit_stream_t stream)
+IVIT_EXPORT int ivit_window_attention_i8(const int8_t* qkv, int8_t* out, int64_t ldo, const int16_t* bias_add,
+                                         const uint8_t* mask_region, int mask_value, int windows, int windows_per_image,
+                                         int heads, int tokens, int head_dim, uint32_t m_s, int32_t e_s, uint32_t m_b,
+                                         int32_t e_b, float s_attn, uint32_t m_o, int32_t e_o, ivit_stream_t stream)
 {
     IVIT_REQUIRE(qkv && out && bias_add, "ivit_window_attention_i8: NULL operand");
     IVIT_REQUIRE(windows > 0 && heads > 0 && windows_per_image > 0 && windows % windows_per_image == 0,
@@ -446,9 +592,11 @@ IVIT_EXPORT int ivit_window_attention_i8(const int8_t* qkv, int8_t* out, int64_t
     }
     IVIT_REQUIRE(((uintptr_t)qkv % 16 == 0) && ((uintptr_t)out % 4 == 0) && ldo % 4 == 0 && ldo >= (int64_t)heads * head_dim,
                  "ivit_window_attention_i8: misaligned operand or ldo too small");
+    IVIT_REQUIRE(((uintptr_t)bias_add % 8 == 0) && ((uintptr_t)mask_region % 4 == 0), "ivit_window_attention_i8: misaligned table");
+    IVIT_REQUIRE(mask_value <= 0 && mask_value >= -32768, "ivit_window_attention_i8: mask_value=%d outside [-32768, 0]", mask_value);
     IVIT_REQUIRE(s_attn > 0.0f, "ivit_window_attention_i8: scale must be positive");
     WinAttnArgs a;
-    a.qkv = qkv; a.out = out; a.ldo = ldo; a.bias = bias_add; a.mask = mask_add;
+    a.qkv = qkv; a.out = out; a.ldo = ldo; a.bias = bias_add; a.region = mask_region; a.mask_value = mask_value;
     a.nwin = windows; a.heads = heads; a.T = tokens; a.nW = windows_per_image;
     a.Ms = ivit_dyadic_to_double(m_s, e_s);
     a.Mb = ivit_dyadic_to_double(m_b, e_b);

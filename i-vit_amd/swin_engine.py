@@ -146,18 +146,21 @@ class IntSwinEngine:
                 bias = ktab[rel_position_index(win).reshape(-1)].reshape(N, N, nH).transpose(2, 0, 1)
                 bias_add = requant_host(bias, m2[0], e2[0])                    # identity operand of qact2, :143-147
                 assert np.abs(bias_add).max() < 32768
-                mask_add = None
+                bias_pad = np.zeros((nH, N, 64), np.int16)
+                bias_pad[:, :, :N] = bias_add
+                region, mask_value = None, 0
                 if shift:
-                    reg = shift_mask_regions(H, W, win, shift)
                     mval = f32(-100.0) / s_A                                    # :149-155: (k*s + (-100)) / s
                     if mval != np.rint(mval) or abs(mval) >= 32768:
                         raise ValueError("shift mask / attention scale is not a 16-bit integer (outside the pow2 regime)")
-                    mask_add = np.where(reg[:, :, None] != reg[:, None, :], int(mval), 0).astype(np.int16)
+                    mask_value = int(mval)
+                    region = np.zeros(((H // win) * (W // win), 64), np.uint8)
+                    region[:, :N] = shift_mask_regions(H, W, win, shift)
                 s_pv = f32(f32(1.0 / 128.0) * s_a1)
                 s_a3 = s(p + "attn.qact3")
                 blk["attn"] = dict(ms=sme(s_S, s_at), mb=sme(s_at, s_A), s_attn=float(s_A), mo=sme(s_pv, s_a3),
-                                   bias=dev(bias_add.astype(np.int16)), mask=None if mask_add is None else dev(mask_add),
-                                   nW=(H // win) * (W // win))
+                                   bias=dev(bias_pad), region=None if region is None else dev(region),
+                                   mask_value=mask_value, nW=(H // win) * (W // win))
                 lp, d = lin_host(p + "attn.proj", s_a3)
                 s_a4 = s(p + "attn.qact4", 16)
                 mp, ep = dyadic(lp.s_acc, s_a4)
@@ -294,7 +297,7 @@ class IntSwinEngine:
                     taps[p + "attn.qact1"] = hm.permute(1, 3, 0, 2, 4).reshape(nwin, N, 3 * C).clone()
                 a = blk["attn"]
                 _lib.call("ivit_window_attention_i8", _lib.ptr(ws["qkv"]), _lib.ptr(ws["ao"]), ld, _lib.ptr(a["bias"]),
-                          _lib.ptr(a["mask"]), nwin, a["nW"], nH, N, HEAD_DIM, a["ms"][0], a["ms"][1], a["mb"][0],
+                          _lib.ptr(a["region"]), a["mask_value"], nwin, a["nW"], nH, N, HEAD_DIM, a["ms"][0], a["ms"][1], a["mb"][0],
                           a["mb"][1], a["s_attn"], a["mo"][0], a["mo"][1], st)
                 tap(p + "attn.qact3", ws["ao"], M, C, ld)
                 pj = blk["proj"]

@@ -244,17 +244,19 @@ int ivit_avgpool_requant_i8(const int8_t* x, int8_t* out, int batch, int tokens,
  * two-operand qact2 -> + shift mask -> Shiftmax -> matmul_2 -> qact3, one wave per (window, head).
  *   qkv      [3][windows][heads][tokens][32] int8 (ivit_gemm_i8_requant_qkv on window-ordered rows)
  *   out      [windows*tokens, ldo] int8, column h*32 + d
- *   bias_add [heads][tokens][tokens] int16 = RNE(qact_table(table)[index] * m2 / 2^e2): the identity operand of
- *            qact2, a load-time constant
- *   mask_add [windows_per_image][tokens][tokens] int16 in {0, -100/s_attn} or NULL (un-shifted block); added after
- *            qact2's clamp, as the reference adds the float mask to the fake-quantised scores (:149-155)
+ *   bias_add [heads][tokens][64] int16 = RNE(qact_table(table)[index] * m2 / 2^e2) (key index padded to 64): the
+ *            identity operand of qact2, a load-time constant
+ *   mask_region [windows_per_image][64] uint8 or NULL (un-shifted block): region id of every token of a window of
+ *            the rolled image (the img_mask of swin_quant.py:223-243); scores of (query, key) pairs from different
+ *            regions get mask_value = -100 / s_attn (an integer in the supported regime) added after qact2's clamp,
+ *            as the reference adds the float mask to the fake-quantised scores (:149-155, 243-246)
  *   (m_s,e_s): q.k^T -> qact_attn1;  (m_b,e_b): qact_attn1 -> qact2;  s_attn: scale of qact2 (Shiftmax input);
  *   (m_o,e_o): P.v -> qact3.
  * Supported: head_dim 32, 2 <= tokens <= 64. */
 int ivit_window_attention_i8(const int8_t* qkv, int8_t* out, int64_t ldo, const int16_t* bias_add,
-                             const int16_t* mask_add, int windows, int windows_per_image, int heads, int tokens,
-                             int head_dim, uint32_t m_s, int32_t e_s, uint32_t m_b, int32_t e_b, float s_attn,
-                             uint32_t m_o, int32_t e_o, ivit_stream_t stream);
+                             const uint8_t* mask_region, int mask_value, int windows, int windows_per_image, int heads,
+                             int tokens, int head_dim, uint32_t m_s, int32_t e_s, uint32_t m_b, int32_t e_b,
+                             float s_attn, uint32_t m_o, int32_t e_o, ivit_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,50 @@
+"""Throughput of every BASELINE.json config that fits one GPU (SURVEY.md §8d "per-config throughput"):
+  1 DeiT-T b1, 2 DeiT-S b64, 3 DeiT-B b256, 4 ViT-B b128 (= one rank's shard of b1024 over 8 GPUs), 5 Swin-T b128.
+Synthetic weights + ranges from tests/golden, random N(0,1) images resident in HBM, whole forward timed with
+events on the launch stream.  Prints one JSON line per config; `python scripts/bench_configs.py 5` runs one."""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+import ivit_amd  # noqa: E402,F401
+from ivit_amd import synth  # noqa: E402
+from ivit_amd.checkpoint import load_synthetic_model  # noqa: E402
+from ivit_amd.engine import IntViTEngine  # noqa: E402
+from ivit_amd.swin_engine import IntSwinEngine  # noqa: E402
+
+DEV = "cuda:0"
+CONFIGS = {1: ("deit_tiny", 1), 2: ("deit_small", 64), 3: ("deit_base", 256), 4: ("vit_base", 128), 5: ("swin_tiny", 128)}
+GMAC = {"deit_tiny": 1.2537, "deit_small": 4.5989, "deit_base": 17.5638, "vit_base": 17.5638, "swin_tiny": 4.4906}
+
+
+def run(cid, steps=20, warmup=5):
+    tag, B = CONFIGS[cid]
+    fs, ranges, cfg, meta, z = load_synthetic_model(tag)
+    if tag.startswith("swin"):
+        eng = IntSwinEngine(fs, ranges, cfg["embed_dim"], cfg["depths"], cfg["num_heads"], cfg["window"], device=DEV,
+                            max_batch=B)
+    else:
+        eng = IntViTEngine(fs, ranges, cfg["embed_dim"], cfg["depth"], cfg["num_heads"], device=DEV, max_batch=B)
+    imgs = torch.from_numpy(synth.make_images(min(B, 16), 1000 + cid)).to(DEV)
+    imgs = imgs.repeat((B + imgs.shape[0] - 1) // imgs.shape[0], 1, 1, 1)[:B].contiguous()
+    for _ in range(warmup):
+        eng.forward(imgs)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        eng.forward(imgs)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / steps
+    ips = B / ms * 1e3
+    print(json.dumps({"config": cid, "model": tag, "batch": B, "ms_per_forward": round(ms, 3), "images_per_s": round(ips, 1),
+                      "int8_tops": round(ips * GMAC[tag] * 2e9 / 1e12, 1)}), flush=True)
+
+
+if __name__ == "__main__":
+    for c in ([int(a) for a in sys.argv[1:]] or sorted(CONFIGS)):
+        run(c)

@@ -1,0 +1,79 @@
+"""Time the Swin-specific kernels in isolation at the Swin-T batch-128 shapes (events on the launch stream)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import ivit_amd  # noqa: E402,F401
+from ivit_amd import _lib  # noqa: E402
+from ivit_amd.prepare import LayerNormParams, dyadic  # noqa: E402
+
+DEV = "cuda:0"
+rng = np.random.default_rng(0)
+st = _lib.stream_ptr
+B = int(os.environ.get("IVIT_B", "128"))
+
+
+def d(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def timeit(fn, n=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+
+
+which = sys.argv[1:] or ["ln", "attn", "res"]
+STAGES = [(56, 96, 3), (28, 192, 6), (14, 384, 12), (7, 768, 24)]
+if "ln" in which:
+    for H, C, nH in STAGES + [(28, 384, 0), (14, 768, 0), (7, 1536, 0)]:
+        rows = B * H * H
+        x = d(rng.integers(-20000, 20000, size=(rows, C)).astype(np.int16))
+        out = torch.empty(rows, C, dtype=torch.int8, device=DEV)
+        lp = LayerNormParams(rng.uniform(0.5, 1.5, C).astype(np.float32), rng.normal(0, 0.1, C).astype(np.float32), np.float32(2.0 ** -5))
+        bi, sl, mm, ee = d(lp.bias_int), d(lp.s_ln), d(lp.m.view(np.int32)), d(lp.e)
+        for ws, sh in ((0, 0), (7, 3)) if nH else ((0, 0),):
+            us = timeit(lambda: _lib.call("ivit_layernorm_i16_i8", _lib.ptr(x), rows, C, _lib.ptr(bi), _lib.ptr(sl), _lib.ptr(mm),
+                                          _lib.ptr(ee), _lib.ptr(out), C, H, H, ws, sh if H > 7 else 0, st()))
+            print(f"ln16 rows={rows:7d} C={C:5d} ws={ws} shift={sh}: {us:8.1f} us  ({3 * rows * C / us / 1e3:7.1f} GB/s algorithmic)", flush=True)
+if "attn" in which:
+    for H, C, nH in STAGES:
+        nwin = B * (H // 7) ** 2
+        qkv = d(np.clip(np.rint(rng.normal(0, 40, size=(3, nwin, nH, 49, 32))), -128, 127).astype(np.int8))
+        out = torch.empty(nwin * 49, C, dtype=torch.int8, device=DEV)
+        bias = d(rng.integers(-60, 61, size=(nH, 49, 64)).astype(np.int16))
+        mask = d(rng.integers(0, 3, size=((H // 7) ** 2, 64)).astype(np.uint8))
+        ms, es = dyadic(np.float32(2.0 ** -9), np.float32(0.25))
+        mo, eo = dyadic(np.float32(2.0 ** -11), np.float32(2.0 ** -3))
+        for mk in (None, mask):
+            us = timeit(lambda: _lib.call("ivit_window_attention_i8", _lib.ptr(qkv), _lib.ptr(out), C, _lib.ptr(bias), _lib.ptr(mk), -400, nwin,
+                                          (H // 7) ** 2, nH, 49, 32, int(ms[0]), int(es[0]), 1 << 30, 30, 0.25, int(mo[0]), int(eo[0]), st()))
+            print(f"window attention windows={nwin:5d} heads={nH:2d} mask={mk is not None}: {us:8.1f} us  "
+                  f"({4 * nwin * 49 * C / us / 1e3:7.1f} GB/s algorithmic, {4 * nwin * nH * 49 * 49 * 32 / us / 1e6:6.1f} TOPS)", flush=True)
+if "res" in which:
+    for H, C, nH in STAGES:
+        rows = B * H * H
+        acc = d(rng.integers(-100000, 100000, size=(rows, C)).astype(np.int32))
+        a8 = d(rng.integers(-128, 128, size=(rows, C)).astype(np.int8))
+        res = d(rng.integers(-20000, 20000, size=(rows, C)).astype(np.int16))
+        out = torch.empty(rows, C, dtype=torch.int16, device=DEV)
+        pre = (rng.uniform(0.5, 1.0, size=C) * 2.0 ** -4).astype(np.float32)
+        mp, ep = dyadic(pre, np.float32(1.0))
+        mpd, epd = d(mp.view(np.int32)), d(ep)
+        ma, ea = dyadic(np.float32(0.013), np.float32(0.02))
+        us = timeit(lambda: _lib.call("ivit_residual_requant_i16", _lib.ptr(acc), 32, _lib.ptr(mpd), _lib.ptr(epd), int(ma[0]), int(ea[0]),
+                                      _lib.ptr(res), int(ma[0]), int(ea[0]), _lib.ptr(out), rows, C, H, H, 7, 3 if H > 7 else 0, st()))
+        print(f"residual i32->i16 rows={rows:7d} C={C:4d}: {us:8.1f} us  ({8 * rows * C / us / 1e3:7.1f} GB/s algorithmic)", flush=True)
+        us = timeit(lambda: _lib.call("ivit_residual_requant_i16", _lib.ptr(a8), 8, None, None, int(ma[0]), int(ea[0]),
+                                      _lib.ptr(res), int(ma[0]), int(ea[0]), _lib.ptr(out), rows, C, 0, 0, 0, 0, st()))
+        print(f"residual i8->i16  rows={rows:7d} C={C:4d}: {us:8.1f} us  ({5 * rows * C / us / 1e3:7.1f} GB/s algorithmic)", flush=True)

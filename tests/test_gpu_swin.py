@@ -230,17 +230,19 @@ def test_window_attention(B_, nW, nH, N, s_attn, masked):
         mb, omB = sme(s_at * np.float32(0.75), s_at), ome(s_at * np.float32(0.75), s_at)
     mo, omO = sme(np.float32(2.0 ** -7 * 0.05), 0.043), ome(np.float32(2.0 ** -7 * 0.05), 0.043)
     bias_add = rng.integers(-60, 61, size=(nH, N, N)).astype(np.int16)
-    mask_add = None
+    bias_pad = np.full((nH, N, 64), 99, np.int16)      # pad entries must never be used
+    bias_pad[:, :, :N] = bias_add
+    mask_add, region, mval = None, None, 0
     if masked:
         mval = int(np.float32(-100.0) / s_at)
-        mask_add = np.where(rng.random((nW, N, N)) < 0.3, mval, 0).astype(np.int16)
-        for w in range(nW):
-            np.fill_diagonal(mask_add[w], 0)
+        region = np.full((nW, 64), 200, np.uint8)
+        region[:, :N] = rng.integers(0, 4, size=(nW, N))
+        mask_add = np.where(region[:, :N, None] != region[:, None, :N], mval, 0).astype(np.int16)
     ref, kA, Pm = window_attention_ref(qkv[0], qkv[1], qkv[2], bias_add, mask_add, nW, omS, omB, s_at, omO)
     ld = nH * hd + 32
     out = torch.zeros(B_ * N, ld, dtype=torch.int8, device=DEV)
-    _lib.call("ivit_window_attention_i8", _lib.ptr(dev(qkv)), _lib.ptr(out), ld, _lib.ptr(dev(bias_add)),
-              _lib.ptr(None if mask_add is None else dev(mask_add)), B_, nW, nH, N, hd, ms[0], ms[1], mb[0], mb[1],
+    _lib.call("ivit_window_attention_i8", _lib.ptr(dev(qkv)), _lib.ptr(out), ld, _lib.ptr(dev(bias_pad)),
+              _lib.ptr(None if region is None else dev(region)), mval, B_, nW, nH, N, hd, ms[0], ms[1], mb[0], mb[1],
               float(s_at), mo[0], mo[1], st())
     got = out.cpu().numpy()
     assert np.array_equal(got[:, : nH * hd].astype(np.int32).reshape(B_, N, nH * hd), ref)
@@ -251,12 +253,12 @@ def test_window_attention(B_, nW, nH, N, s_attn, masked):
 def test_window_attention_rejects_unsupported_geometry():
     q = dev(np.zeros(3 * 49 * 64, np.int8))
     o = torch.empty(49 * 64, dtype=torch.int8, device=DEV)
-    b = dev(np.zeros(49 * 49, np.int16))
+    b = dev(np.zeros(49 * 64, np.int16))
     with pytest.raises(_lib.IvitError):
-        _lib.call("ivit_window_attention_i8", _lib.ptr(q), _lib.ptr(o), 64, _lib.ptr(b), None, 1, 1, 1, 49, 64,
+        _lib.call("ivit_window_attention_i8", _lib.ptr(q), _lib.ptr(o), 64, _lib.ptr(b), None, 0, 1, 1, 1, 49, 64,
                   1 << 30, 40, 1 << 30, 31, 0.25, 1 << 30, 40, st())
     with pytest.raises(_lib.IvitError):
-        _lib.call("ivit_window_attention_i8", _lib.ptr(q), _lib.ptr(o), 32, _lib.ptr(b), None, 1, 1, 1, 65, 32,
+        _lib.call("ivit_window_attention_i8", _lib.ptr(q), _lib.ptr(o), 32, _lib.ptr(b), None, 0, 1, 1, 1, 65, 32,
                   1 << 30, 40, 1 << 30, 31, 0.25, 1 << 30, 40, st())
 
 
