@@ -851,18 +851,40 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_pers_kernel(GemmArgs g)
         for (int j = 0; j < 4; ++j) aoff[ks][j] = swz(arow0 + 32 * j, 2 * ks + h);
     }
     v4i wf0[2], af0[4], wf1[2], af1[4];
-    auto load_frags = [&](const char* st, int ks, v4i (&wf)[2], v4i (&af)[4]) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) wf[i] = *reinterpret_cast<const v4i*>(st + woff[ks][i]);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) af[j] = *reinterpret_cast<const v4i*>(st + aoff[ks][j]);
+    // Fragment reads are issued as inline asm so that their completion is tracked HERE (explicit counted s_waitcnt tied to
+    // the registers they guard) and not by the compiler's waitcnt insertion, which drains lgkmcnt to 0 in front of the
+    // first MFMA after each group and so exposes a full LDS round trip per half step.  Per lane the 4 token sub-tiles are
+    // 2048 B apart and the 2 channel sub-tiles likewise (the swizzle term depends on (row >> 2) & 3 only), so each
+    // operand needs one address register per k sub-step and immediate offsets.
+    const unsigned smem_base = (unsigned)(__UINTPTR_TYPE__)(lptr_t)smem;
+    const unsigned wbase[2] = {smem_base + (unsigned)woff[0][0], smem_base + (unsigned)woff[1][0]};
+    const unsigned abase[2] = {smem_base + (unsigned)aoff[0][0], smem_base + (unsigned)aoff[1][0]};
+    auto load_frags = [&](unsigned stage_off, int ks, v4i (&wf)[2], v4i (&af)[4]) {
+        const unsigned wa = wbase[ks] + stage_off, aa = abase[ks] + stage_off;
+        asm volatile("ds_read_b128 %0, %1" : "=v"(wf[0]) : "v"(wa));
+        asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(wf[1]) : "v"(wa));
+        asm volatile("ds_read_b128 %0, %1" : "=v"(af[0]) : "v"(aa));
+        asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(af[1]) : "v"(aa));
+        asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(af[2]) : "v"(aa));
+        asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(af[3]) : "v"(aa));
     };
+    // wait until at most N LDS reads of this wave are outstanding; the "+v" ties order every later use of the guarded
+    // fragments after the wait
+#define IVIT_LGKM_WAIT(N, wf, af)                                                                                     \
+    asm volatile("s_waitcnt lgkmcnt(" #N ")"                                                                            \
+                 : "+v"(wf[0]), "+v"(wf[1]), "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3])::"memory")
     v16i acc[2][4];
+    // Pipeline per K step kt (3 LDS stages, fragments double-buffered in registers):
+    //   read frags(kt, ks=1)            | wait frags(kt, ks=0) (issued one half step ago; the new reads stay in flight)
+    //   MFMA on frags(kt, ks=0) interleaved with the DMA of stage kt+2
+    //   wait own DMA of stage kt+1 and all own LDS reads | barrier
+    //   read frags(kt+1, ks=0)          | MFMA on frags(kt, ks=1)  (already complete: drained before the barrier)
     auto step = [&](int kt, auto dma_tag, auto last_tag) {
         constexpr bool DMA = decltype(dma_tag)::value;
         constexpr bool LAST = decltype(last_tag)::value;
-        const char* st = smem + (kt % BIG_STAGES) * BIG_STAGE;
-        load_frags(st, 1, wf1, af1);
+        load_frags((unsigned)((kt % BIG_STAGES) * BIG_STAGE), 1, wf1, af1);
+        IVIT_LGKM_WAIT(6, wf0, af0);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -871,16 +893,23 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_pers_kernel(GemmArgs g)
                 if constexpr (DMA)
                     if (4 * i + j < 6) issue_one(kt + 2, 4 * i + j);
             }
-        if constexpr (DMA) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (DMA)
+            asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)"
+                         : "+v"(wf1[0]), "+v"(wf1[1]), "+v"(af1[0]), "+v"(af1[1]), "+v"(af1[2]), "+v"(af1[3])::"memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
+                         : "+v"(wf1[0]), "+v"(wf1[1]), "+v"(af1[0]), "+v"(af1[1]), "+v"(af1[2]), "+v"(af1[3])::"memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if constexpr (!LAST) load_frags(smem + ((kt + 1) % BIG_STAGES) * BIG_STAGE, 0, wf0, af0);
+        if constexpr (!LAST) load_frags((unsigned)(((kt + 1) % BIG_STAGES) * BIG_STAGE), 0, wf0, af0);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf1[i], af1[j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
     };
     using T = std::true_type;
     using F = std::false_type;
@@ -922,7 +951,7 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_pers_kernel(GemmArgs g)
                     acc[i][j][4 * q + 3] = b4.w;
                 }
             }
-        load_frags(smem, 0, wf0, af0);
+        load_frags(0u, 0, wf0, af0);
         int kt = 0;
         for (; kt + 2 < nk; ++kt) step(kt, T{}, F{});
         if (kt + 1 < nk) { step(kt, F{}, F{}); ++kt; }
