@@ -608,6 +608,56 @@ static int gelu_x0(float s, const char* who, int* x0_out)
 
 }  // namespace
 
+// ------------------------------------------------------------------------------------------------
+// calibration statistics: min / max of a float tensor (QuantAct running_stat mode, quant_modules.py:310-349)
+// float -> order-preserving uint32 key so that integer atomics reduce across workgroups
+// ------------------------------------------------------------------------------------------------
+IVIT_DEV unsigned f32_key(float v)
+{
+    const unsigned b = (unsigned)__float_as_int(v);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+IVIT_DEV float key_f32(unsigned k)
+{
+    return __int_as_float((int)((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k));
+}
+
+__global__ void minmax_init_kernel(unsigned* keys)
+{
+    keys[0] = 0xffffffffu;   // running min
+    keys[1] = 0u;            // running max
+}
+
+__global__ __launch_bounds__(NT) void minmax_kernel(const float* x, int64_t n, unsigned* keys)
+{
+    unsigned kmin = 0xffffffffu, kmax = 0u;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+        const float v = x[i];
+        if (v == v) {   // NaNs do not take part (torch.min/max would propagate them; a calibrated range must not)
+            const unsigned k = f32_key(v);
+            kmin = min(kmin, k);
+            kmax = max(kmax, k);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        kmin = min(kmin, (unsigned)__shfl_xor((int)kmin, o));
+        kmax = max(kmax, (unsigned)__shfl_xor((int)kmax, o));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(keys, kmin);
+        atomicMax(keys + 1, kmax);
+    }
+}
+
+__global__ void minmax_finish_kernel(unsigned* keys)
+{
+    const unsigned a = keys[0], b = keys[1];
+    reinterpret_cast<float*>(keys)[0] = key_f32(a);
+    reinterpret_cast<float*>(keys)[1] = key_f32(b);
+}
+
 // ================================================================================================
 IVIT_EXPORT int ivit_layernorm_i8(const int8_t* x, int64_t ldx, int rows, int C, const float* bias_int,
                                   const float* s_ln, const uint32_t* m, const int32_t* e, int8_t* out, int64_t ldo,
@@ -729,6 +779,18 @@ IVIT_EXPORT int ivit_shiftmax_i32_i8(const int32_t* x, int64_t ldx, int rows, in
                                      ivit_stream_t stream)
 {
     return launch_shiftmax<int32_t>("ivit_shiftmax_i32_i8", x, ldx, rows, L, s, out, ldo, stream);
+}
+
+IVIT_EXPORT int ivit_minmax_f32(const float* x, int64_t n, float* out_min_max, ivit_stream_t stream)
+{
+    IVIT_REQUIRE(x && out_min_max && n > 0, "ivit_minmax_f32: bad operand");
+    IVIT_REQUIRE(((uintptr_t)out_min_max % 4 == 0) && ((uintptr_t)x % 4 == 0), "ivit_minmax_f32: misaligned");
+    hipStream_t st = ivit_stream(stream);
+    unsigned* keys = reinterpret_cast<unsigned*>(out_min_max);
+    hipLaunchKernelGGL(minmax_init_kernel, dim3(1), dim3(1), 0, st, keys);
+    hipLaunchKernelGGL(minmax_kernel, dim3(ew_grid(n) < 2048 ? ew_grid(n) : 2048), dim3(NT), 0, st, x, n, keys);
+    hipLaunchKernelGGL(minmax_finish_kernel, dim3(1), dim3(1), 0, st, keys);
+    IVIT_CHECK_LAUNCH("ivit_minmax_f32");
 }
 
 IVIT_EXPORT int ivit_quantize_input_f32_i8(const float* x, int8_t* out, int64_t n, float inv_scale,

@@ -173,8 +173,12 @@ class QuantAct(nn.Module):
         self.running_stat = True
 
     def _observe(self, x_act):
-        """calibration statistics (quant_modules.py:310-360); torch reductions, not a hot path"""
-        x_min, x_max = x_act.detach().min(), x_act.detach().max()
+        """calibration statistics (quant_modules.py:310-360): min / max by the HIP reduction, then the reference's
+        initialise / running-min-max / EMA update on the two scalars"""
+        xa = x_act.detach().contiguous().float()
+        mm = torch.empty(2, dtype=torch.float32, device=xa.device)
+        _lib.call("ivit_minmax_f32", _lib.ptr(xa), xa.numel(), _lib.ptr(mm), _st())
+        x_min, x_max = mm[0], mm[1]
         if torch.eq(self.x_min, self.x_max).all():
             self.x_min = self.x_min + x_min
             self.x_max = self.x_max + x_max

@@ -39,6 +39,11 @@ typedef void* ivit_stream_t; /* hipStream_t */
 int ivit_version(void);
 const char* ivit_last_error_string(void);
 
+/* ---- calibration statistics -----------------------------------------------------------------
+ * QuantAct running_stat mode (quant_modules.py:310-349) observes x.min() / x.max() of the float view it is handed.
+ * out_min_max[0] = min, out_min_max[1] = max over x[0..n) (device float[2]; NaNs are skipped). */
+int ivit_minmax_f32(const float* x, int64_t n, float* out_min_max, ivit_stream_t stream);
+
 /* ---- input quantisation ---------------------------------------------------------------
  * QuantAct input mode = SymmetricQuantFunction.forward (quant_utils.py:79-97,
  * linear_quantize :13-49):  q = clamp(round(inv_scale * x), -128, 127), inv_scale = fl(1/s)

@@ -10,7 +10,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 ivit = pytest.importorskip("ivit_amd")
-from ivit_amd import synth  # noqa: E402
+from ivit_amd import _lib, synth  # noqa: E402
 from ivit_amd.checkpoint import load_synthetic_model  # noqa: E402
 import ivit_amd.quantization_utils as q  # noqa: E402
 
@@ -249,3 +249,55 @@ def test_swin_calibration_then_freeze_runs():
     assert called == synth.swin_qact_names(cfg["depths"])      # act_out is constructed but never called
     ivit.freeze_model(model)
     assert model.is_frozen()
+
+
+# ----------------------------------------------------------------------------------- calibration + harness (rows f1, f4)
+def test_minmax_kernel():
+    rng = np.random.default_rng(3)
+    for n in (1, 63, 1000, 3 * 224 * 224 * 4 + 1):
+        x = rng.standard_normal(n).astype(np.float32) * 7
+        x[rng.integers(0, n)] = -123.5
+        t = torch.from_numpy(x).to(DEV)
+        mm = torch.empty(2, dtype=torch.float32, device=DEV)
+        _lib.call("ivit_minmax_f32", _lib.ptr(t), n, _lib.ptr(mm), _lib.stream_ptr())
+        assert mm.cpu().numpy().tolist() == [float(x.min()), float(x.max())]
+    t = torch.tensor([float("nan"), -0.0, 0.0, float("nan")], device=DEV)
+    mm = torch.empty(2, dtype=torch.float32, device=DEV)
+    _lib.call("ivit_minmax_f32", _lib.ptr(t), 4, _lib.ptr(mm), _lib.stream_ptr())
+    assert mm.cpu().numpy().tolist() == [0.0, 0.0] and np.signbit(mm.cpu().numpy()[0])
+
+
+def test_quantact_running_stat_matches_reference_update_rule():
+    """first call initialises the range, later calls apply the EMA (quant_modules.py:346-360)"""
+    qa = q.QuantAct().to(DEV)
+    a = torch.linspace(-3.0, 5.0, 1001, device=DEV).reshape(1, -1)
+    b = torch.linspace(-7.0, 1.0, 1001, device=DEV).reshape(1, -1)
+    qa(a, torch.ones(1, device=DEV))
+    assert (float(qa.x_min), float(qa.x_max)) == (-3.0, 5.0)
+    qa(b, torch.ones(1, device=DEV))
+    f32 = np.float32
+    exp_min = f32(f32(-3.0) * f32(0.95)) + f32(f32(-7.0) * f32(1 - 0.95))
+    assert abs(float(qa.x_min) - float(exp_min)) < 1e-6 and abs(float(qa.x_max) - (5 * 0.95 + 1 * 0.05)) < 1e-6
+
+
+def test_checkpoint_harness_end_to_end(tmp_path):
+    """save a reference-format checkpoint of the synthetic DeiT-S, load it back strictly, evaluate on the golden images
+    with the golden top-1 as labels (scripts/inference.py load_model -> evaluate_dataset)"""
+    from ivit_amd import inference
+    model, meta, z = load_model("deit_small")
+    path = tmp_path / "ckpt.pth.tar"
+    inference.save_checkpoint(model, path, {"model_name": "deit_small_patch16_224", "gelu_type": "ivit",
+                                            "softmax_type": "ivit", "layernorm_type": "ivit"}, epoch=0)
+    m2 = inference.load_model(path, device=DEV, strict_load=True)
+    imgs = torch.from_numpy(synth.make_images(meta["n_images"], meta["image_seed"]))
+    labels = torch.from_numpy(z["top1"])
+    loader = [(imgs[:2], labels[:2]), (imgs[2:], labels[2:])]
+    assert inference.evaluate_dataset(m2, loader, DEV, print_batch_stats=False) == (100.0, 100.0, 100.0)
+    wrong = [(imgs, (labels + 1) % 1000)]
+    t1, _, _ = inference.evaluate_dataset(m2, wrong, DEV, print_batch_stats=False)
+    assert t1 == 0.0
+    with torch.no_grad():
+        assert np.array_equal(bits(m2(imgs.to(DEV))), z["logits_f32_bits"])
+    # non-strict load with the random warm-up forward, then frozen (inference.py:209-223)
+    m3 = inference.load_model(path, device=DEV, strict_load=False, use_random_calibration_warmup=True)
+    assert m3.is_frozen()

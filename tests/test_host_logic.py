@@ -121,3 +121,46 @@ def test_module_tree_matches_reference_state_dict_schema(golden_dir):
         assert mine == ref, name
     with pytest.raises(RuntimeError, match="no network"):
         ivit_amd.deit_tiny_patch16_224(pretrained=True)
+
+
+def test_checkpoint_harness_cpu(tmp_path):
+    """load_model / save_checkpoint with the reference's checkpoint layouts (scripts/inference.py:94-224): dict with
+    'model' + 'model_config', bare state_dict, scalar buffers of older checkpoints, overrides; no GPU involved."""
+    import torch
+    import ivit_amd.quantization_utils as q
+    from ivit_amd import inference
+    fs, ranges, cfg, meta, z = load_synthetic_model("deit_tiny")
+    model = ivit_amd.deit_tiny_patch16_224()
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in fs.items()}, strict=False)
+    for name, mod in model.named_modules():
+        if isinstance(mod, q.QuantAct):
+            mod.x_min.fill_(float(ranges[name][0]))
+            mod.x_max.fill_(float(ranges[name][1]))
+    path = tmp_path / "checkpoint.pth.tar"
+    inference.save_checkpoint(model, path, {"model_name": "deit_tiny", "num_classes": 1000, "gelu_type": "ivit",
+                                            "softmax_type": "ivit", "layernorm_type": "ivit", "att_block_out_bw": 8},
+                              epoch=3, best_acc1=12.5)
+    m2 = inference.load_model(path, device="cpu", strict_load=True)
+    assert m2.is_frozen() and not m2.training
+    assert float(m2.blocks[3].qact2.x_max) == float(ranges["blocks.3.qact2"][1])
+    assert torch.equal(m2.head.weight, model.head.weight)
+    # bare state_dict + a scalar buffer, non-strict, no warm-up
+    sd = model.state_dict()
+    sd["qact_input.x_min"] = sd["qact_input.x_min"].reshape(())
+    bare = tmp_path / "bare.pth"
+    torch.save(sd, bare)
+    m3 = inference.load_model(bare, device="cpu", strict_load=False)
+    assert m3.qact_input.x_min.shape == (1,) and m3.is_frozen()
+    # model_name selects the factory; unknown operator families are refused
+    assert type(inference.build_model({"model_name": "swin_tiny_patch4_window7_224"})).__name__ == "SwinTransformer"
+    assert inference.build_model({"model_name": "deit_small"}).embed_dim == 384
+    with pytest.raises(KeyError):
+        inference.build_model({"model_name": "deit_tiny", "gelu_type": "ibert"})
+    # evaluate_dataset arithmetic on a stub model
+    class Stub(torch.nn.Module):
+        def forward(self, x):
+            return x
+    logits = torch.eye(10)[:6] * 5 + torch.arange(10) * 0.01
+    t1, t3, t5 = inference.evaluate_dataset(Stub(), [(logits, torch.tensor([0, 1, 2, 9, 8, 0]))], "cpu",
+                                            print_batch_stats=False)
+    assert (round(t1, 3), round(t3, 3), round(t5, 3)) == (50.0, 83.333, 83.333)
