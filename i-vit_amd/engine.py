@@ -21,7 +21,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .prepare import LayerNormParams, LinearParams, dyadic, f32, quant_sym, requant_host, sym_scale
+from .prepare import dyadic, f32, quant_sym, requant_host
 from .synth import IMG_SIZE, NUM_CLASSES, NUM_PATCHES, NUM_TOKENS, PATCH
 
 
@@ -32,10 +32,11 @@ def _np(v):
 
 
 class IntViTEngine:
-    def __init__(self, float_state, ranges, embed_dim: int, depth: int, num_heads: int,
-                 device="cuda:0", max_batch: int = 256):
+    def __init__(self, float_state=None, ranges=None, embed_dim: int = 768, depth: int = 12, num_heads: int = 12,
+                 device="cuda:0", max_batch: int = 256, source=None):
         """float_state: name -> float32 array (the reference's state_dict names, SURVEY Appendix D);
-        ranges: QuantAct name -> (x_min, x_max) of the frozen model."""
+        ranges: QuantAct name -> (x_min, x_max) of the frozen model.  Alternatively `source`: any object with the
+        FloatSource interface of export.py (e.g. export.ExportSource: integer parameters + scale table, no floats)."""
         self.C, self.D, self.H = embed_dim, depth, num_heads
         self.hd = embed_dim // num_heads
         if self.hd != 64:
@@ -43,14 +44,12 @@ class IntViTEngine:
         self.dev = torch.device(device)
         self.max_batch = max_batch
         _lib.lib()  # fail loudly now if the HIP library is absent
-        P = {k: _np(v).astype(np.float32) for k, v in float_state.items()}
-        R = ranges
+        if source is None:
+            from .export import FloatSource
+            source = FloatSource({k: _np(v) for k, v in float_state.items()}, ranges)
         C, H, hd = self.C, self.H, self.hd
         T = NUM_TOKENS
-
-        def s(name):
-            lo, hi = R[name]
-            return sym_scale(lo, hi, 8)
+        s = source.act_scale
 
         def dev(a, dtype=None):
             t = torch.from_numpy(np.ascontiguousarray(a))
@@ -58,12 +57,12 @@ class IntViTEngine:
                 t = t.to(dtype)
             return t.to(self.dev)
 
-        def lin_dev(lp: LinearParams, s_out):
+        def lin_dev(lp, s_out):
             m, e = lp.requant_to(s_out)
             return dict(W=dev(lp.W8), b=dev(lp.b32), m=dev(m.view(np.int32)), e=dev(e), K=lp.K, N=lp.W8.shape[0])
 
         def ln_dev(prefix, s_out):
-            lp = LayerNormParams(P[prefix + ".weight"], P[prefix + ".bias"], s_out)
+            lp = source.layernorm(prefix, s_out)
             return dict(bias=dev(lp.bias_int), s=dev(lp.s_ln), m=dev(lp.m.view(np.int32)), e=dev(lp.e))
 
         def scalar_me(pre, z):
@@ -73,15 +72,15 @@ class IntViTEngine:
         # ---- stem
         s0 = s("qact_input")
         self.inv_s0 = float(f32(1.0) / s0)
-        pe = LinearParams(P["patch_embed.proj.weight"], P["patch_embed.proj.bias"], s0)
+        pe = source.linear("patch_embed.proj", s0)
         s_pe = s("patch_embed.qact")
         self.patch = lin_dev(pe, s_pe)
         s_pos, s_x = s("qact_pos"), s("qact1")
         m1, e1 = dyadic(s_pe, s_x)
         m2, e2 = dyadic(s_pos, s_x)
-        kpos = quant_sym(P["pos_embed"].reshape(T, C), s_pos, 8)
+        kpos = quant_sym(source.tensor("pos_embed").reshape(T, C), s_pos, 8)
         pos_add = requant_host(kpos, m2[0], e2[0])                       # RNE(k_pos * m2 / 2^e2)
-        z_cls = np.rint((P["cls_token"].reshape(C) / s_pe).astype(f32))   # quant_utils.py:220 on the raw cls row
+        z_cls = np.rint((source.tensor("cls_token").reshape(C) / s_pe).astype(f32))   # quant_utils.py:220 on the raw cls row
         cls_row = np.clip(requant_host(z_cls, m1[0], e1[0]) + pos_add[0], -128, 127)
         assert np.abs(pos_add).max() < 32768
         self.pos_add = dev(pos_add.astype(np.int16))
@@ -96,20 +95,20 @@ class IntViTEngine:
             s_q1 = s(p + "qact1")
             blk["ln1"] = ln_dev(p + "norm1", s_q1)
             s_a1 = s(p + "attn.qact1")
-            blk["qkv"] = lin_dev(LinearParams(P[p + "attn.qkv.weight"], P[p + "attn.qkv.bias"], s_q1), s_a1)
+            blk["qkv"] = lin_dev(source.linear(p + "attn.qkv", s_q1), s_a1)
             s_S = f32(f32(s_a1 * s_a1) * f32(hd ** -0.5))                 # vit_quant.py:72-75
             s_at = s(p + "attn.qact_attn1")
             s_pv = f32(f32(1.0 / 128.0) * s_a1)                           # Shiftmax scale 2^-7 x value scale
             s_a2 = s(p + "attn.qact2")
             blk["attn"] = dict(ms=scalar_me(s_S, s_at), s_attn=float(s_at), mo=scalar_me(s_pv, s_a2))
             s_a3 = s(p + "attn.qact3")
-            blk["proj"] = lin_dev(LinearParams(P[p + "attn.proj.weight"], P[p + "attn.proj.bias"], s_a2), s_a3)
+            blk["proj"] = lin_dev(source.linear(p + "attn.proj", s_a2), s_a3)
             s_b2 = s(p + "qact2")
             blk["res1"] = scalar_me(s_a3, s_b2) + scalar_me(s_x, s_b2)
             s_b3 = s(p + "qact3")
             blk["ln2"] = ln_dev(p + "norm2", s_b3)
             s_g = s(p + "mlp.qact_gelu")
-            blk["fc1"] = lin_dev(LinearParams(P[p + "mlp.fc1.weight"], P[p + "mlp.fc1.bias"], s_b3), s_g)
+            blk["fc1"] = lin_dev(source.linear(p + "mlp.fc1", s_b3), s_g)
             s_go = f32(s_g * f32(1.0 / 128.0))                             # ivit_modules.py:121,124
             s_m1 = s(p + "mlp.qact1")
             mg, eg = scalar_me(s_go, s_m1)
@@ -117,7 +116,7 @@ class IntViTEngine:
             _lib.call("ivit_shiftgelu_build_lut", float(s_g), mg, eg, _lib.ptr(lut), self._stream())
             blk["gelu_lut"] = lut
             s_m2 = s(p + "mlp.qact2")
-            blk["fc2"] = lin_dev(LinearParams(P[p + "mlp.fc2.weight"], P[p + "mlp.fc2.bias"], s_m1), s_m2)
+            blk["fc2"] = lin_dev(source.linear(p + "mlp.fc2", s_m1), s_m2)
             s_b4 = s(p + "qact4")
             blk["res2"] = scalar_me(s_m2, s_b4) + scalar_me(s_b2, s_b4)
             s_x = s_b4
@@ -126,7 +125,7 @@ class IntViTEngine:
         # ---- tail
         s_q2 = s("qact2")
         self.ln_f = ln_dev("norm", s_q2)
-        head = LinearParams(P["head.weight"], P["head.bias"], s_q2)
+        head = source.linear("head", s_q2)
         self.head = dict(W=dev(head.W8), b=dev(head.b32), K=head.K, N=head.W8.shape[0])
         self.head_scale = dev(head.s_acc)
         self.int8_weight_bytes = sum(int(b[k]["W"].numel()) for b in self.blocks for k in ("qkv", "proj", "fc1", "fc2")) \

@@ -103,3 +103,37 @@ def test_headline_batch_256_deit_base():
     # determinism
     li_b, _, _ = eng.forward(torch.from_numpy(imgs_np).to(DEV))
     assert np.array_equal(li_b.cpu().numpy(), li)
+
+
+def test_engine_from_integer_export(tmp_path):
+    """Row f2: params.npy + qconfig.npy (integer weights and scale table only) rebuild an engine whose logits equal the
+    reference golden; and the module mirror's state_dict exports the same integers through the reference's route."""
+    from ivit_amd import export
+    fs, ranges, cfg, meta, z = load_synthetic_model("deit_small")
+    params, qconfig = export.export_integer_params(fs, ranges, cfg["depth"])
+    export.save_export(params, qconfig, str(tmp_path))
+    p2, q2 = export.load_export(str(tmp_path))
+    eng = IntViTEngine(embed_dim=cfg["embed_dim"], depth=cfg["depth"], num_heads=cfg["num_heads"], device=DEV, max_batch=4,
+                       source=export.ExportSource(p2, q2))
+    imgs = torch.from_numpy(synth.make_images(meta["n_images"], meta["image_seed"])).to(DEV)
+    li, lf, t1 = eng.forward(imgs)
+    assert np.array_equal(li.cpu().numpy(), z["logits_int32"])
+    assert np.array_equal(lf.cpu().numpy().view(np.int32), z["logits_f32_bits"])
+    # state_dict route (convert_model.py:12-66 on the module mirror after a frozen module-path forward)
+    import ivit_amd as ivit
+    import ivit_amd.quantization_utils as q
+    model = ivit.deit_small_patch16_224()
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in fs.items()}, strict=False)
+    for name, mod in model.named_modules():
+        if isinstance(mod, q.QuantAct):
+            mod.x_min.fill_(float(ranges[name][0]))
+            mod.x_max.fill_(float(ranges[name][1]))
+    model.to(DEV)
+    ivit.freeze_model(model)
+    model.use_engine = False
+    with torch.no_grad():
+        model(imgs[:1])
+    out = export.save_params_from_state_dict(model.state_dict(), cfg["depth"], str(tmp_path / "sd"))
+    assert sorted(out) == sorted(params)
+    for k in params:
+        assert out[k].dtype == params[k].dtype and np.array_equal(out[k], params[k]), k

@@ -164,3 +164,48 @@ def test_checkpoint_harness_cpu(tmp_path):
     t1, t3, t5 = inference.evaluate_dataset(Stub(), [(logits, torch.tensor([0, 1, 2, 9, 8, 0]))], "cpu",
                                             print_batch_stats=False)
     assert (round(t1, 3), round(t3, 3), round(t5, 3)) == (50.0, 83.333, 83.333)
+
+
+def test_integer_export_matches_reference_integers(tmp_path):
+    """Row f2: the exported int8 weights / int32 biases (TVM_benchmark/convert_model.py:12-66 key names) carry exactly
+    the integers the reference derived (SHA-256 in the fixture), survive the params.npy round trip, and the
+    ExportSource rebuilt from the two files yields the same engine constants as the float checkpoint."""
+    from ivit_amd import export
+    fs, ranges, cfg, meta, z = load_synthetic_model("deit_tiny")
+    depth = cfg["depth"]
+    params, qconfig = export.export_integer_params(fs, ranges, depth)
+    sha = dict(zip([str(n) for n in z["wint_names"]], [str(d) for d in z["wint_sha"]]))
+    ren = {"patch_embed.proj": "embed_conv_", "head": "head_"}
+    for i in range(depth):
+        for lin in ("attn.qkv", "attn.proj", "mlp.fc1", "mlp.fc2"):
+            ren[f"blocks.{i}.{lin}"] = f"block_{i}_{lin.replace('.', '_')}_"
+    checked = 0
+    for ref_name, new in ren.items():
+        w, b = params[new + "weight"], params[new + "bias"]
+        assert w.dtype == np.int8 and b.dtype == np.int32
+        assert hashlib.sha256(w.astype(np.int32).tobytes()).hexdigest()[:16] == sha[ref_name + ".weight_integer"]
+        assert hashlib.sha256(b.reshape(-1).tobytes()).hexdigest()[:16] == sha[ref_name + ".bias_integer"]
+        checked += 2
+    assert checked == len(sha)
+    assert params["embed_conv_weight"].shape == (192, 3, 16, 16) and params["embed_conv_bias"].shape == (1, 192, 1, 1)
+    assert params["block_0_norm1_bias"].dtype == np.int32 and params["pos_embed_weight"].shape == (1, 197, 192)
+    assert set(qconfig) >= {"qconfig_pos", "qconfig_addpos", "qconfig_embed_conv", "block_11_qconfig_add2", "qconfig_norm",
+                            "qconfig_head"} and len([k for k in qconfig if "qconfig" in k]) == 5 + 12 * depth
+    e = qconfig["block_2_qconfig_qkv"]
+    assert np.array_equal(e["output_scale"], (np.float32(e["input_scale"]) * e["kernel_scale"]).astype(np.float32))
+    assert qconfig["block_0_qconfig_add1"]["input_dtype"] == "int16" and e["from_scale"] == 65.0
+
+    export.save_export(params, qconfig, str(tmp_path))
+    p2, q2 = export.load_export(str(tmp_path))
+    assert sorted(p2) == sorted(params) and all(np.array_equal(p2[k], params[k]) for k in params)
+    a, b = export.FloatSource(fs, ranges), export.ExportSource(p2, q2)
+    for name, qa in (("patch_embed.proj", "qact_input"), ("blocks.5.mlp.fc2", "blocks.5.mlp.qact1"), ("head", "qact2")):
+        s_in = a.act_scale(qa)
+        assert s_in == b.act_scale(qa)
+        la, lb = a.linear(name, s_in), b.linear(name, s_in)
+        assert np.array_equal(la.W8, lb.W8) and np.array_equal(la.b32, lb.b32) and np.array_equal(la.s_acc, lb.s_acc)
+        s_out = np.float32(2.0 ** -3)
+        assert all(np.array_equal(x, y) for x, y in zip(la.requant_to(s_out), lb.requant_to(s_out)))
+    na, nb = a.layernorm("blocks.7.norm2", np.float32(0.03125)), b.layernorm("blocks.7.norm2", np.float32(0.03125))
+    assert np.array_equal(na.bias_int, nb.bias_int) and np.array_equal(na.s_ln, nb.s_ln) and np.array_equal(na.m, nb.m)
+    assert np.array_equal(a.tensor("cls_token"), b.tensor("cls_token"))
