@@ -798,30 +798,41 @@ IVIT_DEV void pers_table_write(const PersTableLoad& r, char* tab, int tid)
     }
 }
 
-template <int EPI>
-__global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_pers_kernel(GemmArgs g)
+// NW = waves per workgroup: 4 (2 x 2, wave tile 64 ch x 128 tok, <= 256 registers) or 8 (2 x 4, wave tile 64 ch x 64 tok,
+// <= 128 registers).  Both keep two workgroups per CU; the 8-wave form puts four waves on every SIMD, so that the
+// long issue stalls of the LDS-DMA instructions and the per-step barrier of one wave are covered by three others
+// (at the price of one third more fragment reads per MFMA).
+template <int EPI, int NW>
+__global__ __launch_bounds__(64 * NW, NW / 2) void gemm_i8_pers_kernel(GemmArgs g)
 {
+    constexpr int NTH = 64 * NW;
+    constexpr int WT = NW / 2;                 // waves along the token dimension
+    constexpr int WTOK = BTOK / WT;            // tokens per wave: 128 or 64
+    constexpr int TJ = WTOK / 32;              // token sub-tiles per wave: 4 or 2
+    constexpr int NA = 16 / NW, NWP = 8 / NW;  // DMA pieces per wave and stage: token tile, weight tile
+    constexpr int PIECES = NA + NWP;           // 6 or 3
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves");
     __shared__ __attribute__((aligned(16))) char smem[PERS_SMEM];
     const int ntiles = g.tiles_m * g.tiles_n;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wc = wave >> 1, wt = wave & 1;
+    const int wc = wave / WT, wt = wave % WT;
     const int h = lane >> 5, l31 = lane & 31;
     const int lrow = lane >> 2, lslot = lane & 3;
     const int nk = g.K / BK;
 
-    const int8_t* asrc[4];
-    const int8_t* wsrc[2];
+    const int8_t* asrc[NA];
+    const int8_t* wsrc[NWP];
     auto set_sources = [&](const PersTile& t) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int row = 16 * (wave + 4 * i) + lrow;
+        for (int i = 0; i < NA; ++i) {
+            int row = 16 * (wave + NW * i) + lrow;
             int c = lslot ^ ((row >> 2) & 3);
             asrc[i] = g.A + (int64_t)min(t.m0 + row, g.M - 1) * g.lda + 16 * c;
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            int row = 16 * (wave + 4 * i) + lrow;
+        for (int i = 0; i < NWP; ++i) {
+            int row = 16 * (wave + NW * i) + lrow;
             int c = lslot ^ ((row >> 2) & 3);
             wsrc[i] = g.W + (int64_t)min(t.n0 + row, g.N - 1) * g.ldw + 16 * c;
         }
@@ -829,77 +840,94 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_pers_kernel(GemmArgs g)
     auto issue_one = [&](int kt, int idx) {
         char* base = smem + (kt % BIG_STAGES) * BIG_STAGE;
         const int koff = kt * BK;
-        if (idx < 4)
-            __builtin_amdgcn_global_load_lds((gptr_t)(asrc[idx] + koff), (lptr_t)(base + 1024 * (wave + 4 * idx)), 16, 0,
+        if (idx < NA)
+            __builtin_amdgcn_global_load_lds((gptr_t)(asrc[idx] + koff), (lptr_t)(base + 1024 * (wave + NW * idx)), 16, 0,
                                              0);
         else
-            __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[idx - 4] + koff),
-                                             (lptr_t)(base + BIG_A_BYTES + 1024 * (wave + 4 * (idx - 4))), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[idx - NA] + koff),
+                                             (lptr_t)(base + BIG_A_BYTES + 1024 * (wave + NW * (idx - NA))), 16, 0, 0);
     };
     auto issue = [&](int kt) {
 #pragma unroll
-        for (int idx = 0; idx < 6; ++idx) issue_one(kt, idx);
+        for (int idx = 0; idx < PIECES; ++idx) issue_one(kt, idx);
+    };
+    // wait for this wave's pieces of the OLDER of two stages in flight / of everything
+    auto wait_older_stage = [&]() {
+        if constexpr (PIECES == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     };
 
-    const int wrow0 = 64 * wc + l31, arow0 = 128 * wt + l31;
-    int woff[2][2], aoff[2][4];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) woff[ks][i] = BIG_A_BYTES + swz(wrow0 + 32 * i, 2 * ks + h);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) aoff[ks][j] = swz(arow0 + 32 * j, 2 * ks + h);
-    }
-    v4i wf0[2], af0[4], wf1[2], af1[4];
+    const int wrow0 = 64 * wc + l31, arow0 = WTOK * wt + l31;
     // Fragment reads are issued as inline asm so that their completion is tracked HERE (explicit counted s_waitcnt tied to
     // the registers they guard) and not by the compiler's waitcnt insertion, which drains lgkmcnt to 0 in front of the
-    // first MFMA after each group and so exposes a full LDS round trip per half step.  Per lane the 4 token sub-tiles are
+    // first MFMA after each group and so exposes a full LDS round trip per half step.  Per lane the token sub-tiles are
     // 2048 B apart and the 2 channel sub-tiles likewise (the swizzle term depends on (row >> 2) & 3 only), so each
     // operand needs one address register per k sub-step and immediate offsets.
     const unsigned smem_base = (unsigned)(__UINTPTR_TYPE__)(lptr_t)smem;
-    const unsigned wbase[2] = {smem_base + (unsigned)woff[0][0], smem_base + (unsigned)woff[1][0]};
-    const unsigned abase[2] = {smem_base + (unsigned)aoff[0][0], smem_base + (unsigned)aoff[1][0]};
-    auto load_frags = [&](unsigned stage_off, int ks, v4i (&wf)[2], v4i (&af)[4]) {
+    const unsigned wbase[2] = {smem_base + (unsigned)(BIG_A_BYTES + swz(wrow0, h)), smem_base + (unsigned)(BIG_A_BYTES + swz(wrow0, 2 + h))};
+    const unsigned abase[2] = {smem_base + (unsigned)swz(arow0, h), smem_base + (unsigned)swz(arow0, 2 + h)};
+    v4i wf0[2], af0[TJ], wf1[2], af1[TJ];
+    auto load_frags = [&](unsigned stage_off, int ks, v4i (&wf)[2], v4i (&af)[TJ]) {
         const unsigned wa = wbase[ks] + stage_off, aa = abase[ks] + stage_off;
         asm volatile("ds_read_b128 %0, %1" : "=v"(wf[0]) : "v"(wa));
         asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(wf[1]) : "v"(wa));
         asm volatile("ds_read_b128 %0, %1" : "=v"(af[0]) : "v"(aa));
         asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(af[1]) : "v"(aa));
-        asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(af[2]) : "v"(aa));
-        asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(af[3]) : "v"(aa));
+        if constexpr (TJ == 4) {
+            asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(af[2]) : "v"(aa));
+            asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(af[3]) : "v"(aa));
+        }
     };
-    // wait until at most N LDS reads of this wave are outstanding; the "+v" ties order every later use of the guarded
-    // fragments after the wait
-#define IVIT_LGKM_WAIT(N, wf, af)                                                                                     \
-    asm volatile("s_waitcnt lgkmcnt(" #N ")"                                                                            \
-                 : "+v"(wf[0]), "+v"(wf[1]), "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3])::"memory")
-    v16i acc[2][4];
+    // wait until at most one group of fragment reads (2 + TJ) / none (together with the DMA wait, below) is
+    // outstanding; the "+v" ties order every later use of the guarded fragments after the wait
+    auto wait_frags = [&](v4i (&wf)[2], v4i (&af)[TJ]) {
+        if constexpr (TJ == 4)
+            asm volatile("s_waitcnt lgkmcnt(6)"
+                         : "+v"(wf[0]), "+v"(wf[1]), "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3])::"memory");
+        else
+            asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(wf[0]), "+v"(wf[1]), "+v"(af[0]), "+v"(af[1])::"memory");
+    };
+    auto wait_dma_and_frags = [&](auto dma_tag, v4i (&wf)[2], v4i (&af)[TJ]) {
+        constexpr bool DMA = decltype(dma_tag)::value;
+        if constexpr (TJ == 4) {
+            if constexpr (DMA)
+                asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)"
+                             : "+v"(wf[0]), "+v"(wf[1]), "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3])::"memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
+                             : "+v"(wf[0]), "+v"(wf[1]), "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3])::"memory");
+        } else {
+            if constexpr (DMA)
+                asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" : "+v"(wf[0]), "+v"(wf[1]), "+v"(af[0]), "+v"(af[1])::"memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(wf[0]), "+v"(wf[1]), "+v"(af[0]), "+v"(af[1])::"memory");
+        }
+    };
+    v16i acc[2][TJ];
     // Pipeline per K step kt (3 LDS stages, fragments double-buffered in registers):
     //   read frags(kt, ks=1)            | wait frags(kt, ks=0) (issued one half step ago; the new reads stay in flight)
     //   MFMA on frags(kt, ks=0) interleaved with the DMA of stage kt+2
     //   wait own DMA of stage kt+1 and all own LDS reads | barrier
     //   read frags(kt+1, ks=0)          | MFMA on frags(kt, ks=1)  (already complete: drained before the barrier)
+    // RAW: stage kt+1 is read only after the barrier of step kt, which every wave reaches after its counted vmcnt.
+    // WAR: the DMA of stage kt+2 overwrites the buffer of stage kt-1; it is issued after the barrier of step kt-1, and
+    //      every wave waited lgkmcnt(0) (all its reads of stage kt-1 returned) before that barrier.
     auto step = [&](int kt, auto dma_tag, auto last_tag) {
         constexpr bool DMA = decltype(dma_tag)::value;
         constexpr bool LAST = decltype(last_tag)::value;
         load_frags((unsigned)((kt % BIG_STAGES) * BIG_STAGE), 1, wf1, af1);
-        IVIT_LGKM_WAIT(6, wf0, af0);
+        wait_frags(wf0, af0);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < TJ; ++j) {
                 acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf0[i], af0[j], acc[i][j], 0, 0, 0);
                 if constexpr (DMA)
-                    if (4 * i + j < 6) issue_one(kt + 2, 4 * i + j);
+                    if (TJ * i + j < PIECES) issue_one(kt + 2, TJ * i + j);
             }
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (DMA)
-            asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)"
-                         : "+v"(wf1[0]), "+v"(wf1[1]), "+v"(af1[0]), "+v"(af1[1]), "+v"(af1[2]), "+v"(af1[3])::"memory");
-        else
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
-                         : "+v"(wf1[0]), "+v"(wf1[1]), "+v"(af1[0]), "+v"(af1[1]), "+v"(af1[2]), "+v"(af1[3])::"memory");
+        wait_dma_and_frags(dma_tag, wf1, af1);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if constexpr (!LAST) load_frags((unsigned)(((kt + 1) % BIG_STAGES) * BIG_STAGE), 0, wf0, af0);
@@ -907,7 +935,7 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_pers_kernel(GemmArgs g)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < TJ; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf1[i], af1[j], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -934,7 +962,7 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_pers_kernel(GemmArgs g)
         char* tab_next = smem + PT_OFF + ((it + 1) & 1) * PT_BYTES;
         // stage 0 of this tile is in flight (or landed); the table was written during the previous epilogue
         if (nk > 1) issue(1);
-        if (nk > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // own pieces of stage 0 (and everything older)
+        if (nk > 1) wait_older_stage();                                   // own pieces of stage 0 (and everything older)
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                                     // everyone's stage 0; table visible
         asm volatile("" ::: "memory");
@@ -944,7 +972,7 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_pers_kernel(GemmArgs g)
             for (int q = 0; q < 4; ++q) {
                 const int4 b4 = *reinterpret_cast<const int4*>(tab + BCH * 8 + 4 * (64 * wc + 32 * i + 8 * q + 4 * h));
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < TJ; ++j) {
                     acc[i][j][4 * q + 0] = b4.x;
                     acc[i][j][4 * q + 1] = b4.y;
                     acc[i][j][4 * q + 2] = b4.z;
@@ -977,8 +1005,8 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_pers_kernel(GemmArgs g)
             IVIT_DEV void consume() const { if (more) pers_table_write(ld, dst, tid); }
         };
         Hook hook{g, nxt.n0, tid, tab_next, more, PersTableLoad{0u, 0, 0, false}};
-        epilogue_i8<EPI, 2, 4, BTOK, BIG_NT, 0, BCH, Hook>(acc, g, smem + BIG_STAGE, tab, cur.m0, cur.n0, 64 * wc, 128 * wt,
-                                                          tid, h, l31, hook);
+        epilogue_i8<EPI, 2, TJ, BTOK, NTH, 0, BCH, Hook>(acc, g, smem + BIG_STAGE, tab, cur.m0, cur.n0, 64 * wc, WTOK * wt,
+                                                        tid, h, l31, hook);
         cur = nxt;
         __syncthreads();   // staging reads done before the next tile's stage 1 DMA overwrites buffer 1
     }
@@ -1047,7 +1075,10 @@ int launch_gemm(GemmArgs& g, const char* name, ivit_stream_t stream)
             g.tiles_n = (g.N + BCH - 1) / BCH;
             const int ntiles = g.tiles_m * g.tiles_n;
             const int grid = ntiles < 512 ? ntiles : 512;
-            hipLaunchKernelGGL((gemm_i8_pers_kernel<EPI>), dim3(grid), dim3(BIG_NT), 0, ivit_stream(stream), g);
+            if (g_debug_flags & 2048)   // A/B: the 8-wave form (4 waves per SIMD)
+                hipLaunchKernelGGL((gemm_i8_pers_kernel<EPI, 8>), dim3(grid), dim3(512), 0, ivit_stream(stream), g);
+            else
+                hipLaunchKernelGGL((gemm_i8_pers_kernel<EPI, 4>), dim3(grid), dim3(BIG_NT), 0, ivit_stream(stream), g);
             IVIT_CHECK_LAUNCH(name);
         }
         if (g.M >= 2048 && g.N >= BCH && !g_force_small) {

@@ -193,7 +193,14 @@ def test_gemm_both_kernels_agree():
                   _lib.ptr(out), N, M, N, K, st())
         outs.append(out.cpu().numpy())
     _lib.call("ivit_debug_force_small_gemm", 0)
-    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    for flags in (1024, 2048):   # relaunch-per-tile form; 8-wave persistent form
+        _lib.call("ivit_debug_set_gemm_flags", flags)
+        out = torch.empty(M, N, dtype=torch.int8, device=DEV)
+        _lib.call("ivit_gemm_i8_requant", _lib.ptr(dA), K, _lib.ptr(dW), K, _lib.ptr(db), _lib.ptr(md), _lib.ptr(ed),
+                  _lib.ptr(out), N, M, N, K, st())
+        outs.append(out.cpu().numpy())
+    _lib.call("ivit_debug_set_gemm_flags", 0)
+    assert all(np.array_equal(outs[0], o) for o in outs[1:])
     assert np.array_equal(outs[0].astype(np.int32), orc.requant(orc.gemm_i8(A, W, b), m.astype(np.float64), e, 8))
 
 
