@@ -131,13 +131,20 @@ __global__ __launch_bounds__(NT, 3) void attention_kernel(AttnArgs a)
         rmax = max(rmax, __shfl_xor(rmax, 32));
 
         // ---- Shiftmax (ivit_modules.py:164-175): e = exp_int(k - max), sum, factor, e*factor >> 24
+        // k - max is in [-255, 0] for every real key: the 256-entry table covers it without a clamp (the entries from
+        // ksat on are identical anyway); only the padding keys of the last tile carry the -1000 sentinel
         unsigned esum = 0;
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                unsigned e = lut[min(rmax - s[kt][r], a.ksat) & 255];
-                if (kt == NKT - 1) e = (s[kt][r] == -1000) ? 0u : e;
+                unsigned e;
+                if (kt == NKT - 1) {
+                    e = lut[min(rmax - s[kt][r], 255)];
+                    e = (s[kt][r] == -1000) ? 0u : e;
+                } else {
+                    e = lut[rmax - s[kt][r]];
+                }
                 s[kt][r] = (int)e;
                 esum += e;
             }
@@ -155,12 +162,14 @@ __global__ __launch_bounds__(NT, 3) void attention_kernel(AttnArgs a)
             for (int t = 0; t < 4; ++t) {
                 unsigned w = 0;
                 if (4 * ks + t < NKT) {
+                    unsigned p[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float pr = (float)(unsigned)s[4 * ks + t][r] * factor;  // float32 product (:175)
-                        unsigned p = ((unsigned)pr) >> 24;                       // floor(. / 2^24)
-                        w |= (p & 0xffu) << (8 * r);
-                    }
+                    for (int r = 0; r < 4; ++r)
+                        p[r] = (unsigned)((float)(unsigned)s[4 * ks + t][r] * factor);  // float32 product (:175), < 2^31
+                    // floor(. / 2^24) = the top byte of each product: gather the four top bytes with two byte permutes
+                    const unsigned lo = __builtin_amdgcn_perm(p[1], p[0], 0x0c0c0703u);  // [p0.b3, p1.b3, 0, 0]
+                    const unsigned hi = __builtin_amdgcn_perm(p[3], p[2], 0x07030c0cu);  // [0, 0, p2.b3, p3.b3]
+                    w = lo | hi;
                 }
                 pk[ks][t] = (int)w;
             }
