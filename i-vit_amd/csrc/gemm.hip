@@ -54,6 +54,7 @@ struct GemmArgs {
     int tiles_m, tiles_n;
     int flags;
     int stagger;  // number of first-generation blocks subject to the start stagger (0 = off)
+    int split_from;  // persistent kernel: tiles [split_from, tiles_m*tiles_n) are processed as two half tiles each
 };
 
 IVIT_DEV int nk_of(const GemmArgs& g) { return g.K / 64; }
@@ -798,172 +799,184 @@ IVIT_DEV void pers_table_write(const PersTableLoad& r, char* tab, int tid)
     }
 }
 
-// NW = waves per workgroup: 4 (2 x 2, wave tile 64 ch x 128 tok, <= 256 registers) or 8 (2 x 4, wave tile 64 ch x 64 tok,
-// <= 128 registers).  Both keep two workgroups per CU; the 8-wave form puts four waves on every SIMD, so that the
-// long issue stalls of the LDS-DMA instructions and the per-step barrier of one wave are covered by three others
-// (at the price of one third more fragment reads per MFMA).
-template <int EPI, int NW>
-__global__ __launch_bounds__(64 * NW, NW / 2) void gemm_i8_pers_kernel(GemmArgs g)
+// Work items of one workgroup.  The launch has G workgroups (2 per CU); tile t < split_from belongs to workgroup
+// t % G.  If the last round of full tiles would be at most half full (R = F mod G tiles, 2R <= G), those R tiles are
+// split into 2R half tiles of 128 tokens, one per workgroup 0 .. 2R-1, so the tail costs half a tile time instead of a
+// whole one (DeiT-B, N = 768: 1182 tiles on 512 workgroups = 2.31 rounds -> 2.5 instead of 3).
+struct PersWork {
+    int m0, n0, half;   // m0 < 0: none
+};
+
+IVIT_DEV PersWork pers_work(const GemmArgs& g, int i, int b, int G)
 {
-    constexpr int NTH = 64 * NW;
-    constexpr int WT = NW / 2;                 // waves along the token dimension
-    constexpr int WTOK = BTOK / WT;            // tokens per wave: 128 or 64
-    constexpr int TJ = WTOK / 32;              // token sub-tiles per wave: 4 or 2
-    constexpr int NA = 16 / NW, NWP = 8 / NW;  // DMA pieces per wave and stage: token tile, weight tile
-    constexpr int PIECES = NA + NWP;           // 6 or 3
-    static_assert(NW == 4 || NW == 8, "4 or 8 waves");
+    const int F = g.tiles_m * g.tiles_n;
+    const int t = b + i * G;
+    if (t < g.split_from) {
+        const PersTile pt = pers_tile(g, t);
+        return PersWork{pt.m0, pt.n0, 0};
+    }
+    // the first index past this workgroup's full tiles: its half tile, if any
+    const int first_past = (g.split_from - b + G - 1) / G;   // number of full tiles of workgroup b (b < G)
+    const int hb = b;
+    if (i == (b < g.split_from ? first_past : 0) && g.split_from + (hb >> 1) < F) {
+        const PersTile pt = pers_tile(g, g.split_from + (hb >> 1));
+        const int m0 = pt.m0 + 128 * (hb & 1);
+        if (m0 < g.M) return PersWork{m0, pt.n0, 1};
+    }
+    return PersWork{-1, 0, 0};
+}
+
+template <int EPI>
+__global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_pers_kernel(GemmArgs g)
+{
     __shared__ __attribute__((aligned(16))) char smem[PERS_SMEM];
-    const int ntiles = g.tiles_m * g.tiles_n;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wc = wave / WT, wt = wave % WT;
+    const int wc = wave >> 1, wt = wave & 1;
     const int h = lane >> 5, l31 = lane & 31;
     const int lrow = lane >> 2, lslot = lane & 3;
     const int nk = g.K / BK;
+    using T = std::true_type;
+    using F = std::false_type;
 
-    const int8_t* asrc[NA];
-    const int8_t* wsrc[NWP];
-    auto set_sources = [&](const PersTile& t) {
+    const int8_t* asrc[4];
+    const int8_t* wsrc[2];
+    auto set_sources = [&](const PersWork& w) {   // a half tile uses asrc[0..1] only (token rows 0..127)
 #pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            int row = 16 * (wave + NW * i) + lrow;
+        for (int i = 0; i < 4; ++i) {
+            int row = 16 * (wave + 4 * i) + lrow;
             int c = lslot ^ ((row >> 2) & 3);
-            asrc[i] = g.A + (int64_t)min(t.m0 + row, g.M - 1) * g.lda + 16 * c;
+            asrc[i] = g.A + (int64_t)min(w.m0 + row, g.M - 1) * g.lda + 16 * c;
         }
 #pragma unroll
-        for (int i = 0; i < NWP; ++i) {
-            int row = 16 * (wave + NW * i) + lrow;
+        for (int i = 0; i < 2; ++i) {
+            int row = 16 * (wave + 4 * i) + lrow;
             int c = lslot ^ ((row >> 2) & 3);
-            wsrc[i] = g.W + (int64_t)min(t.n0 + row, g.N - 1) * g.ldw + 16 * c;
+            wsrc[i] = g.W + (int64_t)min(w.n0 + row, g.N - 1) * g.ldw + 16 * c;
         }
     };
-    auto issue_one = [&](int kt, int idx) {
+    // DMA piece `idx` of K step kt: token pieces first (4, or 2 for a half tile), then the 2 weight pieces
+    auto issue_one = [&](int kt, int idx, auto half_tag) {
+        constexpr int NA = decltype(half_tag)::value ? 2 : 4;
         char* base = smem + (kt % BIG_STAGES) * BIG_STAGE;
         const int koff = kt * BK;
         if (idx < NA)
-            __builtin_amdgcn_global_load_lds((gptr_t)(asrc[idx] + koff), (lptr_t)(base + 1024 * (wave + NW * idx)), 16, 0,
+            __builtin_amdgcn_global_load_lds((gptr_t)(asrc[idx] + koff), (lptr_t)(base + 1024 * (wave + 4 * idx)), 16, 0,
                                              0);
         else
             __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[idx - NA] + koff),
-                                             (lptr_t)(base + BIG_A_BYTES + 1024 * (wave + NW * (idx - NA))), 16, 0, 0);
+                                             (lptr_t)(base + BIG_A_BYTES + 1024 * (wave + 4 * (idx - NA))), 16, 0, 0);
     };
-    auto issue = [&](int kt) {
+    auto issue = [&](int kt, auto half_tag) {
+        constexpr int PIECES = decltype(half_tag)::value ? 4 : 6;
 #pragma unroll
-        for (int idx = 0; idx < PIECES; ++idx) issue_one(kt, idx);
+        for (int idx = 0; idx < PIECES; ++idx) issue_one(kt, idx, half_tag);
     };
-    // wait for this wave's pieces of the OLDER of two stages in flight / of everything
-    auto wait_older_stage = [&]() {
-        if constexpr (PIECES == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    auto issue_rt = [&](int kt, int half) {
+        if (half) issue(kt, T{});
+        else issue(kt, F{});
     };
 
-    const int wrow0 = 64 * wc + l31, arow0 = WTOK * wt + l31;
     // Fragment reads are issued as inline asm so that their completion is tracked HERE (explicit counted s_waitcnt tied to
     // the registers they guard) and not by the compiler's waitcnt insertion, which drains lgkmcnt to 0 in front of the
     // first MFMA after each group and so exposes a full LDS round trip per half step.  Per lane the token sub-tiles are
     // 2048 B apart and the 2 channel sub-tiles likewise (the swizzle term depends on (row >> 2) & 3 only), so each
     // operand needs one address register per k sub-step and immediate offsets.
     const unsigned smem_base = (unsigned)(__UINTPTR_TYPE__)(lptr_t)smem;
-    const unsigned wbase[2] = {smem_base + (unsigned)(BIG_A_BYTES + swz(wrow0, h)), smem_base + (unsigned)(BIG_A_BYTES + swz(wrow0, 2 + h))};
-    const unsigned abase[2] = {smem_base + (unsigned)swz(arow0, h), smem_base + (unsigned)swz(arow0, 2 + h)};
-    v4i wf0[2], af0[TJ], wf1[2], af1[TJ];
-    auto load_frags = [&](unsigned stage_off, int ks, v4i (&wf)[2], v4i (&af)[TJ]) {
-        const unsigned wa = wbase[ks] + stage_off, aa = abase[ks] + stage_off;
-        asm volatile("ds_read_b128 %0, %1" : "=v"(wf[0]) : "v"(wa));
-        asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(wf[1]) : "v"(wa));
-        asm volatile("ds_read_b128 %0, %1" : "=v"(af[0]) : "v"(aa));
-        asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(af[1]) : "v"(aa));
-        if constexpr (TJ == 4) {
-            asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(af[2]) : "v"(aa));
-            asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(af[3]) : "v"(aa));
-        }
-    };
-    // wait until at most one group of fragment reads (2 + TJ) / none (together with the DMA wait, below) is
-    // outstanding; the "+v" ties order every later use of the guarded fragments after the wait
-    auto wait_frags = [&](v4i (&wf)[2], v4i (&af)[TJ]) {
-        if constexpr (TJ == 4)
-            asm volatile("s_waitcnt lgkmcnt(6)"
-                         : "+v"(wf[0]), "+v"(wf[1]), "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3])::"memory");
-        else
-            asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(wf[0]), "+v"(wf[1]), "+v"(af[0]), "+v"(af[1])::"memory");
-    };
-    auto wait_dma_and_frags = [&](auto dma_tag, v4i (&wf)[2], v4i (&af)[TJ]) {
-        constexpr bool DMA = decltype(dma_tag)::value;
-        if constexpr (TJ == 4) {
-            if constexpr (DMA)
-                asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)"
-                             : "+v"(wf[0]), "+v"(wf[1]), "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3])::"memory");
-            else
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
-                             : "+v"(wf[0]), "+v"(wf[1]), "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3])::"memory");
-        } else {
-            if constexpr (DMA)
-                asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" : "+v"(wf[0]), "+v"(wf[1]), "+v"(af[0]), "+v"(af[1])::"memory");
-            else
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(wf[0]), "+v"(wf[1]), "+v"(af[0]), "+v"(af[1])::"memory");
-        }
-    };
-    v16i acc[2][TJ];
-    // Pipeline per K step kt (3 LDS stages, fragments double-buffered in registers):
-    //   read frags(kt, ks=1)            | wait frags(kt, ks=0) (issued one half step ago; the new reads stay in flight)
-    //   MFMA on frags(kt, ks=0) interleaved with the DMA of stage kt+2
-    //   wait own DMA of stage kt+1 and all own LDS reads | barrier
-    //   read frags(kt+1, ks=0)          | MFMA on frags(kt, ks=1)  (already complete: drained before the barrier)
-    // RAW: stage kt+1 is read only after the barrier of step kt, which every wave reaches after its counted vmcnt.
-    // WAR: the DMA of stage kt+2 overwrites the buffer of stage kt-1; it is issued after the barrier of step kt-1, and
-    //      every wave waited lgkmcnt(0) (all its reads of stage kt-1 returned) before that barrier.
-    auto step = [&](int kt, auto dma_tag, auto last_tag) {
-        constexpr bool DMA = decltype(dma_tag)::value;
-        constexpr bool LAST = decltype(last_tag)::value;
-        load_frags((unsigned)((kt % BIG_STAGES) * BIG_STAGE), 1, wf1, af1);
-        wait_frags(wf0, af0);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < TJ; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf0[i], af0[j], acc[i][j], 0, 0, 0);
-                if constexpr (DMA)
-                    if (TJ * i + j < PIECES) issue_one(kt + 2, TJ * i + j);
+    const int wrow0 = 64 * wc + l31;
+    const unsigned wbase[2] = {smem_base + (unsigned)(BIG_A_BYTES + swz(wrow0, h)),
+                               smem_base + (unsigned)(BIG_A_BYTES + swz(wrow0, 2 + h))};
+
+    // One work item: a full tile (256 tokens, wave tile 64 ch x 128 tok) or a half tile (128 tokens, 64 ch x 64 tok).
+    auto run = [&](auto half_tag, const PersWork& cur, const PersWork& nxt, char* tab, char* tab_next) {
+        constexpr bool HALF = decltype(half_tag)::value;
+        constexpr int TJ = HALF ? 2 : 4;
+        constexpr int WTOK = 32 * TJ;
+        constexpr int PIECES = HALF ? 4 : 6;
+        const int arow0 = WTOK * wt + l31;
+        const unsigned abase[2] = {smem_base + (unsigned)swz(arow0, h), smem_base + (unsigned)swz(arow0, 2 + h)};
+        v4i wf0[2], af0[TJ], wf1[2], af1[TJ];
+        auto load_frags = [&](unsigned stage_off, int ks, v4i (&wf)[2], v4i (&af)[TJ]) {
+            const unsigned wa = wbase[ks] + stage_off, aa = abase[ks] + stage_off;
+            asm volatile("ds_read_b128 %0, %1" : "=v"(wf[0]) : "v"(wa));
+            asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(wf[1]) : "v"(wa));
+            asm volatile("ds_read_b128 %0, %1" : "=v"(af[0]) : "v"(aa));
+            asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(af[1]) : "v"(aa));
+            if constexpr (TJ == 4) {
+                asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(af[2]) : "v"(aa));
+                asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(af[3]) : "v"(aa));
             }
-        __builtin_amdgcn_sched_barrier(0);
-        wait_dma_and_frags(dma_tag, wf1, af1);
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if constexpr (!LAST) load_frags((unsigned)(((kt + 1) % BIG_STAGES) * BIG_STAGE), 0, wf0, af0);
-        __builtin_amdgcn_sched_barrier(0);
+        };
+        // wait until at most one group of fragment reads (2 + TJ) / none (together with the DMA wait) is outstanding; the
+        // "+v" ties order every later use of the guarded fragments after the wait
+        auto wait_frags = [&](v4i (&wf)[2], v4i (&af)[TJ]) {
+            if constexpr (TJ == 4)
+                asm volatile("s_waitcnt lgkmcnt(6)"
+                             : "+v"(wf[0]), "+v"(wf[1]), "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3])::"memory");
+            else
+                asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(wf[0]), "+v"(wf[1]), "+v"(af[0]), "+v"(af[1])::"memory");
+        };
+        auto wait_dma_and_frags = [&](auto dma_tag, v4i (&wf)[2], v4i (&af)[TJ]) {
+            constexpr bool DMA = decltype(dma_tag)::value;
+            if constexpr (TJ == 4) {
+                if constexpr (DMA)
+                    asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)"
+                                 : "+v"(wf[0]), "+v"(wf[1]), "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3])::"memory");
+                else
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
+                                 : "+v"(wf[0]), "+v"(wf[1]), "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3])::"memory");
+            } else {
+                if constexpr (DMA)
+                    asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" : "+v"(wf[0]), "+v"(wf[1]), "+v"(af[0]), "+v"(af[1])::"memory");
+                else
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(wf[0]), "+v"(wf[1]), "+v"(af[0]), "+v"(af[1])::"memory");
+            }
+        };
+        v16i acc[2][TJ];
+        // Pipeline per K step kt (3 LDS stages, fragments double-buffered in registers):
+        //   read frags(kt, ks=1)            | wait frags(kt, ks=0) (issued one half step ago; the new reads stay in flight)
+        //   MFMA on frags(kt, ks=0) interleaved with the DMA of stage kt+2
+        //   wait own DMA of stage kt+1 and all own LDS reads | barrier
+        //   read frags(kt+1, ks=0)          | MFMA on frags(kt, ks=1)  (already complete: drained before the barrier)
+        // RAW: stage kt+1 is read only after the barrier of step kt, which every wave reaches after its counted vmcnt.
+        // WAR: the DMA of stage kt+2 overwrites the buffer of stage kt-1; it is issued after the barrier of step kt-1, and
+        //      every wave waited lgkmcnt(0) (all its reads of stage kt-1 returned) before that barrier.
+        auto step = [&](int kt, auto dma_tag, auto last_tag) {
+            constexpr bool DMA = decltype(dma_tag)::value;
+            constexpr bool LAST = decltype(last_tag)::value;
+            load_frags((unsigned)((kt % BIG_STAGES) * BIG_STAGE), 1, wf1, af1);
+            wait_frags(wf0, af0);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < TJ; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf1[i], af1[j], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    using T = std::true_type;
-    using F = std::false_type;
+                for (int j = 0; j < TJ; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf0[i], af0[j], acc[i][j], 0, 0, 0);
+                    if constexpr (DMA)
+                        if (TJ * i + j < PIECES) issue_one(kt + 2, TJ * i + j, half_tag);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+            wait_dma_and_frags(dma_tag, wf1, af1);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if constexpr (!LAST) load_frags((unsigned)(((kt + 1) % BIG_STAGES) * BIG_STAGE), 0, wf0, af0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf1[i], af1[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        };
 
-    // ---- first tile: table + stage 0
-    int tile = blockIdx.x;
-    PersTile cur = pers_tile(g, tile);
-    {
-        PersTableLoad tl = pers_table_issue(g, cur.n0, tid);
-        pers_table_write(tl, smem + PT_OFF, tid);
-    }
-    set_sources(cur);
-    if (g.stagger && blockIdx.x < (unsigned)g.stagger) {   // see gemm_i8_big_kernel: de-phase the two co-resident groups
-        const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1u;
-        if (slot)
-            for (int it = 0; it < (nk + 1) / 2; ++it) __builtin_amdgcn_s_sleep(64);
-    }
-    issue(0);
-
-    for (int it = 0; tile < ntiles; ++it, tile += gridDim.x) {
-        char* tab = smem + PT_OFF + (it & 1) * PT_BYTES;
-        char* tab_next = smem + PT_OFF + ((it + 1) & 1) * PT_BYTES;
-        // stage 0 of this tile is in flight (or landed); the table was written during the previous epilogue
-        if (nk > 1) issue(1);
-        if (nk > 1) wait_older_stage();                                   // own pieces of stage 0 (and everything older)
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // stage 0 of this item is in flight (or landed); the table was written during the previous epilogue
+        if (nk > 1) {
+            issue(1, half_tag);
+            if constexpr (HALF) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // own pieces of stage 0 (and everything older)
+            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();                                     // everyone's stage 0; table visible
         asm volatile("" ::: "memory");
 #pragma unroll
@@ -986,14 +999,11 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_i8_pers_kernel(GemmArgs 
         step(kt, F{}, T{});
         __syncthreads();   // all waves are done with every stage: buffers free
 
-        // ---- prefetch stage 0 of the next tile, then this tile's epilogue (staging in buffers 1-2)
-        const int next = tile + gridDim.x;
-        const bool more = next < ntiles;   // uniform
-        PersTile nxt = cur;
+        // ---- prefetch stage 0 of the next item, then this item's epilogue (staging in buffers 1-2)
+        const bool more = nxt.m0 >= 0;   // uniform
         if (more) {
-            nxt = pers_tile(g, next);
             set_sources(nxt);
-            issue(0);
+            issue_rt(0, nxt.half);
         }
         struct Hook {
             const GemmArgs& g;
@@ -1005,10 +1015,34 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_i8_pers_kernel(GemmArgs 
             IVIT_DEV void consume() const { if (more) pers_table_write(ld, dst, tid); }
         };
         Hook hook{g, nxt.n0, tid, tab_next, more, PersTableLoad{0u, 0, 0, false}};
-        epilogue_i8<EPI, 2, TJ, BTOK, NTH, 0, BCH, Hook>(acc, g, smem + BIG_STAGE, tab, cur.m0, cur.n0, 64 * wc, WTOK * wt,
-                                                        tid, h, l31, hook);
+        epilogue_i8<EPI, 2, TJ, (HALF ? 128 : BTOK), BIG_NT, 0, BCH, Hook>(acc, g, smem + BIG_STAGE, tab, cur.m0, cur.n0,
+                                                                           64 * wc, WTOK * wt, tid, h, l31, hook);
+        __syncthreads();   // staging reads done before the next item's stage 1 DMA overwrites buffer 1
+    };
+
+    // ---- first item: table + stage 0
+    const int G = gridDim.x, b = blockIdx.x;
+    PersWork cur = pers_work(g, 0, b, G);
+    if (cur.m0 < 0) return;   // uniform
+    {
+        PersTableLoad tl = pers_table_issue(g, cur.n0, tid);
+        pers_table_write(tl, smem + PT_OFF, tid);
+    }
+    set_sources(cur);
+    if (g.stagger && blockIdx.x < (unsigned)g.stagger) {   // see gemm_i8_big_kernel: de-phase the two co-resident groups
+        const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1u;
+        if (slot)
+            for (int it = 0; it < (nk + 1) / 2; ++it) __builtin_amdgcn_s_sleep(64);
+    }
+    issue_rt(0, cur.half);
+
+    for (int it = 0; cur.m0 >= 0; ++it) {
+        char* tab = smem + PT_OFF + (it & 1) * PT_BYTES;
+        char* tab_next = smem + PT_OFF + ((it + 1) & 1) * PT_BYTES;
+        const PersWork nxt = pers_work(g, it + 1, b, G);
+        if (cur.half) run(T{}, cur, nxt, tab, tab_next);
+        else run(F{}, cur, nxt, tab, tab_next);
         cur = nxt;
-        __syncthreads();   // staging reads done before the next tile's stage 1 DMA overwrites buffer 1
     }
 }
 
@@ -1074,11 +1108,18 @@ int launch_gemm(GemmArgs& g, const char* name, ivit_stream_t stream)
             g.tiles_m = (g.M + BTOK - 1) / BTOK;
             g.tiles_n = (g.N + BCH - 1) / BCH;
             const int ntiles = g.tiles_m * g.tiles_n;
-            const int grid = ntiles < 512 ? ntiles : 512;
-            if (g_debug_flags & 2048)   // A/B: the 8-wave form (4 waves per SIMD)
-                hipLaunchKernelGGL((gemm_i8_pers_kernel<EPI, 8>), dim3(grid), dim3(512), 0, ivit_stream(stream), g);
-            else
-                hipLaunchKernelGGL((gemm_i8_pers_kernel<EPI, 4>), dim3(grid), dim3(BIG_NT), 0, ivit_stream(stream), g);
+            // 2 resident workgroups x 256 CUs; debug bit 12: one workgroup per CU (extra dynamic LDS blocks the second)
+            const bool one_per_cu = (g_debug_flags & 4096) != 0;
+            const int SLOTS = one_per_cu ? 256 : 512;
+            // tail split (see PersWork): R tiles of a last round that is at most half full become 2R half tiles.
+            // Measured slower (proj 47.7 -> 50.0 us, fc2 162 -> 173 us): a CU left with one workgroup runs it nearly
+            // twice as fast, so the sparse last round is not the cost the tile count suggests.  Opt-in (debug bit 11).
+            const int rounds = ntiles / SLOTS, R = ntiles - rounds * SLOTS;
+            const bool split = R > 0 && 2 * R <= SLOTS && (g_debug_flags & 2048);
+            g.split_from = split ? rounds * SLOTS : ntiles;
+            const int grid = rounds > 0 ? SLOTS : (split ? 2 * R : R);
+            hipLaunchKernelGGL((gemm_i8_pers_kernel<EPI>), dim3(grid), dim3(BIG_NT), one_per_cu ? 20480 : 0,
+                               ivit_stream(stream), g);
             IVIT_CHECK_LAUNCH(name);
         }
         if (g.M >= 2048 && g.N >= BCH && !g_force_small) {

@@ -102,57 +102,49 @@ __global__ __launch_bounds__(NT) void layernorm_i8_kernel(LnArgs a)
     // (G rows in parallel across lanes) and the results come back as wave-uniform values through v_readlane.
     constexpr int G = (NJ <= 4) ? 4 : 1;
     for (int row0 = (blockIdx.x * WPB + wave) * G; row0 < a.rows; row0 += gridDim.x * WPB * G) {
-        int w[G][NJ], sum[G], var[G];
+        int w[G][NJ], sum[G], var[G];   // var[]: sum of squares
 #pragma unroll
         for (int rr = 0; rr < G; ++rr) {
             const int row = min(row0 + rr, a.rows - 1);
             const int* xr = reinterpret_cast<const int*>(xin + (int64_t)row * a.ldx);
             sum[rr] = 0;
+            var[rr] = 0;
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 int d = lane + 64 * j;
                 w[rr][j] = (d < nd) ? xr[d] : 0;
-                sum[rr] += sx8(w[rr][j], 0) + sx8(w[rr][j], 1) + sx8(w[rr][j], 2) + sx8(w[rr][j], 3);
+                // v_dot4_i32_i8: sum and sum of squares of the 4 int8 of a dword, one instruction each
+                sum[rr] = __builtin_amdgcn_sdot4(w[rr][j], 0x01010101, sum[rr], false);
+                var[rr] = __builtin_amdgcn_sdot4(w[rr][j], w[rr][j], var[rr], false);   // <= 4096 * 128^2 = 2^26
             }
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1)
 #pragma unroll
-            for (int rr = 0; rr < G; ++rr) sum[rr] += __shfl_xor(sum[rr], o);
-        // lane rr: mean of row rr (:37), computed once
-        int my_sum = sum[0];
+            for (int rr = 0; rr < G; ++rr) {
+                sum[rr] += __shfl_xor(sum[rr], o);
+                var[rr] += __shfl_xor(var[rr], o);
+            }
+        // lane rr: statistics of row rr, computed once.  mean_int as the reference (:37); the variance sum (:40-42)
+        // sum_c (x_c - mean)^2 = sum x^2 - 2*mean*sum x + C*mean^2 exactly, in integers (all terms < 2^31)
+        int my_sum = sum[0], my_sq = var[0];
 #pragma unroll
-        for (int rr = 1; rr < G; ++rr) my_sum = (lane == rr) ? sum[rr] : my_sum;
+        for (int rr = 1; rr < G; ++rr) {
+            my_sum = (lane == rr) ? sum[rr] : my_sum;
+            my_sq = (lane == rr) ? var[rr] : my_sq;
+        }
         int my_mean;
         ln_mean(my_sum, C, my_mean);
+        const int my_var = my_sq - 2 * my_mean * my_sum + C * my_mean * my_mean;
         int mean_int[G];
 #pragma unroll
-        for (int rr = 0; rr < G; ++rr) {
-            mean_int[rr] = __builtin_amdgcn_readlane(my_mean, rr);
-            var[rr] = 0;  // <= 4096 * 255^2 < 2^31
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                if (lane + 64 * j < nd) {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        int dlt = sx8(w[rr][j], c) - mean_int[rr];
-                        var[rr] += dlt * dlt;
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-            for (int rr = 0; rr < G; ++rr) var[rr] += __shfl_xor(var[rr], o);
-        int my_var = var[0];
-#pragma unroll
-        for (int rr = 1; rr < G; ++rr) my_var = (lane == rr) ? var[rr] : my_var;
+        for (int rr = 0; rr < G; ++rr) mean_int[rr] = __builtin_amdgcn_readlane(my_mean, rr);
         const float my_factor = ln_factor((long long)my_var);   // :45-51, lane rr <-> row rr
 #pragma unroll
         for (int rr = 0; rr < G; ++rr) {
             if (row0 + rr >= a.rows) continue;
-            const float factor = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_factor), rr));
+            // :52 floor((y * factor) / 2): halving commutes with the float32 product (exact scaling), so fold it into the factor
+            const float hfactor = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_factor), rr)) * 0.5f;
             int* orow = reinterpret_cast<int*>(out + (int64_t)(row0 + rr) * a.ldo);
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
@@ -162,7 +154,7 @@ __global__ __launch_bounds__(NT) void layernorm_i8_kernel(LnArgs a)
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         float dl = (float)(sx8(w[rr][j], c) - mean_int[rr]);
-                        float v = floorf((dl * factor) * 0.5f);          // :52  float32 product, /2, floor
+                        float v = floorf(dl * hfactor);                    // :52  float32 product, /2, floor
                         float y = v + bias[j][c];                          // :61  float32 add
                         float x = y * sln[j][c];                           // :63  float32 product
                         // quant_utils.py:220  z = round(x / s): the correctly rounded float32 quotient,
