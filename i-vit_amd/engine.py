@@ -21,6 +21,7 @@ import numpy as np
 import torch
 
 from . import _lib
+from .graph import GraphReplay
 from .prepare import dyadic, f32, quant_sym, requant_host
 from .synth import IMG_SIZE, NUM_CLASSES, NUM_PATCHES, NUM_TOKENS, PATCH
 
@@ -31,7 +32,7 @@ def _np(v):
     return np.asarray(v)
 
 
-class IntViTEngine:
+class IntViTEngine(GraphReplay):
     def __init__(self, float_state=None, ranges=None, embed_dim: int = 768, depth: int = 12, num_heads: int = 12,
                  device="cuda:0", max_batch: int = 256, source=None):
         """float_state: name -> float32 array (the reference's state_dict names, SURVEY Appendix D);

@@ -21,6 +21,7 @@ import numpy as np
 import torch
 
 from . import _lib
+from .graph import GraphReplay
 from .prepare import LayerNormParams, LinearParams, dyadic, f32, quant_sym, requant_host, sym_scale
 from .synth import IMG_SIZE, NUM_CLASSES
 
@@ -66,7 +67,7 @@ def window_row_map(B: int, H: int, W: int, ws: int, shift: int) -> np.ndarray:
     return (np.arange(B)[:, None] * (H * W) + idx.reshape(-1)[None, :]).reshape(-1)
 
 
-class IntSwinEngine:
+class IntSwinEngine(GraphReplay):
     def __init__(self, float_state, ranges, embed_dim=96, depths=(2, 2, 6, 2), num_heads=(3, 6, 12, 24), window=7,
                  device="cuda:0", max_batch: int = 64):
         self.C0, self.depths, self.heads, self.window = embed_dim, tuple(depths), tuple(num_heads), window

@@ -20,7 +20,7 @@ CONFIGS = {1: ("deit_tiny", 1), 2: ("deit_small", 64), 3: ("deit_base", 256), 4:
 GMAC = {"deit_tiny": 1.2537, "deit_small": 4.5989, "deit_base": 17.5638, "vit_base": 17.5638, "swin_tiny": 4.4906}
 
 
-def run(cid, steps=20, warmup=5):
+def run(cid, steps=20, warmup=5, graph=False):
     tag, B = CONFIGS[cid]
     fs, ranges, cfg, meta, z = load_synthetic_model(tag)
     if tag.startswith("swin"):
@@ -30,21 +30,25 @@ def run(cid, steps=20, warmup=5):
         eng = IntViTEngine(fs, ranges, cfg["embed_dim"], cfg["depth"], cfg["num_heads"], device=DEV, max_batch=B)
     imgs = torch.from_numpy(synth.make_images(min(B, 16), 1000 + cid)).to(DEV)
     imgs = imgs.repeat((B + imgs.shape[0] - 1) // imgs.shape[0], 1, 1, 1)[:B].contiguous()
+    fwd = eng.forward_graph if graph else eng.forward
     for _ in range(warmup):
-        eng.forward(imgs)
+        fwd(imgs)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(steps):
-        eng.forward(imgs)
+        fwd(imgs)
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / steps
     ips = B / ms * 1e3
-    print(json.dumps({"config": cid, "model": tag, "batch": B, "ms_per_forward": round(ms, 3), "images_per_s": round(ips, 1),
+    print(json.dumps({"config": cid, "model": tag, "batch": B, "hip_graph": graph, "ms_per_forward": round(ms, 3), "images_per_s": round(ips, 1),
                       "int8_tops": round(ips * GMAC[tag] * 2e9 / 1e12, 1)}), flush=True)
 
 
 if __name__ == "__main__":
-    for c in ([int(a) for a in sys.argv[1:]] or sorted(CONFIGS)):
+    args = [a for a in sys.argv[1:] if a != "--graph"]
+    for c in ([int(a) for a in args] or sorted(CONFIGS)):
         run(c)
+        if "--graph" in sys.argv:
+            run(c, graph=True)

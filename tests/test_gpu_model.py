@@ -137,3 +137,20 @@ def test_engine_from_integer_export(tmp_path):
     assert sorted(out) == sorted(params)
     for k in params:
         assert out[k].dtype == params[k].dtype and np.array_equal(out[k], params[k]), k
+
+
+def test_graph_replay_matches_eager():
+    """HIP-graph replay of the forward (launch-bound shapes) returns the same logits as the eager launches, also after
+    the inputs change and for a second batch size"""
+    eng, fs, ranges, cfg, meta, z = build("deit_tiny", 8)
+    imgs = torch.from_numpy(synth.make_images(8, meta["image_seed"])).to(DEV)
+    li, _, _ = eng.forward(imgs)
+    want = li.cpu().numpy().copy()
+    assert np.array_equal(want, z["logits_int32"])
+    g1, _, _ = eng.forward_graph(imgs)
+    assert np.array_equal(g1.cpu().numpy(), want)
+    perm = torch.arange(7, -1, -1, device=DEV)
+    g2, _, t2 = eng.forward_graph(imgs[perm].contiguous())
+    assert np.array_equal(g2.cpu().numpy(), want[::-1])
+    g3, _, _ = eng.forward_graph(imgs[:1].contiguous())
+    assert np.array_equal(g3.cpu().numpy(), want[:1])

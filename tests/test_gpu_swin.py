@@ -309,3 +309,12 @@ def test_swin_batch_invariance_and_oracle_on_fresh_images():
     assert np.array_equal(li2.cpu().numpy(), li[perm])
     li3, _, _ = eng.forward(imgs[5:6].contiguous())
     assert np.array_equal(li3.cpu().numpy(), li[5:6])
+
+
+def test_swin_graph_replay_matches_eager():
+    eng, fs, ranges, cfg, meta, z = build_swin(4)
+    imgs = torch.from_numpy(synth.make_images(meta["n_images"], meta["image_seed"])).to(DEV)
+    g1, _, _ = eng.forward_graph(imgs)
+    assert np.array_equal(g1.cpu().numpy(), z["logits_int32"])
+    g2, _, _ = eng.forward_graph(torch.flip(imgs, dims=[0]).contiguous())
+    assert np.array_equal(g2.cpu().numpy(), z["logits_int32"][::-1])
