@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include "../../include/ivit_hip.h"
+#include "../../include/ivit_hip_debug.h"
 
 #define IVIT_EXPORT extern "C" __attribute__((visibility("default")))
 

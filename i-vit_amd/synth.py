@@ -122,6 +122,10 @@ def qact_names(depth: int = 12):
 # (/root/reference/models/swin_quant.py:567-585): patch 4, window 7, embed 96, depths (2,2,6,2), heads (3,6,12,24)
 SWIN_CONFIGS = {
     "swin_tiny_patch4_window7_224": dict(embed_dim=96, depths=(2, 2, 6, 2), num_heads=(3, 6, 12, 24), window=7),
+    "swin_small_patch4_window7_224": dict(embed_dim=96, depths=(2, 2, 18, 2), num_heads=(3, 6, 12, 24), window=7),
+    "swin_base_patch4_window7_224": dict(embed_dim=128, depths=(2, 2, 18, 2), num_heads=(4, 8, 16, 32), window=7),
+    # Swin-B widths with two blocks per stage: a test-sized stand-in that exercises C = 128 * 2^k and heads 4..32
+    "swin_base_shallow": dict(embed_dim=128, depths=(2, 2, 2, 2), num_heads=(4, 8, 16, 32), window=7),
 }
 REL_POS_STD = 0.5   # reference init is 0.02 (swin_quant.py:112); widened so the bias path is exercised
 

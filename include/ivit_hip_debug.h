@@ -1,0 +1,27 @@
+/*
+ * ivit_hip_debug.h -- test and measurement hooks of libivit_hip.so.  NOT part of the drop-in boundary
+ * (include/ivit_hip.h): process-wide, not thread-safe, for tests/ and scripts/ only.
+ */
+#ifndef IVIT_HIP_DEBUG_H
+#define IVIT_HIP_DEBUG_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Test hook: ivit_gemm_i8_* pick between two kernels by problem size (a 256x128-tile LDS-DMA kernel
+ * for M >= 2048, N >= 128; a 128x128-tile kernel otherwise).  on != 0 forces the small-tile kernel so
+ * tests can cover both on the same inputs.  Process-wide, not thread-safe; not for production use. */
+int ivit_debug_force_small_gemm(int on);
+/* Perf-ablation hook for scripts/gemm_ablate.py (bit 0: skip the in-loop DMA, bit 1: skip the MFMAs,
+ * bit 2: skip the epilogue, ...); results are WRONG whenever flags & 1023 != 0.  Bits that keep results correct
+ * (A/B timing): 32 the 256x256-tile kernel, 64 no start stagger, 1024 the relaunch-per-tile form instead of the
+ * persistent one, 2048 split a sparse last round of tiles into half tiles, 4096 one workgroup per CU. */
+int ivit_debug_set_gemm_flags(int flags);
+/* Diagnostic timeline buffer (8 x uint64 per workgroup) for the stamped build (flags = 512); scripts/gemm_timeline.py */
+int ivit_debug_set_stamp_buffer(void* buf);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IVIT_HIP_DEBUG_H */

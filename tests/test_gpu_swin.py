@@ -318,3 +318,44 @@ def test_swin_graph_replay_matches_eager():
     assert np.array_equal(g1.cpu().numpy(), z["logits_int32"])
     g2, _, _ = eng.forward_graph(torch.flip(imgs, dims=[0]).contiguous())
     assert np.array_equal(g2.cpu().numpy(), z["logits_int32"][::-1])
+
+
+def test_swin_base_widths_calibrated_on_gpu_match_oracle():
+    """Swin-B channel widths (C = 128..1024, heads 4..32, two blocks per stage): ranges come from a calibration forward
+    of the module mirror on the GPU (running-stat QuantActs, HIP min/max), snapped to powers of two; then the fused
+    engine, the module-by-module path and the CPU oracle agree on the INT32 logits."""
+    import ivit_amd as ivit
+    import ivit_amd.quantization_utils as q
+    from ivit_amd.swin_quant import SwinTransformer
+    from functools import partial
+    cfg = synth.SWIN_CONFIGS["swin_base_shallow"]
+    fs = synth.make_swin_float_state("swin_base_shallow", 33)
+    model = SwinTransformer(embed_dim=cfg["embed_dim"], depths=cfg["depths"], num_heads=cfg["num_heads"],
+                            window_size=cfg["window"], norm_layer=partial(q.IntLayerNorm, eps=1e-6))
+    missing, unexpected = model.load_state_dict({k: torch.from_numpy(v) for k, v in fs.items()}, strict=False)
+    assert not unexpected
+    model.to(DEV).eval()
+    with torch.no_grad():
+        model(torch.from_numpy(synth.make_images(2, 909)).to(DEV))           # calibration forward
+    ranges = {}
+    for name, mod in model.named_modules():
+        if isinstance(mod, q.QuantAct) and name != "act_out":
+            mx = max(-float(mod.x_min), float(mod.x_max))
+            qmax = 2 ** (mod.activation_bit - 1) - 1
+            p = int(np.ceil(np.log2(mx / qmax)))
+            mod.x_max.fill_(qmax * 2.0 ** p)
+            mod.x_min.fill_(-qmax * 2.0 ** p)
+            ranges[name] = (np.float32(-qmax * 2.0 ** p), np.float32(qmax * 2.0 ** p))
+    assert list(ranges) == synth.swin_qact_names(cfg["depths"])
+    ivit.freeze_model(model)
+    imgs_np = synth.make_images(2, 910)
+    imgs = torch.from_numpy(imgs_np).to(DEV)
+    with torch.no_grad():
+        y_engine = model(imgs)                       # fused engine (head_dim 32 everywhere)
+        model.use_engine = False
+        y_modules = model(imgs)
+    assert np.array_equal(y_engine.cpu().numpy().view(np.int32), y_modules.cpu().numpy().view(np.int32))
+    om = orc.OracleSwin(fs, ranges, cfg["embed_dim"], cfg["depths"], cfg["num_heads"], cfg["window"])
+    ref = om.forward(imgs_np)
+    assert np.array_equal(y_engine.cpu().numpy().view(np.int32), ref["logits_f32"].view(np.int32))
+    assert om.max_acc < 2 ** 24

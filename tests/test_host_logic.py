@@ -89,9 +89,9 @@ def test_images_are_order_independent():
 
 
 def test_c_abi_library_exports_every_declared_symbol():
-    """include/ivit_hip.h <-> libivit_hip.so <-> the ctypes table agree (loads the library, calls nothing
+    """include/*.h <-> libivit_hip.so <-> the ctypes table agree (loads the library, calls nothing
     that needs a GPU)."""
-    hdr = open(os.path.join(ROOT, "include", "ivit_hip.h")).read()
+    hdr = "".join(open(os.path.join(ROOT, "include", f)).read() for f in sorted(os.listdir(os.path.join(ROOT, "include"))))
     declared = set(re.findall(r"\b(?:int|const char\*)\s+(ivit_[a-z0-9_]+)\s*\(", hdr))
     assert declared == set(_lib.SIGNATURES) | {"ivit_version", "ivit_last_error_string"}
     L = _lib.lib()
