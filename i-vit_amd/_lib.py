@@ -55,6 +55,10 @@ SIGNATURES = {
     "ivit_layernorm_i16_i8": [vp, ci, ci, vp, vp, vp, vp, vp, i64, ci, ci, ci, ci, vp],
     "ivit_patch_merge_i16": [vp, vp, ci, ci, ci, ci, vp],
     "ivit_avgpool_requant_i8": [vp, vp, ci, ci, ci, u32, i32, vp],
+    # I-BERT operator family (include/ivit_hip.h, last section)
+    "ivit_ibert_gelu_i32": [vp, i64, f32, f32, f32, vp, vp],
+    "ivit_ibert_softmax_i32": [vp, i64, ci, ci, f32, f32, f32, f32, f32, u32, i32, ci, vp, i64, vp, vp],
+    "ivit_ibert_layernorm_i32_f32": [vp, i64, ci, ci, vp, vp, f32, vp, i64, vp],
     "ivit_window_attention_i8": [vp, vp, i64, vp, vp, ci, ci, ci, ci, ci, ci, u32, i32, u32, i32, f32, u32, i32, vp],
 }
 

@@ -1,0 +1,213 @@
+// ibert.hip -- the I-BERT operator family of the reference (IBERTIntGELU, IBERTIntSoftmax, IBERTIntLayerNorm,
+// /root/reference/models/quantization_utils/ibert_modules.py), module-level kernels.
+//
+// The reference evaluates these operators in float32 tensors holding (mostly) integers.  Each kernel performs the same
+// IEEE float32 operations on the same operands in the same order (build flags -ffp-contract=off -fno-fast-math;
+// division and square root are the correctly rounded forms), so results are bit-identical to the reference wherever
+// the reference itself is deterministic: the three row sums are taken exactly (integers / float64) and rounded once,
+// which equals the reference's float32 reduction whenever that reduction is exact (sum < 2^24; oracle/ibert.py counts
+// the rows where it is not).  Scalar constants (b_int, c_int, x0_int, scales) are computed by the caller in float32
+// exactly as the reference computes them on the host side of every call.
+#include <limits.h>
+
+#include "common.h"
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int WPB = NT / 64;
+
+static inline int ew_grid(int64_t n)
+{
+    int64_t b = (n + NT - 1) / NT;
+    return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+
+static inline int grid_for_rows(int64_t rows)
+{
+    int64_t blocks = (rows + WPB - 1) / WPB;
+    return (int)(blocks < 4096 ? blocks : 4096);
+}
+
+// ------------------------------------------------------------------------------------------------ GELU
+// ibert_modules.py:203-235 with x_int = k (integer activations):
+//   sign * ((min(|x|, -b) + b)^2 + c) -> floor(. / 2^6) = sigmoid_int;  out = x * (sigmoid_int + shift_int)
+__global__ __launch_bounds__(NT) void ibert_gelu_kernel(const int32_t* k, int64_t n, float b_int, float c_int,
+                                                        float shift_int, int32_t* out)
+{
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+        const float x = (float)k[i];
+        const float sgn = (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f);   // :209
+        const float a = fminf(fabsf(x), -b_int);                             // :210-211
+        const float t = a + b_int;
+        float y = t * t;                                                     // :212 (. ** 2)
+        y = y + c_int;
+        y = sgn * y;                                                         // :213
+        y = floorf(y / 64.0f);                                               // :215  2 ** self.n, n = 6
+        out[i] = (int)(x * (y + shift_int));                                 // :231
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ Softmax
+struct IbSoftmaxArgs {
+    const int32_t* k;
+    int64_t ldx;
+    int rows, L;
+    float x0_int, b_int, c_int, exp_sf, act_sf;
+    double M;          // dyadic multiplier of the internal QuantAct(16): m * 2^-e
+    float out_div;     // 2^(32 - output_bit + 1)
+    int32_t* out;
+    int64_t ldo;
+    float* exp_out;    // optional [rows, L]: exp_int before the internal QuantAct (calibration statistics)
+};
+
+IVIT_DEV float ib_exp_int(float x, const IbSoftmaxArgs& a)
+{
+    // int_exp, :285-295 (n = 30)
+    x = fmaxf(x, 30.0f * a.x0_int);                       // :288
+    const float q = floorf(x / a.x0_int);                 // :290
+    const float r = x - a.x0_int * q;                     // :291
+    float z = r + a.b_int;                                // :279
+    z = r * z;                                            // :280
+    z = z + a.c_int;                                      // :281
+    float e = floorf(z * ldexpf(1.0f, 30 - (int)q));      // :293  2 ** (n - q): exact power of two
+    return fmaxf(e, 0.0f);
+}
+
+__global__ __launch_bounds__(NT) void ibert_softmax_kernel(IbSoftmaxArgs a)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int row = blockIdx.x * WPB + wave; row < a.rows; row += gridDim.x * WPB) {
+        const int32_t* kr = a.k + (int64_t)row * a.ldx;
+        int kmax = INT_MIN;
+        for (int i = lane; i < a.L; i += 64) kmax = max(kmax, kr[i]);
+        kmax = wave_reduce_max_i32(kmax);
+        if (a.exp_out) {   // calibration pass: only exp_int is wanted
+            for (int i = lane; i < a.L; i += 64)
+                a.exp_out[(int64_t)row * a.L + i] = ib_exp_int((float)(kr[i] - kmax), a);
+            continue;
+        }
+        double sum = 0.0;
+        for (int i = lane; i < a.L; i += 64) {
+            const float e = ib_exp_int((float)(kr[i] - kmax), a);
+            // internal QuantAct(16): fixedpoint_mul(exp_int, exp_sf, 16) (quant_utils.py:220-245)
+            const float z_int = rintf(e / a.exp_sf);
+            double q16 = __builtin_rint((double)z_int * a.M);
+            q16 = fmin(fmax(q16, -32768.0), 32767.0);
+            const float exp_int = ((float)q16 * a.act_sf) / a.act_sf;        // :309-310
+            sum += (double)exp_int;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const long long b = __double_as_longlong(sum);
+            const int lo = __shfl_xor((int)(b & 0xffffffffll), o), hi = __shfl_xor((int)(b >> 32), o);
+            sum += __longlong_as_double(((long long)hi << 32) | (unsigned)lo);   // integer-valued terms: exact in any order
+        }
+        const float ssum = (float)sum;                                        // :311
+        const float factor = floorf(4294967296.0f / ssum);                    // :313
+        for (int i = lane; i < a.L; i += 64) {
+            const float e = ib_exp_int((float)(kr[i] - kmax), a);
+            const float z_int = rintf(e / a.exp_sf);
+            double q16 = __builtin_rint((double)z_int * a.M);
+            q16 = fmin(fmax(q16, -32768.0), 32767.0);
+            const float exp_int = ((float)q16 * a.act_sf) / a.act_sf;
+            const float o = floorf((exp_int * factor) / a.out_div);          // :314
+            a.out[(int64_t)row * a.ldo + i] = (int)o;   // in [0, 2^(output_bit-1)]: the upper end is reachable (a one-hot row)
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ LayerNorm
+struct IbLnArgs {
+    const int32_t* k;
+    int64_t ldx;
+    int rows, C;
+    const float* bias_int;
+    const float* s_out;
+    float shift_pow2;   // 2 ** self.shift
+    float* out;
+    int64_t ldo;
+};
+
+__global__ __launch_bounds__(NT) void ibert_layernorm_kernel(IbLnArgs a)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int C = a.C;
+    for (int row = blockIdx.x * WPB + wave; row < a.rows; row += gridDim.x * WPB) {
+        const int32_t* kr = a.k + (int64_t)row * a.ldx;
+        long long sum = 0;
+        for (int c = lane; c < C; c += 64) sum += kr[c];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const int lo = __shfl_xor((int)(sum & 0xffffffffll), o), hi = __shfl_xor((int)(sum >> 32), o);
+            sum += ((long long)hi << 32) | (unsigned)lo;
+        }
+        const float mean_int = rintf((float)sum / (float)C);                  // :127
+        double var = 0.0;
+        for (int c = lane; c < C; c += 64) {
+            const float y = (float)kr[c] - mean_int;                          // :128
+            const float ys = floorf(y / a.shift_pow2);                        // :129
+            const float sq = ys * ys;                                         // :130 float32 square
+            var += (double)sq;                                                // :131 (sum of integer-valued terms)
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const long long b = __double_as_longlong(var);
+            const int lo = __shfl_xor((int)(b & 0xffffffffll), o), hi = __shfl_xor((int)(b >> 32), o);
+            var += __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+        }
+        const float var_int = (float)var;
+        const float std_int = floorf(sqrtf(var_int)) * a.shift_pow2;          // :142
+        const float factor = floorf(2147483648.0f / std_int);                 // :143
+        float* orow = a.out + (int64_t)row * a.ldo;
+        for (int c = lane; c < C; c += 64) {
+            const float y = (float)kr[c] - mean_int;
+            float v = floorf((y * factor) / 2.0f);                            // :144
+            v = v + a.bias_int[c];                                            // :151
+            orow[c] = v * a.s_out[c];                                         // :153
+        }
+    }
+}
+
+}  // namespace
+
+// ================================================================================================
+IVIT_EXPORT int ivit_ibert_gelu_i32(const int32_t* k, int64_t n, float b_int, float c_int, float shift_int, int32_t* out,
+                                    ivit_stream_t stream)
+{
+    IVIT_REQUIRE(k && out && n > 0, "ivit_ibert_gelu_i32: bad operand");
+    IVIT_REQUIRE(b_int < 0.0f, "ivit_ibert_gelu_i32: b_int must be negative (floor(-1.769 / (s / 1.4142)))");
+    hipLaunchKernelGGL(ibert_gelu_kernel, dim3(ew_grid(n)), dim3(NT), 0, ivit_stream(stream), k, n, b_int, c_int,
+                       shift_int, out);
+    IVIT_CHECK_LAUNCH("ivit_ibert_gelu_i32");
+}
+
+IVIT_EXPORT int ivit_ibert_softmax_i32(const int32_t* k, int64_t ldx, int rows, int L, float x0_int, float b_int,
+                                          float c_int, float exp_sf, float act_sf, uint32_t m_act, int32_t e_act,
+                                          int output_bit, int32_t* out, int64_t ldo, float* exp_out, ivit_stream_t stream)
+{
+    IVIT_REQUIRE(k && (out || exp_out) && rows > 0 && L > 0 && ldx >= L, "ivit_ibert_softmax_i32: bad operand");
+    IVIT_REQUIRE(!out || ldo >= L, "ivit_ibert_softmax_i32: ldo < L");
+    IVIT_REQUIRE(x0_int < 0.0f && exp_sf > 0.0f && act_sf > 0.0f, "ivit_ibert_softmax_i32: bad scalar constants");
+    IVIT_REQUIRE(output_bit >= 2 && output_bit <= 16, "ivit_ibert_softmax_i32: output_bit=%d unsupported", output_bit);
+    IbSoftmaxArgs a{};
+    a.k = k; a.ldx = ldx; a.rows = rows; a.L = L;
+    a.x0_int = x0_int; a.b_int = b_int; a.c_int = c_int; a.exp_sf = exp_sf; a.act_sf = act_sf;
+    a.M = ivit_dyadic_to_double(m_act, e_act);
+    a.out_div = __builtin_ldexpf(1.0f, 32 - output_bit + 1);
+    a.out = out; a.ldo = ldo; a.exp_out = exp_out;
+    hipLaunchKernelGGL(ibert_softmax_kernel, dim3(grid_for_rows(rows)), dim3(NT), 0, ivit_stream(stream), a);
+    IVIT_CHECK_LAUNCH("ivit_ibert_softmax_i32");
+}
+
+IVIT_EXPORT int ivit_ibert_layernorm_i32_f32(const int32_t* k, int64_t ldx, int rows, int C, const float* bias_int,
+                                             const float* s_out, float shift_pow2, float* out, int64_t ldo,
+                                             ivit_stream_t stream)
+{
+    IVIT_REQUIRE(k && out && bias_int && s_out && rows > 0 && C > 0 && ldx >= C && ldo >= C,
+                 "ivit_ibert_layernorm_i32_f32: bad operand");
+    IVIT_REQUIRE(shift_pow2 >= 1.0f, "ivit_ibert_layernorm_i32_f32: shift_pow2 = 2^shift must be >= 1");
+    IbLnArgs a{k, ldx, rows, C, bias_int, s_out, shift_pow2, out, ldo};
+    hipLaunchKernelGGL(ibert_layernorm_kernel, dim3(grid_for_rows(rows)), dim3(NT), 0, ivit_stream(stream), a);
+    IVIT_CHECK_LAUNCH("ivit_ibert_layernorm_i32_f32");
+}

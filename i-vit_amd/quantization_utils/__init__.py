@@ -1,10 +1,11 @@
 """Same public names as /root/reference/models/quantization_utils/__init__.py:1-4 (the 'ivit' family)."""
 from .quant_modules import QuantLinear, QuantAct, QuantConv2d, QuantMatMul
 from .ivit_modules import IVITIntGELU, IVITIntSoftmax, IVITIntLayerNorm
+from .ibert_modules import IBERTIntGELU, IBERTIntSoftmax, IBERTIntLayerNorm
 from .layer_selection import get_gelu, get_softmax, get_layernorm
 
 # upstream I-ViT names, which the reference's swin_quant.py imports (swin_quant.py:11)
 IntLayerNorm, IntSoftmax, IntGELU = IVITIntLayerNorm, IVITIntSoftmax, IVITIntGELU
 
 __all__ = ["QuantLinear", "QuantAct", "QuantConv2d", "QuantMatMul", "IVITIntGELU", "IVITIntSoftmax",
-           "IVITIntLayerNorm", "IntLayerNorm", "IntSoftmax", "IntGELU", "get_gelu", "get_softmax", "get_layernorm"]
+           "IVITIntLayerNorm", "IBERTIntGELU", "IBERTIntSoftmax", "IBERTIntLayerNorm", "IntLayerNorm", "IntSoftmax", "IntGELU", "get_gelu", "get_softmax", "get_layernorm"]

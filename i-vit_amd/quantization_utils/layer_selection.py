@@ -1,11 +1,12 @@
 """String -> operator class registry (/root/reference/models/quantization_utils/layer_selection.py:116-236).
-Only the 'ivit' family is implemented on MI355X; the other names of the reference ('ibert', 'ppoly',
+The integer families 'ivit' and 'ibert' are implemented on MI355X; the other names of the reference ('ppoly',
 'float') are outside this build's scope and raise."""
+from .ibert_modules import IBERTIntGELU, IBERTIntLayerNorm, IBERTIntSoftmax
 from .ivit_modules import IVITIntGELU, IVITIntLayerNorm, IVITIntSoftmax
 
-GELU_REGISTRY = {"ivit": IVITIntGELU}
-SOFTMAX_REGISTRY = {"ivit": IVITIntSoftmax}
-LN_REGISTRY = {"ivit": IVITIntLayerNorm}
+GELU_REGISTRY = {"ivit": IVITIntGELU, "ibert": IBERTIntGELU}
+SOFTMAX_REGISTRY = {"ivit": IVITIntSoftmax, "ibert": IBERTIntSoftmax}
+LN_REGISTRY = {"ivit": IVITIntLayerNorm, "ibert": IBERTIntLayerNorm}
 
 
 def _parse_layer_name(name: str):

@@ -211,6 +211,12 @@ class QuantAct(nn.Module):
         else:
             z = to_int32(x, pre_act_scaling_factor)
             C = x.shape[-1]
+            if pre_act_scaling_factor.numel() == 1 and float(pre_act_scaling_factor.reshape(-1)[0]) < 0:
+                # a negative incoming scale (the I-BERT GELU's, ibert_modules.py:213,232): round-half-even and the
+                # half-away-from-zero mantissa rounding of batch_frexp are both odd functions, so
+                # requant(z, s) == requant(-z, -s) exactly
+                z = -z
+                pre_act_scaling_factor = -pre_act_scaling_factor
             m, e, n_me = _me_tables(pre_act_scaling_factor, s_out, x.device)
             z2 = m2 = e2 = None
             n2 = 0

@@ -106,14 +106,17 @@ def make_images(batch: int, seed: int, start: int = 0) -> np.ndarray:
     return out
 
 
-def qact_names(depth: int = 12):
+def qact_names(depth: int = 12, family: str = "ivit"):
     """Names of every QuantAct in a DeiT/ViT model, in module order
-    (/root/reference/models/vit_quant.py:201-248, layers_quant.py:129-188)."""
+    (/root/reference/models/vit_quant.py:201-248, layers_quant.py:129-188).  With the I-BERT operators the softmax
+    module owns one more (16 bit, ibert_modules.py:260), registered after attn.qact3 (vit_quant.py:41-59)."""
     names = ["qact_input", "patch_embed.qact", "qact_pos", "qact1"]
     for i in range(depth):
         p = f"blocks.{i}."
-        names += [p + "qact1", p + "attn.qact1", p + "attn.qact_attn1", p + "attn.qact2", p + "attn.qact3",
-                  p + "qact2", p + "qact3", p + "mlp.qact_gelu", p + "mlp.qact1", p + "mlp.qact2", p + "qact4"]
+        names += [p + "qact1", p + "attn.qact1", p + "attn.qact_attn1", p + "attn.qact2", p + "attn.qact3"]
+        if family == "ibert":
+            names += [p + "attn.int_softmax.act"]
+        names += [p + "qact2", p + "qact3", p + "mlp.qact_gelu", p + "mlp.qact1", p + "mlp.qact2", p + "qact4"]
     names += ["qact2"]
     return names
 

@@ -95,6 +95,7 @@ class VisionTransformer(nn.Module):
         self.num_classes = num_classes
         self.num_features = self.embed_dim = embed_dim
         self.depth, self.num_heads = depth, num_heads
+        self.op_types = (str(gelu_type).lower(), str(softmax_type).lower(), str(layernorm_type).lower())
         gelu_layer, softmax_cls, norm_layer = get_gelu(gelu_type), get_softmax(softmax_type), get_layernorm(layernorm_type)
 
         self.qact_input = QuantAct()
@@ -166,7 +167,8 @@ class VisionTransformer(nn.Module):
         return self._engine[1]
 
     def forward(self, x):
-        if self.use_engine and not self.training and self.is_frozen() and x.is_cuda and self.embed_dim // self.num_heads == 64:
+        engine_ok = self.embed_dim // self.num_heads == 64 and all(t == "ivit" for t in self.op_types)   # fused engine: I-ViT operators
+        if self.use_engine and not self.training and self.is_frozen() and x.is_cuda and engine_ok:
             _, logits_f32, _ = self.engine(x.shape[0])(x.contiguous().float())
             return logits_f32.clone()
         x, s = self.forward_features(x)

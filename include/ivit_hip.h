@@ -253,6 +253,36 @@ int ivit_window_attention_i8(const int8_t* qkv, int8_t* out, int64_t ldo, const 
                              int tokens, int head_dim, uint32_t m_s, int32_t e_s, uint32_t m_b, int32_t e_b,
                              float s_attn, uint32_t m_o, int32_t e_o, ivit_stream_t stream);
 
+/* =================================================================================================
+ * I-BERT operator family (models/quantization_utils/ibert_modules.py; registry key 'ibert', the fork's default,
+ * vit_quant.py:188-190).  Module-level kernels: integer activations in, the module's output out.  The scalar
+ * constants are the float32 values the reference computes on the host side of every call (floor(coef / scale) ...);
+ * the caller passes them by value.  Each kernel performs the reference's float32 operations in the reference's
+ * order (see csrc/ibert.hip).
+ * ================================================================================================= */
+
+/* IBERTIntGELU.forward (:220-235) on integers k (= x / scaling_factor):
+ *   sigmoid_int = floor(sign(k) * ((min(|k|, -b_int) + b_int)^2 + c_int) / 2^6);  out = k * (sigmoid_int + shift_int)
+ * out holds the integer x_int of :231; the module's float output is out * s_out (s_out computed by the caller, :232). */
+int ivit_ibert_gelu_i32(const int32_t* k, int64_t n, float b_int, float c_int, float shift_int, int32_t* out,
+                        ivit_stream_t stream);
+
+/* IBERTIntSoftmax.forward (:297-319) on rows of L integers: int_exp (:285-295, n = 30) with x0_int, b_int, c_int and
+ * scale exp_sf; the module's internal QuantAct(16) (self.act, :260,308) as the dyadic (m_act, e_act) = batch_frexp(
+ * exp_sf / act_sf) with the fake-quant round trip through act_sf; row sum; factor = floor(2^32 / sum);
+ * out = floor(exp_int * factor / 2^(32 - output_bit + 1)) in [0, 2^(output_bit-1)], scale 2 / 2^output_bit.
+ * If exp_out != NULL only exp_int (float, [rows, L] dense) is produced: the statistics pass of the internal QuantAct
+ * in calibration mode (out may then be NULL). */
+int ivit_ibert_softmax_i32(const int32_t* k, int64_t ldx, int rows, int L, float x0_int, float b_int, float c_int,
+                           float exp_sf, float act_sf, uint32_t m_act, int32_t e_act, int output_bit, int32_t* out,
+                           int64_t ldo, float* exp_out, ivit_stream_t stream);
+
+/* IBERTIntLayerNorm.forward (:112-158, use_int_sqrt = False): mean_int = round(sum / C); y = k - mean_int;
+ * var = sum floor(y / 2^shift)^2; std = floor(sqrt(var)) * 2^shift; factor = floor(2^31 / std);
+ * out[c] = (floor(y * factor / 2) + bias_int[c]) * s_out[c]  (float32, the module's output; s_out = sqrt(C)/2^30 * gamma). */
+int ivit_ibert_layernorm_i32_f32(const int32_t* k, int64_t ldx, int rows, int C, const float* bias_int,
+                                 const float* s_out, float shift_pow2, float* out, int64_t ldo, ivit_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -234,19 +234,23 @@ MODEL_PLAN = {
     "deit_small": ("deit_small_patch16_224", 12, 102, 4, 1002, 4, False),
     "deit_base": ("deit_base_patch16_224", 13, 103, 4, 1003, 4, False),
     "vit_base": ("vit_base_patch16_224", 14, 104, 2, 1004, 2, False),
+    # the fork's default operator family (vit_quant.py:188-190), same synthetic weights as deit_tiny
+    "deit_tiny_ibert": ("deit_tiny_patch16_224", 11, 101, 4, 1001, 4, False),
 }
 
 
 def gen_model(tag):
     factory, wseed, cseed, cb, iseed, nimg, full = MODEL_PLAN[tag]
+    family = "ibert" if tag.endswith("_ibert") else "ivit"
     cfg = synth.MODEL_CONFIGS[factory]
     t0 = time.time()
-    model = getattr(ref_models, factory)(pretrained=False, gelu_type="ivit", softmax_type="ivit",
-                                         layernorm_type="ivit")
+    model = getattr(ref_models, factory)(pretrained=False, gelu_type=family, softmax_type=family,
+                                         layernorm_type=family)
     fs = synth.make_float_state(factory, wseed)
     missing, unexpected = model.load_state_dict({k: torch.from_numpy(v) for k, v in fs.items()}, strict=False)
     assert not unexpected, unexpected
-    assert all(("scaling_factor" in k or "integer" in k or "x_min" in k or "x_max" in k) for k in missing), missing
+    assert all(("scaling_factor" in k or "integer" in k or "x_min" in k or "x_max" in k or k.endswith(".shift"))
+               for k in missing), missing[:5]
     model.eval()
     # calibration forward (running_stat defaults to True)
     model(torch.from_numpy(synth.make_images(cb, cseed)))
@@ -256,11 +260,12 @@ def gen_model(tag):
         if isinstance(mod, rq.QuantAct):
             mx = float(torch.max(-mod.x_min, mod.x_max))
             assert mx > 0, name
-            p = int(np.ceil(np.log2(mx / 127.0)))
-            mod.x_max.fill_(127.0 * 2.0 ** p)
-            mod.x_min.fill_(-127.0 * 2.0 ** p)
+            q = float(2 ** (mod.activation_bit - 1) - 1)     # 127; 32767 for the QuantAct(16) inside IBERTIntSoftmax
+            p = int(np.ceil(np.log2(mx / q)))
+            mod.x_max.fill_(q * 2.0 ** p)
+            mod.x_min.fill_(-q * 2.0 ** p)
             ranges[name] = (np.float32(mod.x_min.item()), np.float32(mod.x_max.item()))
-    assert list(ranges) == synth.qact_names(cfg["depth"]), "QuantAct order drifted"
+    assert list(ranges) == synth.qact_names(cfg["depth"], family), "QuantAct order drifted"
     ref_models.freeze_model(model)
 
     taps = {}
@@ -272,8 +277,9 @@ def gen_model(tag):
         return fn
 
     for name, mod in model.named_modules():
-        if isinstance(mod, (rq.QuantAct, rq.IVITIntSoftmax, rq.IVITIntGELU)):
-            mod.register_forward_hook(hook(name))
+        if isinstance(mod, (rq.QuantAct, rq.IVITIntSoftmax, rq.IVITIntGELU, rq.IBERTIntSoftmax, rq.IBERTIntGELU)):
+            if not name.endswith("int_softmax.act"):   # internal to IBERTIntSoftmax: its input is not an activation view
+                mod.register_forward_hook(hook(name))
 
     imgs = synth.make_images(nimg, iseed)
     y = model(torch.from_numpy(imgs))
@@ -285,7 +291,7 @@ def gen_model(tag):
 
     # ---- check the oracle against the reference right here
     t1 = time.time()
-    om = orc.OracleViT(fs, ranges, cfg["embed_dim"], cfg["depth"], cfg["num_heads"])
+    om = orc.OracleViT(fs, ranges, cfg["embed_dim"], cfg["depth"], cfg["num_heads"], family=family)
     otaps = {}
     res = om.forward(imgs, otaps)
     bad = [n for n in taps if n in otaps and not np.array_equal(taps[n].reshape(-1), otaps[n].reshape(-1))]
@@ -296,14 +302,16 @@ def gen_model(tag):
     assert np.array_equal(res["logits_f32"].view(np.int32), logits_f32.view(np.int32)), "float logits differ"
     assert np.array_equal(res["top1"], top1)
     print(f"[{tag}] reference {t_ref:.1f}s, oracle {time.time()-t1:.1f}s: {len(taps)} taps + logits bit-equal; "
-          f"max|acc|={om.max_acc} softmax rows with sum>=2^24: {om.softmax_inexact_rows}")
+          f"max|acc|={om.max_acc} softmax rows with sum>=2^24: {om.softmax_inexact_rows}, "
+          f"LN rows with an inexact float32 sum: {om.ln_inexact_rows}")
     assert om.max_acc < 2 ** 24
 
     names = sorted(taps)
     out = {
-        "meta": np.array(json.dumps(dict(tag=tag, factory=factory, weight_seed=wseed, calib_seed=cseed,
+        "meta": np.array(json.dumps(dict(tag=tag, factory=factory, family=family, weight_seed=wseed, calib_seed=cseed,
                                          calib_batch=cb, image_seed=iseed, n_images=nimg, qkv_gain=synth.QKV_GAIN,
                                          max_abs_acc=om.max_acc, softmax_inexact_rows=om.softmax_inexact_rows,
+                                         ln_inexact_rows=om.ln_inexact_rows,
                                          torch=torch.__version__, numpy=np.__version__))),
         "range_names": np.array(list(ranges)),
         "x_min": np.array([v[0] for v in ranges.values()], np.float32),
@@ -427,6 +435,72 @@ def gen_swin(tag="swin_tiny"):
     print(f"[{tag}] wrote fixtures; top1 = {top1.tolist()}")
 
 
+
+def gen_ibert_ops():
+    """Known-answer vectors of the reference's I-BERT operator modules (ibert_modules.py), checked on the spot against
+    oracle/ibert.py.  Inputs are integer activations with power-of-two scales (the regime of the parity contract)."""
+    from oracle import ibert as ib
+    rng = np.random.default_rng(20260202)
+    out = {}
+    gelu = rq.IBERTIntGELU()
+    for i, p in enumerate((-2, -3, -4, -5, -6)):
+        s = np.float32(2.0 ** p)
+        k = rng.integers(-128, 128, size=(3, 5, 96)).astype(np.int32)
+        k[0, 0, :4] = (-128, 127, 0, 1)
+        y, so = gelu(torch.from_numpy((k.astype(np.float32) * s).astype(np.float32)), torch.tensor([s]))
+        oi, s_o = ib.gelu(k, s)
+        assert float(so) == float(s_o) and np.array_equal(y.numpy().view(np.int32), (oi * s_o).astype(np.float32).view(np.int32))
+        out[f"gelu{i}_k"], out[f"gelu{i}_s"] = k.astype(np.int16), s
+        out[f"gelu{i}_out"], out[f"gelu{i}_sout"] = oi.astype(np.int32), np.float32(s_o)
+    sm = rq.IBERTIntSoftmax(8)
+    for i, (p, L) in enumerate(((-2, 197), (-3, 197), (-1, 49), (0, 64), (-4, 33))):
+        s = np.float32(2.0 ** p)
+        k = rng.integers(-128, 128, size=(2, 3, 17, L)).astype(np.int32)
+        k[0, 0, 0, :] = 5          # a constant row
+        k[0, 0, 1, :] = -128
+        k[0, 0, 1, 3] = 127        # one dominant key
+        x = torch.from_numpy((k.astype(np.float32) * s).astype(np.float32))
+        sm.act.running_stat = True
+        sm.act.x_min.zero_()
+        sm.act.x_max.zero_()
+        sm(x, torch.tensor([s]))                      # first call initialises the internal QuantAct(16) range
+        mx = float(torch.max(-sm.act.x_min, sm.act.x_max))
+        pp = int(np.ceil(np.log2(mx / 32767.0)))
+        if i == 4:                                    # one case with the raw (non power-of-two) calibrated range
+            lo, hi = float(sm.act.x_min), float(sm.act.x_max)
+        else:
+            lo, hi = -32767.0 * 2.0 ** pp, 32767.0 * 2.0 ** pp
+        sm.act.x_min.fill_(lo)
+        sm.act.x_max.fill_(hi)
+        sm.act.running_stat = False
+        y, so = sm(x, torch.tensor([s]))
+        o, s_o, ninx = ib.softmax(k, s, lo, hi)
+        assert ninx == 0 and float(so) == float(s_o)
+        assert np.array_equal(y.numpy().view(np.int32), (o * s_o).astype(np.float32).view(np.int32)), (i, p, L)
+        out[f"softmax{i}_k"], out[f"softmax{i}_s"] = k.astype(np.int16), s
+        out[f"softmax{i}_range"] = np.array([lo, hi], np.float32)
+        out[f"softmax{i}_out"] = o.astype(np.int32)
+    for i, (C, amp, p) in enumerate(((192, 30, -4), (384, 60, -3), (768, 20, -5), (96, 127, -2))):
+        ln = rq.IBERTIntLayerNorm(C)
+        ln.weight.data = torch.from_numpy(rng.uniform(0.5, 1.5, C).astype(np.float32))
+        ln.bias.data = torch.from_numpy((rng.standard_normal(C) * 0.1).astype(np.float32))
+        ln.fix()
+        s = np.float32(2.0 ** p)
+        k = np.clip(np.rint(rng.normal(0, amp, size=(2, 9, C))), -128, 127).astype(np.int32)
+        k[0, 0, :] = 3                                 # constant row: var = 0 -> std = 0 -> factor = inf (as the reference)
+        y, so = ln(torch.from_numpy((k.astype(np.float32) * s).astype(np.float32)), torch.tensor([s]))
+        yi, s_o, ninx = ib.layernorm(k, s, ln.weight.numpy(), ln.bias.numpy())
+        assert ninx == 0 and np.array_equal(so.numpy(), s_o)
+        mine = (yi * s_o).astype(np.float32)
+        assert np.array_equal(y.numpy().view(np.int32), mine.view(np.int32)), (i, C)
+        out[f"ln{i}_k"], out[f"ln{i}_s"] = k.astype(np.int16), s
+        out[f"ln{i}_gamma"], out[f"ln{i}_beta"] = ln.weight.numpy().copy(), ln.bias.numpy().copy()
+        out[f"ln{i}_out_bits"] = y.numpy().view(np.int32).copy()
+        out[f"ln{i}_sout"] = s_o
+    np.savez_compressed(os.path.join(GOLD, "ibert_kat.npz"), **out)
+    print("ibert_kat.npz written:", len(out), "arrays; oracle/ibert.py bit-equal to the reference modules on all cases")
+
+
 def gen_schema():
     """state_dict keys and shapes of the reference's DeiT and Swin models (the on-disk checkpoint format)"""
     out = {}
@@ -434,6 +508,9 @@ def gen_schema():
         model = getattr(ref_models, factory)(pretrained=False, gelu_type="ivit", softmax_type="ivit",
                                              layernorm_type="ivit")
         out[factory] = {k: list(v.shape) for k, v in model.state_dict().items()}
+    # the same DeiT with the I-BERT operators (the fork's default family): different buffers (shift, internal QuantAct)
+    model = ref_models.deit_tiny_patch16_224(pretrained=False, gelu_type="ibert", softmax_type="ibert", layernorm_type="ibert")
+    out["deit_tiny_patch16_224@ibert"] = {k: list(v.shape) for k, v in model.state_dict().items()}
     sq = _import_swin()
     for factory in ("swin_tiny_patch4_window7_224",):
         out[factory] = {k: list(v.shape) for k, v in getattr(sq, factory)(pretrained=False).state_dict().items()}
@@ -448,6 +525,8 @@ if __name__ == "__main__":
     for w in what:
         if w == "ops":
             gen_ops()
+        elif w == "ibert_ops":
+            gen_ibert_ops()
         elif w == "schema":
             gen_schema()
         elif w.startswith("swin"):

@@ -156,13 +156,16 @@ def test_gelu_softmax_modules_kat(kat):
 def test_registry_and_aliases():
     assert q.get_gelu("ivit") is q.IVITIntGELU and q.get_softmax("ivit") is q.IVITIntSoftmax
     assert q.get_layernorm("ivit") is q.IVITIntLayerNorm and q.IntGELU is q.IVITIntGELU
+    assert q.get_gelu("ibert") is q.IBERTIntGELU and q.get_layernorm("ibert") is q.IBERTIntLayerNorm
     with pytest.raises(KeyError, match="only"):
-        q.get_gelu("ibert")
+        q.get_gelu("ppoly")
 
 
 def load_model(tag):
     fs, ranges, cfg, meta, z = load_synthetic_model(tag)
-    model = getattr(ivit, meta["factory"])()
+    fam = meta.get("family", "ivit")
+    kw = dict(gelu_type=fam, softmax_type=fam, layernorm_type=fam) if fam != "ivit" else {}
+    model = getattr(ivit, meta["factory"])(**kw)
     missing, unexpected = model.load_state_dict({k: torch.from_numpy(v) for k, v in fs.items()}, strict=False)
     assert not unexpected
     for name, mod in model.named_modules():
@@ -301,3 +304,70 @@ def test_checkpoint_harness_end_to_end(tmp_path):
     # non-strict load with the random warm-up forward, then frozen (inference.py:209-223)
     m3 = inference.load_model(path, device=DEV, strict_load=False, use_random_calibration_warmup=True)
     assert m3.is_frozen()
+
+
+# ----------------------------------------------------------------------------------- I-BERT operator family (row f3)
+@pytest.fixture(scope="module")
+def ikat(golden_dir):
+    return np.load(os.path.join(golden_dir, "ibert_kat.npz"))
+
+
+def test_ibert_gelu_module_kat(ikat):
+    g = q.IBERTIntGELU().to(DEV)
+    for i in range(5):
+        k, s = ikat[f"gelu{i}_k"].astype(np.float32), ikat[f"gelu{i}_s"]
+        x = torch.from_numpy((k * s).astype(np.float32)).to(DEV)
+        y, so = g(x, torch.tensor([float(s)], device=DEV))
+        assert float(so) == float(ikat[f"gelu{i}_sout"])
+        want = (ikat[f"gelu{i}_out"].astype(np.float32) * ikat[f"gelu{i}_sout"]).astype(np.float32)
+        assert np.array_equal(bits(y), want.view(np.int32))
+
+
+def test_ibert_softmax_module_kat(ikat):
+    sm = q.IBERTIntSoftmax(8).to(DEV)
+    for i in range(5):
+        k, s = ikat[f"softmax{i}_k"].astype(np.float32), ikat[f"softmax{i}_s"]
+        lo, hi = ikat[f"softmax{i}_range"]
+        sm.act.x_min.fill_(float(lo))
+        sm.act.x_max.fill_(float(hi))
+        sm.act.fix()
+        x = torch.from_numpy((k * s).astype(np.float32)).to(DEV)
+        y, so = sm(x, torch.tensor([float(s)], device=DEV))
+        assert float(so) == 2.0 ** -7
+        want = (ikat[f"softmax{i}_out"].astype(np.float32) * np.float32(2.0 ** -7)).astype(np.float32)
+        assert np.array_equal(bits(y), want.view(np.int32)), i
+    # calibration mode: the internal QuantAct(16) initialises its range from exp_int of the batch
+    sm2 = q.IBERTIntSoftmax(8).to(DEV)
+    k, s = ikat["softmax0_k"].astype(np.float32), ikat["softmax0_s"]
+    sm2(torch.from_numpy((k * s).astype(np.float32)).to(DEV), torch.tensor([float(s)], device=DEV))
+    from oracle import ibert as ib
+    ex = ib.softmax(k, s, -1.0, 1.0, return_exp=True)[3]
+    assert float(sm2.act.x_min) == float(ex.min()) and float(sm2.act.x_max) == float(ex.max())
+
+
+def test_ibert_layernorm_module_kat(ikat):
+    for i in range(4):
+        k, s = ikat[f"ln{i}_k"].astype(np.float32), ikat[f"ln{i}_s"]
+        C = k.shape[-1]
+        ln = q.IBERTIntLayerNorm(C).to(DEV)
+        ln.weight.data = torch.from_numpy(ikat[f"ln{i}_gamma"]).to(DEV)
+        ln.bias.data = torch.from_numpy(ikat[f"ln{i}_beta"]).to(DEV)
+        ln.fix()
+        y, so = ln(torch.from_numpy((k * s).astype(np.float32)).to(DEV), torch.tensor([float(s)], device=DEV))
+        assert np.array_equal(so.cpu().numpy(), ikat[f"ln{i}_sout"])
+        got, want = y.cpu().numpy(), ikat[f"ln{i}_out_bits"].view(np.float32)
+        nan = np.isnan(want)                       # the constant row: std = 0 -> 0 * inf (NaN payload / sign is not compared)
+        assert np.array_equal(np.isnan(got), nan) and nan.sum() == C
+        assert np.array_equal(got[~nan].view(np.int32), want[~nan].view(np.int32))
+
+
+def test_ibert_model_module_path_matches_reference_golden():
+    """DeiT-T with gelu / softmax / layernorm = 'ibert' (the fork's default operator family) through the module path:
+    float logits bitwise equal to the reference's."""
+    model, meta, z = load_model("deit_tiny_ibert")
+    assert meta["family"] == "ibert" and type(model.blocks[0].attn.int_softmax).__name__ == "IBERTIntSoftmax"
+    imgs = torch.from_numpy(synth.make_images(2, meta["image_seed"])).to(DEV)
+    with torch.no_grad():
+        y = model(imgs)             # no fused engine for this family: module by module
+    assert np.array_equal(bits(y), z["logits_f32_bits"][:2])
+    assert np.array_equal(y.argmax(dim=1).cpu().numpy(), z["top1"][:2])

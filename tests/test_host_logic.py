@@ -116,7 +116,9 @@ def test_module_tree_matches_reference_state_dict_schema(golden_dir):
     import json
     sch = json.load(open(os.path.join(golden_dir, "state_dict_schema.json")))
     for name, ref in sch.items():
-        mine = {k: list(v.shape) for k, v in getattr(ivit_amd, name)().state_dict().items()}
+        factory, _, family = name.partition("@")     # "<factory>@ibert": the same model with the I-BERT operators
+        kw = dict(gelu_type=family, softmax_type=family, layernorm_type=family) if family else {}
+        mine = {k: list(v.shape) for k, v in getattr(ivit_amd, factory)(**kw).state_dict().items()}
         assert list(mine) == list(ref), name
         assert mine == ref, name
     with pytest.raises(RuntimeError, match="no network"):
@@ -154,8 +156,9 @@ def test_checkpoint_harness_cpu(tmp_path):
     # model_name selects the factory; unknown operator families are refused
     assert type(inference.build_model({"model_name": "swin_tiny_patch4_window7_224"})).__name__ == "SwinTransformer"
     assert inference.build_model({"model_name": "deit_small"}).embed_dim == 384
+    assert type(inference.build_model({"model_name": "deit_tiny", "gelu_type": "ibert"}).blocks[0].mlp.act).__name__ == "IBERTIntGELU"
     with pytest.raises(KeyError):
-        inference.build_model({"model_name": "deit_tiny", "gelu_type": "ibert"})
+        inference.build_model({"model_name": "deit_tiny", "gelu_type": "ppoly_deg_2_seg_16"})
     # evaluate_dataset arithmetic on a stub model
     class Stub(torch.nn.Module):
         def forward(self, x):
