@@ -118,7 +118,8 @@ def layernorm(k, s, gamma, beta, shift=0.0):
     exact = (y_sh * y_sh).astype(f32).astype(np.float64).sum(axis=-1, keepdims=True)        # :130 float32 squares
     var_int = exact.astype(f32)                                                # :130-131, exact below 2^24
     ninexact = int(((exact >= 2 ** 24) | (np.abs(sx) >= 2 ** 24)).sum())
-    std_int = (np.floor(np.sqrt(var_int).astype(f32)) * sh).astype(f32)        # :142
-    factor = np.floor((f32(2 ** 31) / std_int).astype(f32))                    # :143
-    y = np.floor(((y_int * factor).astype(f32) / f32(2)).astype(f32))          # :144
+    with np.errstate(divide="ignore", invalid="ignore"):   # a constant row has std = 0: factor = inf, 0 * inf = NaN, as the reference
+        std_int = (np.floor(np.sqrt(var_int).astype(f32)) * sh).astype(f32)    # :142
+        factor = np.floor((f32(2 ** 31) / std_int).astype(f32))                # :143
+        y = np.floor(((y_int * factor).astype(f32) / f32(2)).astype(f32))      # :144
     return (y + bias_int).astype(f32), s_out, ninexact                         # :151
