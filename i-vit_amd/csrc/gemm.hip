@@ -54,6 +54,8 @@ struct GemmArgs {
     int tiles_m, tiles_n;
     int flags;
     int stagger;  // number of first-generation blocks subject to the start stagger (0 = off)
+    int cu_turns;       // persistent kernel: 1 = co-resident workgroups alternate main loops through the per-CU token
+    int stagger_units;  // persistent kernel: start delay of the second co-resident workgroup, in s_sleep(16) (~1K cycle) units
     int split_from;  // persistent kernel: tiles [split_from, tiles_m*tiles_n) are processed as two half tiles each
 };
 
@@ -803,6 +805,10 @@ IVIT_DEV void pers_table_write(const PersTableLoad& r, char* tab, int tid)
 // t % G.  If the last round of full tiles would be at most half full (R = F mod G tiles, 2R <= G), those R tiles are
 // split into 2R half tiles of 128 tokens, one per workgroup 0 .. 2R-1, so the tail costs half a tile time instead of a
 // whole one (DeiT-B, N = 768: 1182 tiles on 512 workgroups = 2.31 rounds -> 2.5 instead of 3).
+// One token per physical CU (XCC id, SE, SH, CU of HW_ID): the two co-resident workgroups of the persistent kernel take
+// turns in their DMA-bound main loops (see gemm_i8_pers_kernel).  Zero between launches: every holder releases.
+__device__ int g_cu_token[2048];
+
 struct PersWork {
     int m0, n0, half;   // m0 < 0: none
 };
@@ -831,6 +837,9 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_pers_kernel(GemmArgs g)
 {
     __shared__ __attribute__((aligned(16))) char smem[PERS_SMEM];
     const int tid = threadIdx.x;
+    const unsigned hw_id = __builtin_amdgcn_s_getreg((16 - 1) << 11 | (0 << 6) | 4);    // HW_ID[15:0]: .. cu_id[11:8] sh_id[12] se_id[15:13]
+    const unsigned xcc_id = __builtin_amdgcn_s_getreg((4 - 1) << 11 | (0 << 6) | 20);   // XCC_ID[3:0]
+    int* cu_token = &g_cu_token[((xcc_id & 7u) << 8) | ((hw_id >> 8) & 0xffu)];
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wc = wave >> 1, wt = wave & 1;
     const int h = lane >> 5, l31 = lane & 31;
@@ -992,12 +1001,22 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_pers_kernel(GemmArgs g)
                     acc[i][j][4 * q + 3] = b4.w;
                 }
             }
+        // The main loop is bound by the CU's global->LDS DMA path (~29 B/clk/CU: a 24 KiB stage per ~830 cycles against
+        // 512 cycles of MFMA), the epilogue by VALU.  Two workgroups that run their main loops at the same time just
+        // halve each other's DMA rate and then sit in their epilogues together with the DMA path idle.  The per-CU token
+        // makes them take turns: one streams its K loop at the full DMA rate while the other requantises and stores.
+        if (g.cu_turns) {
+            if (tid == 0)
+                while (atomicCAS(cu_token, 0, 1) != 0) __builtin_amdgcn_s_sleep(8);
+            __syncthreads();
+        }
         load_frags(0u, 0, wf0, af0);
         int kt = 0;
         for (; kt + 2 < nk; ++kt) step(kt, T{}, F{});
         if (kt + 1 < nk) { step(kt, F{}, F{}); ++kt; }
         step(kt, F{}, T{});
         __syncthreads();   // all waves are done with every stage: buffers free
+        if (g.cu_turns && tid == 0) atomicExch(cu_token, 0);
 
         // ---- prefetch stage 0 of the next item, then this item's epilogue (staging in buffers 1-2)
         const bool more = nxt.m0 >= 0;   // uniform
@@ -1032,7 +1051,7 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_pers_kernel(GemmArgs g)
     if (g.stagger && blockIdx.x < (unsigned)g.stagger) {   // see gemm_i8_big_kernel: de-phase the two co-resident groups
         const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1u;
         if (slot)
-            for (int it = 0; it < (nk + 1) / 2; ++it) __builtin_amdgcn_s_sleep(64);
+            for (int it = 0; it < g.stagger_units; ++it) __builtin_amdgcn_s_sleep(16);
     }
     issue_rt(0, cur.half);
 
@@ -1044,6 +1063,204 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_pers_kernel(GemmArgs g)
         else run(F{}, cur, nxt, tab, tab_next);
         cur = nxt;
     }
+}
+
+// ================================================================================================
+// Deep-ring form: ONE workgroup per CU (4 waves, wave tile 64 ch x 128 tok as above) with a FIVE-stage LDS ring
+// (120 KiB), so that up to four stages (96 KiB) of LDS-DMA are in flight per CU.  Rationale: the
+// global->LDS path has a latency of more than two K steps; with three stages per workgroup a stage is awaited one
+// step after it was issued and every step waits for the DMA.  Here a stage is issued four steps before it is
+// consumed, and the first four stages of the NEXT tile are issued before this tile's epilogue (which has its own
+// staging area), so the main loop of a tile starts on data that has already landed.
+// ================================================================================================
+constexpr int RING_STAGES = 5;
+constexpr int RING_BYTES = RING_STAGES * BIG_STAGE;            // 120 KiB
+constexpr int RING_EPI_OFF = RING_BYTES;                        // 256 x 132 B int8 staging tile
+constexpr int RING_EPI_BYTES = BTOK * (BCH + 4);
+constexpr int RING_PT_OFF = RING_EPI_OFF + RING_EPI_BYTES;      // 2 x table
+constexpr int RING_SMEM = RING_PT_OFF + 2 * PT_BYTES;           // 159 744 B <= 160 KiB
+
+template <int EPI>
+__global__ __launch_bounds__(BIG_NT, 1) void gemm_i8_ring_kernel(GemmArgs g)
+{
+    __shared__ __attribute__((aligned(16))) char smem[RING_SMEM];
+    static_assert(RING_SMEM <= 160 * 1024, "LDS budget");
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wc = wave >> 1, wt = wave & 1;
+    const int h = lane >> 5, l31 = lane & 31;
+    const int lrow = lane >> 2, lslot = lane & 3;
+    const int nk = g.K / BK;
+    const int ntiles = g.tiles_m * g.tiles_n;
+    using T = std::true_type;
+    using F = std::false_type;
+
+    const int8_t* asrc[4];
+    const int8_t* wsrc[2];
+    auto set_sources = [&](const PersTile& t) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int row = 16 * (wave + 4 * i) + lrow;
+            int c = lslot ^ ((row >> 2) & 3);
+            asrc[i] = g.A + (int64_t)min(t.m0 + row, g.M - 1) * g.lda + 16 * c;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int row = 16 * (wave + 4 * i) + lrow;
+            int c = lslot ^ ((row >> 2) & 3);
+            wsrc[i] = g.W + (int64_t)min(t.n0 + row, g.N - 1) * g.ldw + 16 * c;
+        }
+    };
+    // DMA piece `idx` (0..3 token tile, 4..5 weight tile) of K step kt into ring buffer kt % RING_STAGES
+    auto issue_one = [&](int kt, int idx) {
+        char* base = smem + (kt % RING_STAGES) * BIG_STAGE;
+        const int koff = kt * BK;
+        if (idx < 4)
+            __builtin_amdgcn_global_load_lds((gptr_t)(asrc[idx] + koff), (lptr_t)(base + 1024 * (wave + 4 * idx)), 16, 0,
+                                             0);
+        else
+            __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[idx - 4] + koff),
+                                             (lptr_t)(base + BIG_A_BYTES + 1024 * (wave + 4 * (idx - 4))), 16, 0, 0);
+    };
+    auto issue = [&](int kt) {
+#pragma unroll
+        for (int idx = 0; idx < 6; ++idx) issue_one(kt, idx);
+    };
+
+    const unsigned smem_base = (unsigned)(__UINTPTR_TYPE__)(lptr_t)smem;
+    const int wrow0 = 64 * wc + l31, arow0 = 128 * wt + l31;
+    const unsigned wbase[2] = {smem_base + (unsigned)(BIG_A_BYTES + swz(wrow0, h)),
+                               smem_base + (unsigned)(BIG_A_BYTES + swz(wrow0, 2 + h))};
+    const unsigned abase[2] = {smem_base + (unsigned)swz(arow0, h), smem_base + (unsigned)swz(arow0, 2 + h)};
+    v4i wf0[2], af0[4], wf1[2], af1[4];
+    auto load_frags = [&](unsigned stage_off, int ks, v4i (&wf)[2], v4i (&af)[4]) {
+        const unsigned wa = wbase[ks] + stage_off, aa = abase[ks] + stage_off;
+        asm volatile("ds_read_b128 %0, %1" : "=v"(wf[0]) : "v"(wa));
+        asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(wf[1]) : "v"(wa));
+        asm volatile("ds_read_b128 %0, %1" : "=v"(af[0]) : "v"(aa));
+        asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(af[1]) : "v"(aa));
+        asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(af[2]) : "v"(aa));
+        asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(af[3]) : "v"(aa));
+    };
+#define RING_TIE(wf, af) "+v"(wf[0]), "+v"(wf[1]), "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3])
+    v16i acc[2][4];
+    // One K step.  AHEAD = number of later stages whose DMA may still be in flight when this step ends (each stage is
+    // 6 pieces per wave): the counted vmcnt leaves exactly those outstanding, i.e. stage kt+1 has landed.
+    // ISSUE: this step also issues the DMA of stage kt + RING_STAGES - 1 into the buffer freed by the previous step.
+    auto step = [&](int kt, auto issue_tag, auto ahead_tag, auto last_tag) {
+        constexpr bool ISSUE = decltype(issue_tag)::value;
+        constexpr int AHEAD = decltype(ahead_tag)::value;
+        constexpr bool LAST = decltype(last_tag)::value;
+        load_frags((unsigned)((kt % RING_STAGES) * BIG_STAGE), 1, wf1, af1);
+        asm volatile("s_waitcnt lgkmcnt(6)" : RING_TIE(wf0, af0)::"memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf0[i], af0[j], acc[i][j], 0, 0, 0);
+                if constexpr (ISSUE)
+                    if (4 * i + j < 6) issue_one(kt + RING_STAGES - 1, 4 * i + j);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (AHEAD == 3) asm volatile("s_waitcnt vmcnt(18) lgkmcnt(0)" : RING_TIE(wf1, af1)::"memory");
+        else if constexpr (AHEAD == 2) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" : RING_TIE(wf1, af1)::"memory");
+        else if constexpr (AHEAD == 1) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" : RING_TIE(wf1, af1)::"memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : RING_TIE(wf1, af1)::"memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if constexpr (!LAST) load_frags((unsigned)(((kt + 1) % RING_STAGES) * BIG_STAGE), 0, wf0, af0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf1[i], af1[j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    using A0 = std::integral_constant<int, 0>;
+    using A1 = std::integral_constant<int, 1>;
+    using A2 = std::integral_constant<int, 2>;
+    using A3 = std::integral_constant<int, 3>;
+    // issue the first min(nk, RING_STAGES - 1) stages of a tile
+    auto prefetch_head = [&]() {
+        const int nh = nk < RING_STAGES - 1 ? nk : RING_STAGES - 1;
+        for (int kt = 0; kt < nh; ++kt) issue(kt);
+    };
+
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    PersTile cur = pers_tile(g, tile);
+    {
+        PersTableLoad tl = pers_table_issue(g, cur.n0, tid);
+        pers_table_write(tl, smem + RING_PT_OFF, tid);
+    }
+    set_sources(cur);
+    prefetch_head();
+
+    for (int it = 0; tile < ntiles; ++it, tile += gridDim.x) {
+        char* tab = smem + RING_PT_OFF + (it & 1) * PT_BYTES;
+        char* tab_next = smem + RING_PT_OFF + ((it + 1) & 1) * PT_BYTES;
+        // The head stages of this tile were issued before the previous epilogue (or just above): wait for stage 0.
+        // Everything older (the previous tile's stores included) is allowed to drain with it.
+        {
+            const int nh = nk < RING_STAGES - 1 ? nk : RING_STAGES - 1;   // stages in flight now
+            // one stage stricter than needed: the previous epilogue's stores are younger than these pieces and may retire
+            // out of order with respect to loads, so do not let them stand in for DMA pieces in the count
+            if (nh >= 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else if (nh == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int4 b4 = *reinterpret_cast<const int4*>(tab + BCH * 8 + 4 * (64 * wc + 32 * i + 8 * q + 4 * h));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[i][j][4 * q + 0] = b4.x;
+                    acc[i][j][4 * q + 1] = b4.y;
+                    acc[i][j][4 * q + 2] = b4.z;
+                    acc[i][j][4 * q + 3] = b4.w;
+                }
+            }
+        load_frags(0u, 0, wf0, af0);
+        // steps that still issue a stage (kt + 4 < nk), then the drain: 3, 2, 1, 0 later stages in flight
+        int kt = 0;
+        for (; kt + RING_STAGES - 1 < nk; ++kt) step(kt, T{}, A3{}, F{});
+        if (kt + 3 < nk) { step(kt, F{}, A2{}, F{}); ++kt; }
+        if (kt + 2 < nk) { step(kt, F{}, A1{}, F{}); ++kt; }
+        if (kt + 1 < nk) { step(kt, F{}, A0{}, F{}); ++kt; }
+        step(kt, F{}, A0{}, T{});
+        __syncthreads();   // all waves are done with every ring buffer
+
+        // ---- head of the next tile into the (now free) ring, then this tile's epilogue from its own staging area
+        const int next = tile + gridDim.x;
+        const bool more = next < ntiles;   // uniform
+        PersTile nxt = cur;
+        if (more) {
+            nxt = pers_tile(g, next);
+            set_sources(nxt);
+            prefetch_head();
+        }
+        struct Hook {
+            const GemmArgs& g;
+            int n0, tid;
+            char* dst;
+            bool more;
+            mutable PersTableLoad ld;
+            IVIT_DEV void issue() const { if (more) ld = pers_table_issue(g, n0, tid); }
+            IVIT_DEV void consume() const { if (more) pers_table_write(ld, dst, tid); }
+        };
+        Hook hook{g, nxt.n0, tid, tab_next, more, PersTableLoad{0u, 0, 0, false}};
+        epilogue_i8<EPI, 2, 4, BTOK, BIG_NT, 0, BCH, Hook>(acc, g, smem + RING_EPI_OFF, tab, cur.m0, cur.n0, 64 * wc,
+                                                          128 * wt, tid, h, l31, hook);
+        cur = nxt;
+        __syncthreads();   // staging tile and table free for the next round
+    }
+#undef RING_TIE
 }
 
 template <int EPI>
@@ -1103,6 +1320,16 @@ int launch_gemm(GemmArgs& g, const char* name, ivit_stream_t stream)
             }
             IVIT_CHECK_LAUNCH(name);
         }
+        if (g.M >= 2048 && g.N >= BCH && !g_force_small && g.flags == 0 && (g_debug_flags & 8192)) {
+            g.stagger = 0;
+            g.tiles_m = (g.M + BTOK - 1) / BTOK;
+            g.tiles_n = (g.N + BCH - 1) / BCH;
+            g.split_from = g.tiles_m * g.tiles_n;
+            const int ntiles = g.tiles_m * g.tiles_n;
+            hipLaunchKernelGGL((gemm_i8_ring_kernel<EPI>), dim3(ntiles < 256 ? ntiles : 256), dim3(BIG_NT), 0,
+                               ivit_stream(stream), g);
+            IVIT_CHECK_LAUNCH(name);
+        }
         if (g.M >= 2048 && g.N >= BCH && !g_force_small && g.flags == 0 && !(g_debug_flags & 1024)) {
             g.stagger = (g_debug_flags & 64) ? 0 : 512;  // 2 workgroups x 256 CUs
             g.tiles_m = (g.M + BTOK - 1) / BTOK;
@@ -1117,6 +1344,10 @@ int launch_gemm(GemmArgs& g, const char* name, ivit_stream_t stream)
             const int rounds = ntiles / SLOTS, R = ntiles - rounds * SLOTS;
             const bool split = R > 0 && 2 * R <= SLOTS && (g_debug_flags & 2048);
             g.split_from = split ? rounds * SLOTS : ntiles;
+            g.cu_turns = (g_debug_flags & 32768) ? 1 : 0;
+            // start delay of the second co-resident workgroup: measured (scripts/gemm_ab.py, interleaved) 0..10 units are
+            // equivalent and the former half-main-loop delay (26 / 98 units at K = 768 / 3072) cost 4-8 %: off by default
+            g.stagger_units = (g_debug_flags >> 16) & 63;
             const int grid = rounds > 0 ? SLOTS : (split ? 2 * R : R);
             hipLaunchKernelGGL((gemm_i8_pers_kernel<EPI>), dim3(grid), dim3(BIG_NT), one_per_cu ? 20480 : 0,
                                ivit_stream(stream), g);

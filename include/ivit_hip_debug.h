@@ -16,7 +16,9 @@ int ivit_debug_force_small_gemm(int on);
 /* Perf-ablation hook for scripts/gemm_ablate.py (bit 0: skip the in-loop DMA, bit 1: skip the MFMAs,
  * bit 2: skip the epilogue, ...); results are WRONG whenever flags & 1023 != 0.  Bits that keep results correct
  * (A/B timing): 32 the 256x256-tile kernel, 64 no start stagger, 1024 the relaunch-per-tile form instead of the
- * persistent one, 2048 split a sparse last round of tiles into half tiles, 4096 one workgroup per CU. */
+ * persistent one, 2048 split a sparse last round of tiles into half tiles, 4096 one workgroup per CU, 8192 the
+ * deep-ring (5-stage, one workgroup per CU) kernel, 32768 per-CU turn-taking of the main loops, bits 16-21 start delay
+ * of the second co-resident workgroup in ~1K-cycle units. */
 int ivit_debug_set_gemm_flags(int flags);
 /* Diagnostic timeline buffer (8 x uint64 per workgroup) for the stamped build (flags = 512); scripts/gemm_timeline.py */
 int ivit_debug_set_stamp_buffer(void* buf);

@@ -1,0 +1,53 @@
+"""Interleaved A/B timing of GEMM kernel variants (debug flags): every round runs each variant once, in turn, so that clock /
+thermal drift hits all variants alike; reports median and min per variant.  usage: gemm_ab.py [shape ...] -- flag flag ..."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import ivit_amd  # noqa: E402,F401
+from ivit_amd import _lib  # noqa: E402
+
+DEV = "cuda:0"
+M = 197 * 256
+SHAPES = {"qkv": (2304, 768), "proj": (768, 768), "fc1": (3072, 768), "fc2": (768, 3072)}
+args = sys.argv[1:]
+split = args.index("--") if "--" in args else 0
+names = args[:split] or list(SHAPES)
+flags = [int(x) for x in args[split + 1:]] if "--" in args else [0]
+ROUNDS, ITERS = 7, 10
+rng = np.random.default_rng(0)
+for name in names:
+    N, K = SHAPES[name]
+    A = torch.from_numpy(rng.integers(-128, 128, size=(M, K)).astype(np.int8)).to(DEV)
+    W = torch.from_numpy(rng.integers(-128, 128, size=(N, K)).astype(np.int8)).to(DEV)
+    b = torch.zeros(N, dtype=torch.int32, device=DEV)
+    m = torch.full((N,), (1 << 30) + 12345, dtype=torch.int32, device=DEV)
+    e = torch.full((N,), 42, dtype=torch.int32, device=DEV)
+    out = torch.empty(M, N, dtype=torch.int8, device=DEV)
+
+    def run():
+        _lib.call("ivit_gemm_i8_requant", _lib.ptr(A), K, _lib.ptr(W), K, _lib.ptr(b), _lib.ptr(m), _lib.ptr(e), _lib.ptr(out),
+                  N, M, N, K, _lib.stream_ptr())
+    for _ in range(10):
+        run()
+    res = {f: [] for f in flags}
+    for r in range(ROUNDS):
+        for f in (flags if r % 2 == 0 else flags[::-1]):
+            _lib.call("ivit_debug_set_gemm_flags", f)
+            run()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(ITERS):
+                run()
+            e1.record()
+            torch.cuda.synchronize()
+            res[f].append(e0.elapsed_time(e1) / ITERS * 1e3)
+    _lib.call("ivit_debug_set_gemm_flags", 0)
+    for f in flags:
+        v = sorted(res[f])
+        med, mn = v[len(v) // 2], v[0]
+        print(f"{name:5s} flags={f:8d}  median {med:7.1f} us ({2 * M * N * K / med / 1e6:7.1f} TOPS)   min {mn:7.1f} us", flush=True)
