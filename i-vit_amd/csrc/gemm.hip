@@ -141,8 +141,14 @@ IVIT_DEV void epilogue_i8(v16i (&acc)[TI][TJ], const GemmArgs& g, char* smem, co
                         const float a = (float)acc[i][j][4 * q + jj];
                         const int tl = __float_as_int(__builtin_fmaf(a, lo[jj], 12582912.0f));
                         const int th = __float_as_int(__builtin_fmaf(a, hi[jj], 12582912.0f));
-                        unc |= (unsigned)(tl ^ th);
-                        asm volatile("" : "+v"(unc));  // keep the xor/or form (no per-element compare + select)
+                        // unc += |tl - th| in ONE instruction (v_sad_u32): zero iff every certificate of the batch holds.
+                        // tl, th are bit patterns of floats next to 1.5 * 2^23, their differences are tiny: no wrap-around.
+                        if constexpr (ABL & 32) {   // A/B: the former two-instruction form
+                            unc |= (unsigned)(tl ^ th);
+                            asm volatile("" : "+v"(unc));
+                        } else {
+                            asm("v_sad_u32 %0, %1, %2, %3" : "=v"(unc) : "v"(tl), "v"(th), "v"(unc));
+                        }
                         amax = fmaxf(amax, fabsf(a));
                         b[j][jj] = clamp_i32(tl, 0x4B400000 - 128, 0x4B400000 + 127);  // low byte = int8 result
                     }
@@ -832,7 +838,7 @@ IVIT_DEV PersWork pers_work(const GemmArgs& g, int i, int b, int G)
     return PersWork{-1, 0, 0};
 }
 
-template <int EPI>
+template <int EPI, int EABL = 0>
 __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_pers_kernel(GemmArgs g)
 {
     __shared__ __attribute__((aligned(16))) char smem[PERS_SMEM];
@@ -1034,7 +1040,7 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_pers_kernel(GemmArgs g)
             IVIT_DEV void consume() const { if (more) pers_table_write(ld, dst, tid); }
         };
         Hook hook{g, nxt.n0, tid, tab_next, more, PersTableLoad{0u, 0, 0, false}};
-        epilogue_i8<EPI, 2, TJ, (HALF ? 128 : BTOK), BIG_NT, 0, BCH, Hook>(acc, g, smem + BIG_STAGE, tab, cur.m0, cur.n0,
+        epilogue_i8<EPI, 2, TJ, (HALF ? 128 : BTOK), BIG_NT, EABL, BCH, Hook>(acc, g, smem + BIG_STAGE, tab, cur.m0, cur.n0,
                                                                            64 * wc, WTOK * wt, tid, h, l31, hook);
         __syncthreads();   // staging reads done before the next item's stage 1 DMA overwrites buffer 1
     };
@@ -1349,8 +1355,12 @@ int launch_gemm(GemmArgs& g, const char* name, ivit_stream_t stream)
             // equivalent and the former half-main-loop delay (26 / 98 units at K = 768 / 3072) cost 4-8 %: off by default
             g.stagger_units = (g_debug_flags >> 16) & 63;
             const int grid = rounds > 0 ? SLOTS : (split ? 2 * R : R);
-            hipLaunchKernelGGL((gemm_i8_pers_kernel<EPI>), dim3(grid), dim3(BIG_NT), one_per_cu ? 20480 : 0,
-                               ivit_stream(stream), g);
+            if (EPI == EPI_RQ && (g_debug_flags & 16384))   // A/B of epilogue variants (EPI_RQ only)
+                hipLaunchKernelGGL((gemm_i8_pers_kernel<EPI_RQ, 32>), dim3(grid), dim3(BIG_NT), one_per_cu ? 20480 : 0,
+                                   ivit_stream(stream), g);
+            else
+                hipLaunchKernelGGL((gemm_i8_pers_kernel<EPI>), dim3(grid), dim3(BIG_NT), one_per_cu ? 20480 : 0,
+                                   ivit_stream(stream), g);
             IVIT_CHECK_LAUNCH(name);
         }
         if (g.M >= 2048 && g.N >= BCH && !g_force_small) {
