@@ -1,0 +1,311 @@
+// gemm_common.h -- shared pieces of the INT8 GEMM kernels: tile constants, argument block, LDS swizzle, the requantising
+// int8 epilogue and the persistent-kernel helpers.  Included by gemm.hip (the product kernels) and gemm_lab.hip (kernel
+// forms kept for A/B measurement and ablation).
+#pragma once
+#include <type_traits>
+
+#include "common.h"
+
+// test / measurement state set through include/ivit_hip_debug.h (defined in gemm_lab.hip)
+extern int g_kernel_choice;   // 0 = automatic, 1 = never the 256x256 kernel
+extern bool g_force_small;    // route every problem through the small-tile kernel
+extern void* g_stamp_buf;     // timeline buffer of the stamped builds
+extern int g_debug_flags;     // see ivit_debug_set_gemm_flags
+
+namespace {
+
+constexpr int BM = 128;  // tokens per block
+constexpr int BN = 128;  // channels per block
+constexpr int BK = 64;   // K bytes per stage
+constexpr int NT = 256;
+constexpr int STAGE_BYTES = (BM + BN) * BK;  // 16 KiB
+constexpr int W_OFF = BM * BK;               // weight tile behind the token tile
+constexpr int SMEM_BYTES = 2 * STAGE_BYTES;  // 32 KiB >= 128 * 132
+
+enum { EPI_RQ = 0, EPI_RESID = 1, EPI_QKV = 2, EPI_I32 = 3 };
+
+
+struct GemmArgs {
+    const int8_t* A;
+    int64_t lda;
+    const int8_t* W;
+    int64_t ldw;
+    const int32_t* bias;
+    const uint32_t* m;
+    const int32_t* e;
+    void* out;
+    int64_t ldo;
+    const int8_t* res;
+    int64_t ldr;
+    double M_main, M_res;
+    int M, N, K;
+    int tokens, heads, head_dim;
+    int tiles_m, tiles_n;
+    int flags;
+    int stagger;  // number of first-generation blocks subject to the start stagger (0 = off)
+    int cu_turns;       // persistent kernel: 1 = co-resident workgroups alternate main loops through the per-CU token
+    int stagger_units;  // persistent kernel: start delay of the second co-resident workgroup, in s_sleep(16) (~1K cycle) units
+    int split_from;  // persistent kernel: tiles [split_from, tiles_m*tiles_n) are processed as two half tiles each
+};
+
+IVIT_DEV int nk_of(const GemmArgs& g) { return g.K / 64; }
+
+// byte offset of 16-byte chunk c (0..3) of tile row r; rows are 64 B, four rows per 256-B bank row.
+IVIT_DEV int swz(int r, int c) { return r * BK + ((c ^ ((r >> 2) & 3)) << 4); }
+
+IVIT_DEV int pack4_i8(int a, int b, int c, int d)
+{
+    return (a & 0xff) | ((b & 0xff) << 8) | ((c & 0xff) << 16) | ((d & 0xff) << 24);
+}
+
+
+// ---- shared int8 epilogue --------------------------------------------------------------------
+// acc[TI][TJ]: TI channel sub-tiles x TJ token sub-tiles of 32x32 owned by this wave, channel origin
+// `wch`, token origin `wtok` inside a block tile of TOK tokens x 128 channels.
+// Phase 1: per-channel requant -> int8, 4 channels per dword -> LDS tile Cs[token][channel].
+// Phase 2: 16-byte row-contiguous chunks: optional residual QuantAct, optional head-major remap, store.
+// Per-block table of the float32 neighbours (lo, hi) of each channel's requant multiplier, written once at
+// kernel start (one thread per channel); visible to the epilogue through the main loop's barriers.
+IVIT_DEV void fill_rq_table(const GemmArgs& g, char* rq_lds, int n0, int nch, int tid)
+{
+    if (tid < nch) {
+        float2 lh = make_float2(0.f, 0.f);
+        const int c = n0 + tid;
+        if (c < g.N) {
+            const double M = dyadic_mult(g.m[c], g.e[c]);
+            const float mf = (float)M;
+            const double back = (double)mf;
+            const int bits = __float_as_int(mf);
+            lh.x = (back > M) ? __int_as_float(bits - 1) : mf;  // largest float32 <= M
+            lh.y = (back < M) ? __int_as_float(bits + 1) : mf;  // smallest float32 >= M
+        }
+        reinterpret_cast<float2*>(rq_lds)[tid] = lh;
+    }
+}
+
+struct NoHook {
+    IVIT_DEV void issue() const {}
+    IVIT_DEV void consume() const {}
+};
+
+template <int EPI, int TI, int TJ, int TOK, int NTHREADS, int ABL = 0, int CH = 128, typename Hook = NoHook>
+IVIT_DEV void epilogue_i8(v16i (&acc)[TI][TJ], const GemmArgs& g, char* smem, const char* rq_lds, int m0, int n0,
+                          int wch, int wtok, int tid, int h, int l31, const Hook& hook = Hook())
+{
+    // The epilogue is a short VALU burst next to the co-resident workgroup's MFMA stream: give it issue priority
+    // so its dependent chains do not wait behind queued MFMAs (which run in the matrix pipe once issued).
+    __builtin_amdgcn_s_setprio(2);
+    constexpr int CSS = CH + 4;       // LDS row stride: (CH/4 + 1) dwords, odd -> conflict-free dword writes
+    constexpr int CPR = CH / 16;      // 16-byte chunks per row
+    // Phase 1.  out = clamp8(RNE(acc * M)), M = m * 2^-e, must equal the reference's float64
+    // evaluation (quant_utils.py:229-230) bit for bit.  Fast path on the ordinary float32 VALU (the
+    // float64 ops contend with the MFMA pipe): with lo <= M <= hi the two float32 neighbours of M,
+    //   t_lo = fma(acc, lo, 1.5*2^23), t_hi = fma(acc, hi, 1.5*2^23)
+    // are RNE(acc*lo) and RNE(acc*hi) exactly (one rounding, ulp 1), and RNE is monotone, so
+    // t_lo == t_hi certifies RNE(acc*M) -- including exact ties, which straddle and fail the test.
+    // Valid while acc is exact in float32 and |acc*hi| < 2^22 (M <= 1 is part of the contract), i.e.
+    // |acc| < 2^22; anything else, and any failed certificate, takes the float64 path for that quad.
+    const float2* rq = reinterpret_cast<const float2*>(rq_lds);
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int cl = wch + 32 * i + 8 * q + 4 * h;  // local channel of the quad
+            const float4 lh01 = *reinterpret_cast<const float4*>(rq + cl);      // lo0 hi0 lo1 hi1
+            const float4 lh23 = *reinterpret_cast<const float4*>(rq + cl + 2);  // lo2 hi2 lo3 hi3
+            const float lo[4] = {lh01.x, lh01.z, lh23.x, lh23.z};
+            const float hi[4] = {lh01.y, lh01.w, lh23.y, lh23.w};
+            // one branch-free batch of TJ*4 independent chains (instruction-level parallelism: the wave that
+            // runs this shares its SIMD with a main-loop wave, so there is no second VALU wave to hide latency)
+            int b[TJ][4];
+            unsigned unc = 0;      // OR of (t_lo ^ t_hi): non-zero <=> some certificate failed
+            float amax = 0.0f;
+#pragma unroll
+            for (int j = 0; j < TJ; ++j)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    if constexpr (ABL & 8) {
+                        b[j][jj] = acc[i][j][4 * q + jj] + (int)lo[jj];
+                    } else {
+                        const float a = (float)acc[i][j][4 * q + jj];
+                        const int tl = __float_as_int(__builtin_fmaf(a, lo[jj], 12582912.0f));
+                        const int th = __float_as_int(__builtin_fmaf(a, hi[jj], 12582912.0f));
+                        // unc += |tl - th| in ONE instruction (v_sad_u32): zero iff every certificate of the batch holds.
+                        // tl, th are bit patterns of floats next to 1.5 * 2^23, their differences are tiny: no wrap-around.
+                        if constexpr (ABL & 32) {   // A/B: the former two-instruction form
+                            unc |= (unsigned)(tl ^ th);
+                            asm volatile("" : "+v"(unc));
+                        } else {
+                            asm("v_sad_u32 %0, %1, %2, %3" : "=v"(unc) : "v"(tl), "v"(th), "v"(unc));
+                        }
+                        amax = fmaxf(amax, fabsf(a));
+                        b[j][jj] = clamp_i32(tl, 0x4B400000 - 128, 0x4B400000 + 127);  // low byte = int8 result
+                    }
+                }
+            if constexpr (!(ABL & 8)) {
+                const bool bad = (unc != 0) | (amax >= 4194304.0f);
+                if (__builtin_amdgcn_ballot_w64(bad) != 0) {  // rare: exact float64 evaluation of the batch
+                    const int c0 = min(n0 + cl, g.N - 4);
+                    const uint4 m4 = *reinterpret_cast<const uint4*>(g.m + c0);
+                    const int4 e4 = *reinterpret_cast<const int4*>(g.e + c0);
+                    const double Mc[4] = {dyadic_mult(m4.x, e4.x), dyadic_mult(m4.y, e4.y), dyadic_mult(m4.z, e4.z),
+                                          dyadic_mult(m4.w, e4.w)};
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j)
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) {
+                            // quant_utils.py:229-230: float64 product (53-bit rounding), /2^e, round-half-even
+                            double p = (double)acc[i][j][4 * q + jj] * Mc[jj];
+                            double t = p + IVIT_MAGIC;
+                            b[j][jj] = clamp_i32((int)(unsigned)__double_as_longlong(t), -128, 127);
+                        }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                const int tl_ = wtok + 32 * j + l31;
+                const unsigned w01 = __builtin_amdgcn_perm((unsigned)b[j][1], (unsigned)b[j][0], 0x0c0c0400u);
+                const unsigned w23 = __builtin_amdgcn_perm((unsigned)b[j][3], (unsigned)b[j][2], 0x04000c0cu);
+                *reinterpret_cast<unsigned*>(smem + tl_ * CSS + cl) = w01 | w23;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    unsigned long long t_p1 = 0, t_sync = 0;
+    if constexpr (ABL & 512) t_p1 = __builtin_amdgcn_s_memtime();
+    __syncthreads();
+    if constexpr (ABL & 512) {
+        t_sync = __builtin_amdgcn_s_memtime();
+        if (tid == 0 && g.res != nullptr) {
+            unsigned long long* d = reinterpret_cast<unsigned long long*>(const_cast<int8_t*>(g.res)) + 8ull * blockIdx.x;
+            d[4] = t_p1; d[5] = t_sync;
+        }
+    }
+    if constexpr (ABL & 16) return;
+
+    int8_t* out = reinterpret_cast<int8_t*>(g.out);
+    constexpr int NIT = TOK * CPR / NTHREADS;
+    int v[NIT][4];
+    int4 rv[NIT];
+    hook.issue();    // persistent kernel: next tile's table loads go out before this tile's stores
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int q = tid + NTHREADS * it;
+        const int tl = q / CPR, cc = q % CPR;
+        const int* src = reinterpret_cast<const int*>(smem + tl * CSS + 16 * cc);
+        v[it][0] = src[0]; v[it][1] = src[1]; v[it][2] = src[2]; v[it][3] = src[3];
+        if constexpr (EPI == EPI_RESID) {
+            const int t = min(m0 + tl, g.M - 1), cn = min(n0 + 16 * cc, g.N - 16);
+            rv[it] = *reinterpret_cast<const int4*>(g.res + (int64_t)t * g.ldr + cn);
+        }
+    }
+    hook.consume();
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int q = tid + NTHREADS * it;
+        const int tl = q / CPR, cc = q % CPR;
+        const int t = m0 + tl, cn = n0 + 16 * cc;
+        if (t >= g.M || cn >= g.N) continue;
+        if constexpr (EPI == EPI_RESID) {
+            const int rr[4] = {rv[it].x, rv[it].y, rv[it].z, rv[it].w};
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                int o[4];
+#pragma unroll
+                for (int bb = 0; bb < 4; ++bb) {
+                    int k3 = (int)(int8_t)(v[it][d] >> (8 * bb));
+                    int xr = (int)(int8_t)(rr[d] >> (8 * bb));
+                    // quant_utils.py:229-245: two independently rounded products, then the sum
+                    int sres = requant_exact(k3, g.M_main) + requant_exact(xr, g.M_res);
+                    o[bb] = clamp_i32(sres, -128, 127);
+                }
+                v[it][d] = pack4_i8(o[0], o[1], o[2], o[3]);
+            }
+        }
+        int64_t off;
+        if constexpr (EPI == EPI_QKV) {
+            const int cdim = g.heads * g.head_dim;
+            const int which = cn / cdim, rem = cn - which * cdim;
+            const int hh = rem / g.head_dim, d0 = rem - hh * g.head_dim;
+            const int b = t / g.tokens, tok = t - b * g.tokens;
+            const int nb = g.M / g.tokens;
+            off = ((((int64_t)which * nb + b) * g.heads + hh) * g.tokens + tok) * g.head_dim + d0;
+        } else {
+            off = (int64_t)t * g.ldo + cn;
+        }
+        *reinterpret_cast<int4*>(out + off) = make_int4(v[it][0], v[it][1], v[it][2], v[it][3]);
+    }
+}
+
+// ---- 256 x 128 LDS-DMA tiles (persistent kernel, relaunch form, deep-ring form)
+constexpr int BTOK = 256, BCH = 128, BIG_NT = 256, BIG_STAGES = 3;
+constexpr int BIG_A_BYTES = BTOK * BK;                 // 16 KiB
+constexpr int BIG_STAGE = (BTOK + BCH) * BK;           // 24 KiB
+constexpr int BIG_SMEM = BIG_STAGES * BIG_STAGE;       // 72 KiB  (>= 256 * 132 epilogue tile)
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// ---- persistent-kernel helpers
+constexpr int PT_OFF = BIG_SMEM;          // tables: 2 x { float2 lohi[128]; int bias[128] }
+constexpr int PT_BYTES = BCH * 12;
+constexpr int PERS_SMEM = BIG_SMEM + 2 * PT_BYTES;
+
+struct PersTile {
+    int m0, n0;
+};
+
+IVIT_DEV PersTile pers_tile(const GemmArgs& g, int t)
+{
+    const int nblk = g.tiles_m * g.tiles_n;
+    const int q8 = nblk >> 3, r8 = nblk & 7, xcd = t & 7;
+    const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (t >> 3);
+    const int tm = lid / g.tiles_n, tn = lid - tm * g.tiles_n;
+    return PersTile{tm * BTOK, tn * BCH};
+}
+
+// loads of one channel's table entry (issued early, consumed later)
+struct PersTableLoad {
+    unsigned m;
+    int e, bias;
+    bool valid;
+};
+
+IVIT_DEV PersTableLoad pers_table_issue(const GemmArgs& g, int n0, int tid)
+{
+    PersTableLoad r{0u, 0, 0, false};
+    const int c = n0 + tid;
+    if (tid < BCH && c < g.N) {
+        r.m = g.m[c];
+        r.e = g.e[c];
+        r.bias = g.bias ? g.bias[c] : 0;
+        r.valid = true;
+    }
+    return r;
+}
+
+IVIT_DEV void pers_table_write(const PersTableLoad& r, char* tab, int tid)
+{
+    if (tid < BCH) {
+        float2 lh = make_float2(0.f, 0.f);
+        if (r.valid) {
+            const double M = dyadic_mult(r.m, r.e);
+            const float mf = (float)M;
+            const int bits = __float_as_int(mf);
+            lh.x = ((double)mf > M) ? __int_as_float(bits - 1) : mf;
+            lh.y = ((double)mf < M) ? __int_as_float(bits + 1) : mf;
+        }
+        reinterpret_cast<float2*>(tab)[tid] = lh;
+        reinterpret_cast<int*>(tab + BCH * 8)[tid] = r.bias;
+    }
+}
+
+// Work items of one workgroup.  The launch has G workgroups (2 per CU); tile t < split_from belongs to workgroup
+// t % G.  If the last round of full tiles would be at most half full (R = F mod G tiles, 2R <= G), those R tiles are
+// split into 2R half tiles of 128 tokens, one per workgroup 0 .. 2R-1, so the tail costs half a tile time instead of a
+// whole one (DeiT-B, N = 768: 1182 tiles on 512 workgroups = 2.31 rounds -> 2.5 instead of 3).
+
+}  // namespace
+
+// kernel forms of gemm_lab.hip: returns 1 if `g_debug_flags` selected one of them and it was launched (status in *rc)
+int ivit_gemm_lab_launch(int epi, void* gemm_args, const char* name, ivit_stream_t stream, int* rc);

@@ -1,0 +1,691 @@
+// gemm_lab.hip -- forms of the large INT8 GEMM kernel that are NOT on the product path: kept, bit-identical, for A/B
+// measurement and ablation through include/ivit_hip_debug.h (scripts/gemm_ablate.py, gemm_ab.py, gemm_timeline.py,
+// ring_timeline.py; tests/test_gpu_ops.py::test_gemm_both_kernels_agree).  See DESIGN.md section 5 for what each taught.
+#include "gemm_common.h"
+
+int g_kernel_choice = 0;
+bool g_force_small = false;
+void* g_stamp_buf = nullptr;
+int g_debug_flags = 0;   // bits: see include/ivit_hip_debug.h
+
+namespace {
+
+// ================================================================================================
+// Large-problem kernel: block tile 256 tokens x 128 channels x 64 K-bytes, 4 waves (2 x 2, each
+// 64 channels x 128 tokens = 2 x 4 MFMA tiles, 128 accumulator registers), THREE LDS stages filled by
+// LDS-DMA (global_load_lds_dwordx4: no staging registers), one raw s_barrier per K step with a
+// counted vmcnt so the next stage's DMA stays in flight across it.  72 KiB LDS and <= 256 registers
+// give two workgroups per CU: one block's requant epilogue (VALU/float64 pipe) overlaps the other's
+// MFMA main loop.  LDS images are lane-linear per DMA instruction (16 rows x 64 B); the bank swizzle
+// is applied on the per-lane SOURCE address and again on the fragment read.
+// ================================================================================================
+template <int EPI, int ABL>
+__global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_big_kernel(GemmArgs g)
+{
+    __shared__ __attribute__((aligned(16))) char smem[BIG_SMEM + BCH * 8];
+    unsigned long long t_start = 0, t_loop = 0, t_epi = 0, r_start = 0;
+    if constexpr (ABL & 512) {
+        t_start = __builtin_amdgcn_s_memtime();
+        r_start = __builtin_amdgcn_s_memrealtime();
+    }
+
+    const int nblk = g.tiles_m * g.tiles_n;
+    const int bid = blockIdx.x;
+    const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
+    const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int tm = lid / g.tiles_n, tn = lid - tm * g.tiles_n;
+    const int m0 = tm * BTOK, n0 = tn * BCH;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wc = wave >> 1, wt = wave & 1;
+    const int h = lane >> 5, l31 = lane & 31;
+
+    // ---- LDS-DMA sources: instruction q covers tile rows 16q..16q+15 (1 KiB); lane -> row 16q + lane/4,
+    // stored slot lane%4 holds global chunk (lane%4) ^ ((row>>2)&3)
+    const int8_t* asrc[4];
+    const int8_t* wsrc[2];
+    const int lrow = lane >> 2, lslot = lane & 3;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int row = 16 * (wave + 4 * i) + lrow;
+        int c = lslot ^ ((row >> 2) & 3);
+        asrc[i] = g.A + (int64_t)min(m0 + row, g.M - 1) * g.lda + 16 * c;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int row = 16 * (wave + 4 * i) + lrow;
+        int c = lslot ^ ((row >> 2) & 3);
+        wsrc[i] = g.W + (int64_t)min(n0 + row, g.N - 1) * g.ldw + 16 * c;
+    }
+
+    const int nk = g.K / BK;
+    // DMA piece `idx` (0..3: token tile, 4..5: weight tile) of K step kt
+    auto issue_one = [&](int kt, int idx) {
+        char* base = smem + (kt % BIG_STAGES) * BIG_STAGE;
+        const int koff = kt * BK;
+        if (idx < 4)
+            __builtin_amdgcn_global_load_lds((gptr_t)(asrc[idx] + koff), (lptr_t)(base + 1024 * (wave + 4 * idx)), 16, 0,
+                                             0);
+        else
+            __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[idx - 4] + koff),
+                                             (lptr_t)(base + BIG_A_BYTES + 1024 * (wave + 4 * (idx - 4))), 16, 0, 0);
+    };
+    auto issue = [&](int kt) {
+#pragma unroll
+        for (int idx = 0; idx < 6; ++idx) issue_one(kt, idx);
+    };
+
+    // Two workgroups share a CU (one wave of each per SIMD).  Launched together they would run in
+    // lockstep -- both in the MFMA main loop, then both in the VALU/float64 epilogue -- and the two
+    // pipes would never overlap.  Stagger the first generation: the workgroup that landed in the odd
+    // wave slot of its SIMD sleeps for about half a main loop, so that from then on one workgroup's
+    // epilogue runs under the other's MFMAs.  Later generations inherit the phase shift.  (Speed only.)
+    if (g.stagger && blockIdx.x < (unsigned)g.stagger) {
+        const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1u;  // HW_ID.wave_id[0]
+        if (slot)
+            for (int it = 0; it < (nk_of(g) + 1) / 2; ++it) __builtin_amdgcn_s_sleep(64);
+    }
+    // Start the DMA ring first, then fetch the bias / requant tables under its latency.  The ordinary loads'
+    // results are consumed right here, where a full vmcnt(0) drain (which also retires both stages) is wanted
+    // anyway; no ordinary load remains in flight once the main loop starts.
+    issue(0);
+    if (nk > 1) issue(1);
+    fill_rq_table(g, smem + BIG_SMEM, n0, BCH, tid);
+    v16i acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c0 = n0 + 64 * wc + 32 * i + 8 * q + 4 * h;   // 4 consecutive channels of this register quad
+            int4 b4 = make_int4(0, 0, 0, 0);
+            if (g.bias != nullptr && c0 < g.N) b4 = *reinterpret_cast<const int4*>(g.bias + c0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[i][j][4 * q + 0] = b4.x;
+                acc[i][j][4 * q + 1] = b4.y;
+                acc[i][j][4 * q + 2] = b4.z;
+                acc[i][j][4 * q + 3] = b4.w;
+            }
+        }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    const int wrow0 = 64 * wc + l31, arow0 = 128 * wt + l31;
+    // fragment byte offsets inside a stage for k-sub-step 0 / 1 (the swizzle depends on the row only)
+    int woff[2][2], aoff[2][4];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) woff[ks][i] = BIG_A_BYTES + swz(wrow0 + 32 * i, 2 * ks + h);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) aoff[ks][j] = swz(arow0 + 32 * j, 2 * ks + h);
+    }
+    v4i wf0[2], af0[4], wf1[2], af1[4];
+    bool frags_once = false;
+    auto load_frags = [&](const char* st, int ks, v4i (&wf)[2], v4i (&af)[4]) {
+        if constexpr (ABL & 128) {
+            if (frags_once) return;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) wf[i] = *reinterpret_cast<const v4i*>(st + woff[ks][i]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) af[j] = *reinterpret_cast<const v4i*>(st + aoff[ks][j]);
+    };
+
+    // Pipeline (3 LDS stages, fragments double-buffered in registers):
+    //   iteration kt:  read frags(kt, ks=1) | MFMA on frags(kt, ks=0) interleaved with the DMA of stage kt+2
+    //                  wait own DMA of stage kt+1 + own LDS reads | barrier B_kt
+    //                  read frags(kt+1, ks=0) | MFMA on frags(kt, ks=1)
+    // RAW: stage kt+1 is read only after B_kt, which every wave reaches after its counted vmcnt.
+    // WAR: the DMA of stage kt+2 overwrites the buffer of stage kt-1; it is issued after B_{kt-1}, and
+    //      every wave waited lgkmcnt(0) (all its reads of stage kt-1 returned) before B_{kt-1}.
+    auto step = [&](int kt, auto dma_tag, auto last_tag) {
+        constexpr bool DMA = decltype(dma_tag)::value && !(ABL & 1);
+        constexpr bool LAST = decltype(last_tag)::value;
+        const char* st = smem + (kt % BIG_STAGES) * BIG_STAGE;
+        load_frags(st, 1, wf1, af1);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if constexpr (!(ABL & 2))
+                    acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf0[i], af0[j], acc[i][j], 0, 0, 0);
+                else
+                    asm volatile("" ::"v"(wf0[i]), "v"(af0[j]));
+                if constexpr (DMA)
+                    if (4 * i + j < 6) issue_one(kt + 2, 4 * i + j);
+            }
+        if constexpr (!(ABL & 256)) {
+            if constexpr (decltype(dma_tag)::value) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+        if constexpr (!LAST) load_frags(smem + ((kt + 1) % BIG_STAGES) * BIG_STAGE, 0, wf0, af0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if constexpr (!(ABL & 2))
+                    acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf1[i], af1[j], acc[i][j], 0, 0, 0);
+                else
+                    asm volatile("" ::"v"(wf1[i]), "v"(af1[j]));
+            }
+    };
+    using T = std::true_type;
+    using F = std::false_type;
+
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    load_frags(smem, 0, wf0, af0);
+    if constexpr (ABL & 128) {
+        load_frags(smem, 1, wf1, af1);
+        frags_once = true;
+    }
+    int kt = 0;
+    for (; kt + 2 < nk; ++kt) step(kt, T{}, F{});
+    if (kt + 1 < nk) { step(kt, F{}, F{}); ++kt; }
+    step(kt, F{}, T{});
+    __syncthreads();  // every wave is done with the last stage before the tile is reused
+    if constexpr (ABL & 512) t_loop = __builtin_amdgcn_s_memtime();
+    if constexpr (ABL & 4) {
+        int x = 0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) x ^= acc[i][j][r];
+        if (x == 0x7fffffff) reinterpret_cast<int*>(g.out)[tid] = x;
+        return;
+    }
+    epilogue_i8<EPI, 2, 4, BTOK, BIG_NT, ABL>(acc, g, smem, smem + BIG_SMEM, m0, n0, 64 * wc, 128 * wt, tid, h, l31);
+    if constexpr (ABL & 512) {   // diagnostic build only: per-workgroup timeline into a buffer nothing else reads
+        t_epi = __builtin_amdgcn_s_memtime();
+        if (tid == 0 && g.res != nullptr) {
+            unsigned long long* d = reinterpret_cast<unsigned long long*>(const_cast<int8_t*>(g.res)) + 8ull * blockIdx.x;
+            d[0] = __builtin_amdgcn_s_getreg((15 << 11) | (0 << 6) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) << 32);
+            d[1] = t_start; d[2] = t_loop; d[3] = t_epi;
+            d[6] = r_start; d[7] = __builtin_amdgcn_s_memrealtime();
+        }
+    }
+}
+
+// ================================================================================================
+// XL kernel: block tile 256 tokens x 256 channels x 64 K-bytes, 8 waves (4 channel groups x 2 token
+// groups, each 64 channels x 128 tokens = 2 x 4 MFMA tiles), FOUR LDS stages of 32 KiB filled by
+// LDS-DMA.  With int8 MFMAs the L2 -> LDS stream is the scarce resource and it is latency bound
+// (~1 us per piece under load): the tile moves the fewest bytes per MAC (0.0078 B) and the four-deep
+// ring keeps up to three stages (96 KiB per CU) in flight at all times.  One workgroup per CU.
+//   iteration kt:  read F(kt, ks=1) | MFMA F(kt, ks=0) interleaved with the 4 DMA pieces of stage kt+3
+//                  counted vmcnt: own pieces of stage kt+1 landed | lgkmcnt(0) | barrier B_kt
+//                  read F(kt+1, ks=0) | MFMA F(kt, ks=1)
+// RAW: stage kt+1 is read only after B_kt.  WAR: stage kt+3 reuses the buffer of stage kt-1, whose
+// reads every wave completed (lgkmcnt(0)) before B_{kt-1}; the DMA is issued after B_{kt-1}.
+// ================================================================================================
+constexpr int XTOK = 256, XCH = 256, XL_NT = 512, XL_STAGES = 4;
+constexpr int XL_A_BYTES = XTOK * BK;             // 16 KiB
+constexpr int XL_STAGE = (XTOK + XCH) * BK;       // 32 KiB
+constexpr int XL_SMEM = XL_STAGES * XL_STAGE;     // 128 KiB (>= 256 * 260 epilogue tile)
+
+template <int EPI, int ABL>
+__global__ __launch_bounds__(XL_NT, 2) void gemm_i8_xl_kernel(GemmArgs g)
+{
+    __shared__ __attribute__((aligned(16))) char smem[XL_SMEM + XCH * 8];
+
+    const int nblk = g.tiles_m * g.tiles_n;
+    const int bid = blockIdx.x;
+    const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
+    const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int tm = lid / g.tiles_n, tn = lid - tm * g.tiles_n;
+    const int m0 = tm * XTOK, n0 = tn * XCH;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wc = wave >> 1, wt = wave & 1;  // 4 x 2
+    const int h = lane >> 5, l31 = lane & 31;
+    fill_rq_table(g, smem + XL_SMEM, n0, XCH, tid);
+
+    // ---- LDS-DMA sources: piece q covers tile rows 16q..16q+15 (1 KiB); lane -> row 16q + lane/4, stored
+    // slot lane%4 holds global chunk (lane%4) ^ ((row>>2)&3).  Wave w owns pieces w and w + 8 of each tile.
+    const int8_t* asrc[2];
+    const int8_t* wsrc[2];
+    const int lrow = lane >> 2, lslot = lane & 3;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int row = 16 * (wave + 8 * i) + lrow;
+        int c = lslot ^ ((row >> 2) & 3);
+        asrc[i] = g.A + (int64_t)min(m0 + row, g.M - 1) * g.lda + 16 * c;
+        wsrc[i] = g.W + (int64_t)min(n0 + row, g.N - 1) * g.ldw + 16 * c;
+    }
+
+    v16i acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int cn = n0 + 64 * wc + 32 * i + 8 * (r >> 2) + 4 * h + (r & 3);
+            int b = (g.bias != nullptr && cn < g.N) ? g.bias[cn] : 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j][r] = b;
+        }
+
+    const int nk = g.K / BK;
+    auto issue_one = [&](int kt, int idx) {
+        char* base = smem + (kt % XL_STAGES) * XL_STAGE;
+        const int koff = kt * BK;
+        if (idx < 2)
+            __builtin_amdgcn_global_load_lds((gptr_t)(asrc[idx] + koff), (lptr_t)(base + 1024 * (wave + 8 * idx)), 16, 0,
+                                             0);
+        else
+            __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[idx - 2] + koff),
+                                             (lptr_t)(base + XL_A_BYTES + 1024 * (wave + 8 * (idx - 2))), 16, 0, 0);
+    };
+    auto issue = [&](int kt) {
+        if constexpr (!(ABL & 1)) {
+#pragma unroll
+            for (int idx = 0; idx < 4; ++idx) issue_one(kt, idx);
+        }
+    };
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // bias / table loads retired before the DMA pipeline starts
+    issue(0);
+    if (nk > 1) issue(1);
+    if (nk > 2) issue(2);
+
+    const int wrow0 = 64 * wc + l31, arow0 = 128 * wt + l31;
+    int woff[2][2], aoff[2][4];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) woff[ks][i] = XL_A_BYTES + swz(wrow0 + 32 * i, 2 * ks + h);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) aoff[ks][j] = swz(arow0 + 32 * j, 2 * ks + h);
+    }
+    v4i wf0[2], af0[4], wf1[2], af1[4];
+    auto load_frags = [&](const char* st, int ks, v4i (&wf)[2], v4i (&af)[4]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) wf[i] = *reinterpret_cast<const v4i*>(st + woff[ks][i]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) af[j] = *reinterpret_cast<const v4i*>(st + aoff[ks][j]);
+    };
+    // VM = number of this wave's DMA pieces allowed to stay in flight at the barrier (the stages after kt+1)
+    auto step = [&](int kt, auto dma_tag, auto vm_tag, auto last_tag) {
+        constexpr bool DMA = decltype(dma_tag)::value && !(ABL & 1);
+        constexpr int VM = decltype(vm_tag)::value;
+        constexpr bool LAST = decltype(last_tag)::value;
+        const char* st = smem + (kt % XL_STAGES) * XL_STAGE;
+        load_frags(st, 1, wf1, af1);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if constexpr (!(ABL & 2))
+                    acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf0[i], af0[j], acc[i][j], 0, 0, 0);
+                else
+                    asm volatile("" ::"v"(wf0[i]), "v"(af0[j]));
+                if constexpr (DMA)
+                    if (((4 * i + j) & 1) == 0 && (4 * i + j) < 8) issue_one(kt + 3, (4 * i + j) >> 1);
+            }
+        if constexpr (VM == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        else if constexpr (VM == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if constexpr (!LAST) load_frags(smem + ((kt + 1) % XL_STAGES) * XL_STAGE, 0, wf0, af0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if constexpr (!(ABL & 2))
+                    acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf1[i], af1[j], acc[i][j], 0, 0, 0);
+                else
+                    asm volatile("" ::"v"(wf1[i]), "v"(af1[j]));
+            }
+    };
+    using T = std::true_type;
+    using F = std::false_type;
+    using V8 = std::integral_constant<int, 8>;
+    using V4 = std::integral_constant<int, 4>;
+    using V0 = std::integral_constant<int, 0>;
+
+    // stage 0 landed: everything issued after it may stay in flight
+    if (nk > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    load_frags(smem, 0, wf0, af0);
+    int kt = 0;
+    for (; kt + 3 < nk; ++kt) step(kt, T{}, V8{}, F{});
+    if (kt + 2 < nk) { step(kt, F{}, V4{}, F{}); ++kt; }
+    if (kt + 1 < nk) { step(kt, F{}, V0{}, F{}); ++kt; }
+    step(kt, F{}, V0{}, T{});
+
+    __syncthreads();
+    if constexpr (ABL & 4) {
+        int x = 0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) x ^= acc[i][j][r];
+        if (x == 0x7fffffff) reinterpret_cast<int*>(g.out)[tid] = x;
+        return;
+    }
+    epilogue_i8<EPI, 2, 4, XTOK, XL_NT, ABL, XCH>(acc, g, smem, smem + XL_SMEM, m0, n0, 64 * wc, 128 * wt, tid, h, l31);
+}
+
+// ================================================================================================
+// Deep-ring form: ONE workgroup per CU (4 waves, wave tile 64 ch x 128 tok as above) with a FIVE-stage LDS ring
+// (120 KiB), so that up to four stages (96 KiB) of LDS-DMA are in flight per CU.  Rationale: the
+// global->LDS path has a latency of more than two K steps; with three stages per workgroup a stage is awaited one
+// step after it was issued and every step waits for the DMA.  Here a stage is issued four steps before it is
+// consumed, and the first four stages of the NEXT tile are issued before this tile's epilogue (which has its own
+// staging area), so the main loop of a tile starts on data that has already landed.
+// ================================================================================================
+constexpr int RING_STAGES = 5;
+constexpr int RING_BYTES = RING_STAGES * BIG_STAGE;            // 120 KiB
+constexpr int RING_EPI_OFF = RING_BYTES;                        // 256 x 132 B int8 staging tile
+constexpr int RING_EPI_BYTES = BTOK * (BCH + 4);
+constexpr int RING_PT_OFF = RING_EPI_OFF + RING_EPI_BYTES;      // 2 x table
+constexpr int RING_SMEM = RING_PT_OFF + 2 * PT_BYTES;           // 159 744 B <= 160 KiB
+
+template <int EPI>
+__global__ __launch_bounds__(BIG_NT, 1) void gemm_i8_ring_kernel(GemmArgs g)
+{
+    __shared__ __attribute__((aligned(16))) char smem[RING_SMEM];
+    static_assert(RING_SMEM <= 160 * 1024, "LDS budget");
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wc = wave >> 1, wt = wave & 1;
+    const int h = lane >> 5, l31 = lane & 31;
+    const int lrow = lane >> 2, lslot = lane & 3;
+    const int nk = g.K / BK;
+    const int ntiles = g.tiles_m * g.tiles_n;
+    using T = std::true_type;
+    using F = std::false_type;
+
+    const int8_t* asrc[4];
+    const int8_t* wsrc[2];
+    auto set_sources = [&](const PersTile& t) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int row = 16 * (wave + 4 * i) + lrow;
+            int c = lslot ^ ((row >> 2) & 3);
+            asrc[i] = g.A + (int64_t)min(t.m0 + row, g.M - 1) * g.lda + 16 * c;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int row = 16 * (wave + 4 * i) + lrow;
+            int c = lslot ^ ((row >> 2) & 3);
+            wsrc[i] = g.W + (int64_t)min(t.n0 + row, g.N - 1) * g.ldw + 16 * c;
+        }
+    };
+    // DMA piece `idx` (0..3 token tile, 4..5 weight tile) of K step kt into ring buffer kt % RING_STAGES
+    auto issue_one = [&](int kt, int idx) {
+        char* base = smem + (kt % RING_STAGES) * BIG_STAGE;
+        const int koff = kt * BK;
+        if (idx < 4)
+            __builtin_amdgcn_global_load_lds((gptr_t)(asrc[idx] + koff), (lptr_t)(base + 1024 * (wave + 4 * idx)), 16, 0,
+                                             0);
+        else
+            __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[idx - 4] + koff),
+                                             (lptr_t)(base + BIG_A_BYTES + 1024 * (wave + 4 * (idx - 4))), 16, 0, 0);
+    };
+    auto issue = [&](int kt) {
+#pragma unroll
+        for (int idx = 0; idx < 6; ++idx) issue_one(kt, idx);
+    };
+
+    const unsigned smem_base = (unsigned)(__UINTPTR_TYPE__)(lptr_t)smem;
+    const int wrow0 = 64 * wc + l31, arow0 = 128 * wt + l31;
+    const unsigned wbase[2] = {smem_base + (unsigned)(BIG_A_BYTES + swz(wrow0, h)),
+                               smem_base + (unsigned)(BIG_A_BYTES + swz(wrow0, 2 + h))};
+    const unsigned abase[2] = {smem_base + (unsigned)swz(arow0, h), smem_base + (unsigned)swz(arow0, 2 + h)};
+    v4i wf0[2], af0[4], wf1[2], af1[4];
+    auto load_frags = [&](unsigned stage_off, int ks, v4i (&wf)[2], v4i (&af)[4]) {
+        const unsigned wa = wbase[ks] + stage_off, aa = abase[ks] + stage_off;
+        asm volatile("ds_read_b128 %0, %1" : "=v"(wf[0]) : "v"(wa));
+        asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(wf[1]) : "v"(wa));
+        asm volatile("ds_read_b128 %0, %1" : "=v"(af[0]) : "v"(aa));
+        asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(af[1]) : "v"(aa));
+        asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(af[2]) : "v"(aa));
+        asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(af[3]) : "v"(aa));
+    };
+#define RING_TIE(wf, af) "+v"(wf[0]), "+v"(wf[1]), "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3])
+    v16i acc[2][4];
+    // One K step.  AHEAD = number of later stages whose DMA may still be in flight when this step ends (each stage is
+    // 6 pieces per wave): the counted vmcnt leaves exactly those outstanding, i.e. stage kt+1 has landed.
+    // ISSUE: this step also issues the DMA of stage kt + RING_STAGES - 1 into the buffer freed by the previous step.
+    auto step = [&](int kt, auto issue_tag, auto ahead_tag, auto last_tag) {
+        constexpr bool ISSUE = decltype(issue_tag)::value;
+        constexpr int AHEAD = decltype(ahead_tag)::value;
+        constexpr bool LAST = decltype(last_tag)::value;
+        load_frags((unsigned)((kt % RING_STAGES) * BIG_STAGE), 1, wf1, af1);
+        asm volatile("s_waitcnt lgkmcnt(6)" : RING_TIE(wf0, af0)::"memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf0[i], af0[j], acc[i][j], 0, 0, 0);
+                if constexpr (ISSUE)
+                    if (4 * i + j < 6) issue_one(kt + RING_STAGES - 1, 4 * i + j);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (AHEAD == 3) asm volatile("s_waitcnt vmcnt(18) lgkmcnt(0)" : RING_TIE(wf1, af1)::"memory");
+        else if constexpr (AHEAD == 2) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" : RING_TIE(wf1, af1)::"memory");
+        else if constexpr (AHEAD == 1) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" : RING_TIE(wf1, af1)::"memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : RING_TIE(wf1, af1)::"memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if constexpr (!LAST) load_frags((unsigned)(((kt + 1) % RING_STAGES) * BIG_STAGE), 0, wf0, af0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf1[i], af1[j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    using A0 = std::integral_constant<int, 0>;
+    using A1 = std::integral_constant<int, 1>;
+    using A2 = std::integral_constant<int, 2>;
+    using A3 = std::integral_constant<int, 3>;
+    // issue the first min(nk, RING_STAGES - 1) stages of a tile
+    auto prefetch_head = [&]() {
+        const int nh = nk < RING_STAGES - 1 ? nk : RING_STAGES - 1;
+        for (int kt = 0; kt < nh; ++kt) issue(kt);
+    };
+
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    PersTile cur = pers_tile(g, tile);
+    {
+        PersTableLoad tl = pers_table_issue(g, cur.n0, tid);
+        pers_table_write(tl, smem + RING_PT_OFF, tid);
+    }
+    set_sources(cur);
+    prefetch_head();
+
+    for (int it = 0; tile < ntiles; ++it, tile += gridDim.x) {
+        char* tab = smem + RING_PT_OFF + (it & 1) * PT_BYTES;
+        char* tab_next = smem + RING_PT_OFF + ((it + 1) & 1) * PT_BYTES;
+        // The head stages of this tile were issued before the previous epilogue (or just above): wait for stage 0.
+        // Everything older (the previous tile's stores included) is allowed to drain with it.
+        {
+            const int nh = nk < RING_STAGES - 1 ? nk : RING_STAGES - 1;   // stages in flight now
+            // one stage stricter than needed: the previous epilogue's stores are younger than these pieces and may retire
+            // out of order with respect to loads, so do not let them stand in for DMA pieces in the count
+            if (nh >= 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else if (nh == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int4 b4 = *reinterpret_cast<const int4*>(tab + BCH * 8 + 4 * (64 * wc + 32 * i + 8 * q + 4 * h));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[i][j][4 * q + 0] = b4.x;
+                    acc[i][j][4 * q + 1] = b4.y;
+                    acc[i][j][4 * q + 2] = b4.z;
+                    acc[i][j][4 * q + 3] = b4.w;
+                }
+            }
+        load_frags(0u, 0, wf0, af0);
+        // steps that still issue a stage (kt + 4 < nk), then the drain: 3, 2, 1, 0 later stages in flight
+        int kt = 0;
+        for (; kt + RING_STAGES - 1 < nk; ++kt) step(kt, T{}, A3{}, F{});
+        if (kt + 3 < nk) { step(kt, F{}, A2{}, F{}); ++kt; }
+        if (kt + 2 < nk) { step(kt, F{}, A1{}, F{}); ++kt; }
+        if (kt + 1 < nk) { step(kt, F{}, A0{}, F{}); ++kt; }
+        step(kt, F{}, A0{}, T{});
+        __syncthreads();   // all waves are done with every ring buffer
+
+        // ---- head of the next tile into the (now free) ring, then this tile's epilogue from its own staging area
+        const int next = tile + gridDim.x;
+        const bool more = next < ntiles;   // uniform
+        PersTile nxt = cur;
+        if (more) {
+            nxt = pers_tile(g, next);
+            set_sources(nxt);
+            prefetch_head();
+        }
+        struct Hook {
+            const GemmArgs& g;
+            int n0, tid;
+            char* dst;
+            bool more;
+            mutable PersTableLoad ld;
+            IVIT_DEV void issue() const { if (more) ld = pers_table_issue(g, n0, tid); }
+            IVIT_DEV void consume() const { if (more) pers_table_write(ld, dst, tid); }
+        };
+        Hook hook{g, nxt.n0, tid, tab_next, more, PersTableLoad{0u, 0, 0, false}};
+        epilogue_i8<EPI, 2, 4, BTOK, BIG_NT, 0, BCH, Hook>(acc, g, smem + RING_EPI_OFF, tab, cur.m0, cur.n0, 64 * wc,
+                                                          128 * wt, tid, h, l31, hook);
+        cur = nxt;
+        __syncthreads();   // staging tile and table free for the next round
+    }
+#undef RING_TIE
+}
+
+template <int EPI>
+int launch_lab(GemmArgs& g, const char* name, ivit_stream_t stream, int* handled)
+{
+    *handled = 1;
+    if constexpr (EPI != EPI_I32) {
+        if (g.M >= 2048 && g.N % XCH == 0 && !g_force_small && g_kernel_choice != 1 &&
+            (g_debug_flags & 32)) {
+            g.tiles_m = (g.M + XTOK - 1) / XTOK;
+            g.tiles_n = g.N / XCH;
+            dim3 grid(g.tiles_m * g.tiles_n), blk(XL_NT);
+            hipStream_t st = ivit_stream(stream);
+            if (EPI == EPI_RQ && g.flags != 0) {
+                switch (g.flags) {
+                    case 1: hipLaunchKernelGGL((gemm_i8_xl_kernel<EPI_RQ, 1>), grid, blk, 0, st, g); break;
+                    case 2: hipLaunchKernelGGL((gemm_i8_xl_kernel<EPI_RQ, 2>), grid, blk, 0, st, g); break;
+                    case 4: hipLaunchKernelGGL((gemm_i8_xl_kernel<EPI_RQ, 4>), grid, blk, 0, st, g); break;
+                    case 5: hipLaunchKernelGGL((gemm_i8_xl_kernel<EPI_RQ, 5>), grid, blk, 0, st, g); break;
+                    case 6: hipLaunchKernelGGL((gemm_i8_xl_kernel<EPI_RQ, 6>), grid, blk, 0, st, g); break;
+                    case 7: hipLaunchKernelGGL((gemm_i8_xl_kernel<EPI_RQ, 7>), grid, blk, 0, st, g); break;
+                    case 8: hipLaunchKernelGGL((gemm_i8_xl_kernel<EPI_RQ, 8>), grid, blk, 0, st, g); break;
+                    case 16: hipLaunchKernelGGL((gemm_i8_xl_kernel<EPI_RQ, 16>), grid, blk, 0, st, g); break;
+                    default: hipLaunchKernelGGL((gemm_i8_xl_kernel<EPI_RQ, 3>), grid, blk, 0, st, g); break;
+                }
+            } else {
+                hipLaunchKernelGGL((gemm_i8_xl_kernel<EPI, 0>), grid, blk, 0, st, g);
+            }
+            IVIT_CHECK_LAUNCH(name);
+        }
+        if (g.M >= 2048 && g.N >= BCH && !g_force_small && g.flags == 0 && (g_debug_flags & 8192)) {
+            g.stagger = 0;
+            g.tiles_m = (g.M + BTOK - 1) / BTOK;
+            g.tiles_n = (g.N + BCH - 1) / BCH;
+            g.split_from = g.tiles_m * g.tiles_n;
+            const int ntiles = g.tiles_m * g.tiles_n;
+            hipLaunchKernelGGL((gemm_i8_ring_kernel<EPI>), dim3(ntiles < 256 ? ntiles : 256), dim3(BIG_NT), 0,
+                               ivit_stream(stream), g);
+            IVIT_CHECK_LAUNCH(name);
+        }
+        if (g.M >= 2048 && g.N >= BCH && !g_force_small && (g.flags != 0 || (g_debug_flags & 1024))) {   // relaunch-per-tile form
+            g.stagger = (g_debug_flags & 64) ? 0 : 512;  // 2 workgroups x 256 CUs
+            g.tiles_m = (g.M + BTOK - 1) / BTOK;
+            g.tiles_n = (g.N + BCH - 1) / BCH;
+            dim3 grid(g.tiles_m * g.tiles_n), blk(BIG_NT);
+            hipStream_t st = ivit_stream(stream);
+            if (EPI == EPI_RQ && g.flags != 0) {  // perf ablations (scripts/gemm_ablate.py), EPI_RQ only
+                switch (g.flags) {
+                    case 1: hipLaunchKernelGGL((gemm_i8_big_kernel<EPI_RQ, 1>), grid, blk, 0, st, g); break;
+                    case 2: hipLaunchKernelGGL((gemm_i8_big_kernel<EPI_RQ, 2>), grid, blk, 0, st, g); break;
+                    case 3: hipLaunchKernelGGL((gemm_i8_big_kernel<EPI_RQ, 3>), grid, blk, 0, st, g); break;
+                    case 4: hipLaunchKernelGGL((gemm_i8_big_kernel<EPI_RQ, 4>), grid, blk, 0, st, g); break;
+                    case 5: hipLaunchKernelGGL((gemm_i8_big_kernel<EPI_RQ, 5>), grid, blk, 0, st, g); break;
+                    case 6: hipLaunchKernelGGL((gemm_i8_big_kernel<EPI_RQ, 6>), grid, blk, 0, st, g); break;
+                    case 7: hipLaunchKernelGGL((gemm_i8_big_kernel<EPI_RQ, 7>), grid, blk, 0, st, g); break;
+                    case 8: hipLaunchKernelGGL((gemm_i8_big_kernel<EPI_RQ, 8>), grid, blk, 0, st, g); break;
+                    case 16: hipLaunchKernelGGL((gemm_i8_big_kernel<EPI_RQ, 16>), grid, blk, 0, st, g); break;
+                    case 24: hipLaunchKernelGGL((gemm_i8_big_kernel<EPI_RQ, 24>), grid, blk, 0, st, g); break;
+                    case 11: hipLaunchKernelGGL((gemm_i8_big_kernel<EPI_RQ, 11>), grid, blk, 0, st, g); break;
+                    case 19: hipLaunchKernelGGL((gemm_i8_big_kernel<EPI_RQ, 19>), grid, blk, 0, st, g); break;
+                    case 133: hipLaunchKernelGGL((gemm_i8_big_kernel<EPI_RQ, 133>), grid, blk, 0, st, g); break;
+                    case 389: hipLaunchKernelGGL((gemm_i8_big_kernel<EPI_RQ, 389>), grid, blk, 0, st, g); break;
+                    case 512: g.res = (const int8_t*)g_stamp_buf; hipLaunchKernelGGL((gemm_i8_big_kernel<EPI_RQ, 512>), grid, blk, 0, st, g); break;
+                    case 515: g.res = (const int8_t*)g_stamp_buf; hipLaunchKernelGGL((gemm_i8_big_kernel<EPI_RQ, 515>), grid, blk, 0, st, g); break;
+                    case 516: g.res = (const int8_t*)g_stamp_buf; hipLaunchKernelGGL((gemm_i8_big_kernel<EPI_RQ, 516>), grid, blk, 0, st, g); break;
+                    case 517: g.res = (const int8_t*)g_stamp_buf; hipLaunchKernelGGL((gemm_i8_big_kernel<EPI_RQ, 517>), grid, blk, 0, st, g); break;
+                    case 518: g.res = (const int8_t*)g_stamp_buf; hipLaunchKernelGGL((gemm_i8_big_kernel<EPI_RQ, 518>), grid, blk, 0, st, g); break;
+                    case 513: g.res = (const int8_t*)g_stamp_buf; hipLaunchKernelGGL((gemm_i8_big_kernel<EPI_RQ, 513>), grid, blk, 0, st, g); break;
+                    default: hipLaunchKernelGGL((gemm_i8_big_kernel<EPI_RQ, 3>), grid, blk, 0, st, g); break;
+                }
+            } else {
+                hipLaunchKernelGGL((gemm_i8_big_kernel<EPI, 0>), grid, blk, 0, st, g);
+            }
+            IVIT_CHECK_LAUNCH(name);
+        }
+    }
+    *handled = 0;
+    return IVIT_OK;
+}
+
+}  // namespace
+
+int ivit_gemm_lab_launch(int epi, void* gemm_args, const char* name, ivit_stream_t stream, int* rc)
+{
+    GemmArgs& g = *static_cast<GemmArgs*>(gemm_args);
+    int handled = 0;
+    switch (epi) {
+        case EPI_RQ: *rc = launch_lab<EPI_RQ>(g, name, stream, &handled); break;
+        case EPI_RESID: *rc = launch_lab<EPI_RESID>(g, name, stream, &handled); break;
+        case EPI_QKV: *rc = launch_lab<EPI_QKV>(g, name, stream, &handled); break;
+        default: break;
+    }
+    return handled;
+}
+
+// test hook: 1 = always use the 128x128 register-staged kernel (so both kernels stay covered)
+IVIT_EXPORT int ivit_debug_force_small_gemm(int on)
+{
+    g_force_small = (on == 1);   // 1: 128x128 register-staged kernel only
+    g_kernel_choice = (on == 2); // 2: at most the 256x128 LDS-DMA kernel
+    return IVIT_OK;
+}
+
+IVIT_EXPORT int ivit_debug_set_gemm_flags(int flags)
+{
+    g_debug_flags = flags;
+    return IVIT_OK;
+}
+
+// diagnostic: device buffer (8 x uint64 per workgroup) receiving {HW_ID | XCC_ID<<32, t_start, t_loop_end, t_end}
+// from the stamped build selected by ivit_debug_set_gemm_flags(512)
+IVIT_EXPORT int ivit_debug_set_stamp_buffer(void* buf)
+{
+    g_stamp_buf = buf;
+    return IVIT_OK;
+}
