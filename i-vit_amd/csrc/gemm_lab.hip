@@ -378,6 +378,233 @@ __global__ __launch_bounds__(XL_NT, 2) void gemm_i8_xl_kernel(GemmArgs g)
 }
 
 // ================================================================================================
+// Persistent 256 x 256 kernel: ONE workgroup of 8 waves per CU (4 channel groups x 2 token groups, wave tile 64 ch x
+// 128 tok as above, two waves per SIMD), 4-stage ring of 32 KiB.  Why: the CU's global->LDS DMA
+// path moves ~29 B/clk, and a 256 x 128 tile needs 24 KiB per K step (>= 830 cycles against 512 cycles of MFMA per
+// wave); the 256 x 256 tile needs 32 KiB for twice the MACs (~1100 cycles against 2 x 512 per SIMD), so DMA and MFMA
+// are balanced, and its two waves per SIMD overlap each other's stalls in the epilogue.  Stamped per tile: main loop
+// 15.1 K cycles + epilogue 8.5 K for 256 x 256, against 2 x (10 K + 7 K + 3 K) for two 256 x 128 tiles.  Persistence
+// removes most of what a relaunch of a 512-thread / 128 KiB workgroup costs per tile: stage 0 of the next tile is
+// prefetched into ring buffer 3 while the epilogue stages its int8 tile in buffers 0-2, and the next requant table is
+// fetched inside the epilogue.  Tile-local stage kt lives in buffer (kt + 3) & 3 for every tile.
+// Measured (scripts/gemm_ab.py): on par with the persistent 256 x 128 kernel on every DeiT-B shape (its main loop runs at
+// the power-limited MFMA ceiling, 66 % issue at ~1.87 GHz; the epilogue is not overlapped) -- kept for A/B (debug bit 22).
+// ================================================================================================
+constexpr int XL_RING = XL_STAGES * XL_STAGE;     // 128 KiB (buffers 0-2 >= 256 * 260 epilogue tile)
+constexpr int XL_PT_BYTES = XCH * 12;             // { float2 lohi[256]; int bias[256] }
+constexpr int XLP_SMEM = XL_RING + 2 * XL_PT_BYTES;
+
+struct XlTable {
+    unsigned m;
+    int e, bias;
+    bool valid;
+};
+
+IVIT_DEV PersTile xl_tile(const GemmArgs& g, int t)
+{
+    const int nblk = g.tiles_m * g.tiles_n;
+    const int q8 = nblk >> 3, r8 = nblk & 7, xcd = t & 7;
+    const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (t >> 3);
+    const int tm = lid / g.tiles_n, tn = lid - tm * g.tiles_n;
+    return PersTile{tm * XTOK, tn * XCH};
+}
+
+IVIT_DEV XlTable xl_table_issue(const GemmArgs& g, int n0, int tid)
+{
+    XlTable r{0u, 0, 0, false};
+    const int c = n0 + tid;
+    if (tid < XCH && c < g.N) {
+        r.m = g.m[c];
+        r.e = g.e[c];
+        r.bias = g.bias ? g.bias[c] : 0;
+        r.valid = true;
+    }
+    return r;
+}
+
+IVIT_DEV void xl_table_write(const XlTable& r, char* tab, int tid)
+{
+    if (tid < XCH) {
+        float2 lh = make_float2(0.f, 0.f);
+        if (r.valid) {
+            const double M = dyadic_mult(r.m, r.e);
+            const float mf = (float)M;
+            const int bits = __float_as_int(mf);
+            lh.x = ((double)mf > M) ? __int_as_float(bits - 1) : mf;
+            lh.y = ((double)mf < M) ? __int_as_float(bits + 1) : mf;
+        }
+        reinterpret_cast<float2*>(tab)[tid] = lh;
+        reinterpret_cast<int*>(tab + XCH * 8)[tid] = r.bias;
+    }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(XL_NT, 2) void gemm_i8_xlp_kernel(GemmArgs g)
+{
+    __shared__ __attribute__((aligned(16))) char smem[XLP_SMEM];
+    const int ntiles = g.tiles_m * g.tiles_n;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wc = wave >> 1, wt = wave & 1;  // 4 x 2
+    const int h = lane >> 5, l31 = lane & 31;
+    const int lrow = lane >> 2, lslot = lane & 3;
+    const int nk = g.K / BK;
+    using T = std::true_type;
+    using F = std::false_type;
+
+    // LDS-DMA sources: piece q covers tile rows 16q..16q+15 (1 KiB); wave w owns pieces w and w + 8 of each operand tile
+    const int8_t* asrc[2];
+    const int8_t* wsrc[2];
+    auto set_sources = [&](const PersTile& t) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int row = 16 * (wave + 8 * i) + lrow;
+            int c = lslot ^ ((row >> 2) & 3);
+            asrc[i] = g.A + (int64_t)min(t.m0 + row, g.M - 1) * g.lda + 16 * c;
+            wsrc[i] = g.W + (int64_t)min(t.n0 + row, g.N - 1) * g.ldw + 16 * c;
+        }
+    };
+    auto issue_one = [&](int kt, int idx) {
+        char* base = smem + ((kt + 3) & 3) * XL_STAGE;
+        const int koff = kt * BK;
+        if (idx < 2)
+            __builtin_amdgcn_global_load_lds((gptr_t)(asrc[idx] + koff), (lptr_t)(base + 1024 * (wave + 8 * idx)), 16, 0,
+                                             0);
+        else
+            __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[idx - 2] + koff),
+                                             (lptr_t)(base + XL_A_BYTES + 1024 * (wave + 8 * (idx - 2))), 16, 0, 0);
+    };
+    auto issue = [&](int kt) {
+#pragma unroll
+        for (int idx = 0; idx < 4; ++idx) issue_one(kt, idx);
+    };
+
+    // fragment reads as inline asm with explicit counted waits (see gemm_i8_pers_kernel)
+    const unsigned smem_base = (unsigned)(__UINTPTR_TYPE__)(lptr_t)smem;
+    const int wrow0 = 64 * wc + l31, arow0 = 128 * wt + l31;
+    const unsigned wbase[2] = {smem_base + (unsigned)(XL_A_BYTES + swz(wrow0, h)),
+                               smem_base + (unsigned)(XL_A_BYTES + swz(wrow0, 2 + h))};
+    const unsigned abase[2] = {smem_base + (unsigned)swz(arow0, h), smem_base + (unsigned)swz(arow0, 2 + h)};
+    v4i wf0[2], af0[4], wf1[2], af1[4];
+    auto load_frags = [&](int kt, int ks, v4i (&wf)[2], v4i (&af)[4]) {
+        const unsigned off = (unsigned)(((kt + 3) & 3) * XL_STAGE);
+        const unsigned wa = wbase[ks] + off, aa = abase[ks] + off;
+        asm volatile("ds_read_b128 %0, %1" : "=v"(wf[0]) : "v"(wa));
+        asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(wf[1]) : "v"(wa));
+        asm volatile("ds_read_b128 %0, %1" : "=v"(af[0]) : "v"(aa));
+        asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(af[1]) : "v"(aa));
+        asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(af[2]) : "v"(aa));
+        asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(af[3]) : "v"(aa));
+    };
+#define XLP_TIE(wf, af) "+v"(wf[0]), "+v"(wf[1]), "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3])
+    v16i acc[2][4];
+    // One K step; AHEAD = stages after kt+1 whose DMA (4 pieces per wave each) may still be in flight at its end
+    auto step = [&](int kt, auto issue_tag, auto ahead_tag, auto last_tag) {
+        constexpr bool ISSUE = decltype(issue_tag)::value;
+        constexpr int AHEAD = decltype(ahead_tag)::value;
+        constexpr bool LAST = decltype(last_tag)::value;
+        load_frags(kt, 1, wf1, af1);
+        asm volatile("s_waitcnt lgkmcnt(6)" : XLP_TIE(wf0, af0)::"memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf0[i], af0[j], acc[i][j], 0, 0, 0);
+                if constexpr (ISSUE)
+                    if (((4 * i + j) & 1) == 0) issue_one(kt + 3, (4 * i + j) >> 1);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (AHEAD == 2) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" : XLP_TIE(wf1, af1)::"memory");
+        else if constexpr (AHEAD == 1) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" : XLP_TIE(wf1, af1)::"memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : XLP_TIE(wf1, af1)::"memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if constexpr (!LAST) load_frags(kt + 1, 0, wf0, af0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf1[i], af1[j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    using A0 = std::integral_constant<int, 0>;
+    using A1 = std::integral_constant<int, 1>;
+    using A2 = std::integral_constant<int, 2>;
+
+    // ---- first tile: table + stage 0
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    PersTile cur = xl_tile(g, tile);
+    {
+        XlTable tl = xl_table_issue(g, cur.n0, tid);
+        xl_table_write(tl, smem + XL_RING, tid);
+    }
+    set_sources(cur);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // table loads retired before the DMA counting starts
+    issue(0);
+
+    for (int it = 0; tile < ntiles; ++it, tile += gridDim.x) {
+        char* tab = smem + XL_RING + (it & 1) * XL_PT_BYTES;
+        char* tab_next = smem + XL_RING + ((it + 1) & 1) * XL_PT_BYTES;
+        // stage 0 of this tile is in flight (or landed) in buffer 3; buffers 0-2 are free again (staging tile read out)
+        if (nk > 1) issue(1);
+        if (nk > 2) issue(2);
+        if (nk > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");        // own pieces of stage 0 and everything older
+        else if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                        // everyone's stage 0; table visible
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int4 b4 = *reinterpret_cast<const int4*>(tab + XCH * 8 + 4 * (64 * wc + 32 * i + 8 * q + 4 * h));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[i][j][4 * q + 0] = b4.x;
+                    acc[i][j][4 * q + 1] = b4.y;
+                    acc[i][j][4 * q + 2] = b4.z;
+                    acc[i][j][4 * q + 3] = b4.w;
+                }
+            }
+        load_frags(0, 0, wf0, af0);
+        int kt = 0;
+        for (; kt + 3 < nk; ++kt) step(kt, T{}, A2{}, F{});
+        if (kt + 2 < nk) { step(kt, F{}, A1{}, F{}); ++kt; }
+        if (kt + 1 < nk) { step(kt, F{}, A0{}, F{}); ++kt; }
+        step(kt, F{}, A0{}, T{});
+        __syncthreads();   // all waves are done with every ring buffer
+
+        // ---- stage 0 of the next tile into buffer 3, then this tile's epilogue (staging tile in buffers 0-2)
+        const int next = tile + gridDim.x;
+        const bool more = next < ntiles;   // uniform
+        PersTile nxt = cur;
+        if (more) {
+            nxt = xl_tile(g, next);
+            set_sources(nxt);
+            issue(0);
+        }
+        struct Hook {
+            const GemmArgs& g;
+            int n0, tid;
+            char* dst;
+            bool more;
+            mutable XlTable ld;
+            IVIT_DEV void issue() const { if (more) ld = xl_table_issue(g, n0, tid); }
+            IVIT_DEV void consume() const { if (more) xl_table_write(ld, dst, tid); }
+        };
+        Hook hook{g, nxt.n0, tid, tab_next, more, XlTable{0u, 0, 0, false}};
+        epilogue_i8<EPI, 2, 4, XTOK, XL_NT, 0, XCH, Hook>(acc, g, smem, tab, cur.m0, cur.n0, 64 * wc, 128 * wt, tid, h, l31,
+                                                         hook);
+        cur = nxt;
+        __syncthreads();   // staging reads done before the next tile's stages 1-2 overwrite buffers 0-1
+    }
+#undef XLP_TIE
+}
+
+// ================================================================================================
 // Deep-ring form: ONE workgroup per CU (4 waves, wave tile 64 ch x 128 tok as above) with a FIVE-stage LDS ring
 // (120 KiB), so that up to four stages (96 KiB) of LDS-DMA are in flight per CU.  Rationale: the
 // global->LDS path has a latency of more than two K steps; with three stages per workgroup a stage is awaited one
@@ -580,6 +807,15 @@ int launch_lab(GemmArgs& g, const char* name, ivit_stream_t stream, int* handled
 {
     *handled = 1;
     if constexpr (EPI != EPI_I32) {
+        if (g.M >= 2048 && g.N % XCH == 0 && !g_force_small && g_kernel_choice != 1 && g.flags == 0 &&
+            (g_debug_flags & 4194304)) {   // persistent 256 x 256
+            g.tiles_m = (g.M + XTOK - 1) / XTOK;
+            g.tiles_n = g.N / XCH;
+            const int ntiles = g.tiles_m * g.tiles_n;
+            hipLaunchKernelGGL((gemm_i8_xlp_kernel<EPI>), dim3(ntiles < 256 ? ntiles : 256), dim3(XL_NT), 0,
+                               ivit_stream(stream), g);
+            IVIT_CHECK_LAUNCH(name);
+        }
         if (g.M >= 2048 && g.N % XCH == 0 && !g_force_small && g_kernel_choice != 1 &&
             (g_debug_flags & 32)) {
             g.tiles_m = (g.M + XTOK - 1) / XTOK;
