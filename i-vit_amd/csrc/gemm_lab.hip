@@ -802,6 +802,382 @@ __global__ __launch_bounds__(BIG_NT, 1) void gemm_i8_ring_kernel(GemmArgs g)
 #undef RING_TIE
 }
 
+// ================================================================================================
+// Ping-pong form: one workgroup per CU (4 waves, wave tile 64 ch x 128 tok), 4-stage ring that runs continuously across
+// tiles, and the requantisation (phase 1 of the epilogue) of tile t-1 executed INSIDE the K loop of tile t, one batch of
+// 16 outputs per thread in each of the first eight K steps, from a second register set the accumulators are copied
+// to at the end of a tile.  Rationale: neither a co-resident workgroup nor a second wave hides the epilogue on this
+// chip, but VALU instructions of the SAME wave issue for free in the shadow of its MFMAs (32 cycles each).
+// Phase 2 (LDS -> global stores, residual QuantAct) still runs between two K loops.  Needs K >= 512.
+// ================================================================================================
+constexpr int PP_STAGES = 4;
+constexpr int PP_RING = PP_STAGES * BIG_STAGE;             // 96 KiB
+constexpr int PP_EPI_OFF = PP_RING;                        // staging tile 256 x 132 B
+constexpr int PP_PT_OFF = PP_EPI_OFF + BTOK * (BCH + 4);
+constexpr int PP_SMEM = PP_PT_OFF + 2 * PT_BYTES;          // 135 168 B: one workgroup per CU
+
+// phase 1 of epilogue_i8 for ONE unit U = (I, Q, J) of a drained accumulator set: four channels of one token per lane
+// (gemm_common.h, TJ = 4, CH = 128).  Branch-free so that it schedules into the MFMA shadow: the float32 certificate is
+// only ACCUMULATED here (unc, amax); a tile with any uncertified output is redone exactly by pp_exact_tile.
+// lh01 / lh23: (lo, hi) factor pairs of channels cl .. cl+3 read from the table by pp_load_group.
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+template <int U>
+IVIT_DEV void pp_unit(const v16i (&dr)[2][4], const v4f& lh01, const v4f& lh23, unsigned stg_addr, unsigned& unc,
+                      float& amax)
+{
+    constexpr int I = U >> 4, Q = (U >> 2) & 3, J = U & 3;
+    constexpr int CSS = BCH + 4;
+    const float lo[4] = {lh01.x, lh01.z, lh23.x, lh23.z};
+    const float hi[4] = {lh01.y, lh01.w, lh23.y, lh23.w};
+    int b[4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        const float a = (float)dr[I][J][4 * Q + jj];
+        const int tl = __float_as_int(__builtin_fmaf(a, lo[jj], 12582912.0f));
+        const int th = __float_as_int(__builtin_fmaf(a, hi[jj], 12582912.0f));
+        asm("v_sad_u32 %0, %1, %2, %3" : "=v"(unc) : "v"(tl), "v"(th), "v"(unc));
+        amax = fmaxf(amax, fabsf(a));
+        b[jj] = clamp_i32(tl, 0x4B400000 - 128, 0x4B400000 + 127);
+    }
+    const unsigned w01 = __builtin_amdgcn_perm((unsigned)b[1], (unsigned)b[0], 0x0c0c0400u);
+    const unsigned w23 = __builtin_amdgcn_perm((unsigned)b[3], (unsigned)b[2], 0x04000c0cu);
+    const unsigned w = w01 | w23;
+    asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(stg_addr), "v"(w), "n"(J * 32 * CSS + 32 * I + 8 * Q) : "memory");
+}
+
+// (lo, hi) pairs of the four channels of group G = (I, Q): two 16-byte LDS reads, waited for by the caller
+template <int G>
+IVIT_DEV void pp_load_group(v4f& a, v4f& b, unsigned tab_addr)
+{
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a) : "v"(tab_addr), "n"(256 * (G >> 2) + 64 * (G & 3)));
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(b) : "v"(tab_addr), "n"(256 * (G >> 2) + 64 * (G & 3) + 16));
+}
+
+// exact float64 evaluation of a whole drained tile (taken when the certificate of any output of the wave failed)
+IVIT_DEV void pp_exact_tile(const v16i (&dr)[2][4], const GemmArgs& g, char* stg, int n0, int wch,
+                                                      int wtok, int h, int l31)
+{
+    constexpr int CSS = BCH + 4;
+#pragma unroll 1
+    for (int iq = 0; iq < 8; ++iq) {
+        const int i = iq >> 2, q = iq & 3;
+        const int cl = wch + 32 * i + 8 * q + 4 * h;
+        const int c0 = min(n0 + cl, g.N - 4);
+        const uint4 m4 = *reinterpret_cast<const uint4*>(g.m + c0);
+        const int4 e4 = *reinterpret_cast<const int4*>(g.e + c0);
+        const double Mc[4] = {dyadic_mult(m4.x, e4.x), dyadic_mult(m4.y, e4.y), dyadic_mult(m4.z, e4.z),
+                              dyadic_mult(m4.w, e4.w)};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int b[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                int av = 0;
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq)
+                        if (ii == i && qq == q) av = dr[ii][j][4 * qq + jj];
+                double t = (double)av * Mc[jj] + IVIT_MAGIC;
+                b[jj] = clamp_i32((int)(unsigned)__double_as_longlong(t), -128, 127);
+            }
+            *reinterpret_cast<int*>(stg + (wtok + 32 * j + l31) * CSS + cl) = pack4_i8(b[0], b[1], b[2], b[3]);
+        }
+    }
+}
+
+// phase 2 of epilogue_i8 (TOK = 256, 256 threads, CH = 128) from the staging tile
+template <int EPI>
+IVIT_DEV void pp_phase2(const GemmArgs& g, const char* stg, int m0, int n0, int tid)
+{
+    constexpr int CSS = BCH + 4, CPR = BCH / 16, NIT = BTOK * CPR / BIG_NT;
+    int8_t* out = reinterpret_cast<int8_t*>(g.out);
+    int v[NIT][4];
+    int4 rv[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int q = tid + BIG_NT * it;
+        const int tl = q / CPR, cc = q % CPR;
+        const int* src = reinterpret_cast<const int*>(stg + tl * CSS + 16 * cc);
+        v[it][0] = src[0]; v[it][1] = src[1]; v[it][2] = src[2]; v[it][3] = src[3];
+        if constexpr (EPI == EPI_RESID) {
+            const int t = min(m0 + tl, g.M - 1), cn = min(n0 + 16 * cc, g.N - 16);
+            rv[it] = *reinterpret_cast<const int4*>(g.res + (int64_t)t * g.ldr + cn);
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int q = tid + BIG_NT * it;
+        const int tl = q / CPR, cc = q % CPR;
+        const int t = m0 + tl, cn = n0 + 16 * cc;
+        if (t >= g.M || cn >= g.N) continue;
+        if constexpr (EPI == EPI_RESID) {
+            const int rr[4] = {rv[it].x, rv[it].y, rv[it].z, rv[it].w};
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                int o[4];
+#pragma unroll
+                for (int bb = 0; bb < 4; ++bb) {
+                    int k3 = (int)(int8_t)(v[it][d] >> (8 * bb));
+                    int xr = (int)(int8_t)(rr[d] >> (8 * bb));
+                    int sres = requant_exact(k3, g.M_main) + requant_exact(xr, g.M_res);
+                    o[bb] = clamp_i32(sres, -128, 127);
+                }
+                v[it][d] = pack4_i8(o[0], o[1], o[2], o[3]);
+            }
+        }
+        int64_t off;
+        if constexpr (EPI == EPI_QKV) {
+            const int cdim = g.heads * g.head_dim;
+            const int which = cn / cdim, rem = cn - which * cdim;
+            const int hh = rem / g.head_dim, d0 = rem - hh * g.head_dim;
+            const int b = t / g.tokens, tok = t - b * g.tokens;
+            const int nb = g.M / g.tokens;
+            off = ((((int64_t)which * nb + b) * g.heads + hh) * g.tokens + tok) * g.head_dim + d0;
+        } else {
+            off = (int64_t)t * g.ldo + cn;
+        }
+        *reinterpret_cast<int4*>(out + off) = make_int4(v[it][0], v[it][1], v[it][2], v[it][3]);
+    }
+}
+
+template <class F, int... S>
+IVIT_DEV void pp_for_slots(F&& f, std::integer_sequence<int, S...>)
+{
+    (f(std::integral_constant<int, S>{}), ...);
+}
+
+// UPS = units of phase 1 per K step: the 32 units of a tile take NS = ceil(32 / UPS) steps (needs K / 64 >= NS)
+template <int EPI, int UPS>
+__global__ __launch_bounds__(BIG_NT, 1) void gemm_i8_pp_kernel(GemmArgs g)
+{
+    constexpr int NS = (32 + UPS - 1) / UPS;
+    constexpr int CSS = BCH + 4;
+    __shared__ __attribute__((aligned(16))) char smem[PP_SMEM];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wc = wave >> 1, wt = wave & 1;
+    const int h = lane >> 5, l31 = lane & 31;
+    const int lrow = lane >> 2, lslot = lane & 3;
+    const int nk = g.K / BK;
+    const int ntiles = g.tiles_m * g.tiles_n;
+
+    // DMA sources of the current tile and of the next one (the ring runs ahead across the tile boundary)
+    const int8_t* src_cur[6];
+    const int8_t* src_nxt[6];
+    auto set_sources = [&](const int8_t* (&dst)[6], const PersTile& t) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int row = 16 * (wave + 4 * i) + lrow;
+            int c = lslot ^ ((row >> 2) & 3);
+            dst[i] = g.A + (int64_t)min(t.m0 + row, g.M - 1) * g.lda + 16 * c;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int row = 16 * (wave + 4 * i) + lrow;
+            int c = lslot ^ ((row >> 2) & 3);
+            dst[4 + i] = g.W + (int64_t)min(t.n0 + row, g.N - 1) * g.ldw + 16 * c;
+        }
+    };
+    auto issue_piece = [&](int gs, const int8_t* src, int idx) {
+        char* base = smem + (gs & 3) * BIG_STAGE;
+        char* dst = idx < 4 ? base + 1024 * (wave + 4 * idx) : base + BIG_A_BYTES + 1024 * (wave + 4 * (idx - 4));
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
+    };
+
+    const unsigned smem_base = (unsigned)(__UINTPTR_TYPE__)(lptr_t)smem;
+    const int wrow0 = 64 * wc + l31, arow0 = 128 * wt + l31;
+    const unsigned wbase[2] = {smem_base + (unsigned)(BIG_A_BYTES + swz(wrow0, h)),
+                               smem_base + (unsigned)(BIG_A_BYTES + swz(wrow0, 2 + h))};
+    const unsigned abase[2] = {smem_base + (unsigned)swz(arow0, h), smem_base + (unsigned)swz(arow0, 2 + h)};
+    v4i wf0[2], af0[4], wf1[2], af1[4];
+    auto load_frags = [&](int gs, int ks, v4i (&wf)[2], v4i (&af)[4]) {
+        const unsigned off = (unsigned)((gs & 3) * BIG_STAGE);
+        const unsigned wa = wbase[ks] + off, aa = abase[ks] + off;
+        asm volatile("ds_read_b128 %0, %1" : "=v"(wf[0]) : "v"(wa));
+        asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(wf[1]) : "v"(wa));
+        asm volatile("ds_read_b128 %0, %1" : "=v"(af[0]) : "v"(aa));
+        asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(af[1]) : "v"(aa));
+        asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(af[2]) : "v"(aa));
+        asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(af[3]) : "v"(aa));
+    };
+#define PP_TIE(wf, af) "+v"(wf[0]), "+v"(wf[1]), "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3])
+    v16i acc[2][4], dr[2][4];
+    char* stg = smem + PP_EPI_OFF;
+    // this thread's staging address for (token wtok + l31, channel wch + 4h); units add compile-time offsets
+    const unsigned stg_addr = smem_base + (unsigned)(PP_EPI_OFF + (128 * wt + l31) * CSS + 64 * wc + 4 * h);
+
+    // state of the tile being drained (its phase 1 runs inside the next K loop)
+    int prev_m0 = 0, prev_n0 = 0;
+    unsigned prev_tab_addr = 0;
+    unsigned unc = 0;
+    float amax = 0.0f;
+
+    // One K step of the stream.  SLOT >= 0: also requantise units [SLOT * UPS, SLOT * UPS + UPS) of the drained tile.
+    auto step = [&](int gs, int kt, bool next_ok, auto slot_tag) {
+        constexpr int SLOT = decltype(slot_tag)::value;
+        constexpr int U0 = SLOT < 0 ? 32 : SLOT * UPS;
+        constexpr int U1 = (U0 + UPS < 32) ? U0 + UPS : 32;          // units [U0, U1)
+        constexpr int NU = U1 > U0 ? U1 - U0 : 0;
+        constexpr int G0 = U0 >> 2, G1 = (U1 - 1) >> 2;              // their table groups (at most two)
+        constexpr int UH = U0 + NU / 2;                              // units [U0, UH) in the first half of the step
+        v4f ta0, ta1, tb0, tb1;
+        if constexpr (NU > 0) {
+            pp_load_group<G0>(ta0, ta1, prev_tab_addr);
+            if constexpr (G1 != G0) pp_load_group<G1>(tb0, tb1, prev_tab_addr);
+        }
+        load_frags(gs, 1, wf1, af1);
+        if constexpr (NU > 0 && G1 != G0)
+            asm volatile("s_waitcnt lgkmcnt(6)" : PP_TIE(wf0, af0), "+v"(ta0), "+v"(ta1), "+v"(tb0), "+v"(tb1)::"memory");
+        else if constexpr (NU > 0)
+            asm volatile("s_waitcnt lgkmcnt(6)" : PP_TIE(wf0, af0), "+v"(ta0), "+v"(ta1)::"memory");
+        else
+            asm volatile("s_waitcnt lgkmcnt(6)" : PP_TIE(wf0, af0)::"memory");
+        auto unit = [&](auto utag) {
+            constexpr int U = decltype(utag)::value;
+            if constexpr ((U >> 2) == G0) pp_unit<U>(dr, ta0, ta1, stg_addr, unc, amax);
+            else pp_unit<U>(dr, tb0, tb1, stg_addr, unc, amax);
+        };
+        // stage gs + 3 of the stream: this tile's stage kt + 3, else the next tile's stage kt + 3 - nk; the last tile
+        // re-fetches its own first stages into the free buffers (harmless) so that the counted waits stay uniform
+        const bool own = kt + 3 < nk;
+        const int koff = (own ? kt + 3 : kt + 3 - nk) * BK;
+        const bool use_cur = own || !next_ok;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf0[i], af0[j], acc[i][j], 0, 0, 0);
+                if (4 * i + j < 6) {
+                    const int idx = 4 * i + j;
+                    issue_piece(gs + 3, (use_cur ? src_cur[idx] : src_nxt[idx]) + koff, idx);
+                }
+            }
+        if constexpr (U0 + 0 < UH) unit(std::integral_constant<int, (U0 + 0 < 32 ? U0 + 0 : 0)>{});
+        if constexpr (U0 + 1 < UH) unit(std::integral_constant<int, (U0 + 1 < 32 ? U0 + 1 : 0)>{});
+        asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" : PP_TIE(wf1, af1)::"memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        load_frags(gs + 1, 0, wf0, af0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf1[i], af1[j], acc[i][j], 0, 0, 0);
+        if constexpr (UH + 0 < U1) unit(std::integral_constant<int, (UH + 0 < 32 ? UH + 0 : 0)>{});
+        if constexpr (UH + 1 < U1) unit(std::integral_constant<int, (UH + 1 < 32 ? UH + 1 : 0)>{});
+    };
+    using NONE = std::integral_constant<int, -1>;
+
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    PersTile cur = pers_tile(g, tile);
+    {
+        PersTableLoad tl = pers_table_issue(g, cur.n0, tid);
+        pers_table_write(tl, smem + PP_PT_OFF, tid);
+    }
+    set_sources(src_cur, cur);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // head of the stream: stages 0, 1, 2 of the first tile
+    for (int st = 0; st < 3; ++st)
+#pragma unroll
+        for (int idx = 0; idx < 6; ++idx) issue_piece(st, src_cur[idx] + st * BK, idx);
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    load_frags(0, 0, wf0, af0);
+
+    int gs = 0;
+    for (int it = 0; tile < ntiles; ++it, tile += gridDim.x) {
+        char* tab = smem + PP_PT_OFF + (it & 1) * PT_BYTES;
+        char* tab_next = smem + PP_PT_OFF + ((it + 1) & 1) * PT_BYTES;
+        const int next = tile + gridDim.x;
+        const bool more = next < ntiles;   // uniform
+        PersTile nxt = cur;
+        if (more) {
+            nxt = pers_tile(g, next);
+            set_sources(src_nxt, nxt);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int4 b4 = *reinterpret_cast<const int4*>(tab + BCH * 8 + 4 * (64 * wc + 32 * i + 8 * q + 4 * h));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[i][j][4 * q + 0] = b4.x;
+                    acc[i][j][4 * q + 1] = b4.y;
+                    acc[i][j][4 * q + 2] = b4.z;
+                    acc[i][j][4 * q + 3] = b4.w;
+                }
+            }
+        long long* stamp = nullptr;
+        if constexpr (EPI == EPI_RQ) {
+            if (g.res && tid == 0 && it >= 1 && it <= 2)
+                stamp = (long long*)g.res + (blockIdx.x * 2 + (it - 1)) * 8;
+        }
+        if (stamp) stamp[0] = __builtin_amdgcn_s_memtime();
+        if (it > 0 && !(g.stagger_units & 2)) {
+            // K loop with phase 1 of the previous tile riding in its first NS steps
+            int kt = 0;
+            pp_for_slots([&](auto s) { step(gs++, kt++, more, s); }, std::make_integer_sequence<int, NS>{});
+            for (; kt < nk; ++kt) step(gs++, kt, more, NONE{});
+            if (!(g.stagger_units & 1) && __builtin_amdgcn_ballot_w64((unc != 0) | (amax >= 4194304.0f)) != 0)
+                pp_exact_tile(dr, g, stg, prev_n0, 64 * wc, 128 * wt, h, l31);
+            unc = 0;
+            amax = 0.0f;
+        } else {
+            for (int kt = 0; kt < nk; ++kt) step(gs++, kt, more, NONE{});
+        }
+        if (stamp) stamp[1] = __builtin_amdgcn_s_memtime();
+        __syncthreads();   // staging tile of the previous tile complete
+        if (stamp) stamp[2] = __builtin_amdgcn_s_memtime();
+
+        // table of the next tile (its buffer held the previous tile's table, no longer needed)
+        PersTableLoad tln{0u, 0, 0, false};
+        if (more) tln = pers_table_issue(g, nxt.n0, tid);
+        if (it > 0 && !(g.stagger_units & 4)) pp_phase2<EPI>(g, stg, prev_m0, prev_n0, tid);
+        if (stamp) stamp[3] = __builtin_amdgcn_s_memtime();
+        if (more) pers_table_write(tln, tab_next, tid);
+        // hand this tile's accumulators to the drain set
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dr[i][j] = acc[i][j];
+        prev_m0 = cur.m0; prev_n0 = cur.n0;
+        prev_tab_addr = smem_base + (unsigned)(PP_PT_OFF + (it & 1) * PT_BYTES + 8 * (64 * wc + 4 * h));
+        if (more) {
+#pragma unroll
+            for (int idx = 0; idx < 6; ++idx) src_cur[idx] = src_nxt[idx];
+        }
+        cur = nxt;
+        if (stamp) stamp[4] = __builtin_amdgcn_s_memtime();
+        __syncthreads();   // staging tile read out, next table visible
+        if (stamp) stamp[5] = __builtin_amdgcn_s_memtime();
+    }
+    // ---- drain the last tile without overlap
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    pp_for_slots(
+        [&](auto s) {
+            constexpr int G = decltype(s)::value;
+            v4f t0, t1;
+            pp_load_group<G>(t0, t1, prev_tab_addr);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t0), "+v"(t1)::"memory");
+            pp_unit<4 * G + 0>(dr, t0, t1, stg_addr, unc, amax);
+            pp_unit<4 * G + 1>(dr, t0, t1, stg_addr, unc, amax);
+            pp_unit<4 * G + 2>(dr, t0, t1, stg_addr, unc, amax);
+            pp_unit<4 * G + 3>(dr, t0, t1, stg_addr, unc, amax);
+        },
+        std::make_integer_sequence<int, 8>{});
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (__builtin_amdgcn_ballot_w64((unc != 0) | (amax >= 4194304.0f)) != 0)
+        pp_exact_tile(dr, g, stg, prev_n0, 64 * wc, 128 * wt, h, l31);
+    __syncthreads();
+    pp_phase2<EPI>(g, stg, prev_m0, prev_n0, tid);
+#undef PP_TIE
+}
+
 template <int EPI>
 int launch_lab(GemmArgs& g, const char* name, ivit_stream_t stream, int* handled)
 {
@@ -837,6 +1213,21 @@ int launch_lab(GemmArgs& g, const char* name, ivit_stream_t stream, int* handled
             } else {
                 hipLaunchKernelGGL((gemm_i8_xl_kernel<EPI, 0>), grid, blk, 0, st, g);
             }
+            IVIT_CHECK_LAUNCH(name);
+        }
+        if (g.M >= 2048 && g.N >= BCH && g.K >= 8 * BK && !g_force_small && g.flags == 0 && (g_debug_flags & 8388608)) {
+            g.tiles_m = (g.M + BTOK - 1) / BTOK;
+            g.tiles_n = (g.N + BCH - 1) / BCH;
+            const int ntiles = g.tiles_m * g.tiles_n;
+            const dim3 grid(ntiles < 256 ? ntiles : 256);
+            g.stagger_units = (g_debug_flags >> 16) & 63;   // ablation bits of the pp kernel (measurement only)
+            if (EPI == EPI_RQ && (g_debug_flags & 33554432)) g.res = (const int8_t*)g_stamp_buf;   // time stamps
+            if (g.K >= 16 * BK && !(g_debug_flags & 16777216))
+                hipLaunchKernelGGL((gemm_i8_pp_kernel<EPI, 2>), grid, dim3(BIG_NT), 0, ivit_stream(stream), g);
+            else if (g.K >= 11 * BK && !(g_debug_flags & 16777216))
+                hipLaunchKernelGGL((gemm_i8_pp_kernel<EPI, 3>), grid, dim3(BIG_NT), 0, ivit_stream(stream), g);
+            else
+                hipLaunchKernelGGL((gemm_i8_pp_kernel<EPI, 4>), grid, dim3(BIG_NT), 0, ivit_stream(stream), g);
             IVIT_CHECK_LAUNCH(name);
         }
         if (g.M >= 2048 && g.N >= BCH && !g_force_small && g.flags == 0 && (g_debug_flags & 8192)) {

@@ -193,7 +193,7 @@ def test_gemm_both_kernels_agree():
                   _lib.ptr(out), N, M, N, K, st())
         outs.append(out.cpu().numpy())
     _lib.call("ivit_debug_force_small_gemm", 0)
-    for flags in (1024, 2048, 4096, 8192, 32, 4194304):   # relaunch form; tail split; one workgroup per CU; deep ring; 256x256; persistent 256x256
+    for flags in (1024, 2048, 4096, 8192, 32, 4194304, 8388608):   # relaunch form; tail split; one workgroup per CU; deep ring; 256x256; persistent 256x256
         _lib.call("ivit_debug_set_gemm_flags", flags)
         out = torch.empty(M, N, dtype=torch.int8, device=DEV)
         _lib.call("ivit_gemm_i8_requant", _lib.ptr(dA), K, _lib.ptr(dW), K, _lib.ptr(db), _lib.ptr(md), _lib.ptr(ed),
