@@ -457,7 +457,8 @@ int launch_gemm(GemmArgs& g, const char* name, ivit_stream_t stream)
             const int ntiles = g.tiles_m * g.tiles_n;
             // 2 resident workgroups x 256 CUs; debug bit 12: one workgroup per CU (extra dynamic LDS blocks the second)
             const bool one_per_cu = (g_debug_flags & 4096) != 0;
-            const int SLOTS = one_per_cu ? 256 : 512;
+            // debug bit 26: a 256-workgroup grid WITHOUT the LDS blocker (probe: two streams' GEMMs sharing the CUs)
+            const int SLOTS = (one_per_cu || (g_debug_flags & 67108864)) ? 256 : 512;
             // tail split (see PersWork): R tiles of a last round that is at most half full become 2R half tiles.
             // Measured slower (proj 47.7 -> 50.0 us, fc2 162 -> 173 us): a CU left with one workgroup runs it nearly
             // twice as fast, so the sparse last round is not the cost the tile count suggests.  Opt-in (debug bit 11).

@@ -69,13 +69,23 @@ IVIT_DEV float ln_factor(long long var)
 
 // int8 in -> int8 out, NJ dwords (4 channels each) per lane, per-channel constants kept in registers
 // across the rows a wave processes.
+//
+// The tail of the reference's chain for one element is  x = y * s_ln (:63, float32),  z = round(x / s_ln)
+// (quant_utils.py:220, float32 quotient),  out = clamp8(RNE(float64(z) * M)) (:229-230), M = m * 2^-e.  It costs six
+// float64 instructions per element when evaluated literally.  Fast path: z = y * (1 + eps) with |eps| <= 2^-22 (two
+// float32 roundings of relative size 2^-24 each, plus the round() step, which is a no-op for |y| >= 2^23, moves
+// 2^22 <= |y| < 2^23 by at most 1/2 <= |y| * 2^-23 and gives back z = y exactly for |y| < 2^22), so the real number
+// the reference rounds lies between y * lo and y * hi for float32 lo <= M * (1 - 1.25 * 2^-22), hi >= M * (1 + 1.25 * 2^-22).
+// t_lo = fma(y, lo, 1.5 * 2^23) and t_hi = fma(y, hi, 1.5 * 2^23) are RNE(y * lo) and RNE(y * hi) exactly (one rounding,
+// ulp 1) while |y * hi| < 2^22; RNE is monotone, so t_lo == t_hi certifies the reference's result.  Products beyond
+// 2^22 saturate the int8 clamp on either side whatever their rounding (float bit patterns are monotone), so they need
+// no separate range test.  A row with any uncertified element (about 1 % of the rows) is redone literally.
 template <int NJ>
-__global__ __launch_bounds__(NT) void layernorm_i8_kernel(LnArgs a)
+__global__ __launch_bounds__(NT, (NJ <= 3 ? 4 : NJ <= 8 ? 2 : 1)) void layernorm_i8_kernel(LnArgs a)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int C = a.C, nd = C >> 2;
-    float bias[NJ][4], sln[NJ][4];
-    double rs[NJ][4], Mq[NJ][4];
+    float bias[NJ][4], lo[NJ][4], hi[NJ][4];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         int d = lane + 64 * j;
@@ -85,14 +95,24 @@ __global__ __launch_bounds__(NT) void layernorm_i8_kernel(LnArgs a)
             const uint4 m4 = *reinterpret_cast<const uint4*>(a.m + 4 * d);
             const int4 e4 = *reinterpret_cast<const int4*>(a.e + 4 * d);
             bias[j][0] = b4.x; bias[j][1] = b4.y; bias[j][2] = b4.z; bias[j][3] = b4.w;
-            sln[j][0] = s4.x; sln[j][1] = s4.y; sln[j][2] = s4.z; sln[j][3] = s4.w;
-            Mq[j][0] = dyadic_mult(m4.x, e4.x); Mq[j][1] = dyadic_mult(m4.y, e4.y);
-            Mq[j][2] = dyadic_mult(m4.z, e4.z); Mq[j][3] = dyadic_mult(m4.w, e4.w);
+            const float sl[4] = {s4.x, s4.y, s4.z, s4.w};
+            const double Mq[4] = {dyadic_mult(m4.x, e4.x), dyadic_mult(m4.y, e4.y), dyadic_mult(m4.z, e4.z),
+                                  dyadic_mult(m4.w, e4.w)};
 #pragma unroll
-            for (int c = 0; c < 4; ++c) rs[j][c] = 1.0 / (double)sln[j][c];
+            for (int c = 0; c < 4; ++c) {
+                const double lod = Mq[c] * (1.0 - 1.25 / 4194304.0), hid = Mq[c] * (1.0 + 1.25 / 4194304.0);
+                float lf = (float)lod, hf = (float)hid;
+                if ((double)lf > lod) lf = __int_as_float(__float_as_int(lf) - 1);   // largest float32 <= lod (lod > 0)
+                if ((double)hf < hid) hf = __int_as_float(__float_as_int(hf) + 1);   // smallest float32 >= hid
+                // the error bound on z needs normal float32 products y * s_ln: a degenerate scale, or a multiplier outside
+                // the normal float32 range, never certifies
+                const bool ok = fabsf(sl[c]) >= 1e-30f && fabsf(sl[c]) <= 1e30f && lod > 1e-35 && hid < 1e30;
+                lo[j][c] = ok ? lf : 0.0f;
+                hi[j][c] = ok ? hf : __builtin_inff();
+            }
         } else {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) { bias[j][c] = 0.f; sln[j][c] = 1.f; rs[j][c] = 1.0; Mq[j][c] = 0.0; }
+            for (int c = 0; c < 4; ++c) { bias[j][c] = 0.f; lo[j][c] = 0.f; hi[j][c] = 0.f; }
         }
     }
     const int8_t* xin = reinterpret_cast<const int8_t*>(a.x);
@@ -100,7 +120,7 @@ __global__ __launch_bounds__(NT) void layernorm_i8_kernel(LnArgs a)
     // G rows per wave and iteration.  The per-row statistics (mean division, ten Newton steps, reciprocal) are scalar
     // work that a one-row-per-wave kernel repeats in all 64 lanes; here lane r evaluates them for row r of the group
     // (G rows in parallel across lanes) and the results come back as wave-uniform values through v_readlane.
-    constexpr int G = (NJ <= 4) ? 4 : 1;
+    constexpr int G = (NJ <= 3) ? 8 : (NJ <= 4) ? 4 : 1;
     for (int row0 = (blockIdx.x * WPB + wave) * G; row0 < a.rows; row0 += gridDim.x * WPB * G) {
         int w[G][NJ], sum[G], var[G];   // var[]: sum of squares
 #pragma unroll
@@ -145,28 +165,63 @@ __global__ __launch_bounds__(NT) void layernorm_i8_kernel(LnArgs a)
             if (row0 + rr >= a.rows) continue;
             // :52 floor((y * factor) / 2): halving commutes with the float32 product (exact scaling), so fold it into the factor
             const float hfactor = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_factor), rr)) * 0.5f;
-            int* orow = reinterpret_cast<int*>(out + (int64_t)(row0 + rr) * a.ldo);
+            const float mean128 = (float)(mean_int[rr] + 128);
+            int res[NJ];
+            unsigned unc = 0;
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                int d = lane + 64 * j;
-                if (d < nd) {
+                const unsigned wu = (unsigned)w[rr][j] ^ 0x80808080u;      // bytes x + 128: v_cvt_f32_ubyteN below
+                int o[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float dl = (float)((wu >> (8 * c)) & 0xffu) - mean128;   // x - mean, exact
+                    const float v = floorf(dl * hfactor);                  // :52  float32 product, /2, floor
+                    const float y = v + bias[j][c];                        // :61  float32 add
+                    const int tl = __float_as_int(__builtin_fmaf(y, lo[j][c], 12582912.0f));
+                    const int th = __float_as_int(__builtin_fmaf(y, hi[j][c], 12582912.0f));
+                    asm("v_sad_u32 %0, %1, %2, %3" : "=v"(unc) : "v"(tl), "v"(th), "v"(unc));
+                    o[c] = clamp_i32(tl, 0x4B400000 - 128, 0x4B400000 + 127);   // low byte = int8 result
+                }
+                const unsigned w01 = __builtin_amdgcn_perm((unsigned)o[1], (unsigned)o[0], 0x0c0c0400u);
+                const unsigned w23 = __builtin_amdgcn_perm((unsigned)o[3], (unsigned)o[2], 0x04000c0cu);
+                res[j] = (int)(w01 | w23);
+            }
+            // lanes beyond the row (d >= nd) hold lo = hi = 0: always certified
+            if (__builtin_amdgcn_ballot_w64(unc != 0) != 0) {
+                // literal evaluation of the row (wave-uniform branch)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    int d = lane + 64 * j;
+                    if (d >= nd) continue;
+                    const float4 s4 = *reinterpret_cast<const float4*>(a.s_ln + 4 * d);
+                    const uint4 m4 = *reinterpret_cast<const uint4*>(a.m + 4 * d);
+                    const int4 e4 = *reinterpret_cast<const int4*>(a.e + 4 * d);
+                    const float sl[4] = {s4.x, s4.y, s4.z, s4.w};
+                    const double Mq[4] = {dyadic_mult(m4.x, e4.x), dyadic_mult(m4.y, e4.y), dyadic_mult(m4.z, e4.z),
+                                          dyadic_mult(m4.w, e4.w)};
                     int o[4];
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         float dl = (float)(sx8(w[rr][j], c) - mean_int[rr]);
-                        float v = floorf(dl * hfactor);                    // :52  float32 product, /2, floor
-                        float y = v + bias[j][c];                          // :61  float32 add
-                        float x = y * sln[j][c];                           // :63  float32 product
+                        float v = floorf(dl * hfactor);                    // :52
+                        float y = v + bias[j][c];                          // :61
+                        float x = y * sl[c];                               // :63  float32 product
                         // quant_utils.py:220  z = round(x / s): the correctly rounded float32 quotient,
                         // obtained as RN24(RN53(x * RN53(1/s))) (no midpoint can lie within 2^-52 of x/s)
-                        float qf = (float)((double)x * rs[j][c]);
+                        float qf = (float)((double)x * (1.0 / (double)sl[c]));
                         float z = rintf(qf);
-                        double p = (double)z * Mq[j][c];                   // :229 float64 product
+                        double p = (double)z * Mq[c];                      // :229 float64 product
                         double t = p + IVIT_MAGIC;                         // :230 round half to even
                         o[c] = clamp_i32((int)(unsigned)__double_as_longlong(t), -128, 127);
                     }
-                    orow[d] = pack4(o[0], o[1], o[2], o[3]);
+                    res[j] = pack4(o[0], o[1], o[2], o[3]);
                 }
+            }
+            int* orow = reinterpret_cast<int*>(out + (int64_t)(row0 + rr) * a.ldo);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                int d = lane + 64 * j;
+                if (d < nd) orow[d] = res[j];
             }
         }
     }
@@ -665,10 +720,10 @@ IVIT_EXPORT int ivit_layernorm_i8(const int8_t* x, int64_t ldx, int rows, int C,
                  "ivit_layernorm_i8: per-channel tables must be 16-byte aligned");
     LnArgs a{x, ldx, rows, C, bias_int, s_ln, m, e, out, ldo};
     const int nj = (C / 4 + 63) / 64;
-    // each wave sets up its per-channel constants (4*NJ f64 reciprocals per lane) once: launch no more workgroups than
+    // each wave sets up its per-channel constants (bias and the requant bracket, 12*NJ registers per lane) once: launch no more workgroups than
     // stay resident (256 CUs x waves/SIMD at the kernel's register count) and let them stride over the rows
-    const int resident = 256 * (nj <= 1 ? 8 : nj <= 2 ? 4 : nj <= 3 ? 3 : nj <= 8 ? 2 : 1);
-    int grid = grid_for_rows(rows, nj <= 4 ? 4 : 1);
+    const int resident = 256 * (nj <= 1 ? 6 : nj <= 3 ? 4 : nj <= 4 ? 3 : nj <= 8 ? 2 : 1);
+    int grid = grid_for_rows(rows, nj <= 3 ? 8 : nj <= 4 ? 4 : 1);   // rows per wave and iteration: G of the kernel
     if (grid > resident) grid = resident;
     hipStream_t st = ivit_stream(stream);
     if (nj <= 1) hipLaunchKernelGGL(layernorm_i8_kernel<1>, dim3(grid), dim3(NT), 0, st, a);
