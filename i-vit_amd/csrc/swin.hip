@@ -173,8 +173,9 @@ __global__ __launch_bounds__(NT) void layernorm_i16_i8_tiled_kernel(Ln16Args a)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane & (LPR - 1), grp = lane / LPR;
     const int C = a.C, nd = C >> 3;
-    float bias[NJ][8], sln[NJ][8];
-    double rs[NJ][8], Mq[NJ][8];
+    // bias and the float32 bracket (lo, hi) of each channel's QuantAct multiplier: see layernorm_i8_kernel (rowops.hip) for
+    // the certificate that replaces the literal float64 tail of the chain; uncertified wave-iterations are redone literally
+    float bias[NJ][8], lo[NJ][8], hi[NJ][8];
     {
         // all table loads first (vector loads, independent), then the arithmetic: the waves of this kernel have little
         // else in flight to hide a chain of dependent global-load latencies behind
@@ -203,9 +204,14 @@ __global__ __launch_bounds__(NT) void layernorm_i16_i8_tiled_kernel(Ln16Args a)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     bias[j][4 * h + c] = bb[c];
-                    sln[j][4 * h + c] = ss[c];
-                    rs[j][4 * h + c] = 1.0 / (double)ss[c];
-                    Mq[j][4 * h + c] = dyadic_mult(mm[c], ee[c]);
+                    const double M = dyadic_mult(mm[c], ee[c]);
+                    const double lod = M * (1.0 - 1.25 / 4194304.0), hid = M * (1.0 + 1.25 / 4194304.0);
+                    float lf = (float)lod, hf = (float)hid;
+                    if ((double)lf > lod) lf = __int_as_float(__float_as_int(lf) - 1);
+                    if ((double)hf < hid) hf = __int_as_float(__float_as_int(hf) + 1);
+                    const bool ok = fabsf(ss[c]) >= 1e-30f && fabsf(ss[c]) <= 1e30f && lod > 1e-35 && hid < 1e30;
+                    lo[j][4 * h + c] = ok ? lf : 0.0f;
+                    hi[j][4 * h + c] = ok ? hf : __builtin_inff();
                 }
             }
     }
@@ -250,9 +256,10 @@ __global__ __launch_bounds__(NT) void layernorm_i16_i8_tiled_kernel(Ln16Args a)
         for (int it = 0; it < 10; ++it) t = floorf((t + floorf(varf / t)) * 0.5f);
         const float hfactor = floorf((1.0f / t) * 2147483648.0f) * 0.5f;        // :51; the /2 of :52 commutes (exact scaling)
         int8_t* orow = a.out + win_row(a.map, min(row, a.rows - 1)) * a.ldo;
+        int2 res[NJ];
+        unsigned unc = 0;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            const int d = sub + LPR * j;
             int o[8];
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
@@ -260,17 +267,50 @@ __global__ __launch_bounds__(NT) void layernorm_i16_i8_tiled_kernel(Ln16Args a)
                 const float dl = (float)(xv - mean_int);
                 const float v = floorf(dl * hfactor);                           // :52
                 const float y = v + bias[j][c];                                 // :61
-                const float x = y * sln[j][c];                                  // :63
-                const float z = rintf((float)((double)x * rs[j][c]));           // quant_utils.py:220, see layernorm_i8_kernel
-                const double tt = (double)z * Mq[j][c] + IVIT_MAGIC;            // :229-230
-                o[c] = clamp_i32((int)(unsigned)__double_as_longlong(tt), -128, 127);
+                const int tl = __float_as_int(__builtin_fmaf(y, lo[j][c], 12582912.0f));
+                const int th = __float_as_int(__builtin_fmaf(y, hi[j][c], 12582912.0f));
+                asm("v_sad_u32 %0, %1, %2, %3" : "=v"(unc) : "v"(tl), "v"(th), "v"(unc));
+                o[c] = clamp_i32(tl, 0x4B400000 - 128, 0x4B400000 + 127);       // low byte = int8 result
             }
-            if (live && d < nd) {
-                int2 pk;
-                pk.x = pack4(o[0], o[1], o[2], o[3]);
-                pk.y = pack4(o[4], o[5], o[6], o[7]);
-                *reinterpret_cast<int2*>(orow + 8 * d) = pk;
+            res[j].x = pack4(o[0], o[1], o[2], o[3]);
+            res[j].y = pack4(o[4], o[5], o[6], o[7]);
+        }
+        if (__builtin_amdgcn_ballot_w64(unc != 0) != 0) {
+            // literal evaluation (wave-uniform branch): x = y * s_ln (:63), z = round(x / s_ln) (quant_utils.py:220),
+            // RNE(float64(z) * M) (:229-230)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int d = min(sub + LPR * j, nd - 1);
+                int o[8];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const float4 s4 = *reinterpret_cast<const float4*>(a.s_ln + 8 * d + 4 * h);
+                    const uint4 m4 = *reinterpret_cast<const uint4*>(a.m + 8 * d + 4 * h);
+                    const int4 e4 = *reinterpret_cast<const int4*>(a.e + 8 * d + 4 * h);
+                    const float ss[4] = {s4.x, s4.y, s4.z, s4.w};
+                    const double MM[4] = {dyadic_mult(m4.x, e4.x), dyadic_mult(m4.y, e4.y), dyadic_mult(m4.z, e4.z),
+                                          dyadic_mult(m4.w, e4.w)};
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) {
+                        const int c = 4 * h + cc;
+                        const int xv = (c & 1) ? (w[j][c >> 1] >> 16) : (int)(int16_t)w[j][c >> 1];
+                        const float dl = (float)(xv - mean_int);
+                        const float v = floorf(dl * hfactor);
+                        const float y = v + bias[j][c];
+                        const float x = y * ss[cc];
+                        const float z = rintf((float)((double)x * (1.0 / (double)ss[cc])));   // see layernorm_i8_kernel
+                        const double tt = (double)z * MM[cc] + IVIT_MAGIC;
+                        o[c] = clamp_i32((int)(unsigned)__double_as_longlong(tt), -128, 127);
+                    }
+                }
+                res[j].x = pack4(o[0], o[1], o[2], o[3]);
+                res[j].y = pack4(o[4], o[5], o[6], o[7]);
             }
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int d = sub + LPR * j;
+            if (live && d < nd) *reinterpret_cast<int2*>(orow + 8 * d) = res[j];
         }
     }
 }

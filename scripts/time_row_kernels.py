@@ -39,3 +39,14 @@ for C in (768, 384, 192):
     us = timeit(lambda: _lib.call("ivit_layernorm_i8", _lib.ptr(x), C, rows, C, _lib.ptr(b), _lib.ptr(s), _lib.ptr(m), _lib.ptr(e),
                                   _lib.ptr(out), C, _lib.stream_ptr()))
     print(f"layernorm_i8 rows={rows} C={C}: {us:7.1f} us  {2 * rows * C / us / 1e6:6.2f} TB/s", flush=True)
+
+# fused attention, DeiT-B geometry: 256 images x 12 heads x 197 tokens x 64
+B, H, T, HD = 256, 12, 197, 64
+qkv = torch.from_numpy(np.clip(np.rint(rng.normal(0, 40, size=(3, B, H, T, HD))), -128, 127).astype(np.int8)).to(DEV)
+out = torch.empty(B * T, H * HD, dtype=torch.int8, device=DEV)
+from ivit_amd.prepare import dyadic  # noqa: E402
+ms, es = dyadic(np.float32(1.0 / 3000.0), np.float32(1.0))
+mo, eo = dyadic(np.float32(1.0 / 128.0), np.float32(1.0))
+us = timeit(lambda: _lib.call("ivit_attention_fused_i8", _lib.ptr(qkv), _lib.ptr(out), B, H, T, HD, int(ms[0]), int(es[0]), 0.05,
+                              int(mo[0]), int(eo[0]), _lib.stream_ptr()))
+print(f"attention_fused_i8 B={B} H={H} T={T}: {us:7.1f} us", flush=True)
