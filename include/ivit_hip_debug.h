@@ -18,7 +18,10 @@ int ivit_debug_force_small_gemm(int on);
  * (A/B timing): 32 the 256x256-tile kernel, 64 no start stagger, 1024 the relaunch-per-tile form instead of the
  * persistent one, 2048 split a sparse last round of tiles into half tiles, 4096 one workgroup per CU, 8192 the
  * deep-ring (5-stage, one workgroup per CU) kernel, 32768 per-CU turn-taking of the main loops, bits 16-21 start delay
- * of the second co-resident workgroup in ~1K-cycle units, bit 22 the persistent 256x256 kernel. */
+ * of the second co-resident workgroup in ~1K-cycle units, bit 22 the persistent 256x256 kernel, bit 23 the ping-pong
+ * kernel (its ablations reuse bits 16-18: no exact fallback / no in-loop requantisation / no phase 2; bit 24 forces
+ * four units per K step; bit 25 writes time stamps into the stamp buffer), bit 26 a 256-workgroup grid of the
+ * persistent kernel without the LDS blocker (two-stream probe). */
 int ivit_debug_set_gemm_flags(int flags);
 /* Diagnostic timeline buffer (8 x uint64 per workgroup) for the stamped build (flags = 512); scripts/gemm_timeline.py */
 int ivit_debug_set_stamp_buffer(void* buf);
