@@ -144,16 +144,22 @@ def test_gemm_requant_residual(M, N, K):
     b = rng.integers(-50000, 50000, size=N).astype(np.int32)
     res = rng.integers(-128, 128, size=(M, N)).astype(np.int8)
     m, e = rand_me(rng, N, -16, -9)
-    m1, e1 = dyadic(np.float32(0.7 * 2 ** -4), np.float32(2 ** -4))
-    m2, e2 = dyadic(np.float32(2 ** -5), np.float32(2 ** -4))
     k3 = orc.requant(orc.gemm_i8(A, W, b), m.astype(np.float64), e, 8)
-    exp = orc.requant(k3, m1.astype(np.float64), e1, 8, z2=res.astype(np.int32), m2=m2.astype(np.float64), e2=e2)
-    out = torch.empty(M, N, dtype=torch.int8, device=DEV)
     md, ed = me_dev(m, e)
-    _lib.call("ivit_gemm_i8_requant_residual", _lib.ptr(dev(A)), K, _lib.ptr(dev(W)), K, _lib.ptr(dev(b)),
-              _lib.ptr(md), _lib.ptr(ed), _lib.ptr(dev(res)), N, int(m1[0]), int(e1[0]), int(m2[0]), int(e2[0]),
-              _lib.ptr(out), N, M, N, K, st())
-    assert np.array_equal(out.cpu().numpy().astype(np.int32), exp)
+    dA, dW, db, dres = dev(A), dev(W), dev(b), dev(res)
+    # residual QuantAct scale pairs: the usual kind, ratios with exact ties (k * 0.5), identity, arbitrary floats
+    pairs = [(0.7 * 2 ** -4, 2 ** -5, 2 ** -4), (2 ** -5, 2 ** -5, 2 ** -4), (1.0, 1.0, 1.0),
+             (float(rng.uniform(0.01, 0.3)), float(rng.uniform(0.01, 0.3)), float(rng.uniform(0.05, 0.2))),
+             (0.3337, 0.0421, 0.0517)]
+    for s_main, s_res, s_out in pairs:
+        m1, e1 = dyadic(np.float32(s_main), np.float32(s_out))
+        m2, e2 = dyadic(np.float32(s_res), np.float32(s_out))
+        exp = orc.requant(k3, m1.astype(np.float64), e1, 8, z2=res.astype(np.int32), m2=m2.astype(np.float64), e2=e2)
+        out = torch.empty(M, N, dtype=torch.int8, device=DEV)
+        _lib.call("ivit_gemm_i8_requant_residual", _lib.ptr(dA), K, _lib.ptr(dW), K, _lib.ptr(db),
+                  _lib.ptr(md), _lib.ptr(ed), _lib.ptr(dres), N, int(m1[0]), int(e1[0]), int(m2[0]), int(e2[0]),
+                  _lib.ptr(out), N, M, N, K, st())
+        assert np.array_equal(out.cpu().numpy().astype(np.int32), exp), (s_main, s_res, s_out)
 
 
 @pytest.mark.parametrize("B,H", [(3, 3), (11, 6)])
