@@ -306,6 +306,48 @@ def test_layernorm_random_vs_oracle(rows, Cn):
     assert np.array_equal(got, exp), f"{(got != exp).sum()} of {got.size} differ"
 
 
+@pytest.mark.parametrize("regime", ["tiny_gamma", "huge_gamma", "big_bias", "saturating", "vanishing", "constant_rows",
+                                    "two_level_rows", "mixed_sign_gamma_free"])
+@pytest.mark.parametrize("Cn", [768, 192])
+def test_layernorm_certificate_regimes(regime, Cn):
+    """the float32 bracket certificate of layernorm_i8_kernel (and its literal fallback) against the oracle where the
+    pieces of the chain have unusual magnitudes: |y| far below 2^22 / near 2^31, multipliers that saturate or vanish,
+    degenerate rows"""
+    rows = 3000
+    rng = np.random.default_rng(len(regime) * 1000 + Cn)
+    k = np.clip(np.rint(rng.normal(rng.normal(0, 20, size=(rows, 1)), rng.uniform(0.5, 60, size=(rows, 1)), size=(rows, Cn))),
+                -128, 127).astype(np.int8)
+    gamma = rng.uniform(0.5, 1.5, size=Cn).astype(np.float32)
+    beta = rng.normal(0, 0.1, size=Cn).astype(np.float32)
+    scale_out = 0.8
+    if regime == "tiny_gamma":
+        gamma = rng.uniform(1e-4, 3e-3, size=Cn).astype(np.float32)
+        beta = (gamma * rng.normal(0, 0.2, size=Cn)).astype(np.float32)
+    elif regime == "huge_gamma":
+        gamma = rng.uniform(20, 80, size=Cn).astype(np.float32)
+    elif regime == "big_bias":
+        beta = rng.normal(0, 8.0, size=Cn).astype(np.float32)          # |bias_int| up to ~2^30
+    elif regime == "saturating":
+        scale_out = 0.02                                               # most outputs clamp at +-127 / -128
+    elif regime == "vanishing":
+        scale_out = 300.0                                              # outputs in {-1, 0, 1}: every product near a tie
+    elif regime == "constant_rows":
+        k[::3] = k[::3, :1]                                            # variance 0: the Newton chain runs on 0
+    elif regime == "two_level_rows":
+        k[:] = np.where(rng.random((rows, Cn)) < 0.5, -128, 127).astype(np.int8)
+    y, s_ln, _ = orc.layernorm(k.astype(np.int32), gamma, beta)
+    s_out = np.float32(2.0 ** np.ceil(np.log2(max(float(np.abs(y * s_ln).max()), 1e-30) / 127 * scale_out)))
+    m, e = orc.dyadic(s_ln, s_out)
+    exp = orc.requant(orc.roundtrip(y, s_ln), m, e, 8)
+    lp = _ln_host(gamma, beta, s_out)
+    out = torch.empty(rows, Cn, dtype=torch.int8, device=DEV)
+    md, ed = me_dev(lp.m, lp.e)
+    _lib.call("ivit_layernorm_i8", _lib.ptr(dev(k)), Cn, rows, Cn, _lib.ptr(dev(lp.bias_int)),
+              _lib.ptr(dev(lp.s_ln)), _lib.ptr(md), _lib.ptr(ed), _lib.ptr(out), Cn, st())
+    got = out.cpu().numpy().astype(np.int32)
+    assert np.array_equal(got, exp), f"{regime}: {(got != exp).sum()} of {got.size} differ"
+
+
 # ----------------------------------------------------------------------------------- GELU
 def test_shiftgelu_kat_direct_and_lut(kat):
     for ci in kat["gelu_cases"]:

@@ -141,6 +141,37 @@ def test_layernorm_i16_i8(rows, C, amp):
     assert not got[:, C:].any()
 
 
+@pytest.mark.parametrize("regime", ["tiny_gamma", "big_bias", "saturating", "vanishing"])
+@pytest.mark.parametrize("C", [96, 384])
+def test_layernorm_i16_certificate_regimes(regime, C):
+    """float32 bracket certificate of the tiled int16 LayerNorm (and its literal fallback) at unusual magnitudes"""
+    rows = 4000
+    rng = np.random.default_rng(len(regime) * 100 + C)
+    x = np.clip(np.rint(rng.normal(0, rng.uniform(5, 6000, size=(rows, 1)), size=(rows, C))), -32768, 32767).astype(np.int16)
+    gamma = rng.uniform(0.5, 1.5, size=C).astype(np.float32)
+    beta = (rng.standard_normal(C) * 0.1).astype(np.float32)
+    scale_out = 0.8
+    if regime == "tiny_gamma":
+        gamma = rng.uniform(1e-4, 3e-3, size=C).astype(np.float32)
+        beta = (gamma * rng.normal(0, 0.2, size=C)).astype(np.float32)
+    elif regime == "big_bias":
+        beta = rng.normal(0, 8.0, size=C).astype(np.float32)
+    elif regime == "saturating":
+        scale_out = 0.02
+    elif regime == "vanishing":
+        scale_out = 300.0
+    y, s_ln, _ = orc.layernorm(x.astype(np.int32), gamma, beta)
+    s_out = np.float32(2.0 ** np.ceil(np.log2(max(float(np.abs(y * s_ln).max()), 1e-30) / 127 * scale_out)))
+    lp = LayerNormParams(gamma, beta, s_out)
+    om, oe = orc.dyadic(s_ln, s_out)
+    ref = orc.requant(orc.roundtrip(y, s_ln), om, oe, 8)
+    out = torch.zeros(rows, C, dtype=torch.int8, device=DEV)
+    _lib.call("ivit_layernorm_i16_i8", _lib.ptr(dev(x)), rows, C, _lib.ptr(dev(lp.bias_int)), _lib.ptr(dev(lp.s_ln)),
+              _lib.ptr(dev(lp.m.view(np.int32))), _lib.ptr(dev(lp.e)), _lib.ptr(out), C, 0, 0, 0, 0, st())
+    got = out.cpu().numpy().astype(np.int32)
+    assert np.array_equal(got, ref), f"{regime}: {(got != ref).sum()} of {got.size} differ"
+
+
 def test_layernorm_i16_i8_window_order():
     rng = np.random.default_rng(5)
     B, H, ws, shift, C = 2, 14, 7, 3, 96
