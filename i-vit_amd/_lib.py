@@ -24,6 +24,7 @@ SIGNATURES = {
     "ivit_quantize_patchify_f32_i8": [vp, vp, ci, ci, ci, ci, f32, vp],
     "ivit_gemm_i8_requant": [vp, i64, vp, i64, vp, vp, vp, vp, i64, ci, ci, ci, vp],
     "ivit_gemm_i8_requant_residual": [vp, i64, vp, i64, vp, vp, vp, vp, i64, u32, i32, u32, i32, vp, i64, ci, ci, ci, vp],
+    "ivit_gemm_i8_requant_residual_i16": [vp, i64, vp, i64, vp, vp, vp, vp, i64, u32, i32, u32, i32, vp, i64, ci, ci, ci, vp],
     "ivit_gemm_i8_requant_qkv": [vp, i64, vp, i64, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp],
     "ivit_gemm_i8_i32": [vp, i64, vp, i64, vp, vp, i64, ci, ci, ci, vp],
     "ivit_debug_force_small_gemm": [ci],

@@ -438,6 +438,9 @@ int launch_gemm(GemmArgs& g, const char* name, ivit_stream_t stream)
     if (EPI == EPI_RESID)
         IVIT_REQUIRE(g.res && g.ldr >= g.N && g.ldr % 16 == 0 && ((uintptr_t)g.res % 16 == 0),
                      "%s: residual operand missing or misaligned", name);
+    if (EPI == EPI_RESID16)
+        IVIT_REQUIRE(g.res && g.ldr >= g.N && g.ldr % 8 == 0 && ((uintptr_t)g.res % 16 == 0) && g.ldo >= g.N && g.ldo % 8 == 0,
+                     "%s: 16-bit residual / output rows must be 16-byte aligned (ld multiples of 8 elements)", name);
     if (EPI == EPI_QKV) {
         IVIT_REQUIRE(g.tokens > 0 && g.heads > 0 && g.head_dim > 0 && g.head_dim % 16 == 0,
                      "%s: bad head geometry tokens=%d heads=%d head_dim=%d", name, g.tokens, g.heads, g.head_dim);
@@ -446,7 +449,7 @@ int launch_gemm(GemmArgs& g, const char* name, ivit_stream_t stream)
     }
     g.flags = g_debug_flags & (31 | 128 | 256 | 512);
     if constexpr (EPI != EPI_I32) {
-        if (g_debug_flags & (31 | 32 | 128 | 256 | 512 | 1024 | 8192 | 4194304 | 8388608)) {   // a lab form was asked for (tests, scripts)
+        if (EPI <= EPI_QKV && (g_debug_flags & (31 | 32 | 128 | 256 | 512 | 1024 | 8192 | 4194304 | 8388608))) {   // a lab form was asked for (tests, scripts)
             int rc = IVIT_OK;
             if (ivit_gemm_lab_launch(EPI, &g, name, stream, &rc)) return rc;
         }
@@ -511,6 +514,22 @@ IVIT_EXPORT int ivit_gemm_i8_requant_residual(const int8_t* A, int64_t lda, cons
     IVIT_REQUIRE(g.M_main < 1048576.0 && g.M_res < 1048576.0,
                  "ivit_gemm_i8_requant_residual: residual multiplier >= 2^20 is outside the int8 fast path");
     return launch_gemm<EPI_RESID>(g, "ivit_gemm_i8_requant_residual", stream);
+}
+
+IVIT_EXPORT int ivit_gemm_i8_requant_residual_i16(const int8_t* A, int64_t lda, const int8_t* W, int64_t ldw,
+                                                  const int32_t* bias, const uint32_t* m, const int32_t* e,
+                                                  const int16_t* res, int64_t ldr, uint32_t m_main, int32_t e_main,
+                                                  uint32_t m_res, int32_t e_res, int16_t* out, int64_t ldo, int M, int N,
+                                                  int K, ivit_stream_t stream)
+{
+    GemmArgs g{};
+    g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.m = m; g.e = e;
+    g.res = reinterpret_cast<const int8_t*>(res); g.ldr = ldr;
+    g.out = out; g.ldo = ldo; g.M = M; g.N = N; g.K = K;
+    g.M_main = ivit_dyadic_to_double(m_main, e_main);
+    g.M_res = ivit_dyadic_to_double(m_res, e_res);
+    IVIT_REQUIRE(g.M_main < 32768.0 && g.M_res < 32768.0, "ivit_gemm_i8_requant_residual_i16: residual multiplier too large");
+    return launch_gemm<EPI_RESID16>(g, "ivit_gemm_i8_requant_residual_i16", stream);
 }
 
 IVIT_EXPORT int ivit_gemm_i8_requant_qkv(const int8_t* A, int64_t lda, const int8_t* W, int64_t ldw,

@@ -22,7 +22,9 @@ constexpr int STAGE_BYTES = (BM + BN) * BK;  // 16 KiB
 constexpr int W_OFF = BM * BK;               // weight tile behind the token tile
 constexpr int SMEM_BYTES = 2 * STAGE_BYTES;  // 32 KiB >= 128 * 132
 
-enum { EPI_RQ = 0, EPI_RESID = 1, EPI_QKV = 2, EPI_I32 = 3 };
+// EPI_RESID16 (Swin mlp.fc2 + the 16-bit residual QuantAct): int8 requant as EPI_RQ, then
+//   out16 = clamp16(RNE(k8 * M_main) + RNE(res16 * M_res)) with res / out int16 (res, out of GemmArgs reinterpreted)
+enum { EPI_RQ = 0, EPI_RESID = 1, EPI_QKV = 2, EPI_I32 = 3, EPI_RESID16 = 4 };
 
 
 struct GemmArgs {
@@ -187,6 +189,7 @@ IVIT_DEV void epilogue_i8(v16i (&acc)[TI][TJ], const GemmArgs& g, char* smem, co
     constexpr int NIT = TOK * CPR / NTHREADS;
     int v[NIT][4];
     int4 rv[NIT];
+    int4 rw[EPI == EPI_RESID16 ? NIT : 1][2];   // 16 int16 residual values per chunk
     hook.issue();    // persistent kernel: next tile's table loads go out before this tile's stores
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
@@ -197,6 +200,12 @@ IVIT_DEV void epilogue_i8(v16i (&acc)[TI][TJ], const GemmArgs& g, char* smem, co
         if constexpr (EPI == EPI_RESID) {
             const int t = min(m0 + tl, g.M - 1), cn = min(n0 + 16 * cc, g.N - 16);
             rv[it] = *reinterpret_cast<const int4*>(g.res + (int64_t)t * g.ldr + cn);
+        }
+        if constexpr (EPI == EPI_RESID16) {
+            const int t = min(m0 + tl, g.M - 1), cn = min(n0 + 16 * cc, g.N - 16);
+            const int4* rp = reinterpret_cast<const int4*>(reinterpret_cast<const int16_t*>(g.res) + (int64_t)t * g.ldr + cn);
+            rw[it][0] = rp[0];
+            rw[it][1] = rp[1];
         }
     }
     hook.consume();
@@ -221,6 +230,28 @@ IVIT_DEV void epilogue_i8(v16i (&acc)[TI][TJ], const GemmArgs& g, char* smem, co
                 }
                 v[it][d] = pack4_i8(o[0], o[1], o[2], o[3]);
             }
+        }
+        if constexpr (EPI == EPI_RESID16) {
+            // quant_utils.py:232-245 with a 16-bit output range (swin_quant.py:299): two independently rounded products
+            const int rr[8] = {rw[it][0].x, rw[it][0].y, rw[it][0].z, rw[it][0].w, rw[it][1].x, rw[it][1].y, rw[it][1].z, rw[it][1].w};
+            int ow[8];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                int o[4];
+#pragma unroll
+                for (int bb = 0; bb < 4; ++bb) {
+                    const int idx = 4 * d + bb;                                   // channel within the chunk
+                    const int k8 = (int)(int8_t)(v[it][d] >> (8 * bb));
+                    const int xr = (idx & 1) ? (rr[idx >> 1] >> 16) : (int)(int16_t)rr[idx >> 1];
+                    o[bb] = clamp_i32(requant_exact(k8, g.M_main) + requant_exact(xr, g.M_res), -32768, 32767);
+                }
+                ow[2 * d] = (o[0] & 0xffff) | (o[1] << 16);
+                ow[2 * d + 1] = (o[2] & 0xffff) | (o[3] << 16);
+            }
+            int4* op = reinterpret_cast<int4*>(reinterpret_cast<int16_t*>(g.out) + (int64_t)t * g.ldo + cn);
+            op[0] = make_int4(ow[0], ow[1], ow[2], ow[3]);
+            op[1] = make_int4(ow[4], ow[5], ow[6], ow[7]);
+            continue;
         }
         int64_t off;
         if constexpr (EPI == EPI_QKV) {

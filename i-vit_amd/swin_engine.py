@@ -315,11 +315,15 @@ class IntSwinEngine(GraphReplay):
                 _lib.call("ivit_shiftgelu_lut_i8", _lib.ptr(ws["f1"]), 4 * C, M, 4 * C, _lib.ptr(blk["gelu_lut"]),
                           _lib.ptr(ws["g"]), 4 * C, st)
                 tap(p + "mlp.qact1", ws["g"], M, 4 * C)
-                self._gemm(ws["g"], 4 * C, blk["fc2"], ws["f2"], C, M, st)
-                tap(p + "mlp.qact2", ws["f2"], M, C)
                 r = blk["res2"]
-                _lib.call("ivit_residual_requant_i16", _lib.ptr(ws["f2"]), 8, None, None, r[0], r[1], _lib.ptr(x2), r[2],
-                          r[3], _lib.ptr(x), M, C, 0, 0, 0, 0, st)
+                f2 = blk["fc2"]
+                if taps is not None:   # tests: the 8-bit mlp.qact2 tensor is not materialised on the fused path below
+                    self._gemm(ws["g"], 4 * C, f2, ws["f2"], C, M, st)
+                    tap(p + "mlp.qact2", ws["f2"], M, C)
+                # mlp.fc2 + mlp.qact2 + the 16-bit residual QuantAct qact4 in one kernel (swin_quant.py:297-299)
+                _lib.call("ivit_gemm_i8_requant_residual_i16", _lib.ptr(ws["g"]), 4 * C, _lib.ptr(f2["W"]), f2["K"],
+                          _lib.ptr(f2["b"]), _lib.ptr(f2["m"]), _lib.ptr(f2["e"]), _lib.ptr(x2), C, r[0], r[1], r[2], r[3],
+                          _lib.ptr(x), C, M, f2["N"], f2["K"], st)
                 tap(p + "qact4", x, M, C)
             dn = stg["down"]
             if dn is not None:

@@ -85,6 +85,17 @@ int ivit_gemm_i8_requant_residual(const int8_t* A, int64_t lda, const int8_t* W,
                                   uint32_t m_res, int32_t e_res, int8_t* out, int64_t ldo,
                                   int M, int N, int K, ivit_stream_t stream);
 
+/* Swin form of the above: the residual stream is 16 bits wide (swin_quant.py:299, mlp.fc2 + shortcut):
+ *   k = clamp8(RNE(acc * m[n] / 2^e[n]))                       (mlp.qact2)
+ *   out = clamp16(RNE(k * m_main / 2^e_main) + RNE(res[t][n] * m_res / 2^e_res))   (qact4, 16 bit)
+ * res / out: int16 rows, ldr / ldo in elements and multiples of 8.  Replaces ivit_gemm_i8_requant followed by
+ * ivit_residual_requant_i16(a_bits = 8). */
+int ivit_gemm_i8_requant_residual_i16(const int8_t* A, int64_t lda, const int8_t* W, int64_t ldw,
+                                      const int32_t* bias, const uint32_t* m, const int32_t* e,
+                                      const int16_t* res, int64_t ldr, uint32_t m_main, int32_t e_main,
+                                      uint32_t m_res, int32_t e_res, int16_t* out, int64_t ldo,
+                                      int M, int N, int K, ivit_stream_t stream);
+
 /* as ivit_gemm_i8_requant but the output is written head-major for the attention kernel:
  * N = 3 * heads * head_dim, row t = b * tokens + tok  ->
  *   qkv[which][b][h][tok][d],  n = which*heads*head_dim + h*head_dim + d

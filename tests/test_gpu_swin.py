@@ -141,6 +141,37 @@ def test_layernorm_i16_i8(rows, C, amp):
     assert not got[:, C:].any()
 
 
+@pytest.mark.parametrize("M,N,K", [(3136, 96, 384), (6272, 192, 768), (1000, 384, 1536), (2600, 768, 3072)])
+def test_gemm_requant_residual_i16(M, N, K):
+    """mlp.fc2 + mlp.qact2 + 16-bit residual QuantAct in one kernel == the two-kernel form and the oracle"""
+    rng = np.random.default_rng(M + N)
+    A = rng.integers(-128, 128, size=(M, K)).astype(np.int8)
+    W = rng.integers(-128, 128, size=(N, K)).astype(np.int8)
+    b = rng.integers(-50000, 50000, size=N).astype(np.int32)
+    res = rng.integers(-32768, 32768, size=(M, N)).astype(np.int16)
+    m, e = orc.dyadic(rng.uniform(2e-5, 6e-5, size=N).astype(np.float32), np.float32(1.0))
+    k8 = orc.requant(orc.gemm_i8(A, W, b), m, e, 8)
+    dA, dW, db, dres = dev(A), dev(W), dev(b), dev(res)
+    dm, de = dev(m.astype(np.uint32).view(np.int32)), dev(e.astype(np.int32))
+    for s_main, s_res, s_out in [(0.031, 0.0007, 0.0009), (0.5, 0.25, 0.5), (0.02, 0.003, 0.0001)]:
+        m1, e1 = sme(s_main, s_out)
+        m2, e2 = sme(s_res, s_out)
+        exp = np.clip(np.rint(k8.astype(np.float64) * m1 / 2.0 ** e1) + np.rint(res.astype(np.float64) * m2 / 2.0 ** e2),
+                      -32768, 32767).astype(np.int16)
+        out = torch.zeros(M, N, dtype=torch.int16, device=DEV)
+        _lib.call("ivit_gemm_i8_requant_residual_i16", _lib.ptr(dA), K, _lib.ptr(dW), K, _lib.ptr(db), _lib.ptr(dm), _lib.ptr(de),
+                  _lib.ptr(dres), N, m1, e1, m2, e2, _lib.ptr(out), N, M, N, K, st())
+        assert np.array_equal(out.cpu().numpy(), exp), (s_main, s_res, s_out)
+        # the two-kernel form it replaces
+        k8d = torch.empty(M, N, dtype=torch.int8, device=DEV)
+        _lib.call("ivit_gemm_i8_requant", _lib.ptr(dA), K, _lib.ptr(dW), K, _lib.ptr(db), _lib.ptr(dm), _lib.ptr(de),
+                  _lib.ptr(k8d), N, M, N, K, st())
+        out2 = torch.zeros(M, N, dtype=torch.int16, device=DEV)
+        _lib.call("ivit_residual_requant_i16", _lib.ptr(k8d), 8, None, None, m1, e1, _lib.ptr(dres), m2, e2, _lib.ptr(out2), M, N,
+                  0, 0, 0, 0, st())
+        assert torch.equal(out, out2)
+
+
 @pytest.mark.parametrize("regime", ["tiny_gamma", "big_bias", "saturating", "vanishing"])
 @pytest.mark.parametrize("C", [96, 384])
 def test_layernorm_i16_certificate_regimes(regime, C):
