@@ -24,6 +24,11 @@ SIGNATURES = {
     "ivit_quantize_patchify_f32_i8": [vp, vp, ci, ci, ci, ci, f32, vp],
     "ivit_gemm_i8_requant": [vp, i64, vp, i64, vp, vp, vp, vp, i64, ci, ci, ci, vp],
     "ivit_gemm_i8_requant_residual": [vp, i64, vp, i64, vp, vp, vp, vp, i64, u32, i32, u32, i32, vp, i64, ci, ci, ci, vp],
+    "ivit_tile_operand_i8": [vp, i64, i64, ci, vp, vp],
+    "ivit_untile_operand_i8": [vp, i64, ci, vp, i64, vp],
+    "ivit_gemm_i8_requant_ex": [vp, i64, vp, i64, vp, vp, vp, vp, i64, ci, ci, ci, ci, vp],
+    "ivit_gemm_i8_requant_residual_ex": [vp, i64, vp, i64, vp, vp, vp, vp, i64, u32, i32, u32, i32, vp, i64, ci, ci, ci, ci, vp],
+    "ivit_gemm_i8_requant_qkv_ex": [vp, i64, vp, i64, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp],
     "ivit_gemm_i8_requant_residual_i16": [vp, i64, vp, i64, vp, vp, vp, vp, i64, u32, i32, u32, i32, vp, i64, ci, ci, ci, vp],
     "ivit_gemm_i8_requant_qkv": [vp, i64, vp, i64, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp],
     "ivit_gemm_i8_i32": [vp, i64, vp, i64, vp, vp, i64, ci, ci, ci, vp],

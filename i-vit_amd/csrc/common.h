@@ -48,6 +48,18 @@ IVIT_DEV double dyadic_mult(uint32_t m, int32_t e) { return __builtin_ldexp((dou
 
 IVIT_DEV int clamp_i32(int v, int lo, int hi) { return min(max(v, lo), hi); }
 
+// ---- "block" operand layout (IVIT_LAYOUT_BLOCKS, include/ivit_hip.h): an int8 matrix X[rows][K], K % 64 == 0, stored as
+// 1 KB blocks of 16 rows x 64 bytes, block (rb, kb) at ((rb * (K / 64)) + kb) * 1024, and inside a block the 16-byte chunk
+// (r, c) at position 4r + (c ^ ((r >> 2) & 3)): exactly the order in which one global_load_lds_dwordx4 of the GEMM main
+// loop lays a piece into its swizzled LDS stage, so that the instruction reads 1 KB CONTIGUOUS (8 full cache lines)
+// instead of 16 half lines -- the LDS-DMA acceptance rate is per cache line touched.
+// Rows are padded to a multiple of 16 (the buffer holds ceil(rows / 16) * 16 * K bytes).
+__host__ __device__ __forceinline__ int64_t ivit_block_offset(int64_t r, int c, int K)
+{
+    const int rl = (int)(r & 15);
+    return (((r >> 4) * (K >> 6)) + (c >> 6)) * 1024 + ((((rl << 2) + (((c >> 4) & 3) ^ ((rl >> 2) & 3)))) << 4) + (c & 15);
+}
+
 // out = RNE(z * m / 2^e) for |z*m| < 2^53 and |z*M| < 2^31 (GEMM accumulators, int8 operands):
 // the reference's double product (quant_utils.py:229) is exact in that range, so one fused
 // multiply-add against the magic constant performs the single RNE rounding of :230.

@@ -203,24 +203,28 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_pers_kernel(GemmArgs g)
             int row = 16 * (wave + 4 * i) + lrow;
             int c = lslot ^ ((row >> 2) & 3);
             asrc[i] = g.A + (int64_t)min(w.m0 + row, g.M - 1) * g.lda + 16 * c;
+            // block layout: piece (wave + 4i) of the tile IS one 1 KB block row-group, already in LDS order
+            if (g.a_blocks) asrc[i] = g.A + (int64_t)min((w.m0 >> 4) + wave + 4 * i, ((g.M + 15) >> 4) - 1) * (g.K >> 6) * 1024 + lane * 16;
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             int row = 16 * (wave + 4 * i) + lrow;
             int c = lslot ^ ((row >> 2) & 3);
             wsrc[i] = g.W + (int64_t)min(w.n0 + row, g.N - 1) * g.ldw + 16 * c;
+            if (g.w_blocks) wsrc[i] = g.W + (int64_t)min((w.n0 >> 4) + wave + 4 * i, (g.N >> 4) - 1) * (g.K >> 6) * 1024 + lane * 16;
         }
     };
+    // bytes from one K step to the next: 64 along a row, or one 1 KB block
+    const int kstep_a = g.a_blocks ? 1024 : BK, kstep_w = g.w_blocks ? 1024 : BK;
     // DMA piece `idx` of K step kt: token pieces first (4, or 2 for a half tile), then the 2 weight pieces
     auto issue_one = [&](int kt, int idx, auto half_tag) {
         constexpr int NA = decltype(half_tag)::value ? 2 : 4;
         char* base = smem + (kt % BIG_STAGES) * BIG_STAGE;
-        const int koff = kt * BK;
         if (idx < NA)
-            __builtin_amdgcn_global_load_lds((gptr_t)(asrc[idx] + koff), (lptr_t)(base + 1024 * (wave + 4 * idx)), 16, 0,
+            __builtin_amdgcn_global_load_lds((gptr_t)(asrc[idx] + kt * kstep_a), (lptr_t)(base + 1024 * (wave + 4 * idx)), 16, 0,
                                              0);
         else
-            __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[idx - NA] + koff),
+            __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[idx - NA] + kt * kstep_w),
                                              (lptr_t)(base + BIG_A_BYTES + 1024 * (wave + 4 * (idx - NA))), 16, 0, 0);
     };
     auto issue = [&](int kt, auto half_tag) {
@@ -448,8 +452,15 @@ int launch_gemm(GemmArgs& g, const char* name, ivit_stream_t stream)
                      "%s: N=%d != 3*heads*head_dim or M=%d %% tokens=%d != 0", name, g.N, g.M, g.tokens);
     }
     g.flags = g_debug_flags & (31 | 128 | 256 | 512);
+    const bool blocks = g.a_blocks || g.w_blocks;
+    if (blocks) {
+        IVIT_REQUIRE(EPI != EPI_I32 && g.M >= 2048 && g.N >= BCH && !g_force_small,
+                     "%s: block-layout operands need the persistent kernel (M >= 2048, N >= 128, requantising epilogue)", name);
+        IVIT_REQUIRE(!g.a_blocks || g.lda == g.K, "%s: a block-layout A operand is dense (lda == K)", name);
+        IVIT_REQUIRE(!g.w_blocks || g.ldw == g.K, "%s: a block-layout W operand is dense (ldw == K)", name);
+    }
     if constexpr (EPI != EPI_I32) {
-        if (EPI <= EPI_QKV && (g_debug_flags & (31 | 32 | 128 | 256 | 512 | 1024 | 8192 | 4194304 | 8388608))) {   // a lab form was asked for (tests, scripts)
+        if (EPI <= EPI_QKV && !blocks && (g_debug_flags & (31 | 32 | 128 | 256 | 512 | 1024 | 8192 | 4194304 | 8388608))) {   // a lab form was asked for (tests, scripts)
             int rc = IVIT_OK;
             if (ivit_gemm_lab_launch(EPI, &g, name, stream, &rc)) return rc;
         }
@@ -490,14 +501,41 @@ int launch_gemm(GemmArgs& g, const char* name, ivit_stream_t stream)
 
 }  // namespace
 
-IVIT_EXPORT int ivit_gemm_i8_requant(const int8_t* A, int64_t lda, const int8_t* W, int64_t ldw, const int32_t* bias,
+IVIT_EXPORT int ivit_gemm_i8_requant_ex(const int8_t* A, int64_t lda, const int8_t* W, int64_t ldw, const int32_t* bias,
                                      const uint32_t* m, const int32_t* e, int8_t* out, int64_t ldo, int M, int N,
-                                     int K, ivit_stream_t stream)
+                                     int K, int layouts, ivit_stream_t stream)
 {
     GemmArgs g{};
     g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.m = m; g.e = e;
     g.out = out; g.ldo = ldo; g.M = M; g.N = N; g.K = K;
-    return launch_gemm<EPI_RQ>(g, "ivit_gemm_i8_requant", stream);
+    g.a_blocks = layouts & 1; g.w_blocks = (layouts >> 1) & 1;
+    IVIT_REQUIRE((layouts & ~3) == 0, "ivit_gemm_i8_requant_ex: unknown layout bits");
+    return launch_gemm<EPI_RQ>(g, "ivit_gemm_i8_requant_ex", stream);
+}
+
+IVIT_EXPORT int ivit_gemm_i8_requant(const int8_t* A, int64_t lda, const int8_t* W, int64_t ldw, const int32_t* bias,
+                                     const uint32_t* m, const int32_t* e, int8_t* out, int64_t ldo, int M, int N,
+                                     int K, ivit_stream_t stream)
+{
+    return ivit_gemm_i8_requant_ex(A, lda, W, ldw, bias, m, e, out, ldo, M, N, K, 0, stream);
+}
+
+IVIT_EXPORT int ivit_gemm_i8_requant_residual_ex(const int8_t* A, int64_t lda, const int8_t* W, int64_t ldw,
+                                              const int32_t* bias, const uint32_t* m, const int32_t* e,
+                                              const int8_t* res, int64_t ldr, uint32_t m_main, int32_t e_main,
+                                              uint32_t m_res, int32_t e_res, int8_t* out, int64_t ldo, int M, int N,
+                                              int K, int layouts, ivit_stream_t stream)
+{
+    GemmArgs g{};
+    g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.m = m; g.e = e;
+    g.out = out; g.ldo = ldo; g.res = res; g.ldr = ldr; g.M = M; g.N = N; g.K = K;
+    g.M_main = ivit_dyadic_to_double(m_main, e_main);
+    g.M_res = ivit_dyadic_to_double(m_res, e_res);
+    IVIT_REQUIRE(g.M_main < 1048576.0 && g.M_res < 1048576.0,
+                 "ivit_gemm_i8_requant_residual_ex: residual multiplier >= 2^20 is outside the int8 fast path");
+    g.a_blocks = layouts & 1; g.w_blocks = (layouts >> 1) & 1;
+    IVIT_REQUIRE((layouts & ~3) == 0, "ivit_gemm_i8_requant_residual_ex: unknown layout bits");
+    return launch_gemm<EPI_RESID>(g, "ivit_gemm_i8_requant_residual_ex", stream);
 }
 
 IVIT_EXPORT int ivit_gemm_i8_requant_residual(const int8_t* A, int64_t lda, const int8_t* W, int64_t ldw,
@@ -506,14 +544,7 @@ IVIT_EXPORT int ivit_gemm_i8_requant_residual(const int8_t* A, int64_t lda, cons
                                               uint32_t m_res, int32_t e_res, int8_t* out, int64_t ldo, int M, int N,
                                               int K, ivit_stream_t stream)
 {
-    GemmArgs g{};
-    g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.m = m; g.e = e;
-    g.out = out; g.ldo = ldo; g.res = res; g.ldr = ldr; g.M = M; g.N = N; g.K = K;
-    g.M_main = ivit_dyadic_to_double(m_main, e_main);
-    g.M_res = ivit_dyadic_to_double(m_res, e_res);
-    IVIT_REQUIRE(g.M_main < 1048576.0 && g.M_res < 1048576.0,
-                 "ivit_gemm_i8_requant_residual: residual multiplier >= 2^20 is outside the int8 fast path");
-    return launch_gemm<EPI_RESID>(g, "ivit_gemm_i8_requant_residual", stream);
+    return ivit_gemm_i8_requant_residual_ex(A, lda, W, ldw, bias, m, e, res, ldr, m_main, e_main, m_res, e_res, out, ldo, M, N, K, 0, stream);
 }
 
 IVIT_EXPORT int ivit_gemm_i8_requant_residual_i16(const int8_t* A, int64_t lda, const int8_t* W, int64_t ldw,
@@ -532,16 +563,26 @@ IVIT_EXPORT int ivit_gemm_i8_requant_residual_i16(const int8_t* A, int64_t lda, 
     return launch_gemm<EPI_RESID16>(g, "ivit_gemm_i8_requant_residual_i16", stream);
 }
 
-IVIT_EXPORT int ivit_gemm_i8_requant_qkv(const int8_t* A, int64_t lda, const int8_t* W, int64_t ldw,
+IVIT_EXPORT int ivit_gemm_i8_requant_qkv_ex(const int8_t* A, int64_t lda, const int8_t* W, int64_t ldw,
                                          const int32_t* bias, const uint32_t* m, const int32_t* e, int8_t* qkv,
                                          int tokens, int heads, int head_dim, int M, int N, int K,
-                                         ivit_stream_t stream)
+                                         int layouts, ivit_stream_t stream)
 {
     GemmArgs g{};
     g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.m = m; g.e = e;
     g.out = qkv; g.ldo = 0; g.M = M; g.N = N; g.K = K;
     g.tokens = tokens; g.heads = heads; g.head_dim = head_dim;
-    return launch_gemm<EPI_QKV>(g, "ivit_gemm_i8_requant_qkv", stream);
+    g.a_blocks = layouts & 1; g.w_blocks = (layouts >> 1) & 1;
+    IVIT_REQUIRE((layouts & ~3) == 0, "ivit_gemm_i8_requant_qkv_ex: unknown layout bits");
+    return launch_gemm<EPI_QKV>(g, "ivit_gemm_i8_requant_qkv_ex", stream);
+}
+
+IVIT_EXPORT int ivit_gemm_i8_requant_qkv(const int8_t* A, int64_t lda, const int8_t* W, int64_t ldw,
+                                         const int32_t* bias, const uint32_t* m, const int32_t* e, int8_t* qkv,
+                                         int tokens, int heads, int head_dim, int M, int N, int K,
+                                         ivit_stream_t stream)
+{
+    return ivit_gemm_i8_requant_qkv_ex(A, lda, W, ldw, bias, m, e, qkv, tokens, heads, head_dim, M, N, K, 0, stream);
 }
 
 IVIT_EXPORT int ivit_gemm_i8_i32(const int8_t* A, int64_t lda, const int8_t* W, int64_t ldw, const int32_t* bias,

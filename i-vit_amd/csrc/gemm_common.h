@@ -48,6 +48,7 @@ struct GemmArgs {
     int cu_turns;       // persistent kernel: 1 = co-resident workgroups alternate main loops through the per-CU token
     int stagger_units;  // persistent kernel: start delay of the second co-resident workgroup, in s_sleep(16) (~1K cycle) units
     int split_from;  // persistent kernel: tiles [split_from, tiles_m*tiles_n) are processed as two half tiles each
+    int a_blocks, w_blocks;   // operand in the block layout (common.h: ivit_block_offset); persistent kernel only
 };
 
 IVIT_DEV int nk_of(const GemmArgs& g) { return g.K / 64; }

@@ -643,6 +643,21 @@ static inline int ew_grid(int64_t n)
     return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
 }
 
+// row-major <-> block layout (common.h: ivit_block_offset), 16 bytes per thread
+template <bool TO_BLOCKS>
+__global__ __launch_bounds__(NT) void relayout_kernel(const int8_t* src, int8_t* dst, int64_t ld, int64_t rows, int K)
+{
+    const int c16 = K >> 4;
+    const int64_t total = rows * c16;
+    for (int64_t q = (int64_t)blockIdx.x * NT + threadIdx.x; q < total; q += (int64_t)gridDim.x * NT) {
+        const int64_t r = q / c16;
+        const int c = (int)(q - r * c16) << 4;
+        const int64_t rm = r * ld + c, bl = ivit_block_offset(r, c, K);
+        if (TO_BLOCKS) *reinterpret_cast<int4*>(dst + bl) = *reinterpret_cast<const int4*>(src + rm);
+        else *reinterpret_cast<int4*>(dst + rm) = *reinterpret_cast<const int4*>(src + bl);
+    }
+}
+
 static int gelu_x0(float s, const char* who, int* x0_out)
 {
     IVIT_REQUIRE(s > 0.0f, "%s: scale must be positive", who);
@@ -706,6 +721,26 @@ __global__ void minmax_finish_kernel(unsigned* keys)
 }
 
 // ================================================================================================
+IVIT_EXPORT int ivit_tile_operand_i8(const int8_t* src, int64_t ld, int64_t rows, int K, int8_t* dst, ivit_stream_t stream)
+{
+    IVIT_REQUIRE(src && dst && rows > 0 && K > 0 && K % 64 == 0 && ld >= K && ld % 16 == 0 && ((uintptr_t)src % 16 == 0) &&
+                     ((uintptr_t)dst % 16 == 0),
+                 "ivit_tile_operand_i8: bad operand (K must be a multiple of 64, rows 16-byte aligned)");
+    hipLaunchKernelGGL(relayout_kernel<true>, dim3(ew_grid(rows * (K >> 4))), dim3(NT), 0, ivit_stream(stream), src, dst, ld, rows,
+                       K);
+    IVIT_CHECK_LAUNCH("ivit_tile_operand_i8");
+}
+
+IVIT_EXPORT int ivit_untile_operand_i8(const int8_t* src, int64_t rows, int K, int8_t* dst, int64_t ld, ivit_stream_t stream)
+{
+    IVIT_REQUIRE(src && dst && rows > 0 && K > 0 && K % 64 == 0 && ld >= K && ld % 16 == 0 && ((uintptr_t)src % 16 == 0) &&
+                     ((uintptr_t)dst % 16 == 0),
+                 "ivit_untile_operand_i8: bad operand (K must be a multiple of 64, rows 16-byte aligned)");
+    hipLaunchKernelGGL(relayout_kernel<false>, dim3(ew_grid(rows * (K >> 4))), dim3(NT), 0, ivit_stream(stream), src, dst, ld,
+                       rows, K);
+    IVIT_CHECK_LAUNCH("ivit_untile_operand_i8");
+}
+
 IVIT_EXPORT int ivit_layernorm_i8(const int8_t* x, int64_t ldx, int rows, int C, const float* bias_int,
                                   const float* s_ln, const uint32_t* m, const int32_t* e, int8_t* out, int64_t ldo,
                                   ivit_stream_t stream)

@@ -70,10 +70,26 @@ int ivit_quantize_patchify_ld_f32_i8(const float* img, int8_t* A, int64_t lda, i
  * Contract for the requantising forms: e[n] >= 31 (multiplier <= 1: int32 accumulators -> 8 bits).
  */
 
+/* ---- operand layouts of the GEMMs.  IVIT_LAYOUT_ROWS: row-major with a leading dimension (the default of every
+ * entry point).  IVIT_LAYOUT_BLOCKS: 1 KB blocks of 16 rows x 64 bytes, block (row / 16, k / 64) at
+ * ((row / 16) * (K / 64) + k / 64) * 1024, and inside a block the 16-byte chunk (r, c) at position 4r + (c ^ ((r >> 2) & 3))
+ * -- the order in which the GEMM's LDS-DMA lays a piece into its LDS stage, so that one instruction reads 1 KB
+ * contiguous.  Rows padded to a multiple of 16 (ceil(rows / 16) * 16 * K bytes), K % 64 == 0.  The `_ex` forms take
+ * `layouts` = IVIT_A_BLOCKS | IVIT_W_BLOCKS; block operands need M >= 2048 and N >= 128.  Producers that can write the
+ * block layout directly: ivit_layernorm_i8_ex, ivit_attention_fused_i8_ex, ivit_shiftgelu_lut_i8_ex. */
+#define IVIT_A_BLOCKS 1
+#define IVIT_W_BLOCKS 2
+int ivit_tile_operand_i8(const int8_t* src, int64_t ld, int64_t rows, int K, int8_t* dst, ivit_stream_t stream);
+int ivit_untile_operand_i8(const int8_t* src, int64_t rows, int K, int8_t* dst, int64_t ld, ivit_stream_t stream);
+
 /* out[t][n] = clamp8(RNE(acc * m[n] / 2^e[n]));  N % 16 == 0 */
 int ivit_gemm_i8_requant(const int8_t* A, int64_t lda, const int8_t* W, int64_t ldw, const int32_t* bias,
                          const uint32_t* m, const int32_t* e, int8_t* out, int64_t ldo,
                          int M, int N, int K, ivit_stream_t stream);
+
+int ivit_gemm_i8_requant_ex(const int8_t* A, int64_t lda, const int8_t* W, int64_t ldw, const int32_t* bias,
+                            const uint32_t* m, const int32_t* e, int8_t* out, int64_t ldo,
+                            int M, int N, int K, int layouts, ivit_stream_t stream);
 
 /* as above, then the two-operand QuantAct of the residual connection
  * (vit_quant.py:147,153; quant_utils.py:232-245):
@@ -84,6 +100,12 @@ int ivit_gemm_i8_requant_residual(const int8_t* A, int64_t lda, const int8_t* W,
                                   const int8_t* res, int64_t ldr, uint32_t m_main, int32_t e_main,
                                   uint32_t m_res, int32_t e_res, int8_t* out, int64_t ldo,
                                   int M, int N, int K, ivit_stream_t stream);
+
+int ivit_gemm_i8_requant_residual_ex(const int8_t* A, int64_t lda, const int8_t* W, int64_t ldw,
+                                     const int32_t* bias, const uint32_t* m, const int32_t* e,
+                                     const int8_t* res, int64_t ldr, uint32_t m_main, int32_t e_main,
+                                     uint32_t m_res, int32_t e_res, int8_t* out, int64_t ldo,
+                                     int M, int N, int K, int layouts, ivit_stream_t stream);
 
 /* Swin form of the above: the residual stream is 16 bits wide (swin_quant.py:299, mlp.fc2 + shortcut):
  *   k = clamp8(RNE(acc * m[n] / 2^e[n]))                       (mlp.qact2)
@@ -103,6 +125,9 @@ int ivit_gemm_i8_requant_residual_i16(const int8_t* A, int64_t lda, const int8_t
 int ivit_gemm_i8_requant_qkv(const int8_t* A, int64_t lda, const int8_t* W, int64_t ldw, const int32_t* bias,
                              const uint32_t* m, const int32_t* e, int8_t* qkv, int tokens, int heads,
                              int head_dim, int M, int N, int K, ivit_stream_t stream);
+int ivit_gemm_i8_requant_qkv_ex(const int8_t* A, int64_t lda, const int8_t* W, int64_t ldw, const int32_t* bias,
+                                const uint32_t* m, const int32_t* e, int8_t* qkv, int tokens, int heads,
+                                int head_dim, int M, int N, int K, int layouts, ivit_stream_t stream);
 
 /* raw accumulators (classifier head; module-level QuantLinear): out int32 [M, N], N % 4 == 0 */
 int ivit_gemm_i8_i32(const int8_t* A, int64_t lda, const int8_t* W, int64_t ldw, const int32_t* bias,

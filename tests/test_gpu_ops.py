@@ -210,6 +210,73 @@ def test_gemm_both_kernels_agree():
     assert np.array_equal(outs[0].astype(np.int32), orc.requant(orc.gemm_i8(A, W, b), m.astype(np.float64), e, 8))
 
 
+def _block_layout_host(X):
+    """numpy model of IVIT_LAYOUT_BLOCKS (include/ivit_hip.h): [rows, K] int8 -> flat bytes"""
+    rows, K = X.shape
+    R16 = (rows + 15) // 16
+    out = np.zeros(R16 * 16 * K, dtype=np.int8)
+    r = np.arange(rows)[:, None]
+    c = np.arange(K)[None, :]
+    rl = r & 15
+    off = ((r >> 4) * (K >> 6) + (c >> 6)) * 1024 + (((rl << 2) + (((c >> 4) & 3) ^ ((rl >> 2) & 3))) << 4) + (c & 15)
+    out[off.reshape(-1)] = X.reshape(-1)
+    return out
+
+
+@pytest.mark.parametrize("M,N,K", [(2600, 512, 384), (197 * 16, 768, 768), (2049, 128, 64)])
+def test_gemm_block_layout_operands(M, N, K):
+    """ivit_tile_operand_i8 == the documented layout; the GEMMs give identical results for every combination of
+    row-major / block-layout operands (all three requantising epilogues); untile inverts tile"""
+    rng = np.random.default_rng(M + K)
+    A = rng.integers(-128, 128, size=(M, K)).astype(np.int8)
+    W = rng.integers(-128, 128, size=(N, K)).astype(np.int8)
+    b = rng.integers(-50000, 50000, size=N).astype(np.int32)
+    m, e = rand_me(rng, N, -16, -9)
+    md, ed = me_dev(m, e)
+    dA, dW, db = dev(A), dev(W), dev(b)
+    R16 = (M + 15) // 16 * 16
+    At = torch.zeros(R16 * K, dtype=torch.int8, device=DEV)
+    Wt = torch.zeros(N * K, dtype=torch.int8, device=DEV)
+    _lib.call("ivit_tile_operand_i8", _lib.ptr(dA), K, M, K, _lib.ptr(At), st())
+    _lib.call("ivit_tile_operand_i8", _lib.ptr(dW), K, N, K, _lib.ptr(Wt), st())
+    assert np.array_equal(At.cpu().numpy()[: _block_layout_host(A).size], _block_layout_host(A))
+    assert np.array_equal(Wt.cpu().numpy(), _block_layout_host(W))
+    back = torch.empty(M, K, dtype=torch.int8, device=DEV)
+    _lib.call("ivit_untile_operand_i8", _lib.ptr(At), M, K, _lib.ptr(back), K, st())
+    assert np.array_equal(back.cpu().numpy(), A)
+    exp = orc.requant(orc.gemm_i8(A, W, b), m.astype(np.float64), e, 8)
+    res = rng.integers(-128, 128, size=(M, N)).astype(np.int8)
+    dres = dev(res)
+    m1, e1 = dyadic(np.float32(0.7 * 2 ** -4), np.float32(2 ** -4))
+    m2, e2 = dyadic(np.float32(2 ** -5), np.float32(2 ** -4))
+    exp_res = orc.requant(exp, m1.astype(np.float64), e1, 8, z2=res.astype(np.int32), m2=m2.astype(np.float64), e2=e2)
+    for lay in (0, 1, 2, 3):
+        a_op = At if lay & 1 else dA
+        w_op = Wt if lay & 2 else dW
+        out = torch.empty(M, N, dtype=torch.int8, device=DEV)
+        _lib.call("ivit_gemm_i8_requant_ex", _lib.ptr(a_op), K, _lib.ptr(w_op), K, _lib.ptr(db), _lib.ptr(md), _lib.ptr(ed),
+                  _lib.ptr(out), N, M, N, K, lay, st())
+        assert np.array_equal(out.cpu().numpy().astype(np.int32), exp), lay
+        out = torch.empty(M, N, dtype=torch.int8, device=DEV)
+        _lib.call("ivit_gemm_i8_requant_residual_ex", _lib.ptr(a_op), K, _lib.ptr(w_op), K, _lib.ptr(db), _lib.ptr(md),
+                  _lib.ptr(ed), _lib.ptr(dres), N, int(m1[0]), int(e1[0]), int(m2[0]), int(e2[0]), _lib.ptr(out), N, M, N, K,
+                  lay, st())
+        assert np.array_equal(out.cpu().numpy().astype(np.int32), exp_res), lay
+    if M % 197 == 0 and N % 192 == 0:     # head-major q/k/v epilogue
+        T, hd = 197, 64
+        H = N // (3 * hd)
+        outs = []
+        for lay in (0, 3):
+            out = torch.empty(3 * M * H * hd, dtype=torch.int8, device=DEV)
+            _lib.call("ivit_gemm_i8_requant_qkv_ex", _lib.ptr(At if lay else dA), K, _lib.ptr(Wt if lay else dW), K, _lib.ptr(db),
+                      _lib.ptr(md), _lib.ptr(ed), _lib.ptr(out), T, H, hd, M, N, K, lay, st())
+            outs.append(out.cpu().numpy())
+        assert np.array_equal(outs[0], outs[1])
+    with pytest.raises(_lib.IvitError, match="persistent kernel"):   # small problems have no block-layout path
+        _lib.call("ivit_gemm_i8_requant_ex", _lib.ptr(At), K, _lib.ptr(dW), K, _lib.ptr(db), _lib.ptr(md), _lib.ptr(ed),
+                  _lib.ptr(out), N, 512, N, K, 1, st())
+
+
 def test_gemm_rejects_bad_shapes():
     a = torch.zeros(64, 100, dtype=torch.int8, device=DEV)
     with pytest.raises(_lib.IvitError, match="multiple of 64"):
