@@ -39,6 +39,7 @@ struct AttnArgs {
     double Ms, Mo;
     int x0;    // floor(-1/s_attn)
     int ksat;  // first table index whose argument is clamped at n*x0: every later entry is identical
+    int out_blocks;   // output in the GEMM block layout (common.h: ivit_block_offset), row length heads * 64
 };
 
 // K image: 64-byte rows; 16-byte chunk c of row r at slot (c + 2*((r>>2)&1)) & 3.  A 16x16x64 fragment read has
@@ -175,7 +176,8 @@ __global__ __launch_bounds__(NT, 3) void attention_kernel(AttnArgs a)
             }
 
         // ---- O^T = Vt . P^T, requantised (attn.qact2), 4 consecutive d per dword
-        int8_t* orow = a.out + ((int64_t)b * T + qrow) * ((int64_t)a.heads * HD) + hh * HD + 4 * g;
+        const int64_t orow_idx = (int64_t)b * T + qrow;
+        int8_t* orow = a.out + orow_idx * ((int64_t)a.heads * HD) + hh * HD + 4 * g;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
             v4i acc = {0, 0, 0, 0};
@@ -193,7 +195,10 @@ __global__ __launch_bounds__(NT, 3) void attention_kernel(AttnArgs a)
                     int o = clamp_i32(requant_exact(acc[r], a.Mo), -128, 127);
                     w |= ((unsigned)o & 0xffu) << (8 * r);
                 }
-                *reinterpret_cast<unsigned*>(orow + 16 * dt) = w;
+                if (a.out_blocks)
+                    *reinterpret_cast<unsigned*>(a.out + ivit_block_offset(orow_idx, hh * HD + 16 * dt + 4 * g, a.heads * HD)) = w;
+                else
+                    *reinterpret_cast<unsigned*>(orow + 16 * dt) = w;
             }
         }
     }
@@ -201,9 +206,9 @@ __global__ __launch_bounds__(NT, 3) void attention_kernel(AttnArgs a)
 
 }  // namespace
 
-IVIT_EXPORT int ivit_attention_fused_i8(const int8_t* qkv, int8_t* out, int batch, int heads, int tokens,
+IVIT_EXPORT int ivit_attention_fused_i8_ex(const int8_t* qkv, int8_t* out, int batch, int heads, int tokens,
                                         int head_dim, uint32_t m_s, int32_t e_s, float s_attn, uint32_t m_o,
-                                        int32_t e_o, ivit_stream_t stream)
+                                        int32_t e_o, int out_blocks, ivit_stream_t stream)
 {
     IVIT_REQUIRE(qkv && out, "ivit_attention_fused_i8: NULL operand");
     IVIT_REQUIRE(batch > 0 && heads > 0, "ivit_attention_fused_i8: empty batch");
@@ -215,7 +220,9 @@ IVIT_EXPORT int ivit_attention_fused_i8(const int8_t* qkv, int8_t* out, int batc
     IVIT_REQUIRE(((uintptr_t)qkv % 16 == 0) && ((uintptr_t)out % 4 == 0) && ((heads * head_dim) % 4 == 0),
                  "ivit_attention_fused_i8: misaligned operand");
     IVIT_REQUIRE(s_attn > 0.0f, "ivit_attention_fused_i8: scale must be positive");
+    IVIT_REQUIRE(out_blocks == 0 || (out_blocks == 1 && ((uintptr_t)out % 16 == 0)), "ivit_attention_fused_i8_ex: bad output layout");
     AttnArgs a;
+    a.out_blocks = out_blocks;
     a.qkv = qkv; a.out = out; a.batch = batch; a.heads = heads; a.tokens = tokens;
     a.Ms = ivit_dyadic_to_double(m_s, e_s);
     a.Mo = ivit_dyadic_to_double(m_o, e_o);
@@ -234,4 +241,11 @@ IVIT_EXPORT int ivit_attention_fused_i8(const int8_t* qkv, int8_t* out, int batc
     }
     hipLaunchKernelGGL(attention_kernel, dim3(batch * heads), dim3(NT), 0, ivit_stream(stream), a);
     IVIT_CHECK_LAUNCH("ivit_attention_fused_i8");
+}
+
+IVIT_EXPORT int ivit_attention_fused_i8(const int8_t* qkv, int8_t* out, int batch, int heads, int tokens,
+                                        int head_dim, uint32_t m_s, int32_t e_s, float s_attn, uint32_t m_o,
+                                        int32_t e_o, ivit_stream_t stream)
+{
+    return ivit_attention_fused_i8_ex(qkv, out, batch, heads, tokens, head_dim, m_s, e_s, s_attn, m_o, e_o, 0, stream);
 }

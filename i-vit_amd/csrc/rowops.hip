@@ -44,6 +44,7 @@ struct LnArgs {
     const int32_t* e;
     void* out;
     int64_t ldo;
+    int out_blocks;   // int8 output in the GEMM block layout (common.h: ivit_block_offset), row length C
 };
 
 // Per-row statistics exactly as ivit_modules.py:36-51 computes them.
@@ -217,11 +218,13 @@ __global__ __launch_bounds__(NT, (NJ <= 3 ? 4 : NJ <= 8 ? 2 : 1)) void layernorm
                     res[j] = pack4(o[0], o[1], o[2], o[3]);
                 }
             }
-            int* orow = reinterpret_cast<int*>(out + (int64_t)(row0 + rr) * a.ldo);
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 int d = lane + 64 * j;
-                if (d < nd) orow[d] = res[j];
+                if (d < nd) {
+                    const int64_t off = a.out_blocks ? ivit_block_offset(row0 + rr, 4 * d, C) : (int64_t)(row0 + rr) * a.ldo + 4 * d;
+                    *reinterpret_cast<int*>(out + off) = res[j];
+                }
             }
         }
     }
@@ -288,6 +291,7 @@ struct GeluArgs {
     const int8_t* lut;
     void* out;
     int64_t ldo;
+    int out_blocks;   // output in the GEMM block layout (common.h: ivit_block_offset), row length L
 };
 
 // direct arithmetic; OUT_I32: module-level int32 output k*sig, else fused requant -> int8
@@ -396,17 +400,18 @@ __global__ __launch_bounds__(NT) void shiftgelu_lut_apply_kernel(GeluArgs a)
 #pragma unroll
                 for (int r = 0; r < RW; ++r) {
                     const int d = lane + 64 * j;
-                    if (d < nd && row0 + r < a.rows)
-                        reinterpret_cast<int*>(reinterpret_cast<int8_t*>(a.out) + (int64_t)(row0 + r) * a.ldo)[d] =
-                            (int)map4(r, (unsigned)w[r][j]);
+                    if (d < nd && row0 + r < a.rows) {
+                        const int64_t off = a.out_blocks ? ivit_block_offset(row0 + r, 4 * d, a.L) : (int64_t)(row0 + r) * a.ldo + 4 * d;
+                        *reinterpret_cast<int*>(reinterpret_cast<int8_t*>(a.out) + off) = (int)map4(r, (unsigned)w[r][j]);
+                    }
                 }
         } else {
             for (int d = lane; d < nd; d += 64) {
 #pragma unroll
                 for (int r = 0; r < RW; ++r) {
                     if (row0 + r >= a.rows) continue;
-                    reinterpret_cast<int*>(reinterpret_cast<int8_t*>(a.out) + (int64_t)(row0 + r) * a.ldo)[d] =
-                        (int)map4(r, (unsigned)xr[r][d]);
+                    const int64_t off = a.out_blocks ? ivit_block_offset(row0 + r, 4 * d, a.L) : (int64_t)(row0 + r) * a.ldo + 4 * d;
+                    *reinterpret_cast<int*>(reinterpret_cast<int8_t*>(a.out) + off) = (int)map4(r, (unsigned)xr[r][d]);
                 }
             }
         }
@@ -741,9 +746,9 @@ IVIT_EXPORT int ivit_untile_operand_i8(const int8_t* src, int64_t rows, int K, i
     IVIT_CHECK_LAUNCH("ivit_untile_operand_i8");
 }
 
-IVIT_EXPORT int ivit_layernorm_i8(const int8_t* x, int64_t ldx, int rows, int C, const float* bias_int,
+IVIT_EXPORT int ivit_layernorm_i8_ex(const int8_t* x, int64_t ldx, int rows, int C, const float* bias_int,
                                   const float* s_ln, const uint32_t* m, const int32_t* e, int8_t* out, int64_t ldo,
-                                  ivit_stream_t stream)
+                                     int out_blocks, ivit_stream_t stream)
 {
     IVIT_REQUIRE(x && out && bias_int && s_ln && m && e, "ivit_layernorm_i8: NULL operand");
     IVIT_REQUIRE(rows > 0 && C > 0 && C % 4 == 0 && C <= 4096, "ivit_layernorm_i8: rows=%d C=%d unsupported", rows, C);
@@ -753,7 +758,9 @@ IVIT_EXPORT int ivit_layernorm_i8(const int8_t* x, int64_t ldx, int rows, int C,
     IVIT_REQUIRE(((uintptr_t)bias_int % 16 == 0) && ((uintptr_t)s_ln % 16 == 0) && ((uintptr_t)m % 16 == 0) &&
                      ((uintptr_t)e % 16 == 0),
                  "ivit_layernorm_i8: per-channel tables must be 16-byte aligned");
-    LnArgs a{x, ldx, rows, C, bias_int, s_ln, m, e, out, ldo};
+    IVIT_REQUIRE(out_blocks == 0 || (out_blocks == 1 && C % 64 == 0 && ldo == C && ((uintptr_t)out % 16 == 0)),
+                 "ivit_layernorm_i8_ex: block-layout output needs C %% 64 == 0 and ldo == C");
+    LnArgs a{x, ldx, rows, C, bias_int, s_ln, m, e, out, ldo, out_blocks};
     const int nj = (C / 4 + 63) / 64;
     // each wave sets up its per-channel constants (bias and the requant bracket, 12*NJ registers per lane) once: launch no more workgroups than
     // stay resident (256 CUs x waves/SIMD at the kernel's register count) and let them stride over the rows
@@ -770,12 +777,19 @@ IVIT_EXPORT int ivit_layernorm_i8(const int8_t* x, int64_t ldx, int rows, int C,
     IVIT_CHECK_LAUNCH("ivit_layernorm_i8");
 }
 
+IVIT_EXPORT int ivit_layernorm_i8(const int8_t* x, int64_t ldx, int rows, int C, const float* bias_int,
+                                  const float* s_ln, const uint32_t* m, const int32_t* e, int8_t* out, int64_t ldo,
+                                  ivit_stream_t stream)
+{
+    return ivit_layernorm_i8_ex(x, ldx, rows, C, bias_int, s_ln, m, e, out, ldo, 0, stream);
+}
+
 IVIT_EXPORT int ivit_layernorm_i32_f32(const int32_t* x, int64_t ldx, int rows, int C, const float* bias_int,
                                        const float* s_ln, float* out, int64_t ldo, ivit_stream_t stream)
 {
     IVIT_REQUIRE(x && out && bias_int && s_ln, "ivit_layernorm_i32_f32: NULL operand");
     IVIT_REQUIRE(rows > 0 && C > 0 && C <= 4096 && ldx >= C && ldo >= C, "ivit_layernorm_i32_f32: bad shape");
-    LnArgs a{x, ldx, rows, C, bias_int, s_ln, nullptr, nullptr, out, ldo};
+    LnArgs a{x, ldx, rows, C, bias_int, s_ln, nullptr, nullptr, out, ldo, 0};
     hipLaunchKernelGGL(layernorm_i32_f32_kernel, dim3(grid_for_rows(rows)), dim3(NT), 0, ivit_stream(stream), a);
     IVIT_CHECK_LAUNCH("ivit_layernorm_i32_f32");
 }
@@ -819,15 +833,17 @@ IVIT_EXPORT int ivit_shiftgelu_build_lut(float s, uint32_t m, int32_t e, int8_t*
     IVIT_CHECK_LAUNCH("ivit_shiftgelu_build_lut");
 }
 
-IVIT_EXPORT int ivit_shiftgelu_lut_i8(const int8_t* x, int64_t ldx, int rows, int L, const int8_t* lut, int8_t* out,
-                                      int64_t ldo, ivit_stream_t stream)
+IVIT_EXPORT int ivit_shiftgelu_lut_i8_ex(const int8_t* x, int64_t ldx, int rows, int L, const int8_t* lut, int8_t* out,
+                                         int64_t ldo, int out_blocks, ivit_stream_t stream)
 {
     IVIT_REQUIRE(x && out && lut, "ivit_shiftgelu_lut_i8: NULL operand");
     IVIT_REQUIRE(rows > 0 && L > 0 && L % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && ldx >= L && ldo >= L &&
                      ((uintptr_t)x % 4 == 0) && ((uintptr_t)out % 4 == 0) && ((uintptr_t)lut % 4 == 0),
                  "ivit_shiftgelu_lut_i8: rows=%d L=%d must be 4-byte aligned rows", rows, L);
     GeluArgs a{};
-    a.x = x; a.ldx = ldx; a.rows = rows; a.L = L; a.lut = lut; a.out = out; a.ldo = ldo;
+    IVIT_REQUIRE(out_blocks == 0 || (out_blocks == 1 && L % 64 == 0 && ldo == L && ((uintptr_t)out % 16 == 0)),
+                 "ivit_shiftgelu_lut_i8_ex: block-layout output needs L %% 64 == 0 and ldo == L");
+    a.x = x; a.ldx = ldx; a.rows = rows; a.L = L; a.lut = lut; a.out = out; a.ldo = ldo; a.out_blocks = out_blocks;
     const dim3 grid(grid_for_rows(rows, 2)), blk(NT);
     hipStream_t st = ivit_stream(stream);
     const int nj = (L / 4 + 63) / 64;
@@ -836,6 +852,12 @@ IVIT_EXPORT int ivit_shiftgelu_lut_i8(const int8_t* x, int64_t ldx, int rows, in
     else if (nj <= 12) hipLaunchKernelGGL(shiftgelu_lut_apply_kernel<12>, grid, blk, 0, st, a);
     else hipLaunchKernelGGL(shiftgelu_lut_apply_kernel<0>, grid, blk, 0, st, a);
     IVIT_CHECK_LAUNCH("ivit_shiftgelu_lut_i8");
+}
+
+IVIT_EXPORT int ivit_shiftgelu_lut_i8(const int8_t* x, int64_t ldx, int rows, int L, const int8_t* lut, int8_t* out,
+                                      int64_t ldo, ivit_stream_t stream)
+{
+    return ivit_shiftgelu_lut_i8_ex(x, ldx, rows, L, lut, out, ldo, 0, stream);
 }
 
 template <typename TX>

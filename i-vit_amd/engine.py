@@ -60,7 +60,7 @@ class IntViTEngine(GraphReplay):
 
         def lin_dev(lp, s_out):
             m, e = lp.requant_to(s_out)
-            return dict(W=dev(lp.W8), b=dev(lp.b32), m=dev(m.view(np.int32)), e=dev(e), K=lp.K, N=lp.W8.shape[0])
+            return dict(W=dev(lp.W8), b=dev(lp.b32), m=dev(m.view(np.int32)), e=dev(e), K=lp.K, N=lp.W8.shape[0], Wb=None)
 
         def ln_dev(prefix, s_out):
             lp = source.layernorm(prefix, s_out)
@@ -131,6 +131,14 @@ class IntViTEngine(GraphReplay):
         self.head_scale = dev(head.s_acc)
         self.int8_weight_bytes = sum(int(b[k]["W"].numel()) for b in self.blocks for k in ("qkv", "proj", "fc1", "fc2")) \
             + int(self.patch["W"].numel()) + int(self.head["W"].numel())
+        # block-layout copies of the GEMM weights (include/ivit_hip.h IVIT_LAYOUT_BLOCKS): the persistent GEMM then reads
+        # 1 KB contiguous per LDS-DMA instruction instead of 16 half cache lines
+        for lin in [self.patch] + [b[k] for b in self.blocks for k in ("qkv", "proj", "fc1", "fc2")]:
+            if lin["K"] % 64 == 0 and lin["N"] % 16 == 0:
+                lin["Wb"] = torch.empty_like(lin["W"])
+                _lib.call("ivit_tile_operand_i8", _lib.ptr(lin["W"]), lin["K"], lin["N"], lin["K"], _lib.ptr(lin["Wb"]),
+                          self._stream())
+        self.block_operands = True    # False: row-major activations / weights everywhere (tests, A/B timing)
         self.probe = None
         self._alloc(max_batch)
         torch.cuda.synchronize(self.dev)
@@ -142,40 +150,50 @@ class IntViTEngine(GraphReplay):
     def _alloc(self, B):
         C, T = self.C, NUM_TOKENS
         M = B * T
+        M16 = (M + 15) // 16 * 16   # block-layout operands pad their rows to a multiple of 16
         i8 = dict(dtype=torch.int8, device=self.dev)
         self.ws = dict(
             a0=torch.empty(B * NUM_PATCHES, 3 * PATCH * PATCH, **i8),
             pe=torch.empty(B * NUM_PATCHES, C, **i8),
-            x=torch.empty(M, C, **i8), x2=torch.empty(M, C, **i8), h=torch.empty(M, C, **i8),
-            qkv=torch.empty(3 * M * C, **i8), ao=torch.empty(M, C, **i8),
-            f1=torch.empty(M, 4 * C, **i8), g=torch.empty(M, 4 * C, **i8),
+            x=torch.empty(M, C, **i8), x2=torch.empty(M, C, **i8), h=torch.empty(M16, C, **i8),
+            qkv=torch.empty(3 * M * C, **i8), ao=torch.empty(M16, C, **i8),
+            f1=torch.empty(M, 4 * C, **i8), g=torch.empty(M16, 4 * C, **i8), untile=torch.empty(M, 4 * C, **i8),
             cls=torch.empty(B, C, **i8),
             logits=torch.empty(B, NUM_CLASSES, dtype=torch.int32, device=self.dev),
             logits_f=torch.empty(B, NUM_CLASSES, dtype=torch.float32, device=self.dev),
             top1=torch.empty(B, dtype=torch.int32, device=self.dev),
         )
 
-    def _gemm(self, A, lda, lin, out, ldo, M, st):
-        _lib.call("ivit_gemm_i8_requant", _lib.ptr(A), lda, _lib.ptr(lin["W"]), lin["K"], _lib.ptr(lin["b"]),
-                  _lib.ptr(lin["m"]), _lib.ptr(lin["e"]), _lib.ptr(out), ldo, M, lin["N"], lin["K"], st)
+    def _w(self, lin, blocks):
+        """(weight pointer, layout bit) -- the block-layout copy when the call goes to the persistent kernel"""
+        if blocks and lin["Wb"] is not None:
+            return _lib.ptr(lin["Wb"]), 2
+        return _lib.ptr(lin["W"]), 0
 
-    def _gemm_res(self, A, lda, lin, res, me4, out, M, st):
+    def _gemm(self, A, lda, lin, out, ldo, M, st, a_blocks=False, blocks=False):
+        w, lay = self._w(lin, blocks)
+        _lib.call("ivit_gemm_i8_requant_ex", _lib.ptr(A), lda, w, lin["K"], _lib.ptr(lin["b"]),
+                  _lib.ptr(lin["m"]), _lib.ptr(lin["e"]), _lib.ptr(out), ldo, M, lin["N"], lin["K"], lay | int(a_blocks), st)
+
+    def _gemm_res(self, A, lda, lin, res, me4, out, M, st, blocks=False):
         C = self.C
+        w, lay = self._w(lin, blocks)
+        lay |= int(blocks)
         probe = self.probe
         if probe is not None:  # bench.py: HIP events around the dominant kernel, on the launch stream
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        _lib.call("ivit_gemm_i8_requant_residual", _lib.ptr(A), lda, _lib.ptr(lin["W"]), lin["K"],
+        _lib.call("ivit_gemm_i8_requant_residual_ex", _lib.ptr(A), lda, w, lin["K"],
                   _lib.ptr(lin["b"]), _lib.ptr(lin["m"]), _lib.ptr(lin["e"]), _lib.ptr(res), C,
-                  me4[0], me4[1], me4[2], me4[3], _lib.ptr(out), C, M, lin["N"], lin["K"], st)
+                  me4[0], me4[1], me4[2], me4[3], _lib.ptr(out), C, M, lin["N"], lin["K"], lay, st)
         if probe is not None:
             e1.record()
             probe.append((e0, e1, M, lin["N"], lin["K"]))
 
-    def _ln(self, x, ldx, rows, ln, out, st):
+    def _ln(self, x, ldx, rows, ln, out, st, blocks=False):
         C = self.C
-        _lib.call("ivit_layernorm_i8", _lib.ptr(x), ldx, rows, C, _lib.ptr(ln["bias"]), _lib.ptr(ln["s"]),
-                  _lib.ptr(ln["m"]), _lib.ptr(ln["e"]), _lib.ptr(out), C, st)
+        _lib.call("ivit_layernorm_i8_ex", _lib.ptr(x), ldx, rows, C, _lib.ptr(ln["bias"]), _lib.ptr(ln["s"]),
+                  _lib.ptr(ln["m"]), _lib.ptr(ln["e"]), _lib.ptr(out), C, int(blocks), st)
 
     # ------------------------------------------------------------------ forward
     def forward(self, images: torch.Tensor, taps: dict | None = None):
@@ -190,13 +208,21 @@ class IntViTEngine(GraphReplay):
         ws = self.ws
         st = self._stream()
 
-        def tap(name, t, shape):
+        # GEMM operands in the block layout whenever the calls go to the persistent kernel (M >= 2048; N >= 128 always)
+        blk_l = bool(self.block_operands) and M >= 2048 and C % 64 == 0
+
+        def tap(name, t, shape, blocks=False):
             if taps is not None:
+                if blocks:   # back to rows for the caller
+                    rows, K = int(np.prod(shape[:-1])), shape[-1]
+                    _lib.call("ivit_untile_operand_i8", _lib.ptr(t), rows, K, _lib.ptr(ws["untile"]), K, st)
+                    t = ws["untile"]
                 taps[name] = t.reshape(-1)[: int(np.prod(shape))].view(shape).clone()
 
         _lib.call("ivit_quantize_patchify_f32_i8", _lib.ptr(images), _lib.ptr(ws["a0"]), B, 3, IMG_SIZE, PATCH,
                   self.inv_s0, st)
-        self._gemm(ws["a0"], 3 * PATCH * PATCH, self.patch, ws["pe"], C, B * NUM_PATCHES, st)
+        self._gemm(ws["a0"], 3 * PATCH * PATCH, self.patch, ws["pe"], C, B * NUM_PATCHES, st,
+                   blocks=bool(self.block_operands) and B * NUM_PATCHES >= 2048 and C >= 128)
         tap("patch_embed.qact", ws["pe"], (B, NUM_PATCHES, C))
         _lib.call("ivit_embed_assemble_i8", _lib.ptr(ws["pe"]), _lib.ptr(self.pos_add), _lib.ptr(self.cls_row),
                   self.embed_me[0], self.embed_me[1], _lib.ptr(ws["x"]), B, T, C, st)
@@ -204,26 +230,27 @@ class IntViTEngine(GraphReplay):
         x, x2 = ws["x"], ws["x2"]
         for i, blk in enumerate(self.blocks):
             p = f"blocks.{i}."
-            self._ln(x, C, M, blk["ln1"], ws["h"], st)
-            tap(p + "qact1", ws["h"], (B, T, C))
+            self._ln(x, C, M, blk["ln1"], ws["h"], st, blocks=blk_l)
+            tap(p + "qact1", ws["h"], (B, T, C), blk_l)
             q = blk["qkv"]
-            _lib.call("ivit_gemm_i8_requant_qkv", _lib.ptr(ws["h"]), C, _lib.ptr(q["W"]), q["K"], _lib.ptr(q["b"]),
-                      _lib.ptr(q["m"]), _lib.ptr(q["e"]), _lib.ptr(ws["qkv"]), T, H, hd, M, 3 * C, C, st)
+            qw, qlay = self._w(q, blk_l)
+            _lib.call("ivit_gemm_i8_requant_qkv_ex", _lib.ptr(ws["h"]), C, qw, q["K"], _lib.ptr(q["b"]),
+                      _lib.ptr(q["m"]), _lib.ptr(q["e"]), _lib.ptr(ws["qkv"]), T, H, hd, M, 3 * C, C, qlay | int(blk_l), st)
             tap(p + "attn.qkv_headmajor", ws["qkv"], (3, B, H, T, hd))
             a = blk["attn"]
-            _lib.call("ivit_attention_fused_i8", _lib.ptr(ws["qkv"]), _lib.ptr(ws["ao"]), B, H, T, hd,
-                      a["ms"][0], a["ms"][1], a["s_attn"], a["mo"][0], a["mo"][1], st)
-            tap(p + "attn.qact2", ws["ao"], (B, T, C))
-            self._gemm_res(ws["ao"], C, blk["proj"], x, blk["res1"], x2, M, st)
+            _lib.call("ivit_attention_fused_i8_ex", _lib.ptr(ws["qkv"]), _lib.ptr(ws["ao"]), B, H, T, hd,
+                      a["ms"][0], a["ms"][1], a["s_attn"], a["mo"][0], a["mo"][1], int(blk_l), st)
+            tap(p + "attn.qact2", ws["ao"], (B, T, C), blk_l)
+            self._gemm_res(ws["ao"], C, blk["proj"], x, blk["res1"], x2, M, st, blocks=blk_l)
             tap(p + "qact2", x2, (B, T, C))
-            self._ln(x2, C, M, blk["ln2"], ws["h"], st)
-            tap(p + "qact3", ws["h"], (B, T, C))
-            self._gemm(ws["h"], C, blk["fc1"], ws["f1"], 4 * C, M, st)
+            self._ln(x2, C, M, blk["ln2"], ws["h"], st, blocks=blk_l)
+            tap(p + "qact3", ws["h"], (B, T, C), blk_l)
+            self._gemm(ws["h"], C, blk["fc1"], ws["f1"], 4 * C, M, st, a_blocks=blk_l, blocks=blk_l)
             tap(p + "mlp.qact_gelu", ws["f1"], (B, T, 4 * C))
-            _lib.call("ivit_shiftgelu_lut_i8", _lib.ptr(ws["f1"]), 4 * C, M, 4 * C, _lib.ptr(blk["gelu_lut"]),
-                      _lib.ptr(ws["g"]), 4 * C, st)
-            tap(p + "mlp.qact1", ws["g"], (B, T, 4 * C))
-            self._gemm_res(ws["g"], 4 * C, blk["fc2"], x2, blk["res2"], x, M, st)
+            _lib.call("ivit_shiftgelu_lut_i8_ex", _lib.ptr(ws["f1"]), 4 * C, M, 4 * C, _lib.ptr(blk["gelu_lut"]),
+                      _lib.ptr(ws["g"]), 4 * C, int(blk_l), st)
+            tap(p + "mlp.qact1", ws["g"], (B, T, 4 * C), blk_l)
+            self._gemm_res(ws["g"], 4 * C, blk["fc2"], x2, blk["res2"], x, M, st, blocks=blk_l)
             tap(p + "qact4", x, (B, T, C))
         # final LayerNorm is row-wise and only the cls row is consumed (vit_quant.py:302-304)
         self._ln(x, T * C, B, self.ln_f, ws["cls"], st)

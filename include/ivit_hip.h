@@ -146,6 +146,10 @@ int ivit_gemm_i8_i32(const int8_t* A, int64_t lda, const int8_t* W, int64_t ldw,
 int ivit_attention_fused_i8(const int8_t* qkv, int8_t* out, int batch, int heads, int tokens, int head_dim,
                             uint32_t m_s, int32_t e_s, float s_attn, uint32_t m_o, int32_t e_o,
                             ivit_stream_t stream);
+/* out_blocks = 1: `out` ([batch*tokens, heads*head_dim]) is written in IVIT_LAYOUT_BLOCKS (the A operand of attn.proj) */
+int ivit_attention_fused_i8_ex(const int8_t* qkv, int8_t* out, int batch, int heads, int tokens, int head_dim,
+                               uint32_t m_s, int32_t e_s, float s_attn, uint32_t m_o, int32_t e_o, int out_blocks,
+                               ivit_stream_t stream);
 
 /* ---- I-LayerNorm + the QuantAct behind it ---------------------------------------------------
  * IVITIntLayerNorm.forward (ivit_modules.py:30-65) then QuantAct (fixedpoint_mul).
@@ -156,6 +160,10 @@ int ivit_attention_fused_i8(const int8_t* qkv, int8_t* out, int batch, int heads
  *   out [rows, C] int8 (ldo).  C % 4 == 0, C <= 4096. */
 int ivit_layernorm_i8(const int8_t* x, int64_t ldx, int rows, int C, const float* bias_int, const float* s_ln,
                       const uint32_t* m, const int32_t* e, int8_t* out, int64_t ldo, ivit_stream_t stream);
+/* out_blocks = 1: `out` is written in IVIT_LAYOUT_BLOCKS (C % 64 == 0, ldo == C, rows padded to 16) */
+int ivit_layernorm_i8_ex(const int8_t* x, int64_t ldx, int rows, int C, const float* bias_int, const float* s_ln,
+                         const uint32_t* m, const int32_t* e, int8_t* out, int64_t ldo, int out_blocks,
+                         ivit_stream_t stream);
 
 /* module-level form: int32 input (8 or 16 bit values), float32 output y*s_ln (ivit_modules.py:63) */
 int ivit_layernorm_i32_f32(const int32_t* x, int64_t ldx, int rows, int C, const float* bias_int,
@@ -176,6 +184,9 @@ int ivit_shiftgelu_build_lut(float s, uint32_t m, int32_t e, int8_t* lut /* [256
 /* ... then per call: wave-per-row max reduction + LDS-staged table row + byte gather.  L % 4 == 0. */
 int ivit_shiftgelu_lut_i8(const int8_t* x, int64_t ldx, int rows, int L, const int8_t* lut, int8_t* out,
                           int64_t ldo, ivit_stream_t stream);
+/* out_blocks = 1: `out` is written in IVIT_LAYOUT_BLOCKS (L % 64 == 0, ldo == L, rows padded to 16) */
+int ivit_shiftgelu_lut_i8_ex(const int8_t* x, int64_t ldx, int rows, int L, const int8_t* lut, int8_t* out,
+                             int64_t ldo, int out_blocks, ivit_stream_t stream);
 
 /* ---- stand-alone Shiftmax (module-level IVITIntSoftmax, ivit_modules.py:164-179) -----------------
  * x [rows, L] int8 with scale s -> out [rows, L] int8 in [0, 127] (scale 2^-7). L <= 1024. */

@@ -88,6 +88,24 @@ def test_batch_invariance_and_oracle_on_fresh_images():
     assert np.array_equal(li3.cpu().numpy(), li[5:6])
 
 
+def test_block_layout_path_equals_row_major_path():
+    """batch large enough for the persistent GEMM (M = 13 * 197 >= 2048, not a multiple of 16: the last 16-row block of
+    every block-layout operand is partly padding): activations + weights in the block layout vs everything row-major --
+    identical logits AND identical stage-by-stage taps (the block-layout taps are untiled for the caller)"""
+    eng, fs, ranges, cfg, meta, z = build("deit_tiny", 13)
+    imgs = torch.from_numpy(synth.make_images(13, 99)).to(DEV)
+    assert eng.block_operands
+    t_blocks, t_rows = {}, {}
+    li_b = eng.forward(imgs, t_blocks)[0].cpu().numpy().copy()
+    eng.block_operands = False
+    li_r = eng.forward(imgs, t_rows)[0].cpu().numpy().copy()
+    eng.block_operands = True
+    assert np.array_equal(li_b, li_r)
+    assert set(t_blocks) == set(t_rows) and len(t_rows) > 50
+    for k in t_rows:
+        assert torch.equal(t_blocks[k], t_rows[k]), k
+
+
 def test_headline_batch_256_deit_base():
     """Config 3 at full size: golden images embedded in a batch of 256 reproduce the golden logits."""
     eng, fs, ranges, cfg, meta, z = build("deit_base", 256)

@@ -277,6 +277,60 @@ def test_gemm_block_layout_operands(M, N, K):
                   _lib.ptr(out), N, 512, N, K, 1, st())
 
 
+def test_producers_write_block_layout():
+    """LayerNorm, fused attention and the GELU table kernel with out_blocks = 1 == ivit_tile_operand_i8 of their
+    row-major output (ragged row counts: the last 16-row block is partly padding)"""
+    rng = np.random.default_rng(5)
+
+    def tiled_of(rowmajor, rows, K):
+        t = torch.zeros((rows + 15) // 16 * 16 * K, dtype=torch.int8, device=DEV)
+        _lib.call("ivit_tile_operand_i8", _lib.ptr(rowmajor), K, rows, K, _lib.ptr(t), st())
+        return t
+
+    def valid_bytes(rows, K):   # positions of real elements in the block buffer
+        X = np.ones((rows, K), np.int8)
+        return _block_layout_host(X).astype(bool)
+
+    # LayerNorm
+    rows, Cn = 197 * 3 + 5, 768
+    k = np.clip(np.rint(rng.normal(0, 30, size=(rows, Cn))), -128, 127).astype(np.int8)
+    lp = _ln_host(rng.uniform(0.5, 1.5, size=Cn).astype(np.float32), rng.normal(0, 0.1, size=Cn).astype(np.float32), np.float32(2 ** -4))
+    md, ed = me_dev(lp.m, lp.e)
+    args = (_lib.ptr(dev(k)), Cn, rows, Cn, _lib.ptr(dev(lp.bias_int)), _lib.ptr(dev(lp.s_ln)), _lib.ptr(md), _lib.ptr(ed))
+    rm = torch.empty(rows, Cn, dtype=torch.int8, device=DEV)
+    _lib.call("ivit_layernorm_i8", *args, _lib.ptr(rm), Cn, st())
+    bl = torch.zeros((rows + 15) // 16 * 16 * Cn, dtype=torch.int8, device=DEV)
+    _lib.call("ivit_layernorm_i8_ex", *args, _lib.ptr(bl), Cn, 1, st())
+    v = valid_bytes(rows, Cn)
+    assert np.array_equal(bl.cpu().numpy()[v], tiled_of(rm, rows, Cn).cpu().numpy()[v])
+    assert not bl.cpu().numpy()[~v].any()
+    # GELU table form
+    rows, L = 197 * 2 + 3, 3072
+    x = np.clip(np.rint(rng.normal(0, 40, size=(rows, L))), -128, 127).astype(np.int8)
+    mg, eg = dyadic(np.float32(0.05 / 128), np.float32(0.03))
+    lut = torch.empty(65536, dtype=torch.int8, device=DEV)
+    _lib.call("ivit_shiftgelu_build_lut", 0.05, int(mg[0]), int(eg[0]), _lib.ptr(lut), st())
+    rm = torch.empty(rows, L, dtype=torch.int8, device=DEV)
+    _lib.call("ivit_shiftgelu_lut_i8", _lib.ptr(dev(x)), L, rows, L, _lib.ptr(lut), _lib.ptr(rm), L, st())
+    bl = torch.zeros((rows + 15) // 16 * 16 * L, dtype=torch.int8, device=DEV)
+    _lib.call("ivit_shiftgelu_lut_i8_ex", _lib.ptr(dev(x)), L, rows, L, _lib.ptr(lut), _lib.ptr(bl), L, 1, st())
+    v = valid_bytes(rows, L)
+    assert np.array_equal(bl.cpu().numpy()[v], tiled_of(rm, rows, L).cpu().numpy()[v])
+    # fused attention
+    B, H, T, hd = 3, 6, 197, 64
+    qkv = np.clip(np.rint(rng.normal(0, 40, size=(3, B, H, T, hd))), -128, 127).astype(np.int8)
+    ms, es = dyadic(np.float32(2.0 ** -11), np.float32(2.0 ** -2))
+    mo, eo = dyadic(np.float32(2.0 ** -11), np.float32(2.0 ** -3))
+    a = (_lib.ptr(dev(qkv)),)
+    rm = torch.empty(B * T, H * hd, dtype=torch.int8, device=DEV)
+    _lib.call("ivit_attention_fused_i8", a[0], _lib.ptr(rm), B, H, T, hd, int(ms[0]), int(es[0]), 0.25, int(mo[0]), int(eo[0]), st())
+    bl = torch.zeros((B * T + 15) // 16 * 16 * H * hd, dtype=torch.int8, device=DEV)
+    _lib.call("ivit_attention_fused_i8_ex", a[0], _lib.ptr(bl), B, H, T, hd, int(ms[0]), int(es[0]), 0.25, int(mo[0]), int(eo[0]), 1,
+              st())
+    v = valid_bytes(B * T, H * hd)
+    assert np.array_equal(bl.cpu().numpy()[v], tiled_of(rm, B * T, H * hd).cpu().numpy()[v])
+
+
 def test_gemm_rejects_bad_shapes():
     a = torch.zeros(64, 100, dtype=torch.int8, device=DEV)
     with pytest.raises(_lib.IvitError, match="multiple of 64"):
