@@ -139,6 +139,9 @@ class IntViTEngine(GraphReplay):
                 _lib.call("ivit_tile_operand_i8", _lib.ptr(lin["W"]), lin["K"], lin["N"], lin["K"], _lib.ptr(lin["Wb"]),
                           self._stream())
         self.block_operands = True    # False: row-major activations / weights everywhere (tests, A/B timing)
+        # which producers write their output (a GEMM A operand) in the block layout.  Measured per producer / consumer pair
+        # (DESIGN.md section 5): the GEMM gains 4-6 % from a block-layout A, the producer pays for 64-byte row segments
+        self.block_a = {"ln": True, "attn": True, "gelu": True}
         self.probe = None
         self._alloc(max_batch)
         torch.cuda.synchronize(self.dev)
@@ -175,10 +178,10 @@ class IntViTEngine(GraphReplay):
         _lib.call("ivit_gemm_i8_requant_ex", _lib.ptr(A), lda, w, lin["K"], _lib.ptr(lin["b"]),
                   _lib.ptr(lin["m"]), _lib.ptr(lin["e"]), _lib.ptr(out), ldo, M, lin["N"], lin["K"], lay | int(a_blocks), st)
 
-    def _gemm_res(self, A, lda, lin, res, me4, out, M, st, blocks=False):
+    def _gemm_res(self, A, lda, lin, res, me4, out, M, st, blocks=False, a_blocks=False):
         C = self.C
         w, lay = self._w(lin, blocks)
-        lay |= int(blocks)
+        lay |= int(a_blocks)
         probe = self.probe
         if probe is not None:  # bench.py: HIP events around the dominant kernel, on the launch stream
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -209,7 +212,8 @@ class IntViTEngine(GraphReplay):
         st = self._stream()
 
         # GEMM operands in the block layout whenever the calls go to the persistent kernel (M >= 2048; N >= 128 always)
-        blk_l = bool(self.block_operands) and M >= 2048 and C % 64 == 0
+        blk_l = bool(self.block_operands) and M >= 2048 and C % 64 == 0    # weights (always) and, per producer, activations
+        a_ln, a_at, a_ge = (blk_l and self.block_a[k] for k in ("ln", "attn", "gelu"))
 
         def tap(name, t, shape, blocks=False):
             if taps is not None:
@@ -230,27 +234,27 @@ class IntViTEngine(GraphReplay):
         x, x2 = ws["x"], ws["x2"]
         for i, blk in enumerate(self.blocks):
             p = f"blocks.{i}."
-            self._ln(x, C, M, blk["ln1"], ws["h"], st, blocks=blk_l)
-            tap(p + "qact1", ws["h"], (B, T, C), blk_l)
+            self._ln(x, C, M, blk["ln1"], ws["h"], st, blocks=a_ln)
+            tap(p + "qact1", ws["h"], (B, T, C), a_ln)
             q = blk["qkv"]
             qw, qlay = self._w(q, blk_l)
             _lib.call("ivit_gemm_i8_requant_qkv_ex", _lib.ptr(ws["h"]), C, qw, q["K"], _lib.ptr(q["b"]),
-                      _lib.ptr(q["m"]), _lib.ptr(q["e"]), _lib.ptr(ws["qkv"]), T, H, hd, M, 3 * C, C, qlay | int(blk_l), st)
+                      _lib.ptr(q["m"]), _lib.ptr(q["e"]), _lib.ptr(ws["qkv"]), T, H, hd, M, 3 * C, C, qlay | int(a_ln), st)
             tap(p + "attn.qkv_headmajor", ws["qkv"], (3, B, H, T, hd))
             a = blk["attn"]
             _lib.call("ivit_attention_fused_i8_ex", _lib.ptr(ws["qkv"]), _lib.ptr(ws["ao"]), B, H, T, hd,
-                      a["ms"][0], a["ms"][1], a["s_attn"], a["mo"][0], a["mo"][1], int(blk_l), st)
-            tap(p + "attn.qact2", ws["ao"], (B, T, C), blk_l)
-            self._gemm_res(ws["ao"], C, blk["proj"], x, blk["res1"], x2, M, st, blocks=blk_l)
+                      a["ms"][0], a["ms"][1], a["s_attn"], a["mo"][0], a["mo"][1], int(a_at), st)
+            tap(p + "attn.qact2", ws["ao"], (B, T, C), a_at)
+            self._gemm_res(ws["ao"], C, blk["proj"], x, blk["res1"], x2, M, st, blocks=blk_l, a_blocks=a_at)
             tap(p + "qact2", x2, (B, T, C))
-            self._ln(x2, C, M, blk["ln2"], ws["h"], st, blocks=blk_l)
-            tap(p + "qact3", ws["h"], (B, T, C), blk_l)
-            self._gemm(ws["h"], C, blk["fc1"], ws["f1"], 4 * C, M, st, a_blocks=blk_l, blocks=blk_l)
+            self._ln(x2, C, M, blk["ln2"], ws["h"], st, blocks=a_ln)
+            tap(p + "qact3", ws["h"], (B, T, C), a_ln)
+            self._gemm(ws["h"], C, blk["fc1"], ws["f1"], 4 * C, M, st, a_blocks=a_ln, blocks=blk_l)
             tap(p + "mlp.qact_gelu", ws["f1"], (B, T, 4 * C))
             _lib.call("ivit_shiftgelu_lut_i8_ex", _lib.ptr(ws["f1"]), 4 * C, M, 4 * C, _lib.ptr(blk["gelu_lut"]),
-                      _lib.ptr(ws["g"]), 4 * C, int(blk_l), st)
-            tap(p + "mlp.qact1", ws["g"], (B, T, 4 * C), blk_l)
-            self._gemm_res(ws["g"], 4 * C, blk["fc2"], x2, blk["res2"], x, M, st, blocks=blk_l)
+                      _lib.ptr(ws["g"]), 4 * C, int(a_ge), st)
+            tap(p + "mlp.qact1", ws["g"], (B, T, 4 * C), a_ge)
+            self._gemm_res(ws["g"], 4 * C, blk["fc2"], x2, blk["res2"], x, M, st, blocks=blk_l, a_blocks=a_ge)
             tap(p + "qact4", x, (B, T, C))
         # final LayerNorm is row-wise and only the cls row is consumed (vit_quant.py:302-304)
         self._ln(x, T * C, B, self.ln_f, ws["cls"], st)
