@@ -37,6 +37,7 @@ SIGNATURES = {
     "ivit_gemm_i8_i32": [vp, i64, vp, i64, vp, vp, i64, ci, ci, ci, vp],
     "ivit_debug_force_small_gemm": [ci],
     "ivit_debug_set_gemm_flags": [ci],
+    "ivit_debug_ln_wave_per_row": [ci],
     "ivit_debug_set_stamp_buffer": [vp],
     "ivit_attention_fused_i8": [vp, vp, ci, ci, ci, ci, u32, i32, f32, u32, i32, vp],
     "ivit_layernorm_i8": [vp, i64, ci, ci, vp, vp, vp, vp, vp, i64, vp],

@@ -13,6 +13,9 @@
 
 #include "common.h"
 
+// tests / A-B timing: 1 = always the wave-per-row LayerNorm kernel (ivit_debug_ln_wave_per_row)
+int g_ln_wave_per_row = 0;
+
 namespace {
 
 constexpr int NT = 256;
@@ -224,6 +227,156 @@ __global__ __launch_bounds__(NT, (NJ <= 3 ? 4 : NJ <= 8 ? 2 : 1)) void layernorm
                 if (d < nd) {
                     const int64_t off = a.out_blocks ? ivit_block_offset(row0 + rr, 4 * d, C) : (int64_t)(row0 + rr) * a.ldo + 4 * d;
                     *reinterpret_cast<int*>(out + off) = res[j];
+                }
+            }
+        }
+    }
+}
+
+// Half a wave per row (the form the fused engines use, C <= 1536): lanes 0-31 own row r, lanes 32-63 row r + 1, NJ dwords
+// per lane (d = l32 + 32 j); G = 8 rows (4 row pairs) per wave and iteration.  Every load and store instruction touches
+// two full 128-byte lines per row pair, in the row-major layout AND in the GEMM block layout (where rows 2q, 2q + 1 of a
+// 64-byte column block share a line) -- with a whole wave per row the block-layout stores were 64-byte half lines
+// (36.7 vs 29.6 us per call).  The per-channel constants (bias, requant bracket) are computed once per WORKGROUP into LDS
+// and read 16 bytes at a time per dword of channels; row sums reduce over 32 lanes; the statistics of the 8 rows are
+// evaluated in lanes 0-3 of each half.  Arithmetic exactly as layernorm_i8_kernel (certificate, literal fallback).
+template <int NJ>
+__global__ __launch_bounds__(NT, NJ <= 3 ? 4 : 3) void layernorm_i8_pair_kernel(LnArgs a)
+{
+    constexpr int G2 = 4;   // row pairs per wave and iteration
+    extern __shared__ __attribute__((aligned(16))) float lds_tab[];   // [C] bias | [C] lo | [C] hi
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l32 = lane & 31;
+    const int C = a.C, nd = C >> 2;
+    float* t_bias = lds_tab;
+    float* t_lo = lds_tab + C;
+    float* t_hi = lds_tab + 2 * C;
+    for (int c = tid; c < C; c += NT) {
+        const double M = dyadic_mult(a.m[c], a.e[c]);
+        const double lod = M * (1.0 - 1.25 / 4194304.0), hid = M * (1.0 + 1.25 / 4194304.0);
+        float lf = (float)lod, hf = (float)hid;
+        if ((double)lf > lod) lf = __int_as_float(__float_as_int(lf) - 1);   // largest float32 <= lod (lod > 0)
+        if ((double)hf < hid) hf = __int_as_float(__float_as_int(hf) + 1);   // smallest float32 >= hid
+        const float sl = a.s_ln[c];
+        const bool ok = fabsf(sl) >= 1e-30f && fabsf(sl) <= 1e30f && lod > 1e-35 && hid < 1e30;   // see layernorm_i8_kernel
+        t_bias[c] = a.bias_int[c];
+        t_lo[c] = ok ? lf : 0.0f;
+        t_hi[c] = ok ? hf : __builtin_inff();
+    }
+    __syncthreads();
+    const int8_t* xin = reinterpret_cast<const int8_t*>(a.x);
+    int8_t* out = reinterpret_cast<int8_t*>(a.out);
+    for (int row0 = (blockIdx.x * WPB + wave) * (2 * G2); row0 < a.rows; row0 += gridDim.x * WPB * (2 * G2)) {
+        int w[G2][NJ], sum[G2], sq[G2];
+#pragma unroll
+        for (int q = 0; q < G2; ++q) {
+            const int row = min(row0 + 2 * q + half, a.rows - 1);
+            const int* xr = reinterpret_cast<const int*>(xin + (int64_t)row * a.ldx);
+            sum[q] = 0;
+            sq[q] = 0;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int d = l32 + 32 * j;
+                w[q][j] = (d < nd) ? xr[d] : 0;
+                sum[q] = __builtin_amdgcn_sdot4(w[q][j], 0x01010101, sum[q], false);
+                sq[q] = __builtin_amdgcn_sdot4(w[q][j], w[q][j], sq[q], false);   // <= 1536 * 128^2 < 2^25
+            }
+        }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1)   // within the half wave
+#pragma unroll
+            for (int q = 0; q < G2; ++q) {
+                sum[q] += __shfl_xor(sum[q], o);
+                sq[q] += __shfl_xor(sq[q], o);
+            }
+        // lane (half, l32 = q) : statistics of row 2q + half, computed once; ivit_modules.py:37, 40-51
+        int my_sum = sum[0], my_sq = sq[0];
+#pragma unroll
+        for (int q = 1; q < G2; ++q) {
+            my_sum = (l32 == q) ? sum[q] : my_sum;
+            my_sq = (l32 == q) ? sq[q] : my_sq;
+        }
+        int my_mean;
+        ln_mean(my_sum, C, my_mean);
+        const int my_var = my_sq - 2 * my_mean * my_sum + C * my_mean * my_mean;   // exact, see layernorm_i8_kernel
+        const float my_hfactor = ln_factor((long long)my_var) * 0.5f;             // :52: the /2 folds into the factor
+        int mean_int[G2];
+        float hfactor[G2], mean128[G2];
+#pragma unroll
+        for (int q = 0; q < G2; ++q) {
+            mean_int[q] = __shfl(my_mean, (lane & 32) | q);
+            hfactor[q] = __shfl(my_hfactor, (lane & 32) | q);
+            mean128[q] = (float)(mean_int[q] + 128);
+        }
+        // results are stored as they are produced; a row pair whose certificate fails is recomputed literally below and
+        // stored again (same lane, same addresses: program order)
+        unsigned unc[G2];
+#pragma unroll
+        for (int q = 0; q < G2; ++q) unc[q] = 0;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int d = min(l32 + 32 * j, nd - 1);
+            const float4 b4 = *reinterpret_cast<const float4*>(t_bias + 4 * d);
+            const float4 l4 = *reinterpret_cast<const float4*>(t_lo + 4 * d);
+            const float4 h4 = *reinterpret_cast<const float4*>(t_hi + 4 * d);
+            const float bias[4] = {b4.x, b4.y, b4.z, b4.w}, lo[4] = {l4.x, l4.y, l4.z, l4.w}, hi[4] = {h4.x, h4.y, h4.z, h4.w};
+#pragma unroll
+            for (int q = 0; q < G2; ++q) {
+                const unsigned wu = (unsigned)w[q][j] ^ 0x80808080u;   // bytes x + 128: v_cvt_f32_ubyteN below
+                int o[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float dl = (float)((wu >> (8 * c)) & 0xffu) - mean128[q];   // x - mean, exact
+                    const float v = floorf(dl * hfactor[q]);               // :52
+                    const float y = v + bias[c];                           // :61
+                    const int tl = __float_as_int(__builtin_fmaf(y, lo[c], 12582912.0f));
+                    const int th = __float_as_int(__builtin_fmaf(y, hi[c], 12582912.0f));
+                    asm("v_sad_u32 %0, %1, %2, %3" : "=v"(unc[q]) : "v"(tl), "v"(th), "v"(unc[q]));
+                    o[c] = clamp_i32(tl, 0x4B400000 - 128, 0x4B400000 + 127);
+                }
+                const unsigned w01 = __builtin_amdgcn_perm((unsigned)o[1], (unsigned)o[0], 0x0c0c0400u);
+                const unsigned w23 = __builtin_amdgcn_perm((unsigned)o[3], (unsigned)o[2], 0x04000c0cu);
+                const int row = row0 + 2 * q + half, dd = l32 + 32 * j;
+                if (row < a.rows && dd < nd) {
+                    const int64_t off = a.out_blocks ? ivit_block_offset(row, 4 * dd, C) : (int64_t)row * a.ldo + 4 * dd;
+                    *reinterpret_cast<int*>(out + off) = (int)(w01 | w23);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);   // keep the constants of one channel group live at a time
+        }
+#pragma unroll
+        for (int q = 0; q < G2; ++q) {
+            const int row = row0 + 2 * q + half;
+            if (__builtin_amdgcn_ballot_w64(unc[q] != 0) != 0) {
+                // literal evaluation of the row pair (wave-uniform branch), as layernorm_i8_kernel
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const int d = min(l32 + 32 * j, nd - 1);
+                    const float4 b4 = *reinterpret_cast<const float4*>(t_bias + 4 * d);
+                    const float4 s4 = *reinterpret_cast<const float4*>(a.s_ln + 4 * d);
+                    const uint4 m4 = *reinterpret_cast<const uint4*>(a.m + 4 * d);
+                    const int4 e4 = *reinterpret_cast<const int4*>(a.e + 4 * d);
+                    const float bias[4] = {b4.x, b4.y, b4.z, b4.w}, sl[4] = {s4.x, s4.y, s4.z, s4.w};
+                    const double Mq[4] = {dyadic_mult(m4.x, e4.x), dyadic_mult(m4.y, e4.y), dyadic_mult(m4.z, e4.z),
+                                          dyadic_mult(m4.w, e4.w)};
+                    int o[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        float dl = (float)(sx8(w[q][j], c) - mean_int[q]);
+                        float v = floorf(dl * hfactor[q]);
+                        float y = v + bias[c];
+                        float x = y * sl[c];                               // :63
+                        float qf = (float)((double)x * (1.0 / (double)sl[c]));   // quant_utils.py:220, see layernorm_i8_kernel
+                        float z = rintf(qf);
+                        double p = (double)z * Mq[c];                      // :229
+                        double t = p + IVIT_MAGIC;                         // :230
+                        o[c] = clamp_i32((int)(unsigned)__double_as_longlong(t), -128, 127);
+                    }
+                    const int dd = l32 + 32 * j;
+                    if (row < a.rows && dd < nd) {
+                        const int64_t off = a.out_blocks ? ivit_block_offset(row, 4 * dd, C) : (int64_t)row * a.ldo + 4 * dd;
+                        *reinterpret_cast<int*>(out + off) = pack4(o[0], o[1], o[2], o[3]);
+                    }
                 }
             }
         }
@@ -746,6 +899,12 @@ IVIT_EXPORT int ivit_untile_operand_i8(const int8_t* src, int64_t rows, int K, i
     IVIT_CHECK_LAUNCH("ivit_untile_operand_i8");
 }
 
+IVIT_EXPORT int ivit_debug_ln_wave_per_row(int on)
+{
+    g_ln_wave_per_row = on;
+    return IVIT_OK;
+}
+
 IVIT_EXPORT int ivit_layernorm_i8_ex(const int8_t* x, int64_t ldx, int rows, int C, const float* bias_int,
                                   const float* s_ln, const uint32_t* m, const int32_t* e, int8_t* out, int64_t ldo,
                                      int out_blocks, ivit_stream_t stream)
@@ -761,13 +920,25 @@ IVIT_EXPORT int ivit_layernorm_i8_ex(const int8_t* x, int64_t ldx, int rows, int
     IVIT_REQUIRE(out_blocks == 0 || (out_blocks == 1 && C % 64 == 0 && ldo == C && ((uintptr_t)out % 16 == 0)),
                  "ivit_layernorm_i8_ex: block-layout output needs C %% 64 == 0 and ldo == C");
     LnArgs a{x, ldx, rows, C, bias_int, s_ln, m, e, out, ldo, out_blocks};
+    hipStream_t st = ivit_stream(stream);
+    if (C <= 1536 && !(g_ln_wave_per_row)) {   // half a wave per row, constants in LDS (3 * C floats)
+        const int nj2 = (C / 4 + 31) / 32;
+        int grid = grid_for_rows(rows, 8);
+        if (grid > 1024) grid = 1024;          // 4 waves per SIMD resident
+        const size_t lds = (size_t)3 * C * sizeof(float);
+        if (nj2 <= 2) hipLaunchKernelGGL(layernorm_i8_pair_kernel<2>, dim3(grid), dim3(NT), lds, st, a);
+        else if (nj2 <= 3) hipLaunchKernelGGL(layernorm_i8_pair_kernel<3>, dim3(grid), dim3(NT), lds, st, a);
+        else if (nj2 <= 6) hipLaunchKernelGGL(layernorm_i8_pair_kernel<6>, dim3(grid), dim3(NT), lds, st, a);
+        else if (nj2 <= 8) hipLaunchKernelGGL(layernorm_i8_pair_kernel<8>, dim3(grid), dim3(NT), lds, st, a);
+        else hipLaunchKernelGGL(layernorm_i8_pair_kernel<12>, dim3(grid), dim3(NT), lds, st, a);
+        IVIT_CHECK_LAUNCH("ivit_layernorm_i8");
+    }
     const int nj = (C / 4 + 63) / 64;
     // each wave sets up its per-channel constants (bias and the requant bracket, 12*NJ registers per lane) once: launch no more workgroups than
     // stay resident (256 CUs x waves/SIMD at the kernel's register count) and let them stride over the rows
     const int resident = 256 * (nj <= 1 ? 6 : nj <= 3 ? 4 : nj <= 4 ? 3 : nj <= 8 ? 2 : 1);
     int grid = grid_for_rows(rows, nj <= 3 ? 8 : nj <= 4 ? 4 : 1);   // rows per wave and iteration: G of the kernel
     if (grid > resident) grid = resident;
-    hipStream_t st = ivit_stream(stream);
     if (nj <= 1) hipLaunchKernelGGL(layernorm_i8_kernel<1>, dim3(grid), dim3(NT), 0, st, a);
     else if (nj <= 2) hipLaunchKernelGGL(layernorm_i8_kernel<2>, dim3(grid), dim3(NT), 0, st, a);
     else if (nj <= 3) hipLaunchKernelGGL(layernorm_i8_kernel<3>, dim3(grid), dim3(NT), 0, st, a);

@@ -26,6 +26,10 @@ int ivit_debug_set_gemm_flags(int flags);
 /* Diagnostic timeline buffer (8 x uint64 per workgroup) for the stamped build (flags = 512); scripts/gemm_timeline.py */
 int ivit_debug_set_stamp_buffer(void* buf);
 
+/* 1: ivit_layernorm_i8 always takes the wave-per-row kernel (default: half a wave per row for C <= 1536): parity tests of
+ * both forms, A/B timing */
+int ivit_debug_ln_wave_per_row(int on);
+
 #ifdef __cplusplus
 }
 #endif

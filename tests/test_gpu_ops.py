@@ -381,7 +381,7 @@ def _ln_host(gamma, beta, s_out):
     return LayerNormParams(gamma, beta, s_out)
 
 
-def test_layernorm_kat(kat):
+def test_layernorm_kat(kat, ln_form):
     for ci in kat["ln_cases"][:3]:  # 8-bit inputs (the int8 kernel); case 3 is 16-bit -> i32 kernel
         c = f"ln{ci}_"
         k = kat[c + "k"]
@@ -408,7 +408,7 @@ def test_layernorm_f32_module_form_kat(kat):
 
 
 @pytest.mark.parametrize("rows,Cn", [(1000, 768), (513, 192), (64, 384), (7, 1024), (20000, 768), (3000, 2048)])
-def test_layernorm_random_vs_oracle(rows, Cn):
+def test_layernorm_random_vs_oracle(rows, Cn, ln_form):
     rng = np.random.default_rng(rows + Cn)
     k = np.clip(np.rint(rng.normal(rng.normal(0, 10, size=(rows, 1)), rng.uniform(1, 50, size=(rows, 1)),
                                    size=(rows, Cn))), -128, 127).astype(np.int8)
@@ -427,10 +427,18 @@ def test_layernorm_random_vs_oracle(rows, Cn):
     assert np.array_equal(got, exp), f"{(got != exp).sum()} of {got.size} differ"
 
 
+@pytest.fixture(params=[0, 1], ids=["half_wave_per_row", "wave_per_row"])
+def ln_form(request):
+    """both int8 LayerNorm kernels: half a wave per row (default for C <= 1536) and a wave per row"""
+    _lib.call("ivit_debug_ln_wave_per_row", request.param)
+    yield request.param
+    _lib.call("ivit_debug_ln_wave_per_row", 0)
+
+
 @pytest.mark.parametrize("regime", ["tiny_gamma", "huge_gamma", "big_bias", "saturating", "vanishing", "constant_rows",
                                     "two_level_rows", "mixed_sign_gamma_free"])
 @pytest.mark.parametrize("Cn", [768, 192])
-def test_layernorm_certificate_regimes(regime, Cn):
+def test_layernorm_certificate_regimes(regime, Cn, ln_form):
     """the float32 bracket certificate of layernorm_i8_kernel (and its literal fallback) against the oracle where the
     pieces of the chain have unusual magnitudes: |y| far below 2^22 / near 2^31, multipliers that saturate or vanish,
     degenerate rows"""
