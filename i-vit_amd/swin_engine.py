@@ -92,7 +92,11 @@ class IntSwinEngine(GraphReplay):
             Kp = _pad64(lp.K)
             W = np.zeros((lp.W8.shape[0], Kp), np.int8)   # zero K-padding: the operand's pad columns never contribute
             W[:, :lp.K] = lp.W8
-            d = dict(W=dev(W), b=None if lp.b32 is None else dev(lp.b32), K=Kp, N=W.shape[0])
+            d = dict(W=dev(W), b=None if lp.b32 is None else dev(lp.b32), K=Kp, N=W.shape[0], Wb=None)
+            if d["N"] >= 128 and d["N"] % 16 == 0:
+                # block-layout copy (include/ivit_hip.h IVIT_LAYOUT_BLOCKS) for the calls that reach the persistent GEMM
+                d["Wb"] = torch.empty_like(d["W"])
+                _lib.call("ivit_tile_operand_i8", _lib.ptr(d["W"]), Kp, d["N"], Kp, _lib.ptr(d["Wb"]), _lib.stream_ptr())
             return lp, d
 
         def lin_dev(name, s_in, s_out):
@@ -233,9 +237,17 @@ class IntSwinEngine(GraphReplay):
             top1=torch.empty(B, dtype=torch.int32, device=self.dev),
         )
 
+    @staticmethod
+    def _w(lin, M):
+        """(weight pointer, layouts) -- the block-layout copy when the call goes to the persistent kernel"""
+        if lin["Wb"] is not None and M >= 2048:
+            return _lib.ptr(lin["Wb"]), 2
+        return _lib.ptr(lin["W"]), 0
+
     def _gemm(self, A, lda, lin, out, ldo, M, st):
-        _lib.call("ivit_gemm_i8_requant", _lib.ptr(A), lda, _lib.ptr(lin["W"]), lin["K"], _lib.ptr(lin["b"]),
-                  _lib.ptr(lin["m"]), _lib.ptr(lin["e"]), _lib.ptr(out), ldo, M, lin["N"], lin["K"], st)
+        w, lay = self._w(lin, M)
+        _lib.call("ivit_gemm_i8_requant_ex", _lib.ptr(A), lda, w, lin["K"], _lib.ptr(lin["b"]),
+                  _lib.ptr(lin["m"]), _lib.ptr(lin["e"]), _lib.ptr(out), ldo, M, lin["N"], lin["K"], lay, st)
 
     def _ln16(self, x, rows, C, ln, out, ldo, st, H=0, W=0, ws=0, shift=0):
         _lib.call("ivit_layernorm_i16_i8", _lib.ptr(x), rows, C, _lib.ptr(ln["bias"]), _lib.ptr(ln["s"]),
@@ -291,8 +303,9 @@ class IntSwinEngine(GraphReplay):
                 self._ln16(x, M, C, blk["ln1"], ws["h"], ld, st, H, W, win, shift)
                 tap(p + "qact1", ws["h"], M, C, ld, perm)
                 q = blk["qkv"]
-                _lib.call("ivit_gemm_i8_requant_qkv", _lib.ptr(ws["h"]), ld, _lib.ptr(q["W"]), q["K"], _lib.ptr(q["b"]),
-                          _lib.ptr(q["m"]), _lib.ptr(q["e"]), _lib.ptr(ws["qkv"]), N, nH, HEAD_DIM, M, 3 * C, q["K"], st)
+                qw, qlay = self._w(q, M)
+                _lib.call("ivit_gemm_i8_requant_qkv_ex", _lib.ptr(ws["h"]), ld, qw, q["K"], _lib.ptr(q["b"]),
+                          _lib.ptr(q["m"]), _lib.ptr(q["e"]), _lib.ptr(ws["qkv"]), N, nH, HEAD_DIM, M, 3 * C, q["K"], qlay, st)
                 if taps is not None:   # reference layout [B_, N, 3C] (swin_quant.py:131-133)
                     hm = ws["qkv"][: 3 * M * C].view(3, nwin, nH, N, HEAD_DIM)
                     taps[p + "attn.qact1"] = hm.permute(1, 3, 0, 2, 4).reshape(nwin, N, 3 * C).clone()
