@@ -177,6 +177,7 @@ __global__ __launch_bounds__(NT, 3) void attention_kernel(AttnArgs a)
 
         // ---- O^T = Vt . P^T, requantised (attn.qact2), 4 consecutive d per dword
         const int64_t orow_idx = (int64_t)b * T + qrow;
+        const BlockRow obrow = block_row((int)orow_idx, a.heads * HD);
         int8_t* orow = a.out + orow_idx * ((int64_t)a.heads * HD) + hh * HD + 4 * g;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
@@ -195,8 +196,8 @@ __global__ __launch_bounds__(NT, 3) void attention_kernel(AttnArgs a)
                     int o = clamp_i32(requant_exact(acc[r], a.Mo), -128, 127);
                     w |= ((unsigned)o & 0xffu) << (8 * r);
                 }
-                if (a.out_blocks)
-                    *reinterpret_cast<unsigned*>(a.out + ivit_block_offset(orow_idx, hh * HD + 16 * dt + 4 * g, a.heads * HD)) = w;
+                if (a.out_blocks)   // column = 64 hh + 16 dt + 4 g: chunk index dt, column block hh
+                    *reinterpret_cast<unsigned*>(a.out + obrow.base + (unsigned)hh * 1024u + (((unsigned)dt ^ obrow.rs) << 4) + 4u * g) = w;
                 else
                     *reinterpret_cast<unsigned*>(orow + 16 * dt) = w;
             }
@@ -220,7 +221,9 @@ IVIT_EXPORT int ivit_attention_fused_i8_ex(const int8_t* qkv, int8_t* out, int b
     IVIT_REQUIRE(((uintptr_t)qkv % 16 == 0) && ((uintptr_t)out % 4 == 0) && ((heads * head_dim) % 4 == 0),
                  "ivit_attention_fused_i8: misaligned operand");
     IVIT_REQUIRE(s_attn > 0.0f, "ivit_attention_fused_i8: scale must be positive");
-    IVIT_REQUIRE(out_blocks == 0 || (out_blocks == 1 && ((uintptr_t)out % 16 == 0)), "ivit_attention_fused_i8_ex: bad output layout");
+    IVIT_REQUIRE(out_blocks == 0 || (out_blocks == 1 && ((uintptr_t)out % 16 == 0) &&
+                                     ((int64_t)batch * tokens + 15) * heads * head_dim < 2147483648ll),
+                 "ivit_attention_fused_i8_ex: bad output layout (block-layout buffers stay below 2 GiB)");
     AttnArgs a;
     a.out_blocks = out_blocks;
     a.qkv = qkv; a.out = out; a.batch = batch; a.heads = heads; a.tokens = tokens;

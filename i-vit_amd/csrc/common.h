@@ -54,6 +54,18 @@ IVIT_DEV int clamp_i32(int v, int lo, int hi) { return min(max(v, lo), hi); }
 // loop lays a piece into its swizzled LDS stage, so that the instruction reads 1 KB CONTIGUOUS (8 full cache lines)
 // instead of 16 half lines -- the LDS-DMA acceptance rate is per cache line touched.
 // Rows are padded to a multiple of 16 (the buffer holds ceil(rows / 16) * 16 * K bytes).
+// Producers address it as row part + column part + one XOR (32-bit byte offsets: buffers below 4 GB):
+//   block_off(block_row(r, K), block_col(c)) == ivit_block_offset(r, c, K)
+struct BlockRow { unsigned base, rs; };   // per row: block-row origin + 64 * (row & 15); swizzle term (row >> 2) & 3
+struct BlockCol { unsigned base, cc; };   // per byte column: column-block origin + (c & 15); chunk index (c >> 4) & 3
+__device__ __forceinline__ BlockRow block_row(int r, int K)
+{
+    const int rl = r & 15;
+    return BlockRow{(unsigned)((r >> 4) * (K >> 6)) * 1024u + (unsigned)(rl << 6), (unsigned)((rl >> 2) & 3)};
+}
+__device__ __forceinline__ BlockCol block_col(int c) { return BlockCol{(unsigned)(c >> 6) * 1024u + (unsigned)(c & 15), (unsigned)((c >> 4) & 3)}; }
+__device__ __forceinline__ unsigned block_off(BlockRow r, BlockCol c) { return r.base + c.base + ((c.cc ^ r.rs) << 4); }
+
 __host__ __device__ __forceinline__ int64_t ivit_block_offset(int64_t r, int c, int K)
 {
     const int rl = (int)(r & 15);

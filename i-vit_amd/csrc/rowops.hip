@@ -13,7 +13,8 @@
 
 #include "common.h"
 
-// tests / A-B timing: 1 = always the wave-per-row LayerNorm kernel (ivit_debug_ln_wave_per_row)
+// tests / A-B timing: 1 = always the wave-per-row LayerNorm kernel, 2 = the half-wave-per-row one wherever it exists
+// (ivit_debug_ln_wave_per_row)
 int g_ln_wave_per_row = 0;
 
 namespace {
@@ -121,6 +122,9 @@ __global__ __launch_bounds__(NT, (NJ <= 3 ? 4 : NJ <= 8 ? 2 : 1)) void layernorm
     }
     const int8_t* xin = reinterpret_cast<const int8_t*>(a.x);
     int8_t* out = reinterpret_cast<int8_t*>(a.out);
+    BlockCol bcol[NJ];   // block-layout output: the column part of this lane's store addresses
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) bcol[j] = block_col(4 * (lane + 64 * j));
     // G rows per wave and iteration.  The per-row statistics (mean division, ten Newton steps, reciprocal) are scalar
     // work that a one-row-per-wave kernel repeats in all 64 lanes; here lane r evaluates them for row r of the group
     // (G rows in parallel across lanes) and the results come back as wave-uniform values through v_readlane.
@@ -221,12 +225,17 @@ __global__ __launch_bounds__(NT, (NJ <= 3 ? 4 : NJ <= 8 ? 2 : 1)) void layernorm
                     res[j] = pack4(o[0], o[1], o[2], o[3]);
                 }
             }
+            if (a.out_blocks) {
+                const BlockRow br = block_row(row0 + rr, C);
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                int d = lane + 64 * j;
-                if (d < nd) {
-                    const int64_t off = a.out_blocks ? ivit_block_offset(row0 + rr, 4 * d, C) : (int64_t)(row0 + rr) * a.ldo + 4 * d;
-                    *reinterpret_cast<int*>(out + off) = res[j];
+                for (int j = 0; j < NJ; ++j)
+                    if (lane + 64 * j < nd) *reinterpret_cast<int*>(out + block_off(br, bcol[j])) = res[j];
+            } else {
+                int* orow = reinterpret_cast<int*>(out + (int64_t)(row0 + rr) * a.ldo);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    int d = lane + 64 * j;
+                    if (d < nd) orow[d] = res[j];
                 }
             }
         }
@@ -338,7 +347,7 @@ __global__ __launch_bounds__(NT, NJ <= 3 ? 4 : 3) void layernorm_i8_pair_kernel(
                 const unsigned w23 = __builtin_amdgcn_perm((unsigned)o[3], (unsigned)o[2], 0x04000c0cu);
                 const int row = row0 + 2 * q + half, dd = l32 + 32 * j;
                 if (row < a.rows && dd < nd) {
-                    const int64_t off = a.out_blocks ? ivit_block_offset(row, 4 * dd, C) : (int64_t)row * a.ldo + 4 * dd;
+                    const int64_t off = a.out_blocks ? (int64_t)block_off(block_row(row, C), block_col(4 * dd)) : (int64_t)row * a.ldo + 4 * dd;
                     *reinterpret_cast<int*>(out + off) = (int)(w01 | w23);
                 }
             }
@@ -541,6 +550,7 @@ __global__ __launch_bounds__(NT) void shiftgelu_lut_apply_kernel(GeluArgs a)
                 reinterpret_cast<const int*>(a.lut + (int64_t)(kmax[r] + 128) * 256)[lane];
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the table slices are in LDS
+        const BlockRow brow[RW] = {block_row(row0, a.L), block_row(row0 + 1, a.L)};
         auto map4 = [&](int r, unsigned v) {
             v ^= 0x80808080u;  // k + 128 per byte
             const unsigned char* tb = tab[wave][r];
@@ -554,7 +564,7 @@ __global__ __launch_bounds__(NT) void shiftgelu_lut_apply_kernel(GeluArgs a)
                 for (int r = 0; r < RW; ++r) {
                     const int d = lane + 64 * j;
                     if (d < nd && row0 + r < a.rows) {
-                        const int64_t off = a.out_blocks ? ivit_block_offset(row0 + r, 4 * d, a.L) : (int64_t)(row0 + r) * a.ldo + 4 * d;
+                        const int64_t off = a.out_blocks ? (int64_t)block_off(brow[r], block_col(4 * d)) : (int64_t)(row0 + r) * a.ldo + 4 * d;
                         *reinterpret_cast<int*>(reinterpret_cast<int8_t*>(a.out) + off) = (int)map4(r, (unsigned)w[r][j]);
                     }
                 }
@@ -917,11 +927,14 @@ IVIT_EXPORT int ivit_layernorm_i8_ex(const int8_t* x, int64_t ldx, int rows, int
     IVIT_REQUIRE(((uintptr_t)bias_int % 16 == 0) && ((uintptr_t)s_ln % 16 == 0) && ((uintptr_t)m % 16 == 0) &&
                      ((uintptr_t)e % 16 == 0),
                  "ivit_layernorm_i8: per-channel tables must be 16-byte aligned");
-    IVIT_REQUIRE(out_blocks == 0 || (out_blocks == 1 && C % 64 == 0 && ldo == C && ((uintptr_t)out % 16 == 0)),
-                 "ivit_layernorm_i8_ex: block-layout output needs C %% 64 == 0 and ldo == C");
+    IVIT_REQUIRE(out_blocks == 0 || (out_blocks == 1 && C % 64 == 0 && ldo == C && ((uintptr_t)out % 16 == 0) &&
+                                     ((int64_t)rows + 15) * C < 2147483648ll),
+                 "ivit_layernorm_i8_ex: block-layout output needs C %% 64 == 0, ldo == C and a buffer below 2 GiB");
     LnArgs a{x, ldx, rows, C, bias_int, s_ln, m, e, out, ldo, out_blocks};
     hipStream_t st = ivit_stream(stream);
-    if (C <= 1536 && !(g_ln_wave_per_row)) {   // half a wave per row, constants in LDS (3 * C floats)
+    // half a wave per row (constants in LDS, 3 * C floats) where it is the faster form: measured 17.5 vs 20.7 us at
+    // C = 384 and 14.0 vs 14.9 us at C = 192, but 36 vs 30 us at C = 768 (rows = 50 432)
+    if ((C <= 384 || g_ln_wave_per_row == 2) && C <= 1536 && g_ln_wave_per_row != 1) {
         const int nj2 = (C / 4 + 31) / 32;
         int grid = grid_for_rows(rows, 8);
         if (grid > 1024) grid = 1024;          // 4 waves per SIMD resident
@@ -1012,8 +1025,9 @@ IVIT_EXPORT int ivit_shiftgelu_lut_i8_ex(const int8_t* x, int64_t ldx, int rows,
                      ((uintptr_t)x % 4 == 0) && ((uintptr_t)out % 4 == 0) && ((uintptr_t)lut % 4 == 0),
                  "ivit_shiftgelu_lut_i8: rows=%d L=%d must be 4-byte aligned rows", rows, L);
     GeluArgs a{};
-    IVIT_REQUIRE(out_blocks == 0 || (out_blocks == 1 && L % 64 == 0 && ldo == L && ((uintptr_t)out % 16 == 0)),
-                 "ivit_shiftgelu_lut_i8_ex: block-layout output needs L %% 64 == 0 and ldo == L");
+    IVIT_REQUIRE(out_blocks == 0 || (out_blocks == 1 && L % 64 == 0 && ldo == L && ((uintptr_t)out % 16 == 0) &&
+                                     ((int64_t)rows + 15) * L < 2147483648ll),
+                 "ivit_shiftgelu_lut_i8_ex: block-layout output needs L %% 64 == 0, ldo == L and a buffer below 2 GiB");
     a.x = x; a.ldx = ldx; a.rows = rows; a.L = L; a.lut = lut; a.out = out; a.ldo = ldo; a.out_blocks = out_blocks;
     const dim3 grid(grid_for_rows(rows, 2)), blk(NT);
     hipStream_t st = ivit_stream(stream);

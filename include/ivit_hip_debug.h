@@ -26,8 +26,8 @@ int ivit_debug_set_gemm_flags(int flags);
 /* Diagnostic timeline buffer (8 x uint64 per workgroup) for the stamped build (flags = 512); scripts/gemm_timeline.py */
 int ivit_debug_set_stamp_buffer(void* buf);
 
-/* 1: ivit_layernorm_i8 always takes the wave-per-row kernel (default: half a wave per row for C <= 1536): parity tests of
- * both forms, A/B timing */
+/* ivit_layernorm_i8 kernel form: 0 = automatic (half a wave per row for C <= 384, a wave per row above), 1 = always a
+ * wave per row, 2 = half a wave per row wherever it exists (C <= 1536): parity tests of both forms, A/B timing */
 int ivit_debug_ln_wave_per_row(int on);
 
 #ifdef __cplusplus

@@ -299,11 +299,14 @@ def test_producers_write_block_layout():
     args = (_lib.ptr(dev(k)), Cn, rows, Cn, _lib.ptr(dev(lp.bias_int)), _lib.ptr(dev(lp.s_ln)), _lib.ptr(md), _lib.ptr(ed))
     rm = torch.empty(rows, Cn, dtype=torch.int8, device=DEV)
     _lib.call("ivit_layernorm_i8", *args, _lib.ptr(rm), Cn, st())
-    bl = torch.zeros((rows + 15) // 16 * 16 * Cn, dtype=torch.int8, device=DEV)
-    _lib.call("ivit_layernorm_i8_ex", *args, _lib.ptr(bl), Cn, 1, st())
     v = valid_bytes(rows, Cn)
-    assert np.array_equal(bl.cpu().numpy()[v], tiled_of(rm, rows, Cn).cpu().numpy()[v])
-    assert not bl.cpu().numpy()[~v].any()
+    for form in (1, 2):   # a wave per row (permlane-swapped pair stores), half a wave per row
+        _lib.call("ivit_debug_ln_wave_per_row", form)
+        bl = torch.zeros((rows + 15) // 16 * 16 * Cn, dtype=torch.int8, device=DEV)
+        _lib.call("ivit_layernorm_i8_ex", *args, _lib.ptr(bl), Cn, 1, st())
+        _lib.call("ivit_debug_ln_wave_per_row", 0)
+        assert np.array_equal(bl.cpu().numpy()[v], tiled_of(rm, rows, Cn).cpu().numpy()[v]), form
+        assert not bl.cpu().numpy()[~v].any(), form
     # GELU table form
     rows, L = 197 * 2 + 3, 3072
     x = np.clip(np.rint(rng.normal(0, 40, size=(rows, L))), -128, 127).astype(np.int8)
@@ -427,9 +430,9 @@ def test_layernorm_random_vs_oracle(rows, Cn, ln_form):
     assert np.array_equal(got, exp), f"{(got != exp).sum()} of {got.size} differ"
 
 
-@pytest.fixture(params=[0, 1], ids=["half_wave_per_row", "wave_per_row"])
+@pytest.fixture(params=[2, 1], ids=["half_wave_per_row", "wave_per_row"])
 def ln_form(request):
-    """both int8 LayerNorm kernels: half a wave per row (default for C <= 1536) and a wave per row"""
+    """both int8 LayerNorm kernels: half a wave per row (C <= 1536) and a wave per row"""
     _lib.call("ivit_debug_ln_wave_per_row", request.param)
     yield request.param
     _lib.call("ivit_debug_ln_wave_per_row", 0)
