@@ -1,6 +1,6 @@
 """Interleaved A/B timing of GEMM kernel variants (debug flags): every round runs each variant once, in turn, so that clock /
 thermal drift hits all variants alike; reports median and min per variant.
-usage: gemm_ab.py [--resid] [shape ...] -- flag flag ..."""
+usage: gemm_ab.py [--resid] [--blocks] [shape ...] -- flag flag ..."""
 import os
 import sys
 
@@ -15,7 +15,8 @@ DEV = "cuda:0"
 M = 197 * 256
 SHAPES = {"qkv": (2304, 768), "proj": (768, 768), "fc1": (3072, 768), "fc2": (768, 3072)}
 RESID = "--resid" in sys.argv
-args = [a for a in sys.argv[1:] if a != "--resid"]
+BLOCKS = "--blocks" in sys.argv   # both operands in the block layout (persistent kernel only)
+args = [a for a in sys.argv[1:] if a not in ("--resid", "--blocks")]
 split = args.index("--") if "--" in args else 0
 names = args[:split] or list(SHAPES)
 flags = [int(x) for x in args[split + 1:]] if "--" in args else [0]
@@ -30,15 +31,21 @@ for name in names:
     e = torch.full((N,), 42, dtype=torch.int32, device=DEV)
     out = torch.empty(M, N, dtype=torch.int8, device=DEV)
 
+    if BLOCKS:
+        At, Wt = torch.empty_like(A), torch.empty_like(W)
+        _lib.call("ivit_tile_operand_i8", _lib.ptr(A), K, M, K, _lib.ptr(At), _lib.stream_ptr())
+        _lib.call("ivit_tile_operand_i8", _lib.ptr(W), K, N, K, _lib.ptr(Wt), _lib.stream_ptr())
+        A, W = At, Wt
+    LAY = 3 if BLOCKS else 0
     resid_t = torch.from_numpy(rng.integers(-128, 128, size=(M, N)).astype(np.int8)).to(DEV)
 
     def run():
         if RESID:   # the fused residual QuantAct form (attn.proj, mlp.fc2)
-            _lib.call("ivit_gemm_i8_requant_residual", _lib.ptr(A), K, _lib.ptr(W), K, _lib.ptr(b), _lib.ptr(m), _lib.ptr(e),
-                      _lib.ptr(resid_t), N, 1503238554, 31, 1073741824, 32, _lib.ptr(out), N, M, N, K, _lib.stream_ptr())
+            _lib.call("ivit_gemm_i8_requant_residual_ex", _lib.ptr(A), K, _lib.ptr(W), K, _lib.ptr(b), _lib.ptr(m), _lib.ptr(e),
+                      _lib.ptr(resid_t), N, 1503238554, 31, 1073741824, 32, _lib.ptr(out), N, M, N, K, LAY, _lib.stream_ptr())
         else:
-            _lib.call("ivit_gemm_i8_requant", _lib.ptr(A), K, _lib.ptr(W), K, _lib.ptr(b), _lib.ptr(m), _lib.ptr(e), _lib.ptr(out),
-                      N, M, N, K, _lib.stream_ptr())
+            _lib.call("ivit_gemm_i8_requant_ex", _lib.ptr(A), K, _lib.ptr(W), K, _lib.ptr(b), _lib.ptr(m), _lib.ptr(e), _lib.ptr(out),
+                      N, M, N, K, LAY, _lib.stream_ptr())
     for _ in range(10):
         run()
     res = {f: [] for f in flags}
