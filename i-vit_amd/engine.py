@@ -183,7 +183,13 @@ class IntViTEngine(GraphReplay):
         w, lay = self._w(lin, blocks)
         lay |= int(a_blocks)
         probe = self.probe
-        if probe is not None:  # bench.py: HIP events around the dominant kernel, on the launch stream
+        if probe is not None:
+            # bench.py: HIP events around the dominant kernel, on the launch stream.  One launch in three is sampled (attn.proj
+            # and mlp.fc2 in equal numbers): 48 event records per forward cost ~0.25 ms of the timed region
+            self._probe_tick = getattr(self, "_probe_tick", 0) + 1
+            if self._probe_tick % 6 != 1 and self._probe_tick % 6 != 4:
+                probe = None
+        if probe is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
         _lib.call("ivit_gemm_i8_requant_residual_ex", _lib.ptr(A), lda, w, lin["K"],
