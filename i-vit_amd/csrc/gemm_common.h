@@ -210,11 +210,32 @@ IVIT_DEV void epilogue_i8(v16i (&acc)[TI][TJ], const GemmArgs& g, char* smem, co
         }
     }
     hook.consume();
+    // EPI_QKV addressing state (see below)
+    constexpr int qkv_rows_per_it = NTHREADS / CPR;
+    int qkv_b = 0, qkv_tok = 0;
+    int64_t qkv_col = 0;
+    if constexpr (EPI == EPI_QKV) {
+        const int cn0 = min(n0 + 16 * (tid % CPR), g.N - 16);
+        const int cdim = g.heads * g.head_dim;
+        const int which = cn0 / cdim, rem = cn0 - which * cdim;
+        const int hh = rem / g.head_dim, d0 = rem - hh * g.head_dim;
+        const int nb = g.M / g.tokens;
+        qkv_col = ((int64_t)which * nb * g.heads + hh) * g.tokens * g.head_dim + d0;
+    }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int q = tid + NTHREADS * it;
         const int tl = q / CPR, cc = q % CPR;
         const int t = m0 + tl, cn = n0 + 16 * cc;
+        if constexpr (EPI == EPI_QKV) {
+            if (it > 0 && qkv_rows_per_it < g.tokens) {   // the row advanced by qkv_rows_per_it: at most one image boundary
+                qkv_tok += qkv_rows_per_it;
+                if (qkv_tok >= g.tokens) {
+                    qkv_tok -= g.tokens;
+                    ++qkv_b;
+                }
+            }
+        }
         if (t >= g.M || cn >= g.N) continue;
         if constexpr (EPI == EPI_RESID) {
             const int rr[4] = {rv[it].x, rv[it].y, rv[it].z, rv[it].w};
@@ -256,12 +277,14 @@ IVIT_DEV void epilogue_i8(v16i (&acc)[TI][TJ], const GemmArgs& g, char* smem, co
         }
         int64_t off;
         if constexpr (EPI == EPI_QKV) {
-            const int cdim = g.heads * g.head_dim;
-            const int which = cn / cdim, rem = cn - which * cdim;
-            const int hh = rem / g.head_dim, d0 = rem - hh * g.head_dim;
-            const int b = t / g.tokens, tok = t - b * g.tokens;
-            const int nb = g.M / g.tokens;
-            off = ((((int64_t)which * nb + b) * g.heads + hh) * g.tokens + tok) * g.head_dim + d0;
+            // (which, head, d0) depend on the thread's chunk column only (q % CPR == tid % CPR for every it) and the image /
+            // token of a row advances by NTHREADS / CPR rows per it: integer divisions once per tile, not once per chunk
+            // (they were ~100 VALU instructions per chunk, as much as phase 1)
+            if (it == 0 || qkv_rows_per_it >= g.tokens) {
+                qkv_b = t / g.tokens;
+                qkv_tok = t - qkv_b * g.tokens;
+            }
+            off = qkv_col + ((int64_t)qkv_b * g.heads * g.tokens + qkv_tok) * g.head_dim;
         } else {
             off = (int64_t)t * g.ldo + cn;
         }

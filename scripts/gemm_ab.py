@@ -15,8 +15,9 @@ DEV = "cuda:0"
 M = 197 * 256
 SHAPES = {"qkv": (2304, 768), "proj": (768, 768), "fc1": (3072, 768), "fc2": (768, 3072)}
 RESID = "--resid" in sys.argv
+QKV = "--qkv" in sys.argv         # head-major q/k/v epilogue (qkv shape only)
 BLOCKS = "--blocks" in sys.argv   # both operands in the block layout (persistent kernel only)
-args = [a for a in sys.argv[1:] if a not in ("--resid", "--blocks")]
+args = [a for a in sys.argv[1:] if a not in ("--resid", "--blocks", "--qkv")]
 split = args.index("--") if "--" in args else 0
 names = args[:split] or list(SHAPES)
 flags = [int(x) for x in args[split + 1:]] if "--" in args else [0]
@@ -40,7 +41,10 @@ for name in names:
     resid_t = torch.from_numpy(rng.integers(-128, 128, size=(M, N)).astype(np.int8)).to(DEV)
 
     def run():
-        if RESID:   # the fused residual QuantAct form (attn.proj, mlp.fc2)
+        if QKV and N % 192 == 0:
+            _lib.call("ivit_gemm_i8_requant_qkv_ex", _lib.ptr(A), K, _lib.ptr(W), K, _lib.ptr(b), _lib.ptr(m), _lib.ptr(e),
+                      _lib.ptr(out), 197, N // 192, 64, M, N, K, LAY, _lib.stream_ptr())
+        elif RESID:   # the fused residual QuantAct form (attn.proj, mlp.fc2)
             _lib.call("ivit_gemm_i8_requant_residual_ex", _lib.ptr(A), K, _lib.ptr(W), K, _lib.ptr(b), _lib.ptr(m), _lib.ptr(e),
                       _lib.ptr(resid_t), N, 1503238554, 31, 1073741824, 32, _lib.ptr(out), N, M, N, K, LAY, _lib.stream_ptr())
         else:
