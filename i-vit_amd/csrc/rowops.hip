@@ -88,7 +88,7 @@ IVIT_DEV float ln_factor(long long var)
 template <int NJ>
 __global__ __launch_bounds__(NT, (NJ <= 3 ? 4 : NJ <= 8 ? 2 : 1)) void layernorm_i8_kernel(LnArgs a)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: row addresses in SALU
     const int C = a.C, nd = C >> 2;
     float bias[NJ][4], lo[NJ][4], hi[NJ][4];
 #pragma unroll
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(NT, NJ <= 3 ? 4 : 3) void layernorm_i8_pair_kernel(
 // module-level form: int32 in (8- or 16-bit values), float32 out = y * s_ln (ivit_modules.py:63)
 __global__ __launch_bounds__(NT) void layernorm_i32_f32_kernel(LnArgs a)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: row addresses in SALU
     const int C = a.C;
     const int32_t* xin = reinterpret_cast<const int32_t*>(a.x);
     float* out = reinterpret_cast<float*>(a.out);
@@ -460,7 +460,7 @@ struct GeluArgs {
 template <bool OUT_I32>
 __global__ __launch_bounds__(NT) void shiftgelu_kernel(GeluArgs a)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: row addresses in SALU
     for (int row = blockIdx.x * WPB + wave; row < a.rows; row += gridDim.x * WPB) {
         const int8_t* xr = a.x + (int64_t)row * a.ldx;
         int kmax = -128;
@@ -507,7 +507,7 @@ __global__ __launch_bounds__(NT) void shiftgelu_lut_apply_kernel(GeluArgs a)
     constexpr int RW = 2;
     constexpr int NJR = NJ > 0 ? NJ : 1;
     __shared__ __attribute__((aligned(16))) unsigned char tab[WPB][RW][256];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: row addresses in SALU
     const int nd = a.L >> 2;
     for (int row0 = (blockIdx.x * WPB + wave) * RW; row0 < a.rows; row0 += gridDim.x * WPB * RW) {
         const int* xr[RW];
@@ -597,7 +597,7 @@ struct SmArgs {
 template <typename TX>
 __global__ __launch_bounds__(NT) void shiftmax_kernel(SmArgs<TX> a)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: row addresses in SALU
     for (int row = blockIdx.x * WPB + wave; row < a.rows; row += gridDim.x * WPB) {
         const TX* xr = a.x + (int64_t)row * a.ldx;
         int kmax = INT_MIN;
@@ -700,7 +700,7 @@ __global__ __launch_bounds__(NT) void embed_kernel(const int8_t* patch, const in
 __global__ __launch_bounds__(NT) void head_argmax_kernel(const int32_t* acc, const float* s_acc, int batch, int N,
                                                          float* logits, int32_t* top1)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: row addresses in SALU
     for (int row = blockIdx.x * WPB + wave; row < batch; row += gridDim.x * WPB) {
         float best = -__builtin_inff();
         int bi = 0x7fffffff;
