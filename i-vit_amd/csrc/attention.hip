@@ -111,8 +111,10 @@ __global__ __launch_bounds__(NT, 3) void attention_kernel(AttnArgs a)
         const v4i qf = *reinterpret_cast<const v4i*>(qg + (int64_t)qld * HD + 16 * g);
 
         // ---- S^T = K . Q^T, requantised to the 8-bit Shiftmax input (qact_attn1)
+        // scores are kept NEGATED (nk = -k = RNE(S * -Ms): RNE is symmetric): the table index max - k = nk + max is then one
+        // v_add_lshl_u32 per score instead of a subtract and a shift
         int s[NKT][4];
-        int rmax = -1000;
+        int nmin = 1000;
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
             const v4i kf = *reinterpret_cast<const v4i*>(smem + kswz(16 * kt + l15, g));
@@ -121,15 +123,17 @@ __global__ __launch_bounds__(NT, 3) void attention_kernel(AttnArgs a)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 // |S| <= 64*128*128 = 2^20, m < 2^32: the product is exact in float64
-                int ka = clamp_i32(requant_exact(acc[r], a.Ms), -128, 127);
-                if (kt == NKT - 1) ka = (16 * kt + 4 * g + r < T) ? ka : -1000;
-                s[kt][r] = ka;
-                rmax = max(rmax, ka);
+                int nk = clamp_i32(requant_exact(acc[r], -a.Ms), -127, 128);
+                if (kt == NKT - 1) nk = (16 * kt + 4 * g + r < T) ? nk : 1000;
+                s[kt][r] = nk;
+                nmin = min(nmin, nk);
             }
             if ((kt & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // at most 4 K fragments in flight (registers)
         }
-        rmax = max(rmax, __shfl_xor(rmax, 16));
-        rmax = max(rmax, __shfl_xor(rmax, 32));
+        nmin = min(nmin, __shfl_xor(nmin, 16));
+        nmin = min(nmin, __shfl_xor(nmin, 32));
+        int rmax = -nmin;
+        asm volatile("" : "+v"(rmax));   // opaque: keeps (nk + rmax) << 2 one v_add_lshl_u32 instead of a subtract and a shift
 
         // ---- Shiftmax (ivit_modules.py:164-175): e = exp_int(k - max), sum, factor, e*factor >> 24
         // k - max is in [-255, 0] for every real key: the 256-entry table covers it without a clamp (the entries from
@@ -141,10 +145,10 @@ __global__ __launch_bounds__(NT, 3) void attention_kernel(AttnArgs a)
             for (int r = 0; r < 4; ++r) {
                 unsigned e;
                 if (kt == NKT - 1) {
-                    e = lut[min(rmax - s[kt][r], 255)];
-                    e = (s[kt][r] == -1000) ? 0u : e;
+                    e = lut[min(rmax + s[kt][r], 255)];
+                    e = (s[kt][r] == 1000) ? 0u : e;
                 } else {
-                    e = lut[rmax - s[kt][r]];
+                    e = lut[rmax + s[kt][r]];
                 }
                 s[kt][r] = (int)e;
                 esum += e;
