@@ -473,11 +473,15 @@ int launch_gemm(GemmArgs& g, const char* name, ivit_stream_t stream)
             const bool one_per_cu = (g_debug_flags & 4096) != 0;
             // debug bit 26: a 256-workgroup grid WITHOUT the LDS blocker (probe: two streams' GEMMs sharing the CUs)
             const int SLOTS = (one_per_cu || (g_debug_flags & 67108864)) ? 256 : 512;
-            // tail split (see PersWork): R tiles of a last round that is at most half full become 2R half tiles.
-            // Measured slower (proj 47.7 -> 50.0 us, fc2 162 -> 173 us): a CU left with one workgroup runs it nearly
-            // twice as fast, so the sparse last round is not the cost the tile count suggests.  Opt-in (debug bit 11).
+            // tail split (see PersWork): R tiles of a sparse last round become 2R half tiles (256 x 128 -> two 128 x 128).
+            // A CU left with one workgroup runs it nearly twice as fast, so splitting a last round that already occupies more
+            // than half of the CUs does not pay (proj 47.7 -> 50.0 us, fc2 162 -> 173 us with 1182 tiles on 512 slots).
             const int rounds = ntiles / SLOTS, R = ntiles - rounds * SLOTS;
-            const bool split = R > 0 && 2 * R <= SLOTS && (g_debug_flags & 2048);
+            // Default: split only when the 2R half tiles still find a CU each (2R <= 256): then the tail round uses twice the
+            // CUs for half the time (fc1, R = 120: 146 -> 140 us); beyond that two half tiles share a CU and it only adds their
+            // overhead.  Debug bit 11 forces the split up to 2R <= SLOTS, bit 27 disables it.
+            const bool split = R > 0 && !(g_debug_flags & 134217728) &&
+                               ((g_debug_flags & 2048) ? 2 * R <= SLOTS : 2 * R <= 256) && !one_per_cu;
             g.split_from = split ? rounds * SLOTS : ntiles;
             g.cu_turns = (g_debug_flags & 32768) ? 1 : 0;
             // start delay of the second co-resident workgroup: measured (scripts/gemm_ab.py, interleaved) 0..10 units are
