@@ -448,6 +448,8 @@ int launch_gemm(GemmArgs& g, const char* name, ivit_stream_t stream)
     if (EPI == EPI_QKV) {
         IVIT_REQUIRE(g.tokens > 0 && g.heads > 0 && g.head_dim > 0 && g.head_dim % 16 == 0,
                      "%s: bad head geometry tokens=%d heads=%d head_dim=%d", name, g.tokens, g.heads, g.head_dim);
+        IVIT_REQUIRE((int64_t)g.M * g.N < 2147483648ll, "%s: q/k/v output of %lld bytes exceeds the 2 GiB the 32-bit head-major offsets cover",
+                     name, (long long)g.M * g.N);
         IVIT_REQUIRE(g.N == 3 * g.heads * g.head_dim && g.M % g.tokens == 0,
                      "%s: N=%d != 3*heads*head_dim or M=%d %% tokens=%d != 0", name, g.N, g.M, g.tokens);
     }

@@ -213,14 +213,14 @@ IVIT_DEV void epilogue_i8(v16i (&acc)[TI][TJ], const GemmArgs& g, char* smem, co
     // EPI_QKV addressing state (see below)
     constexpr int qkv_rows_per_it = NTHREADS / CPR;
     int qkv_b = 0, qkv_tok = 0;
-    int64_t qkv_col = 0;
+    int qkv_col = 0;
     if constexpr (EPI == EPI_QKV) {
         const int cn0 = min(n0 + 16 * (tid % CPR), g.N - 16);
         const int cdim = g.heads * g.head_dim;
         const int which = cn0 / cdim, rem = cn0 - which * cdim;
         const int hh = rem / g.head_dim, d0 = rem - hh * g.head_dim;
         const int nb = g.M / g.tokens;
-        qkv_col = ((int64_t)which * nb * g.heads + hh) * g.tokens * g.head_dim + d0;
+        qkv_col = ((which * nb * g.heads + hh) * g.tokens) * g.head_dim + d0;
     }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
@@ -284,7 +284,7 @@ IVIT_DEV void epilogue_i8(v16i (&acc)[TI][TJ], const GemmArgs& g, char* smem, co
                 qkv_b = t / g.tokens;
                 qkv_tok = t - qkv_b * g.tokens;
             }
-            off = qkv_col + ((int64_t)qkv_b * g.heads * g.tokens + qkv_tok) * g.head_dim;
+            off = (int64_t)(unsigned)(qkv_col + ((qkv_b * g.heads * g.tokens + qkv_tok) * g.head_dim));   // 32-bit: the launcher checks 3*M*heads*head_dim < 2^31
         } else {
             off = (int64_t)t * g.ldo + cn;
         }
