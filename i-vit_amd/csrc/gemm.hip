@@ -514,8 +514,10 @@ IVIT_EXPORT int ivit_gemm_i8_requant_ex(const int8_t* A, int64_t lda, const int8
     GemmArgs g{};
     g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.m = m; g.e = e;
     g.out = out; g.ldo = ldo; g.M = M; g.N = N; g.K = K;
-    g.a_blocks = layouts & 1; g.w_blocks = (layouts >> 1) & 1;
-    IVIT_REQUIRE((layouts & ~3) == 0, "ivit_gemm_i8_requant_ex: unknown layout bits");
+    g.a_blocks = layouts & 1; g.w_blocks = (layouts >> 1) & 1; g.out_blocks = (layouts >> 2) & 1;
+    IVIT_REQUIRE((layouts & ~7) == 0, "ivit_gemm_i8_requant_ex: unknown layout bits");
+    IVIT_REQUIRE(!g.out_blocks || (N % 64 == 0 && ldo == N && ((int64_t)M + 15) * N < 2147483648ll),
+                 "ivit_gemm_i8_requant_ex: block-layout output needs N %% 64 == 0, ldo == N and a buffer below 2 GiB");
     return launch_gemm<EPI_RQ>(g, "ivit_gemm_i8_requant_ex", stream);
 }
 

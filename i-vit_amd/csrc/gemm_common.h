@@ -49,6 +49,7 @@ struct GemmArgs {
     int stagger_units;  // persistent kernel: start delay of the second co-resident workgroup, in s_sleep(16) (~1K cycle) units
     int split_from;  // persistent kernel: tiles [split_from, tiles_m*tiles_n) are processed as two half tiles each
     int a_blocks, w_blocks;   // operand in the block layout (common.h: ivit_block_offset); persistent kernel only
+    int out_blocks;           // EPI_RQ: the int8 output in the block layout (row length N): it is the next GEMM's A operand
 };
 
 IVIT_DEV int nk_of(const GemmArgs& g) { return g.K / 64; }
@@ -286,7 +287,7 @@ IVIT_DEV void epilogue_i8(v16i (&acc)[TI][TJ], const GemmArgs& g, char* smem, co
             }
             off = (int64_t)(unsigned)(qkv_col + ((qkv_b * g.heads * g.tokens + qkv_tok) * g.head_dim));   // 32-bit: the launcher checks 3*M*heads*head_dim < 2^31
         } else {
-            off = (int64_t)t * g.ldo + cn;
+            off = (EPI == EPI_RQ && g.out_blocks) ? (int64_t)block_off(block_row(t, g.N), block_col(cn)) : (int64_t)t * g.ldo + cn;
         }
         *reinterpret_cast<int4*>(out + off) = make_int4(v[it][0], v[it][1], v[it][2], v[it][3]);
     }

@@ -454,6 +454,7 @@ struct GeluArgs {
     void* out;
     int64_t ldo;
     int out_blocks;   // output in the GEMM block layout (common.h: ivit_block_offset), row length L
+    int in_blocks;    // input in the block layout (table form only)
 };
 
 // direct arithmetic; OUT_I32: module-level int32 output k*sig, else fused requant -> int8
@@ -524,7 +525,11 @@ __global__ __launch_bounds__(NT) void shiftgelu_lut_apply_kernel(GeluArgs a)
 #pragma unroll
                 for (int r = 0; r < RW; ++r) {
                     const int d = lane + 64 * j;
-                    w[r][j] = (d < nd) ? xr[r][d] : (int)0x80808080;
+                    if (a.in_blocks)
+                        w[r][j] = (d < nd) ? *reinterpret_cast<const int*>(a.x + block_off(block_row(min(row0 + r, a.rows - 1), a.L), block_col(4 * d)))
+                                           : (int)0x80808080;
+                    else
+                        w[r][j] = (d < nd) ? xr[r][d] : (int)0x80808080;
                 }
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
@@ -535,7 +540,8 @@ __global__ __launch_bounds__(NT) void shiftgelu_lut_apply_kernel(GeluArgs a)
             for (int d = lane; d < nd; d += 64) {
 #pragma unroll
                 for (int r = 0; r < RW; ++r) {
-                    int v = xr[r][d];
+                    int v = a.in_blocks ? *reinterpret_cast<const int*>(a.x + block_off(block_row(min(row0 + r, a.rows - 1), a.L), block_col(4 * d)))
+                                        : xr[r][d];
                     kmax[r] = max(max(kmax[r], sx8(v, 0)), max(sx8(v, 1), max(sx8(v, 2), sx8(v, 3))));
                 }
             }
@@ -574,7 +580,8 @@ __global__ __launch_bounds__(NT) void shiftgelu_lut_apply_kernel(GeluArgs a)
                 for (int r = 0; r < RW; ++r) {
                     if (row0 + r >= a.rows) continue;
                     const int64_t off = a.out_blocks ? ivit_block_offset(row0 + r, 4 * d, a.L) : (int64_t)(row0 + r) * a.ldo + 4 * d;
-                    *reinterpret_cast<int*>(reinterpret_cast<int8_t*>(a.out) + off) = (int)map4(r, (unsigned)xr[r][d]);
+                    const unsigned vin = a.in_blocks ? *reinterpret_cast<const unsigned*>(a.x + block_off(brow[r], block_col(4 * d))) : (unsigned)xr[r][d];
+                    *reinterpret_cast<int*>(reinterpret_cast<int8_t*>(a.out) + off) = (int)map4(r, vin);
                 }
             }
         }
@@ -1018,17 +1025,20 @@ IVIT_EXPORT int ivit_shiftgelu_build_lut(float s, uint32_t m, int32_t e, int8_t*
 }
 
 IVIT_EXPORT int ivit_shiftgelu_lut_i8_ex(const int8_t* x, int64_t ldx, int rows, int L, const int8_t* lut, int8_t* out,
-                                         int64_t ldo, int out_blocks, ivit_stream_t stream)
+                                         int64_t ldo, int layouts, ivit_stream_t stream)
 {
     IVIT_REQUIRE(x && out && lut, "ivit_shiftgelu_lut_i8: NULL operand");
     IVIT_REQUIRE(rows > 0 && L > 0 && L % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && ldx >= L && ldo >= L &&
                      ((uintptr_t)x % 4 == 0) && ((uintptr_t)out % 4 == 0) && ((uintptr_t)lut % 4 == 0),
                  "ivit_shiftgelu_lut_i8: rows=%d L=%d must be 4-byte aligned rows", rows, L);
     GeluArgs a{};
+    const int out_blocks = layouts & 1, in_blocks = (layouts >> 1) & 1;   // bit 0: output, bit 1: input in the block layout
+    IVIT_REQUIRE((layouts & ~3) == 0 && (!in_blocks || (L % 64 == 0 && ldx == L)) && (x != out || in_blocks == out_blocks),
+                 "ivit_shiftgelu_lut_i8_ex: bad layouts (in place needs the same layout on both sides)");
     IVIT_REQUIRE(out_blocks == 0 || (out_blocks == 1 && L % 64 == 0 && ldo == L && ((uintptr_t)out % 16 == 0) &&
                                      ((int64_t)rows + 15) * L < 2147483648ll),
                  "ivit_shiftgelu_lut_i8_ex: block-layout output needs L %% 64 == 0, ldo == L and a buffer below 2 GiB");
-    a.x = x; a.ldx = ldx; a.rows = rows; a.L = L; a.lut = lut; a.out = out; a.ldo = ldo; a.out_blocks = out_blocks;
+    a.x = x; a.ldx = ldx; a.rows = rows; a.L = L; a.lut = lut; a.out = out; a.ldo = ldo; a.out_blocks = out_blocks; a.in_blocks = in_blocks;
     const dim3 grid(grid_for_rows(rows, 2)), blk(NT);
     hipStream_t st = ivit_stream(stream);
     const int nj = (L / 4 + 63) / 64;

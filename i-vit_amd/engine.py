@@ -142,6 +142,7 @@ class IntViTEngine(GraphReplay):
         # which producers write their output (a GEMM A operand) in the block layout.  Measured per producer / consumer pair
         # (DESIGN.md section 5): the GEMM gains 4-6 % from a block-layout A, the producer pays for 64-byte row segments
         self.block_a = {"ln": True, "attn": True, "gelu": True}
+        self.gelu_in_place = True     # GELU overwrites the fc1 output (same layout on both sides)
         self.probe = None
         self._alloc(max_batch)
         torch.cuda.synchronize(self.dev)
@@ -160,7 +161,7 @@ class IntViTEngine(GraphReplay):
             pe=torch.empty(B * NUM_PATCHES, C, **i8),
             x=torch.empty(M, C, **i8), x2=torch.empty(M, C, **i8), h=torch.empty(M16, C, **i8),
             qkv=torch.empty(3 * M * C, **i8), ao=torch.empty(M16, C, **i8),
-            f1=torch.empty(M, 4 * C, **i8), g=torch.empty(M16, 4 * C, **i8), untile=torch.empty(M, 4 * C, **i8),
+            f1=torch.empty(M16, 4 * C, **i8), g=torch.empty(M16, 4 * C, **i8), untile=torch.empty(M, 4 * C, **i8),
             cls=torch.empty(B, C, **i8),
             logits=torch.empty(B, NUM_CLASSES, dtype=torch.int32, device=self.dev),
             logits_f=torch.empty(B, NUM_CLASSES, dtype=torch.float32, device=self.dev),
@@ -173,10 +174,11 @@ class IntViTEngine(GraphReplay):
             return _lib.ptr(lin["Wb"]), 2
         return _lib.ptr(lin["W"]), 0
 
-    def _gemm(self, A, lda, lin, out, ldo, M, st, a_blocks=False, blocks=False):
+    def _gemm(self, A, lda, lin, out, ldo, M, st, a_blocks=False, blocks=False, out_blocks=False):
         w, lay = self._w(lin, blocks)
         _lib.call("ivit_gemm_i8_requant_ex", _lib.ptr(A), lda, w, lin["K"], _lib.ptr(lin["b"]),
-                  _lib.ptr(lin["m"]), _lib.ptr(lin["e"]), _lib.ptr(out), ldo, M, lin["N"], lin["K"], lay | int(a_blocks), st)
+                  _lib.ptr(lin["m"]), _lib.ptr(lin["e"]), _lib.ptr(out), ldo, M, lin["N"], lin["K"],
+                  lay | int(a_blocks) | (4 if out_blocks else 0), st)
 
     def _gemm_res(self, A, lda, lin, res, me4, out, M, st, blocks=False, a_blocks=False):
         C = self.C
@@ -255,12 +257,15 @@ class IntViTEngine(GraphReplay):
             tap(p + "qact2", x2, (B, T, C))
             self._ln(x2, C, M, blk["ln2"], ws["h"], st, blocks=a_ln)
             tap(p + "qact3", ws["h"], (B, T, C), a_ln)
-            self._gemm(ws["h"], C, blk["fc1"], ws["f1"], 4 * C, M, st, a_blocks=a_ln, blocks=blk_l)
-            tap(p + "mlp.qact_gelu", ws["f1"], (B, T, 4 * C))
+            # mlp.fc1 writes the block layout and GELU works IN PLACE on it: the 155 MB intermediate exists once, so the pair
+            # (GELU output, fc2 operand) stays inside the 256 MB Infinity Cache (separate buffers: 310 MB; -0.18 ms / forward)
+            self._gemm(ws["h"], C, blk["fc1"], ws["f1"], 4 * C, M, st, a_blocks=a_ln, blocks=blk_l, out_blocks=a_ge)
+            tap(p + "mlp.qact_gelu", ws["f1"], (B, T, 4 * C), a_ge)
+            g_buf = ws["f1"] if self.gelu_in_place else ws["g"]
             _lib.call("ivit_shiftgelu_lut_i8_ex", _lib.ptr(ws["f1"]), 4 * C, M, 4 * C, _lib.ptr(blk["gelu_lut"]),
-                      _lib.ptr(ws["g"]), 4 * C, int(a_ge), st)
-            tap(p + "mlp.qact1", ws["g"], (B, T, 4 * C), a_ge)
-            self._gemm_res(ws["g"], 4 * C, blk["fc2"], x2, blk["res2"], x, M, st, blocks=blk_l, a_blocks=a_ge)
+                      _lib.ptr(g_buf), 4 * C, 3 if a_ge else 0, st)
+            tap(p + "mlp.qact1", g_buf, (B, T, 4 * C), a_ge)
+            self._gemm_res(g_buf, 4 * C, blk["fc2"], x2, blk["res2"], x, M, st, blocks=blk_l, a_blocks=a_ge)
             tap(p + "qact4", x, (B, T, C))
         # final LayerNorm is row-wise and only the cls row is consumed (vit_quant.py:302-304)
         self._ln(x, T * C, B, self.ln_f, ws["cls"], st)

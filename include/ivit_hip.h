@@ -79,6 +79,7 @@ int ivit_quantize_patchify_ld_f32_i8(const float* img, int8_t* A, int64_t lda, i
  * block layout directly: ivit_layernorm_i8_ex, ivit_attention_fused_i8_ex, ivit_shiftgelu_lut_i8_ex. */
 #define IVIT_A_BLOCKS 1
 #define IVIT_W_BLOCKS 2
+#define IVIT_OUT_BLOCKS 4   /* ivit_gemm_i8_requant_ex only: the int8 output in the block layout (ldo == N, N % 64 == 0) */
 int ivit_tile_operand_i8(const int8_t* src, int64_t ld, int64_t rows, int K, int8_t* dst, ivit_stream_t stream);
 int ivit_untile_operand_i8(const int8_t* src, int64_t rows, int K, int8_t* dst, int64_t ld, ivit_stream_t stream);
 
@@ -184,9 +185,10 @@ int ivit_shiftgelu_build_lut(float s, uint32_t m, int32_t e, int8_t* lut /* [256
 /* ... then per call: wave-per-row max reduction + LDS-staged table row + byte gather.  L % 4 == 0. */
 int ivit_shiftgelu_lut_i8(const int8_t* x, int64_t ldx, int rows, int L, const int8_t* lut, int8_t* out,
                           int64_t ldo, ivit_stream_t stream);
-/* out_blocks = 1: `out` is written in IVIT_LAYOUT_BLOCKS (L % 64 == 0, ldo == L, rows padded to 16) */
+/* layouts bit 0: `out` is written in IVIT_LAYOUT_BLOCKS (L % 64 == 0, ldo == L, rows padded to 16); bit 1: `x` is read in
+ * it (ldx == L).  In place (out == x) is allowed when both sides use the same layout. */
 int ivit_shiftgelu_lut_i8_ex(const int8_t* x, int64_t ldx, int rows, int L, const int8_t* lut, int8_t* out,
-                             int64_t ldo, int out_blocks, ivit_stream_t stream);
+                             int64_t ldo, int layouts, ivit_stream_t stream);
 
 /* ---- stand-alone Shiftmax (module-level IVITIntSoftmax, ivit_modules.py:164-179) -----------------
  * x [rows, L] int8 with scale s -> out [rows, L] int8 in [0, 127] (scale 2^-7). L <= 1024. */

@@ -272,6 +272,13 @@ def test_gemm_block_layout_operands(M, N, K):
                       _lib.ptr(md), _lib.ptr(ed), _lib.ptr(out), T, H, hd, M, N, K, lay, st())
             outs.append(out.cpu().numpy())
         assert np.array_equal(outs[0], outs[1])
+    # block-layout OUTPUT (the next GEMM's A operand written directly)
+    R16 = (M + 15) // 16 * 16
+    outb = torch.zeros(R16 * N, dtype=torch.int8, device=DEV)
+    _lib.call("ivit_gemm_i8_requant_ex", _lib.ptr(At), K, _lib.ptr(Wt), K, _lib.ptr(db), _lib.ptr(md), _lib.ptr(ed),
+              _lib.ptr(outb), N, M, N, K, 7, st())
+    if N % 64 == 0:
+        assert np.array_equal(outb.cpu().numpy(), _block_layout_host(exp.astype(np.int8)))
     with pytest.raises(_lib.IvitError, match="persistent kernel"):   # small problems have no block-layout path
         _lib.call("ivit_gemm_i8_requant_ex", _lib.ptr(At), K, _lib.ptr(dW), K, _lib.ptr(db), _lib.ptr(md), _lib.ptr(ed),
                   _lib.ptr(out), N, 512, N, K, 1, st())
@@ -319,6 +326,15 @@ def test_producers_write_block_layout():
     _lib.call("ivit_shiftgelu_lut_i8_ex", _lib.ptr(dev(x)), L, rows, L, _lib.ptr(lut), _lib.ptr(bl), L, 1, st())
     v = valid_bytes(rows, L)
     assert np.array_equal(bl.cpu().numpy()[v], tiled_of(rm, rows, L).cpu().numpy()[v])
+    # block-layout input, in place (how the engine chains mlp.fc1 -> GELU -> mlp.fc2); row-major in place too
+    inpl = tiled_of(dev(x), rows, L)
+    _lib.call("ivit_shiftgelu_lut_i8_ex", _lib.ptr(inpl), L, rows, L, _lib.ptr(lut), _lib.ptr(inpl), L, 3, st())
+    assert np.array_equal(inpl.cpu().numpy()[v], bl.cpu().numpy()[v])
+    inpl = dev(x).clone()
+    _lib.call("ivit_shiftgelu_lut_i8_ex", _lib.ptr(inpl), L, rows, L, _lib.ptr(lut), _lib.ptr(inpl), L, 0, st())
+    assert torch.equal(inpl, rm)
+    with pytest.raises(_lib.IvitError, match="same layout"):
+        _lib.call("ivit_shiftgelu_lut_i8_ex", _lib.ptr(inpl), L, rows, L, _lib.ptr(lut), _lib.ptr(inpl), L, 1, st())
     # fused attention
     B, H, T, hd = 3, 6, 197, 64
     qkv = np.clip(np.rint(rng.normal(0, 40, size=(3, B, H, T, hd))), -128, 127).astype(np.int8)
