@@ -145,6 +145,7 @@ class IntViTEngine(GraphReplay):
         self.gelu_in_place = True     # GELU overwrites the fc1 output (same layout on both sides)
         self.probe = None
         self._alloc(max_batch)
+        self._compact(True)
         torch.cuda.synchronize(self.dev)
 
     # ------------------------------------------------------------------ plumbing
@@ -173,6 +174,21 @@ class IntViTEngine(GraphReplay):
         if blocks and lin["Wb"] is not None:
             return _lib.ptr(lin["Wb"]), 2
         return _lib.ptr(lin["W"]), 0
+
+    def _compact(self, on=True):
+        """Alias workspaces whose lifetimes do not overlap, so that one layer touches ~230 MB instead of ~430 MB at batch
+        256 (the Infinity Cache holds 256 MB): the residual QuantActs run in place (x2 = x; the epilogue's thread reads a
+        residual chunk and writes the same chunk), the attention output reuses the LayerNorm buffer (consumed by the qkv
+        GEMM before attention starts), q/k/v live inside the fc1 / GELU buffer (dead before fc1 writes it)."""
+        ws = self.ws
+        if "_own" not in ws:
+            ws["_own"] = {k: ws[k] for k in ("x2", "ao", "qkv")}
+        if on:
+            ws["x2"] = ws["x"]
+            ws["ao"] = ws["h"]
+            ws["qkv"] = ws["f1"].view(-1)[: ws["_own"]["qkv"].numel()]
+        else:
+            ws.update(ws["_own"])
 
     def _gemm(self, A, lda, lin, out, ldo, M, st, a_blocks=False, blocks=False, out_blocks=False):
         w, lay = self._w(lin, blocks)
