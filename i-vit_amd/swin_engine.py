@@ -209,6 +209,7 @@ class IntSwinEngine(GraphReplay):
         self.head = d
         self.head_scale = dev(lp.s_acc)
         self._alloc(max_batch)
+        self._compact(True)
         torch.cuda.synchronize(self.dev)
 
     # ------------------------------------------------------------------ plumbing
@@ -236,6 +237,22 @@ class IntSwinEngine(GraphReplay):
             logits_f=torch.empty(B, NUM_CLASSES, dtype=torch.float32, device=self.dev),
             top1=torch.empty(B, dtype=torch.int32, device=self.dev),
         )
+
+    def _compact(self, on=True):
+        """Alias workspaces whose lifetimes do not overlap (see IntViTEngine._compact): the 16-bit residual QuantActs and the
+        GELU run in place, the attention output reuses the LayerNorm buffer, q/k/v and the projection's int32 accumulators
+        live inside the fc1 / GELU buffer.  One stage-0 block touches ~330 MB instead of ~870 MB at batch 128."""
+        ws = self.ws
+        if "_own" not in ws:
+            ws["_own"] = {k: ws[k] for k in ("x2", "ao", "qkv", "acc", "g")}
+        if on:
+            ws["x2"] = ws["x"]
+            ws["ao"] = ws["h"]
+            ws["g"] = ws["f1"]
+            ws["qkv"] = ws["f1"][: ws["_own"]["qkv"].numel()]
+            ws["acc"] = ws["f1"].view(torch.int32)[: ws["_own"]["acc"].numel()]
+        else:
+            ws.update(ws["_own"])
 
     @staticmethod
     def _w(lin, M):
