@@ -19,6 +19,8 @@ int g_ln_wave_per_row = 0;
 
 namespace {
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
 constexpr int NT = 256;
 constexpr int WPB = NT / 64;  // waves (rows in flight) per block
 
@@ -180,15 +182,23 @@ __global__ __launch_bounds__(NT, (NJ <= 3 ? 4 : NJ <= 8 ? 2 : 1)) void layernorm
             for (int j = 0; j < NJ; ++j) {
                 const unsigned wu = (unsigned)w[rr][j] ^ 0x80808080u;      // bytes x + 128: v_cvt_f32_ubyteN below
                 int o[4];
+                // two channels per packed float32 instruction (v_pk_add / v_pk_mul / v_pk_fma: the same IEEE operations,
+                // two lanes of data per issue slot); floor, the certificate and the clamp stay scalar
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const float dl = (float)((wu >> (8 * c)) & 0xffu) - mean128;   // x - mean, exact
-                    const float v = floorf(dl * hfactor);                  // :52  float32 product, /2, floor
-                    const float y = v + bias[j][c];                        // :61  float32 add
-                    const int tl = __float_as_int(__builtin_fmaf(y, lo[j][c], 12582912.0f));
-                    const int th = __float_as_int(__builtin_fmaf(y, hi[j][c], 12582912.0f));
-                    asm("v_sad_u32 %0, %1, %2, %3" : "=v"(unc) : "v"(tl), "v"(th), "v"(unc));
-                    o[c] = clamp_i32(tl, 0x4B400000 - 128, 0x4B400000 + 127);   // low byte = int8 result
+                for (int c = 0; c < 4; c += 2) {
+                    const v2f xf = {(float)((wu >> (8 * c)) & 0xffu), (float)((wu >> (8 * c + 8)) & 0xffu)};
+                    const v2f dl = xf - (v2f){mean128, mean128};           // x - mean, exact
+                    const v2f pr = dl * (v2f){hfactor, hfactor};           // :52  float32 product (the /2 is in the factor)
+                    const v2f vv = {floorf(pr.x), floorf(pr.y)};
+                    const v2f y = vv + (v2f){bias[j][c], bias[j][c + 1]};  // :61  float32 add
+                    const v2f tlv = __builtin_elementwise_fma(y, (v2f){lo[j][c], lo[j][c + 1]}, (v2f){12582912.0f, 12582912.0f});
+                    const v2f thv = __builtin_elementwise_fma(y, (v2f){hi[j][c], hi[j][c + 1]}, (v2f){12582912.0f, 12582912.0f});
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const int tl = __float_as_int(tlv[k]), th = __float_as_int(thv[k]);
+                        asm("v_sad_u32 %0, %1, %2, %3" : "=v"(unc) : "v"(tl), "v"(th), "v"(unc));
+                        o[c + k] = clamp_i32(tl, 0x4B400000 - 128, 0x4B400000 + 127);   // low byte = int8 result
+                    }
                 }
                 const unsigned w01 = __builtin_amdgcn_perm((unsigned)o[1], (unsigned)o[0], 0x0c0c0400u);
                 const unsigned w23 = __builtin_amdgcn_perm((unsigned)o[3], (unsigned)o[2], 0x04000c0cu);
