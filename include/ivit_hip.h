@@ -95,7 +95,8 @@ int ivit_gemm_i8_requant_ex(const int8_t* A, int64_t lda, const int8_t* W, int64
 /* as above, then the two-operand QuantAct of the residual connection
  * (vit_quant.py:147,153; quant_utils.py:232-245):
  *   k = clamp8(RNE(acc * m[n] / 2^e[n]))
- *   out = clamp8(RNE(k * m_main / 2^e_main) + RNE(res[t][n] * m_res / 2^e_res)) */
+ *   out = clamp8(RNE(k * m_main / 2^e_main) + RNE(res[t][n] * m_res / 2^e_res))
+ * `out` may be `res` itself (in place: one thread reads a residual chunk and writes the same chunk). */
 int ivit_gemm_i8_requant_residual(const int8_t* A, int64_t lda, const int8_t* W, int64_t ldw,
                                   const int32_t* bias, const uint32_t* m, const int32_t* e,
                                   const int8_t* res, int64_t ldr, uint32_t m_main, int32_t e_main,

@@ -106,6 +106,24 @@ def test_block_layout_path_equals_row_major_path():
         assert torch.equal(t_blocks[k], t_rows[k]), k
 
 
+def test_aliased_workspaces_equal_separate_buffers():
+    """the engine's workspace aliasing (in-place residual QuantActs and GELU, attention output over the LayerNorm buffer,
+    q/k/v inside the fc1 buffer) changes no bit: logits and taps against every intermediate in its own buffer"""
+    eng, fs, ranges, cfg, meta, z = build("deit_small", 16)
+    imgs = torch.from_numpy(synth.make_images(16, 4321)).to(DEV)
+    t_alias, t_own = {}, {}
+    li_a = eng.forward(imgs, t_alias)[0].cpu().numpy().copy()
+    eng._compact(False)
+    eng.gelu_in_place = False
+    li_o = eng.forward(imgs, t_own)[0].cpu().numpy().copy()
+    eng._compact(True)
+    eng.gelu_in_place = True
+    assert np.array_equal(li_a, li_o)
+    assert set(t_alias) == set(t_own)
+    for k in t_own:
+        assert torch.equal(t_alias[k], t_own[k]), k
+
+
 def test_headline_batch_256_deit_base():
     """Config 3 at full size: golden images embedded in a batch of 256 reproduce the golden logits."""
     eng, fs, ranges, cfg, meta, z = build("deit_base", 256)

@@ -160,6 +160,12 @@ def test_gemm_requant_residual(M, N, K):
                   _lib.ptr(md), _lib.ptr(ed), _lib.ptr(dres), N, int(m1[0]), int(e1[0]), int(m2[0]), int(e2[0]),
                   _lib.ptr(out), N, M, N, K, st())
         assert np.array_equal(out.cpu().numpy().astype(np.int32), exp), (s_main, s_res, s_out)
+        # in place: the output over the residual operand (how the engines keep one residual-stream buffer)
+        inpl = dres.clone()
+        _lib.call("ivit_gemm_i8_requant_residual", _lib.ptr(dA), K, _lib.ptr(dW), K, _lib.ptr(db),
+                  _lib.ptr(md), _lib.ptr(ed), _lib.ptr(inpl), N, int(m1[0]), int(e1[0]), int(m2[0]), int(e2[0]),
+                  _lib.ptr(inpl), N, M, N, K, st())
+        assert torch.equal(inpl, out), (s_main, s_res, s_out)
 
 
 @pytest.mark.parametrize("B,H", [(3, 3), (11, 6)])

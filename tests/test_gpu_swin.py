@@ -203,6 +203,19 @@ def test_layernorm_i16_certificate_regimes(regime, C):
     assert np.array_equal(got, ref), f"{regime}: {(got != ref).sum()} of {got.size} differ"
 
 
+def test_swin_aliased_workspaces_equal_separate_buffers():
+    """IntSwinEngine._compact changes no bit"""
+    from ivit_amd.checkpoint import load_synthetic_model
+    fs, ranges, cfg, meta, z = load_synthetic_model("swin_tiny")
+    eng = IntSwinEngine(fs, ranges, cfg["embed_dim"], cfg["depths"], cfg["num_heads"], cfg["window"], device=DEV, max_batch=4)
+    imgs = torch.from_numpy(synth.make_images(4, 31)).to(DEV)
+    li_a = eng.forward(imgs)[0].cpu().numpy().copy()
+    eng._compact(False)
+    li_o = eng.forward(imgs)[0].cpu().numpy().copy()
+    eng._compact(True)
+    assert np.array_equal(li_a, li_o)
+
+
 def test_layernorm_i16_i8_window_order():
     rng = np.random.default_rng(5)
     B, H, ws, shift, C = 2, 14, 7, 3, 96
