@@ -1,7 +1,8 @@
-"""HIP-graph replay of an engine's forward for launch-bound shapes (small batch): the ~100 kernel launches of one
-forward are captured once per batch size on a capture stream and replayed with a single graph launch.  All launches go
-through the C ABI on `torch.cuda.current_stream()`, the engines allocate nothing inside `forward`, so the capture is
-exact; results are the same workspace views `forward` returns."""
+"""HIP-graph replay of an engine's forward: the ~100 kernel launches of one forward are captured once per batch size on a
+capture stream and replayed with a single graph launch (launch-bound shapes gain most; at batch 256 it removes the
+host's ~100 ctypes calls per step from the picture).  All launches go through the C ABI on
+`torch.cuda.current_stream()`, the engines allocate nothing inside `forward`, so the capture is exact; results are the
+same workspace views `forward` returns."""
 from __future__ import annotations
 
 import torch
@@ -10,12 +11,19 @@ import torch
 class GraphReplay:
     """Mixin for IntViTEngine / IntSwinEngine."""
 
-    def forward_graph(self, images: torch.Tensor):
+    def forward_graph(self, images: torch.Tensor, resident: bool = False):
+        """resident=False: `images` is copied into the graph's own input buffer before every replay.
+        resident=True: the graph reads `images` itself (the caller keeps that tensor alive and refills it in place,
+        e.g. a loader's device-side staging buffer) -- no copy per step."""
         B = images.shape[0]
         cache = self.__dict__.setdefault("_graphs", {})
-        if B not in cache:
-            static_in = torch.empty_like(images)
-            static_in.copy_(images)
+        key = (B, images.data_ptr()) if resident else B
+        if key not in cache:
+            if resident:
+                static_in = images
+            else:
+                static_in = torch.empty_like(images)
+                static_in.copy_(images)
             side = torch.cuda.Stream(device=self.dev)
             side.wait_stream(torch.cuda.current_stream(self.dev))
             with torch.cuda.stream(side):           # warm-up outside the capture (lazy module loads, first-use paths)
@@ -24,8 +32,12 @@ class GraphReplay:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 out = self.forward(static_in)
-            cache[B] = (graph, static_in, out)
-        graph, static_in, out = cache[B]
-        static_in.copy_(images)
+            cache[key] = (graph, static_in, out)
+        graph, static_in, out = cache[key]
+        if not resident:
+            static_in.copy_(images)
         graph.replay()
         return out
+
+    def drop_graphs(self):
+        self.__dict__.pop("_graphs", None)

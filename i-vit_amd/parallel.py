@@ -26,9 +26,15 @@ def gather_top1(local_top1: torch.Tensor, world: int) -> torch.Tensor:
 
 
 class DataParallelTop1:
-    def __init__(self, engine, world: int):
-        self.engine, self.world = engine, world
+    """graph=True: the local forward is a HIP-graph replay reading `local_images` in place (the caller refills that tensor
+    between steps); the all-gather stays an ordinary stream-ordered RCCL call after it."""
+
+    def __init__(self, engine, world: int, graph: bool = False):
+        self.engine, self.world, self.graph = engine, world, graph
 
     def step(self, local_images: torch.Tensor) -> torch.Tensor:
-        _, _, top1 = self.engine(local_images)
+        if self.graph:
+            _, _, top1 = self.engine.forward_graph(local_images, resident=True)
+        else:
+            _, _, top1 = self.engine(local_images)
         return gather_top1(top1, self.world)

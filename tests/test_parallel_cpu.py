@@ -68,3 +68,35 @@ def test_two_rank_gloo_allgather_matches_single_process():
 def test_single_rank_is_identity():
     x = torch.arange(5, dtype=torch.int32)
     assert gather_top1(x, 1) is x
+
+
+def test_bench_launcher_spawns_ranks_gloo_stub():
+    """`python bench.py --gpus 2` with no rendezvous in the environment (the form the driver uses): the launcher starts two
+    child ranks itself, they meet over gloo, all-gather, and rank 0 prints ONE JSON line.  IVIT_BENCH_STUB=1 swaps the HIP
+    engine for a CPU stub; launch, rendezvous, timing protocol and output are bench.py's real code."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    env["IVIT_BENCH_STUB"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["config"]["global_batch"] == 16 and d["value"] > 0
+
+
+def test_bench_launcher_propagates_failure():
+    """a rank that dies must fail the whole command (non-zero exit), not hang the other rank in a collective"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    env["IVIT_BENCH_STUB"] = "1"
+    env["IVIT_BENCH_STUB_FAIL_RANK"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
