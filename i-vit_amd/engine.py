@@ -22,8 +22,8 @@ import torch
 
 from . import _lib
 from .graph import GraphReplay
-from .prepare import dyadic, f32, quant_sym, requant_host
-from .synth import IMG_SIZE, NUM_CLASSES, NUM_PATCHES, NUM_TOKENS, PATCH
+from .prepare import dyadic, f32, pad_head, quant_sym, requant_host
+from .synth import IMG_SIZE, NUM_PATCHES, NUM_TOKENS, PATCH
 
 
 def _np(v):
@@ -127,8 +127,9 @@ class IntViTEngine(GraphReplay):
         s_q2 = s("qact2")
         self.ln_f = ln_dev("norm", s_q2)
         head = source.linear("head", s_q2)
-        self.head = dict(W=dev(head.W8), b=dev(head.b32), K=head.K, N=head.W8.shape[0])
-        self.head_scale = dev(head.s_acc)
+        hW, hb, hs, self.num_classes = pad_head(head.W8, head.b32, head.s_acc)    # any class count (num_classes=... of the factory)
+        self.head = dict(W=dev(hW), b=dev(hb), K=head.K, N=hW.shape[0])
+        self.head_scale = dev(hs)
         self.int8_weight_bytes = sum(int(b[k]["W"].numel()) for b in self.blocks for k in ("qkv", "proj", "fc1", "fc2")) \
             + int(self.patch["W"].numel()) + int(self.head["W"].numel())
         # block-layout copies of the GEMM weights (include/ivit_hip.h IVIT_LAYOUT_BLOCKS): the persistent GEMM then reads
@@ -164,8 +165,8 @@ class IntViTEngine(GraphReplay):
             qkv=torch.empty(3 * M * C, **i8), ao=torch.empty(M16, C, **i8),
             f1=torch.empty(M16, 4 * C, **i8), g=torch.empty(M16, 4 * C, **i8), untile=torch.empty(M, 4 * C, **i8),
             cls=torch.empty(B, C, **i8),
-            logits=torch.empty(B, NUM_CLASSES, dtype=torch.int32, device=self.dev),
-            logits_f=torch.empty(B, NUM_CLASSES, dtype=torch.float32, device=self.dev),
+            logits=torch.empty(B, self.head["N"], dtype=torch.int32, device=self.dev),
+            logits_f=torch.empty(B, self.head["N"], dtype=torch.float32, device=self.dev),
             top1=torch.empty(B, dtype=torch.int32, device=self.dev),
         )
 
@@ -217,8 +218,8 @@ class IntViTEngine(GraphReplay):
 
     # ------------------------------------------------------------------ forward
     def forward(self, images: torch.Tensor, taps: dict | None = None):
-        """images: float32 [B,3,224,224] on the engine's device.  Returns (logits_int32 [B,1000],
-        logits_f32 [B,1000], top1 int32 [B]) -- views of the engine's workspace, valid until the
+        """images: float32 [B,3,224,224] on the engine's device.  Returns (logits_int32 [B,classes],
+        logits_f32 [B,classes], top1 int32 [B]) -- views of the engine's workspace, valid until the
         next call.  `taps` (debug/tests) receives clones of intermediate int8 tensors."""
         assert images.is_cuda and images.dtype == torch.float32 and images.is_contiguous()
         B = images.shape[0]
@@ -281,9 +282,10 @@ class IntViTEngine(GraphReplay):
         tap("qact2", ws["cls"], (B, C))
         hd_ = self.head
         _lib.call("ivit_gemm_i8_i32", _lib.ptr(ws["cls"]), C, _lib.ptr(hd_["W"]), hd_["K"], _lib.ptr(hd_["b"]),
-                  _lib.ptr(ws["logits"]), NUM_CLASSES, B, NUM_CLASSES, C, st)
-        _lib.call("ivit_head_argmax", _lib.ptr(ws["logits"]), _lib.ptr(self.head_scale), B, NUM_CLASSES,
+                  _lib.ptr(ws["logits"]), hd_["N"], B, hd_["N"], C, st)
+        _lib.call("ivit_head_argmax", _lib.ptr(ws["logits"]), _lib.ptr(self.head_scale), B, hd_["N"],
                   _lib.ptr(ws["logits_f"]), _lib.ptr(ws["top1"]), st)
-        return ws["logits"][:B], ws["logits_f"][:B], ws["top1"][:B]
+        nc = self.num_classes
+        return ws["logits"][:B, :nc], ws["logits_f"][:B, :nc], ws["top1"][:B]
 
     __call__ = forward

@@ -92,3 +92,15 @@ class LayerNormParams:
         if np.any(self.e < 40):
             # |z| < 2^31 after I-LayerNorm, so M <= 2^-9 keeps |z*M| < 2^22 (the kernel's float32 certificate range)
             raise ValueError("LayerNorm requantiser with multiplier > 2^-9 (e < 40) is outside the kernel's contract")
+
+
+def pad_head(W8: np.ndarray, b32: np.ndarray, s_acc: np.ndarray):
+    """The classifier GEMM (`ivit_gemm_i8_i32`) wants N % 4 == 0.  Any other class count is padded with classes that can
+    never win the arg-max: zero weights, bias -2^31, scale 1 (logit -2.1e9).  -> (W8, b32, s_acc, N_true)."""
+    N = W8.shape[0]
+    pad = -N % 4
+    if pad:
+        W8 = np.concatenate([W8, np.zeros((pad, W8.shape[1]), W8.dtype)])
+        b32 = np.concatenate([b32, np.full(pad, -2 ** 31, b32.dtype)])
+        s_acc = np.concatenate([s_acc, np.ones(pad, s_acc.dtype)])
+    return W8, b32, s_acc, N

@@ -22,8 +22,8 @@ import torch
 
 from . import _lib
 from .graph import GraphReplay
-from .prepare import LayerNormParams, LinearParams, dyadic, f32, quant_sym, requant_host, sym_scale
-from .synth import IMG_SIZE, NUM_CLASSES
+from .prepare import LayerNormParams, LinearParams, dyadic, f32, pad_head, quant_sym, requant_host, sym_scale
+from .synth import IMG_SIZE
 
 PATCH = 4
 HEAD_DIM = 32
@@ -205,9 +205,10 @@ class IntSwinEngine(GraphReplay):
         self.ln_f = ln_dev("norm", s_q2)
         s_q3 = s("qact3")
         self.pool_me = sme(s_q2, s_q3)
-        lp, d = lin_host("head", s_q3)
-        self.head = d
-        self.head_scale = dev(lp.s_acc)
+        lp = LinearParams(P["head.weight"], P.get("head.bias"), s_q3)
+        hW, hb, hs, self.num_classes = pad_head(lp.W8, lp.b32, lp.s_acc)      # any class count
+        self.head = dict(W=dev(hW), b=dev(hb), K=lp.K, N=hW.shape[0])
+        self.head_scale = dev(hs)
         self._alloc(max_batch)
         self._compact(True)
         torch.cuda.synchronize(self.dev)
@@ -233,8 +234,8 @@ class IntSwinEngine(GraphReplay):
             f1=torch.empty(M0 * 4 * C0, **i8), g=torch.empty(M0 * 4 * C0, **i8), f2=torch.empty(M0 * C0, **i8),
             xm=torch.empty(M0 * C0, **i16), hm=torch.empty(M0 * C0, **i8), red=torch.empty(M0 * C0 // 2, **i8),
             hN=torch.empty(B * self.T_last * self.C_last, **i8), pooled=torch.empty(B * self.C_last, **i8),
-            logits=torch.empty(B, NUM_CLASSES, dtype=torch.int32, device=self.dev),
-            logits_f=torch.empty(B, NUM_CLASSES, dtype=torch.float32, device=self.dev),
+            logits=torch.empty(B, self.head["N"], dtype=torch.int32, device=self.dev),
+            logits_f=torch.empty(B, self.head["N"], dtype=torch.float32, device=self.dev),
             top1=torch.empty(B, dtype=torch.int32, device=self.dev),
         )
 
@@ -374,9 +375,10 @@ class IntSwinEngine(GraphReplay):
         tap("qact3", ws["pooled"], B, C)
         hd = self.head
         _lib.call("ivit_gemm_i8_i32", _lib.ptr(ws["pooled"]), C, _lib.ptr(hd["W"]), hd["K"], _lib.ptr(hd["b"]),
-                  _lib.ptr(ws["logits"]), NUM_CLASSES, B, NUM_CLASSES, hd["K"], st)
-        _lib.call("ivit_head_argmax", _lib.ptr(ws["logits"]), _lib.ptr(self.head_scale), B, NUM_CLASSES,
+                  _lib.ptr(ws["logits"]), hd["N"], B, hd["N"], hd["K"], st)
+        _lib.call("ivit_head_argmax", _lib.ptr(ws["logits"]), _lib.ptr(self.head_scale), B, hd["N"],
                   _lib.ptr(ws["logits_f"]), _lib.ptr(ws["top1"]), st)
-        return ws["logits"][:B], ws["logits_f"][:B], ws["top1"][:B]
+        nc = self.num_classes
+        return ws["logits"][:B, :nc], ws["logits_f"][:B, :nc], ws["top1"][:B]
 
     __call__ = forward

@@ -19,6 +19,7 @@ from typing import Optional
 import torch
 from torch import nn
 
+from .dispatch import EngineDispatch
 from .layers_quant import DropPath, Mlp, PatchEmbed, to_2tuple, trunc_normal_
 from .quantization_utils import IntGELU, IntLayerNorm, IntSoftmax, QuantAct, QuantLinear, QuantMatMul
 
@@ -203,7 +204,7 @@ class BasicLayer(nn.Module):
         return f"dim={self.dim}, input_resolution={self.input_resolution}, depth={self.depth}"
 
 
-class SwinTransformer(nn.Module):
+class SwinTransformer(EngineDispatch, nn.Module):
     """swin_quant.py:424-564."""
 
     def __init__(self, img_size=224, patch_size=4, in_chans=3, num_classes=1000, embed_dim=96, depths=(2, 2, 6, 2),
@@ -242,8 +243,10 @@ class SwinTransformer(nn.Module):
         self.head = QuantLinear(self.num_features, num_classes) if num_classes > 0 else nn.Identity()
         self.act_out = QuantAct()
         self.apply(self._init_weights)
-        self._engine = None
-        self.use_engine = True   # frozen models take the fused engine
+        self._init_dispatch()
+        # the widths the constructor (= the reference's, swin_quant.py:110, 214, 222, 475) gives every QuantAct are the ones
+        # the Swin kernels hard-wire; a width edited afterwards sends the model down the module path
+        self._reference_widths = {n: int(m.activation_bit) for n, m in self._quant_acts()}
 
     @staticmethod
     def _init_weights(m):
@@ -281,31 +284,32 @@ class SwinTransformer(nn.Module):
         x, s = self.qact3(x.transpose(1, 2), s)                   # channels last for the per-tensor requant kernel
         return torch.flatten(x, 1), s
 
-    # ---------------------------------------------------------------- fused engine path
-    def is_frozen(self):
-        return all(not m.running_stat for n, m in self.named_modules() if isinstance(m, QuantAct) and n != "act_out")
+    # ---------------------------------------------------------------- fused engine path (dispatch.py)
+    _frozen_exempt = ("act_out",)      # constructed by the reference (swin_quant.py:518) and never called
 
-    def engine_supported(self):
-        return (not self.ape and self.patch_norm and self.num_classes > 0
-                and all(int(self.embed_dim * 2 ** i) // h == 32 for i, h in enumerate(self.num_heads)))
+    def engine_unsupported_reason(self):
+        if self.ape or not self.patch_norm:
+            return "absolute position embedding / no patch norm"
+        if self.num_classes <= 0:
+            return "no classification head"
+        if any(int(self.embed_dim * 2 ** i) // h != 32 for i, h in enumerate(self.num_heads)):
+            return "head_dim != 32"
+        for n, m in self._quant_acts():
+            if int(m.activation_bit) != self._reference_widths[n]:
+                return f"QuantAct {n} is {int(m.activation_bit)}-bit (fused engine: {self._reference_widths[n]})"
+        return None
 
-    def engine(self, max_batch):
-        """Build (once) the integer engine from this model's float parameters and QuantAct ranges."""
+    def _build_engine(self, device, max_batch):
         from .swin_engine import IntSwinEngine
-        key = (max_batch, next(self.parameters()).device)
-        if self._engine is None or self._engine[0] != key or self._engine[1].max_batch < max_batch:
-            float_state = {k: v for k, v in self.state_dict().items()}
-            ranges = {n: (float(m.x_min.reshape(-1)[0]), float(m.x_max.reshape(-1)[0]))
-                      for n, m in self.named_modules() if isinstance(m, QuantAct)}
-            eng = IntSwinEngine(float_state, ranges, self.embed_dim, self.depths, self.num_heads, self.window_size,
-                                device=key[1], max_batch=max_batch)
-            self._engine = (key, eng)
-        return self._engine[1]
+        return IntSwinEngine(dict(self.state_dict()), self.ranges(), self.embed_dim, self.depths, self.num_heads,
+                             self.window_size, device=device, max_batch=max_batch)
 
     def forward(self, x):
-        if self.use_engine and not self.training and self.is_frozen() and x.is_cuda and self.engine_supported():
+        if self.takes_engine(x):
             _, logits_f32, _ = self.engine(x.shape[0])(x.contiguous().float())
             return logits_f32.clone()
+        if not self.is_frozen():
+            self.invalidate_engine()
         x, s = self.forward_features(x)
         x, _ = self.head(x, s)
         return x

@@ -14,6 +14,7 @@ from functools import partial
 import torch
 from torch import nn
 
+from .dispatch import EngineDispatch
 from .layers_quant import DropPath, Mlp, PatchEmbed, trunc_normal_
 from .quantization_utils import (QuantAct, QuantLinear, QuantMatMul, get_gelu, get_layernorm, get_softmax)
 
@@ -83,7 +84,7 @@ class Block(nn.Module):
         return self.qact4(self.drop_path(x), s, x_2, s_2)          # residual 2
 
 
-class VisionTransformer(nn.Module):
+class VisionTransformer(EngineDispatch, nn.Module):
     def __init__(self, img_size=224, patch_size=16, in_chans=3, num_classes=1000, embed_dim=768, depth=12,
                  num_heads=12, mlp_ratio=4.0, qkv_bias=True, qk_scale=None, representation_size=None, drop_rate=0.0,
                  attn_drop_rate=0.0, drop_path_rate=0.0, patch_embed_bw=8, pos_encoding_bw=8, block_input_bw=8,
@@ -95,6 +96,7 @@ class VisionTransformer(nn.Module):
         self.num_classes = num_classes
         self.num_features = self.embed_dim = embed_dim
         self.depth, self.num_heads = depth, num_heads
+        self.geometry = (img_size, patch_size, in_chans, float(mlp_ratio), bool(qkv_bias), qk_scale)
         self.op_types = (str(gelu_type).lower(), str(softmax_type).lower(), str(layernorm_type).lower())
         gelu_layer, softmax_cls, norm_layer = get_gelu(gelu_type), get_softmax(softmax_type), get_layernorm(layernorm_type)
 
@@ -121,8 +123,7 @@ class VisionTransformer(nn.Module):
         trunc_normal_(self.pos_embed, std=0.02)
         trunc_normal_(self.cls_token, std=0.02)
         self.apply(self._init_weights)
-        self._engine = None
-        self.use_engine = True   # frozen models take the fused int8 engine
+        self._init_dispatch()
 
     @staticmethod
     def _init_weights(m):
@@ -149,28 +150,36 @@ class VisionTransformer(nn.Module):
         x, s = self.qact2(x[:, 0], s)
         return self.pre_logits(x), s
 
-    # ---------------------------------------------------------------- fused engine path
-    def is_frozen(self):
-        return all(not m.running_stat for m in self.modules() if isinstance(m, QuantAct))
+    # ---------------------------------------------------------------- fused engine path (dispatch.py)
+    def engine_unsupported_reason(self):
+        """None when the fused int8 engine computes exactly what this module tree would; else why not."""
+        if any(t != "ivit" for t in self.op_types):
+            return f"operator family {self.op_types} (fused engine: I-ViT operators)"
+        if self.embed_dim // self.num_heads != 64 or self.embed_dim % 64:
+            return "head_dim != 64"
+        if self.geometry != (224, 16, 3, 4.0, True, None):
+            return f"geometry {self.geometry} (fused engine: 224x224, patch 16, 3 channels, mlp_ratio 4, qkv bias)"
+        if self.num_classes <= 0:
+            return "no classification head"
+        bad = self._width_mismatch({})          # every QuantAct of the DeiT / ViT engine is 8 bit
+        if bad:
+            return bad
+        a, m = self.blocks[0].attn.int_softmax, self.blocks[0].mlp.act
+        if getattr(a, "output_bit", 8) != 8 or getattr(m, "output_bit", 8) != 8:
+            return "Shiftmax / ShiftGELU output width != 8"
+        return None
 
-    def engine(self, max_batch):
-        """Build (once) the int8 engine from this model's float parameters and QuantAct ranges."""
+    def _build_engine(self, device, max_batch):
         from .engine import IntViTEngine
-        key = (max_batch, next(self.parameters()).device)
-        if self._engine is None or self._engine[0] != key or self._engine[1].max_batch < max_batch:
-            float_state = {k: v for k, v in self.state_dict().items()}
-            ranges = {n: (float(m.x_min.reshape(-1)[0]), float(m.x_max.reshape(-1)[0]))
-                      for n, m in self.named_modules() if isinstance(m, QuantAct)}
-            eng = IntViTEngine(float_state, ranges, self.embed_dim, self.depth, self.num_heads,
-                               device=key[1], max_batch=max_batch)
-            self._engine = (key, eng)
-        return self._engine[1]
+        return IntViTEngine(dict(self.state_dict()), self.ranges(), self.embed_dim, self.depth, self.num_heads,
+                            device=device, max_batch=max_batch)
 
     def forward(self, x):
-        engine_ok = self.embed_dim // self.num_heads == 64 and all(t == "ivit" for t in self.op_types)   # fused engine: I-ViT operators
-        if self.use_engine and not self.training and self.is_frozen() and x.is_cuda and engine_ok:
+        if self.takes_engine(x):
             _, logits_f32, _ = self.engine(x.shape[0])(x.contiguous().float())
             return logits_f32.clone()
+        if not self.is_frozen():
+            self.invalidate_engine()     # running-stat QuantActs replace their range buffers: any snapshot is stale
         x, s = self.forward_features(x)
         x, _ = self.head(x, s)
         return x

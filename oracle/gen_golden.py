@@ -501,6 +501,180 @@ def gen_ibert_ops():
     print("ibert_kat.npz written:", len(out), "arrays; oracle/ibert.py bit-equal to the reference modules on all cases")
 
 
+
+# ----------------------------------------------------------------------------- natural (un-snapped) calibration ranges
+
+NATURAL_PLAN = {
+    # tag: (factory, weight seed, calibration seeds (one batch each, EMA as quant_modules.py:346-360), batch, image seed, n)
+    "deit_tiny_natural": ("deit_tiny_patch16_224", 11, (101, 111, 121), 4, 1001, 8),
+    "deit_small_natural": ("deit_small_patch16_224", 12, (102, 112), 4, 1002, 4),
+}
+
+
+def gen_natural(tag):
+    """The reference with its QuantAct ranges AS CALIBRATED (running min/max + EMA over a few batches, then freeze) -- the
+    regime of a real checkpoint (scripts/inference.py:33-91, quant_train.py:470-500), where every activation scale is an
+    arbitrary float32.  Stores the reference's logits / top-1 / tap digests plus, per tap, how far the integer-exact
+    algorithm (oracle/oracle.py, = the HIP engine) is from it: the reference's own `fl(fl(k*s)/s)` fuzz at its float ->
+    integer conversions (SURVEY finding 8) makes them differ, and this fixture is what quantifies it."""
+    factory, wseed, cseeds, cb, iseed, nimg = NATURAL_PLAN[tag]
+    cfg = synth.MODEL_CONFIGS[factory]
+    model = getattr(ref_models, factory)(pretrained=False, gelu_type="ivit", softmax_type="ivit", layernorm_type="ivit")
+    fs = synth.make_float_state(factory, wseed)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in fs.items()}, strict=False)
+    model.eval()
+    for cs in cseeds:
+        model(torch.from_numpy(synth.make_images(cb, cs)))
+    ranges = {n: (np.float32(m.x_min.item()), np.float32(m.x_max.item()))
+              for n, m in model.named_modules() if isinstance(m, rq.QuantAct)}
+    ref_models.freeze_model(model)
+    taps = {}
+
+    def hook(name):
+        def fn(mod, inp, outp):
+            y, sc = outp
+            taps[name] = to_int(y, sc)
+        return fn
+
+    for name, mod in model.named_modules():
+        if isinstance(mod, (rq.QuantAct, rq.IVITIntSoftmax, rq.IVITIntGELU)):
+            mod.register_forward_hook(hook(name))
+    imgs = synth.make_images(nimg, iseed)
+    y = model(torch.from_numpy(imgs))
+    s_head = (model.head.fc_scaling_factor * model.qact2.act_scaling_factor).float()
+    logits_int = torch.round(y / s_head).to(torch.int64).numpy().astype(np.int32)
+    logits_f32 = y.numpy().astype(np.float32)
+    top1 = y.argmax(dim=1).numpy().astype(np.int64)
+
+    # ---- the natural-scale restatement (oracle compat=True) must reproduce the reference bit for bit
+    oc = orc.OracleViT(fs, ranges, cfg["embed_dim"], cfg["depth"], cfg["num_heads"], compat=True)
+    ctaps = {}
+    cres = oc.forward(imgs, ctaps)
+    cbad = [n for n in taps if not np.array_equal(taps[n].reshape(-1), ctaps[n].reshape(-1))]
+    assert not cbad, f"compat oracle != reference at {cbad[:5]} ({len(cbad)} taps)"
+    assert np.array_equal(cres["logits_int32"], logits_int), "compat oracle: INT32 logits differ"
+    # the reference's float logits are F.linear over phi(q) (quant_modules.py:222-226): sgemm over near-integers, equal to
+    # acc * scale only up to its own float32 accumulation -- INT32 logits and top-1 are the contract (BASELINE north_star)
+    ulp = np.abs(cres["logits_f32"].view(np.int32).astype(np.int64) - logits_f32.view(np.int32)).max()
+    err = float(np.abs(cres["logits_f32"] - logits_f32).max() / float(cres["head_scale"].max()))
+    assert err < 0.25, f"compat oracle: float logits off by {err} integer steps"
+    assert np.array_equal(cres["top1"], top1)
+    print(f"[{tag}] float logits: max {ulp} ulp / {err:.4f} integer steps from the reference's sgemm-over-phi values")
+    print(f"[{tag}] compat oracle: {len(taps)} taps + INT32 logits + top-1 bit-equal to the reference "
+          f"({oc.ln_tie_rows} LayerNorm rows decided by the float32 reduction order, "
+          f"{oc.softmax_inexact_rows} Shiftmax rows with sum >= 2^24, max|acc| {oc.max_acc})")
+    assert oc.max_acc < 2 ** 24
+
+    # ---- for the record: how far the plain integer algorithm (compat=False) is from the reference at these scales
+    om = orc.OracleViT(fs, ranges, cfg["embed_dim"], cfg["depth"], cfg["num_heads"])
+    otaps = {}
+    res = om.forward(imgs, otaps)
+    order = synth.qact_names(cfg["depth"])
+    names = sorted(taps)
+    frac = {n: float(np.mean(taps[n].reshape(-1) != otaps[n].reshape(-1))) for n in names}
+    maxd = {n: int(np.abs(taps[n].reshape(-1).astype(np.int64) - otaps[n].reshape(-1)).max()) for n in names}
+    first = next((n for n in order if frac.get(n, 0.0) > 0), None)
+    agree = int((res["top1"] == top1).sum())
+    lg_equal = bool(np.array_equal(res["logits_int32"], logits_int))
+    rel = float(np.abs(res["logits_f32"] - logits_f32).max() / np.abs(logits_f32).max())
+    print(f"[{tag}] plain integer algorithm (no phi) vs reference at natural scales: taps equal {sum(f == 0 for f in frac.values())}/"
+          f"{len(names)}, first differing QuantAct {first}, worst tap {max(frac.values()):.4f} of elements, "
+          f"INT32 logits equal: {lg_equal}, max |dlogit|/max|logit| {rel:.4f}, top-1 agreement {agree}/{nimg}")
+    out = {
+        "meta": np.array(json.dumps(dict(tag=tag, factory=factory, family="ivit", weight_seed=wseed, calib_seeds=list(cseeds),
+                                         calib_batch=cb, image_seed=iseed, n_images=nimg, qkv_gain=synth.QKV_GAIN,
+                                         regime="natural", first_differing_tap=first, top1_agreement=agree,
+                                         logits_int32_equal=lg_equal, logits_rel_err=rel, ln_tie_rows=oc.ln_tie_rows,
+                                         softmax_inexact_rows=oc.softmax_inexact_rows, max_abs_acc=oc.max_acc,
+                                         torch=torch.__version__, cpu_capability=torch.backends.cpu.get_cpu_capability()))),
+        "range_names": np.array(list(ranges)),
+        "x_min": np.array([v[0] for v in ranges.values()], np.float32),
+        "x_max": np.array([v[1] for v in ranges.values()], np.float32),
+        "logits_int32": logits_int, "logits_f32_bits": logits_f32.view(np.int32), "top1": top1,
+        "tap_names": np.array(names), "tap_crc32": np.array([crc(taps[n]) for n in names], np.uint32),
+        "exact_mismatch_frac": np.array([frac[n] for n in names], np.float64),
+        "exact_mismatch_maxabs": np.array([maxd[n] for n in names], np.int64),
+    }
+    np.savez_compressed(os.path.join(GOLD, f"{tag}.npz"), **out)
+    print(f"[{tag}] wrote fixtures; reference top1 = {top1.tolist()}, integer-exact top1 = {res['top1'].tolist()}")
+    return taps, otaps, ranges, fs, imgs
+
+
+
+def gen_compat_ops():
+    """Known-answer vectors of the reference's I-ViT operator modules at NATURAL (non power-of-two) input scales: the input
+    is what a QuantAct emits, q * s in float32 (quant_modules.py:387).  Checked on the spot against the compat oracle."""
+    rng = np.random.default_rng(20260303)
+    out = {}
+    scales = [np.float32(v) for v in (0.0371, 0.11873, 0.0052341, 0.3127, 0.0625)]
+    # --- IVITIntLayerNorm (+ the QuantAct behind it, natural output range)
+    for ci, (rows, Cn, s) in enumerate([(48, 192, scales[0]), (32, 768, scales[1]), (24, 384, scales[2]), (16, 96, scales[3]),
+                                        (16, 1024, scales[0])]):
+        ln = rq.IVITIntLayerNorm(Cn)
+        gamma = rng.uniform(0.5, 1.5, size=Cn).astype(np.float32)
+        beta = rng.normal(0, 0.1, size=Cn).astype(np.float32)
+        ln.weight.data, ln.bias.data = torch.from_numpy(gamma), torch.from_numpy(beta)
+        q = rng.integers(-128, 128, size=(1, rows, Cn)).astype(np.int32)
+        for r in range(0, rows, 2):            # every other row: integer sum == C/2 (mod C), the mean is an exact .5 tie
+            tgt = Cn // 2 + Cn * int(rng.integers(-20, 20))
+            for _ in range(100000):
+                d = tgt - int(q[0, r].sum())
+                if d == 0:
+                    break
+                c = int(rng.integers(0, Cn))
+                nv = int(np.clip(q[0, r, c] + np.clip(d, -60, 60), -128, 127))
+                q[0, r, c] = nv
+            assert int(q[0, r].sum()) == tgt
+        x = (torch.from_numpy(q.astype(np.float32)) * torch.tensor([s])).float()
+        yl, sl = ln(x, torch.tensor([s]))
+        qa = rq.QuantAct()
+        hi = float(np.abs(yl.numpy()).max()) * 0.93
+        qa.x_min.fill_(-hi)
+        qa.x_max.fill_(hi)
+        qa.fix()
+        yq, sq = qa(yl, sl)
+        y, s_ln, _, ties = orc.layernorm_compat(q.reshape(rows, Cn), s, gamma, beta)
+        assert np.array_equal((y * s_ln).astype(np.float32).view(np.int32), yl.numpy().reshape(rows, Cn).view(np.int32)), ci
+        assert ties >= rows // 2
+        c = f"ln{ci}_"
+        out[c + "q"], out[c + "s"] = q.reshape(rows, Cn).astype(np.int8), s
+        out[c + "gamma"], out[c + "beta"] = gamma, beta
+        out[c + "y_bits"] = yl.numpy().reshape(rows, Cn).view(np.int32)
+        out[c + "range"] = np.array([-hi, hi], np.float32)
+        out[c + "q_out"] = torch.round(yq / sq).numpy().reshape(rows, Cn).astype(np.int32)
+    out["ln_cases"] = np.arange(5, dtype=np.int32)
+    # --- IVITIntGELU
+    for ci, (rows, L, s) in enumerate([(16, 768, scales[0]), (8, 3072, scales[1]), (8, 1536, scales[2]), (8, 256, scales[3])]):
+        g = rq.IVITIntGELU()
+        q = rng.integers(-128, 128, size=(1, rows, L)).astype(np.int32)
+        if ci == 3:
+            q[0, :, :] = np.arange(-128, 128)
+        yg, sg = g((torch.from_numpy(q.astype(np.float32)) * torch.tensor([s])).float(), torch.tensor([s]))
+        ref = torch.round(yg / sg).numpy().reshape(rows, L).astype(np.int32)
+        mine, _ = orc.shiftgelu_compat(q.reshape(rows, L), s)
+        assert np.array_equal(mine, ref), ci
+        c = f"gelu{ci}_"
+        out[c + "q"], out[c + "s"], out[c + "out"] = q.reshape(rows, L).astype(np.int8), s, ref
+    out["gelu_cases"] = np.arange(4, dtype=np.int32)
+    # --- IVITIntSoftmax
+    for ci, (rows, L, s, sd) in enumerate([(64, 197, scales[3], 30), (64, 197, scales[1], 50), (32, 49, np.float32(0.271), 25),
+                                           (16, 197, np.float32(0.9113), 8), (16, 64, scales[0], 60)]):
+        sm = rq.IVITIntSoftmax()
+        q = np.clip(np.rint(rng.normal(0, sd, size=(1, 1, rows, L))), -128, 127).astype(np.int32)
+        q[0, 0, 0, :] = 7
+        q[0, 0, 1, :] = -128
+        q[0, 0, 1, 3] = 127
+        ys, ss = sm((torch.from_numpy(q.astype(np.float32)) * torch.tensor([s])).float(), torch.tensor([s]))
+        ref = torch.round(ys / ss).numpy().reshape(rows, L).astype(np.int32)
+        mine = orc.shiftmax_compat(q.reshape(rows, L), s)
+        assert np.array_equal(mine, ref), ci
+        c = f"sm{ci}_"
+        out[c + "q"], out[c + "s"], out[c + "out"] = q.reshape(rows, L).astype(np.int8), s, ref
+    out["sm_cases"] = np.arange(5, dtype=np.int32)
+    np.savez_compressed(os.path.join(GOLD, "compat_kat.npz"), **out)
+    print("compat_kat.npz written:", len(out), "arrays; compat oracle bit-equal to the reference modules on all cases")
+
+
 def gen_schema():
     """state_dict keys and shapes of the reference's DeiT and Swin models (the on-disk checkpoint format)"""
     out = {}
@@ -525,10 +699,14 @@ if __name__ == "__main__":
     for w in what:
         if w == "ops":
             gen_ops()
+        elif w == "compat_ops":
+            gen_compat_ops()
         elif w == "ibert_ops":
             gen_ibert_ops()
         elif w == "schema":
             gen_schema()
+        elif w.endswith("_natural"):
+            gen_natural(w)
         elif w.startswith("swin"):
             gen_swin(w)
         else:
