@@ -26,6 +26,9 @@ SIGNATURES = {
     "ivit_gemm_i8_requant_residual": [vp, i64, vp, i64, vp, vp, vp, vp, i64, u32, i32, u32, i32, vp, i64, ci, ci, ci, vp],
     "ivit_attention_fused_i8_ex": [vp, vp, ci, ci, ci, ci, u32, i32, f32, u32, i32, ci, vp],
     "ivit_layernorm_i8_ex": [vp, i64, ci, ci, vp, vp, vp, vp, vp, i64, ci, vp],
+    "ivit_layernorm_i8_compat": [vp, i64, ci, ci, vp, vp, vp, vp, vp, vp, vp, i64, ci, vp],
+    "ivit_attention_fused_i8_compat": [vp, vp, ci, ci, ci, ci, u32, i32, f32, u32, i32, vp, ci, vp],
+    "ivit_shiftgelu_build_lut_ex": [f32, u32, i32, vp, vp, vp],
     "ivit_shiftgelu_lut_i8_ex": [vp, i64, ci, ci, vp, vp, i64, ci, vp],
     "ivit_tile_operand_i8": [vp, i64, i64, ci, vp, vp],
     "ivit_untile_operand_i8": [vp, i64, ci, vp, i64, vp],
@@ -42,6 +45,8 @@ SIGNATURES = {
     "ivit_attention_fused_i8": [vp, vp, ci, ci, ci, ci, u32, i32, f32, u32, i32, vp],
     "ivit_layernorm_i8": [vp, i64, ci, ci, vp, vp, vp, vp, vp, i64, vp],
     "ivit_layernorm_i32_f32": [vp, i64, ci, ci, vp, vp, vp, i64, vp],
+    "ivit_layernorm_f32_f32": [vp, i64, ci, ci, vp, ci, vp, vp, vp, i64, vp],
+    "ivit_shiftmax_f32_i8": [vp, i64, ci, ci, f32, vp, i64, vp],
     "ivit_shiftgelu_i8": [vp, i64, ci, ci, f32, u32, i32, vp, i64, vp],
     "ivit_shiftgelu_i8_i32": [vp, i64, ci, ci, f32, vp, i64, vp],
     "ivit_shiftgelu_build_lut": [f32, u32, i32, vp, vp],

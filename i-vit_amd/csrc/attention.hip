@@ -40,6 +40,11 @@ struct AttnArgs {
     int x0;    // floor(-1/s_attn)
     int ksat;  // first table index whose argument is clamped at n*x0: every later entry is identical
     int out_blocks;   // output in the GEMM block layout (common.h: ivit_block_offset), row length heads * 64
+    // natural-scale ("compat") Shiftmax: exp_int as a function of (row max q, q), [256][256] u32 indexed
+    // (qmax + 128) * 256 + (q + 128).  The reference's Shiftmax runs its whole float32 sequence on phi(q) = fl(fl(q*s)/s)
+    // (ivit_modules.py:165-170; the .to(int32) of :166 is discarded), so the exponent is no longer a function of qmax - q
+    // alone; the host tabulates it with the reference's float32 steps (prepare.shiftexp2d).  NULL: power-of-two scale.
+    const unsigned* exp2d;
 };
 
 // K image: 64-byte rows; 16-byte chunk c of row r at slot (c + 2*((r>>2)&1)) & 3.  A 16x16x64 fragment read has
@@ -139,6 +144,19 @@ __global__ __launch_bounds__(NT, 3) void attention_kernel(AttnArgs a)
         // k - max is in [-255, 0] for every real key: the 256-entry table covers it without a clamp (the entries from
         // ksat on are identical anyway); only the padding keys of the last tile carry the -1000 sentinel
         unsigned esum = 0;
+        if (a.exp2d) {      // wave-uniform; one L2-resident gather per score instead of the LDS lookup
+            const unsigned* row2d = a.exp2d + ((rmax + 128) << 8) + 128;       // entry of q = -nk
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int nk = s[kt][r];
+                    unsigned e = row2d[-min(nk, 128)];
+                    if (kt == NKT - 1) e = (nk == 1000) ? 0u : e;
+                    s[kt][r] = (int)e;
+                    esum += e;
+                }
+        } else
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
@@ -215,6 +233,14 @@ IVIT_EXPORT int ivit_attention_fused_i8_ex(const int8_t* qkv, int8_t* out, int b
                                         int head_dim, uint32_t m_s, int32_t e_s, float s_attn, uint32_t m_o,
                                         int32_t e_o, int out_blocks, ivit_stream_t stream)
 {
+    return ivit_attention_fused_i8_compat(qkv, out, batch, heads, tokens, head_dim, m_s, e_s, s_attn, m_o, e_o, nullptr,
+                                          out_blocks, stream);
+}
+
+IVIT_EXPORT int ivit_attention_fused_i8_compat(const int8_t* qkv, int8_t* out, int batch, int heads, int tokens,
+                                               int head_dim, uint32_t m_s, int32_t e_s, float s_attn, uint32_t m_o,
+                                               int32_t e_o, const uint32_t* exp2d, int out_blocks, ivit_stream_t stream)
+{
     IVIT_REQUIRE(qkv && out, "ivit_attention_fused_i8: NULL operand");
     IVIT_REQUIRE(batch > 0 && heads > 0, "ivit_attention_fused_i8: empty batch");
     if (head_dim != HD || tokens <= 16 * (NKT - 1) || tokens > KP) {
@@ -228,7 +254,9 @@ IVIT_EXPORT int ivit_attention_fused_i8_ex(const int8_t* qkv, int8_t* out, int b
     IVIT_REQUIRE(out_blocks == 0 || (out_blocks == 1 && ((uintptr_t)out % 16 == 0) &&
                                      ((int64_t)batch * tokens + 15) * heads * head_dim < 2147483648ll),
                  "ivit_attention_fused_i8_ex: bad output layout (block-layout buffers stay below 2 GiB)");
+    IVIT_REQUIRE((uintptr_t)exp2d % 4 == 0, "ivit_attention_fused_i8_compat: misaligned exponent table");
     AttnArgs a;
+    a.exp2d = exp2d;
     a.out_blocks = out_blocks;
     a.qkv = qkv; a.out = out; a.batch = batch; a.heads = heads; a.tokens = tokens;
     a.Ms = ivit_dyadic_to_double(m_s, e_s);

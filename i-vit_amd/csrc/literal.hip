@@ -1,0 +1,186 @@
+// literal.hip -- the module-level (float view in, float / int8 out) forms of I-LayerNorm and Shiftmax that restate the
+// reference's float32 sequence step by step, for ANY input scale.
+//
+// The reference's operators receive x = q * s (float32, quant_modules.py:387) and start with x / s (ivit_modules.py:36,
+// 165).  For a power-of-two s that quotient is the integer q and the integer kernels of rowops.hip apply; for a scale "as
+// calibrated" it is phi = fl(fl(q*s)/s), a float32 next to q, and
+//   * IVITIntLayerNorm takes the MEAN over the phi values in float32 (torch's CPU reduction order decides exact .5
+//     ties) before truncating them with .to(int32) (:37-38);
+//   * IVITIntSoftmax discards its .to(int32) (:166) and runs the whole float32 sequence on phi.
+// The module mirror (quantization_utils/ivit_modules.py) calls these kernels; the fused engine carries the same effect as
+// 256-entry tables in front of its integer kernels (ivit_layernorm_i8_compat, ivit_attention_fused_i8_compat).
+// One wave per row; every arithmetic step is one IEEE float32 operation (-ffp-contract=off, correctly rounded division).
+#include "common.h"
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int WPB = NT / 64;
+
+// float32 sum of elem(0..n-1) in the order of torch's CPU sum kernel (ATen native/cpu/SumKernel.cpp: vectorized_inner_sum ->
+// row_sum -> multi_row_sum, 8-float vectors x 4 accumulator rows, 4-level cascade; oracle/ivit_oracle.c
+// ivo_torch_rowsum_f32 is the checked restatement).  Whole wave calls it; the result is wave-uniform.
+template <class F>
+IVIT_DEV float torch_rowsum(F elem, int n, int lane)
+{
+    if (n < 8) {   // scalar_inner_sum: four scalar accumulators
+        float fin = 0.f;
+        if (lane == 0) {
+            float ps[4] = {0.f, 0.f, 0.f, 0.f};
+            const int size_ilp = n >> 2;
+            for (int i = 0; i < size_ilp; ++i)
+                for (int k = 0; k < 4; ++k) ps[k] += elem(i * 4 + k);
+            for (int i = size_ilp * 4; i < n; ++i) ps[0] += elem(i);
+            for (int k = 1; k < 4; ++k) ps[0] += ps[k];
+            fin = ps[0];
+        }
+        return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(fin), 0));
+    }
+    const int vec_size = n >> 3, size_ilp = vec_size >> 2;
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+    if (lane < 32) {
+        int lg = 0;
+        while ((1 << lg) < size_ilp) ++lg;
+        const int lp = max(4, lg / 4), step = 1 << lp, mask = step - 1;
+        int i = 0;
+        while (i + step <= size_ilp) {
+            for (int j = 0; j < step; ++j, ++i) acc0 += elem(i * 32 + lane);
+            acc1 += acc0; acc0 = 0.f;
+            if ((i & (mask << lp)) == 0) {
+                acc2 += acc1; acc1 = 0.f;
+                if ((i & (mask << (2 * lp))) == 0) { acc3 += acc2; acc2 = 0.f; }
+            }
+        }
+        for (; i < size_ilp; ++i) acc0 += elem(i * 32 + lane);
+        acc0 += acc1; acc0 += acc2; acc0 += acc3;
+    }
+    if (lane < 8)
+        for (int i = size_ilp * 4; i < vec_size; ++i) acc0 += elem(i * 8 + lane);
+    const float p1 = __shfl(acc0, (lane + 8) & 63), p2 = __shfl(acc0, (lane + 16) & 63), p3 = __shfl(acc0, (lane + 24) & 63);
+    const float v = ((acc0 + p1) + p2) + p3;
+    float fin = 0.f;
+    for (int i = vec_size * 8; i < n; ++i) fin += elem(i);
+#pragma unroll
+    for (int l = 0; l < 8; ++l) fin += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+    return fin;
+}
+
+struct LnLitArgs {
+    const float* x;
+    int64_t ldx;
+    int rows, C;
+    const float* s_in;
+    int n_s;
+    const float* bias_int;
+    const float* s_ln;
+    float* out;
+    int64_t ldo;
+};
+
+// IVITIntLayerNorm.forward, ivit_modules.py:36-63, line by line
+__global__ __launch_bounds__(NT) void layernorm_f32_f32_kernel(LnLitArgs a)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int C = a.C;
+    for (int row = blockIdx.x * WPB + wave; row < a.rows; row += gridDim.x * WPB) {
+        const float* xr = a.x + (int64_t)row * a.ldx;
+        auto xint = [&](int c) { return xr[c] / a.s_in[a.n_s == 1 ? 0 : c]; };   // :36  x / scaling_factor
+        const float S = torch_rowsum(xint, C, lane);
+        const float mean = S / (float)C;                                          // :37  mean = sum / C
+        const int mean_int = (int)rintf(mean);                                    //      round_ste
+        long long var = 0;
+        for (int c = lane; c < C; c += 64) {
+            const long long d = (long long)(int)truncf(xint(c)) - mean_int;       // :38-40  .to(int32); y = x - mean
+            var += d * d;                                                         // :41-42  int32 squares, int64 sum
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const int vlo = __shfl_xor((int)(var & 0xffffffffll), o);
+            const int vhi = __shfl_xor((int)(var >> 32), o);
+            var += ((long long)vhi << 32) | (unsigned)vlo;
+        }
+        const float varf = (float)var;
+        float t = 65536.0f;                                                        // :45-49
+#pragma unroll 1
+        for (int it = 0; it < 10; ++it) t = floorf((t + floorf(varf / t)) * 0.5f);
+        const float factor = floorf((1.0f / t) * 2147483648.0f);                  // :51
+        for (int c = lane; c < C; c += 64) {
+            const float dl = (float)((int)truncf(xint(c)) - mean_int);
+            const float v = floorf((dl * factor) * 0.5f);                         // :52
+            const float y = v + a.bias_int[c];                                    // :61
+            a.out[(int64_t)row * a.ldo + c] = y * a.s_ln[c];                      // :63
+        }
+    }
+}
+
+struct SmLitArgs {
+    const float* x;
+    int64_t ldx;
+    int rows, L;
+    float s, x0;
+    int8_t* out;
+    int64_t ldo;
+};
+
+// int_exp_shift on a float32 argument, ivit_modules.py:150-162 verbatim (n = 15)
+IVIT_DEV float shiftexp_lit(float d, float x0)
+{
+    float x = (d + floorf(d / 2.0f)) - floorf(d / 16.0f);     // :151
+    x = fmaxf(x, 15.0f * x0);                                  // :155
+    const float q = floorf(x / x0);                            // :157
+    const float r = x - x0 * q;                                // :158
+    float ex = r / 2.0f - x0;                                  // :159
+    ex = floorf(ex * ldexpf(1.0f, 15 - (int)q));               // :160
+    return fmaxf(ex, 0.0f);
+}
+
+// IVITIntSoftmax.forward, ivit_modules.py:164-176, line by line (output_bit = 8)
+__global__ __launch_bounds__(NT) void shiftmax_f32_i8_kernel(SmLitArgs a)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int row = blockIdx.x * WPB + wave; row < a.rows; row += gridDim.x * WPB) {
+        const float* xr = a.x + (int64_t)row * a.ldx;
+        float xmax = -__builtin_inff();
+        for (int i = lane; i < a.L; i += 64) xmax = fmaxf(xmax, xr[i] / a.s);     // :165, :167
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) xmax = fmaxf(xmax, __shfl_xor(xmax, o));
+        auto ex = [&](int i) { return shiftexp_lit(xr[i] / a.s - xmax, a.x0); };  // :168-170
+        float S = torch_rowsum(ex, a.L, lane);                                    // :171
+        S = fminf(S, 2147483648.0f);                                              // :173
+        const float factor = floorf((1.0f / S) * 2147483648.0f);                  // :174
+        for (int i = lane; i < a.L; i += 64)
+            a.out[(int64_t)row * a.ldo + i] = (int8_t)floorf((ex(i) * factor) / 16777216.0f);   // :175
+    }
+}
+
+static inline int rows_grid(int64_t rows)
+{
+    int64_t b = (rows + WPB - 1) / WPB;
+    return (int)(b < 8192 ? b : 8192);
+}
+
+}  // namespace
+
+IVIT_EXPORT int ivit_layernorm_f32_f32(const float* x, int64_t ldx, int rows, int C, const float* s_in, int n_s,
+                                       const float* bias_int, const float* s_ln, float* out, int64_t ldo,
+                                       ivit_stream_t stream)
+{
+    IVIT_REQUIRE(x && s_in && bias_int && s_ln && out, "ivit_layernorm_f32_f32: NULL operand");
+    IVIT_REQUIRE(rows > 0 && C > 0 && C <= 16384 && ldx >= C && ldo >= C && (n_s == 1 || n_s == C),
+                 "ivit_layernorm_f32_f32: bad shape rows=%d C=%d n_s=%d", rows, C, n_s);
+    LnLitArgs a{x, ldx, rows, C, s_in, n_s, bias_int, s_ln, out, ldo};
+    hipLaunchKernelGGL(layernorm_f32_f32_kernel, dim3(rows_grid(rows)), dim3(NT), 0, ivit_stream(stream), a);
+    IVIT_CHECK_LAUNCH("ivit_layernorm_f32_f32");
+}
+
+IVIT_EXPORT int ivit_shiftmax_f32_i8(const float* x, int64_t ldx, int rows, int L, float s, int8_t* out, int64_t ldo,
+                                     ivit_stream_t stream)
+{
+    IVIT_REQUIRE(x && out && rows > 0 && L > 0 && ldx >= L && ldo >= L, "ivit_shiftmax_f32_i8: bad operand");
+    IVIT_REQUIRE(s > 0.0f, "ivit_shiftmax_f32_i8: scale must be positive");
+    const float x0 = __builtin_floorf((1.0f / s) * -1.0f);      // ivit_modules.py:154
+    IVIT_REQUIRE(x0 <= -1.0f && x0 >= -1048576.0f, "ivit_shiftmax_f32_i8: x0=%g out of range", (double)x0);
+    SmLitArgs a{x, ldx, rows, L, s, x0, out, ldo};
+    hipLaunchKernelGGL(shiftmax_f32_i8_kernel, dim3(rows_grid(rows)), dim3(NT), 0, ivit_stream(stream), a);
+    IVIT_CHECK_LAUNCH("ivit_shiftmax_f32_i8");
+}

@@ -51,6 +51,10 @@ struct LnArgs {
     void* out;
     int64_t ldo;
     int out_blocks;   // int8 output in the GEMM block layout (common.h: ivit_block_offset), row length C
+    // natural-scale ("compat") inputs, ivit_layernorm_i8_compat: the reference's LayerNorm does not see the integer q its
+    // input QuantAct produced but phi(q) = fl(fl(q*s)/s) (quant_modules.py:387, ivit_modules.py:36)
+    const int8_t* remap;   // [256] k'(q) = trunc(phi(q)), indexed q + 128   (ivit_modules.py:38 .to(int32))
+    const float* phi;      // [256] phi(q), indexed q + 128                  (the mean, :37, is taken over these)
 };
 
 // Per-row statistics exactly as ivit_modules.py:36-51 computes them.
@@ -74,6 +78,43 @@ IVIT_DEV float ln_factor(long long var)
     return floorf((1.0f / t) * 2147483648.0f);
 }
 
+
+// float32 sum of phi(q_i) over one row in the order torch's CPU sum kernel uses (ATen native/cpu/SumKernel.cpp:
+// vectorized_inner_sum -> row_sum -> multi_row_sum with 8-float vectors and 4 accumulator rows: 32 partial sums, element
+// i goes to partial i % 32 in increasing i with a 4-level cascade, then rows, then the 8 lanes left to right; restated
+// and checked against torch in oracle/ivit_oracle.c ivo_torch_rowsum_f32).  Called by the whole wave for the rare rows
+// whose mean is an exact .5 tie, where this order decides the reference's result.  phi_lds: [256] floats.
+IVIT_DEV float torch_rowsum_phi(const int8_t* qrow, int C, const float* phi_lds, int lane)
+{
+    const int vec_size = C >> 3, size_ilp = vec_size >> 2;
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+    if (lane < 32) {
+        int lg = 0;
+        while ((1 << lg) < size_ilp) ++lg;
+        const int lp = max(4, lg / 4), step = 1 << lp, mask = step - 1;
+        int i = 0;
+        while (i + step <= size_ilp) {
+            for (int j = 0; j < step; ++j, ++i) acc0 += phi_lds[(int)qrow[i * 32 + lane] + 128];
+            acc1 += acc0; acc0 = 0.f;
+            if ((i & (mask << lp)) == 0) {
+                acc2 += acc1; acc1 = 0.f;
+                if ((i & (mask << (2 * lp))) == 0) { acc3 += acc2; acc2 = 0.f; }
+            }
+        }
+        for (; i < size_ilp; ++i) acc0 += phi_lds[(int)qrow[i * 32 + lane] + 128];
+        acc0 += acc1; acc0 += acc2; acc0 += acc3;
+    }
+    if (lane < 8)   // vectors beyond the last group of four join accumulator row 0
+        for (int i = size_ilp * 4; i < vec_size; ++i) acc0 += phi_lds[(int)qrow[i * 8 + lane] + 128];
+    const float p1 = __shfl(acc0, (lane + 8) & 63), p2 = __shfl(acc0, (lane + 16) & 63), p3 = __shfl(acc0, (lane + 24) & 63);
+    const float v = ((acc0 + p1) + p2) + p3;    // lanes 0-7: the 8 vector lanes
+    float fin = 0.f;
+    for (int i = vec_size * 8; i < C; ++i) fin += phi_lds[(int)qrow[i] + 128];
+#pragma unroll
+    for (int l = 0; l < 8; ++l) fin += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+    return fin;
+}
+
 // int8 in -> int8 out, NJ dwords (4 channels each) per lane, per-channel constants kept in registers
 // across the rows a wave processes.
 //
@@ -87,11 +128,23 @@ IVIT_DEV float ln_factor(long long var)
 // ulp 1) while |y * hi| < 2^22; RNE is monotone, so t_lo == t_hi certifies the reference's result.  Products beyond
 // 2^22 saturate the int8 clamp on either side whatever their rounding (float bit patterns are monotone), so they need
 // no separate range test.  A row with any uncertified element (about 1 % of the rows) is redone literally.
-template <int NJ>
+//
+// COMPAT (natural activation scales): the row is seen through phi.  Bytes are remapped to k' = trunc(phi(q)) through a
+// 256-byte LDS table before anything else; the mean is round(fl(sum phi / C)) -- equal to RNE(sum q / C) except on rows
+// whose integer sum is an exact .5 tie (1 in C), where torch's float32 reduction order over the phi values decides and
+// torch_rowsum_phi restates it; everything downstream of (k', mean) is the same arithmetic.
+template <int NJ, bool COMPAT = false>
 __global__ __launch_bounds__(NT, (NJ <= 3 ? 4 : NJ <= 8 ? 2 : 1)) void layernorm_i8_kernel(LnArgs a)
 {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: row addresses in SALU
     const int C = a.C, nd = C >> 2;
+    __shared__ unsigned char s_remap[COMPAT ? 256 : 4];
+    __shared__ float s_phi[COMPAT ? 256 : 1];
+    if constexpr (COMPAT) {
+        s_remap[threadIdx.x] = (unsigned char)a.remap[threadIdx.x];   // NT == 256
+        s_phi[threadIdx.x] = a.phi[threadIdx.x];
+        __syncthreads();
+    }
     float bias[NJ][4], lo[NJ][4], hi[NJ][4];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
@@ -133,16 +186,24 @@ __global__ __launch_bounds__(NT, (NJ <= 3 ? 4 : NJ <= 8 ? 2 : 1)) void layernorm
     constexpr int G = (NJ <= 3) ? 8 : (NJ <= 4) ? 4 : 1;
     for (int row0 = (blockIdx.x * WPB + wave) * G; row0 < a.rows; row0 += gridDim.x * WPB * G) {
         int w[G][NJ], sum[G], var[G];   // var[]: sum of squares
+        int sumq[COMPAT ? G : 1];       // COMPAT: integer sum of the un-remapped row (the mean is over phi(q) ~ q)
 #pragma unroll
         for (int rr = 0; rr < G; ++rr) {
             const int row = min(row0 + rr, a.rows - 1);
             const int* xr = reinterpret_cast<const int*>(xin + (int64_t)row * a.ldx);
             sum[rr] = 0;
             var[rr] = 0;
+            if constexpr (COMPAT) sumq[rr] = 0;
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 int d = lane + 64 * j;
                 w[rr][j] = (d < nd) ? xr[d] : 0;
+                if constexpr (COMPAT) {
+                    sumq[rr] = __builtin_amdgcn_sdot4(w[rr][j], 0x01010101, sumq[rr], false);
+                    const unsigned u = (unsigned)w[rr][j] ^ 0x80808080u;      // q + 128 per byte
+                    w[rr][j] = (int)((unsigned)s_remap[u & 255] | ((unsigned)s_remap[(u >> 8) & 255] << 8) |
+                                     ((unsigned)s_remap[(u >> 16) & 255] << 16) | ((unsigned)s_remap[u >> 24] << 24));
+                }
                 // v_dot4_i32_i8: sum and sum of squares of the 4 int8 of a dword, one instruction each
                 sum[rr] = __builtin_amdgcn_sdot4(w[rr][j], 0x01010101, sum[rr], false);
                 var[rr] = __builtin_amdgcn_sdot4(w[rr][j], w[rr][j], var[rr], false);   // <= 4096 * 128^2 = 2^26
@@ -154,6 +215,7 @@ __global__ __launch_bounds__(NT, (NJ <= 3 ? 4 : NJ <= 8 ? 2 : 1)) void layernorm
             for (int rr = 0; rr < G; ++rr) {
                 sum[rr] += __shfl_xor(sum[rr], o);
                 var[rr] += __shfl_xor(var[rr], o);
+                if constexpr (COMPAT) sumq[rr] += __shfl_xor(sumq[rr], o);
             }
         // lane rr: statistics of row rr, computed once.  mean_int as the reference (:37); the variance sum (:40-42)
         // sum_c (x_c - mean)^2 = sum x^2 - 2*mean*sum x + C*mean^2 exactly, in integers (all terms < 2^31)
@@ -164,7 +226,26 @@ __global__ __launch_bounds__(NT, (NJ <= 3 ? 4 : NJ <= 8 ? 2 : 1)) void layernorm
             my_sq = (lane == rr) ? var[rr] : my_sq;
         }
         int my_mean;
-        ln_mean(my_sum, C, my_mean);
+        if constexpr (COMPAT) {
+            int my_sumq = sumq[0];
+#pragma unroll
+            for (int rr = 1; rr < G; ++rr) my_sumq = (lane == rr) ? sumq[rr] : my_sumq;
+            ln_mean(my_sumq, C, my_mean);      // = round(fl(sum phi / C)) unless the row is a tie (|sum phi - sum q| < 0.3)
+            // 2*sum - C == 0 (mod 2C)  <=>  the mean is an exact .5 tie; one unit of slack on either side
+            int r2 = (2 * my_sumq - C) % (2 * C);
+            r2 = r2 < 0 ? r2 + 2 * C : r2;
+            const bool tie = (r2 <= 2 || r2 >= 2 * C - 2) && lane < G && row0 + lane < a.rows;
+            unsigned long long tm = __builtin_amdgcn_ballot_w64(tie);
+            while (tm) {                       // wave-uniform: rows decided by the float32 reduction order
+                const int rr = __builtin_ctzll(tm);
+                tm &= tm - 1;
+                const float S = torch_rowsum_phi(xin + (int64_t)(row0 + rr) * a.ldx, C, s_phi, lane);
+                const int fixed = (int)rintf(S / (float)C);     // ivit_modules.py:37
+                my_mean = (lane == rr) ? fixed : my_mean;
+            }
+        } else {
+            ln_mean(my_sum, C, my_mean);
+        }
         const int my_var = my_sq - 2 * my_mean * my_sum + C * my_mean * my_mean;
         int mean_int[G];
 #pragma unroll
@@ -465,6 +546,7 @@ struct GeluArgs {
     int64_t ldo;
     int out_blocks;   // output in the GEMM block layout (common.h: ivit_block_offset), row length L
     int in_blocks;    // input in the block layout (table form only)
+    const int8_t* remap;   // table build only, may be NULL: k'(q) = trunc(phi(q)) for a natural input scale (ivit_modules.py:106-107)
 };
 
 // direct arithmetic; OUT_I32: module-level int32 output k*sig, else fused requant -> int8
@@ -497,9 +579,14 @@ __global__ __launch_bounds__(NT) void shiftgelu_kernel(GeluArgs a)
 __global__ __launch_bounds__(NT) void shiftgelu_lut_kernel(GeluArgs a)
 {
     const int idx = blockIdx.x * NT + threadIdx.x;  // 65536 entries
-    const int kmax = (idx >> 8) - 128, k = (idx & 255) - 128;
+    int kmax = (idx >> 8) - 128, k = (idx & 255) - 128;
     int8_t r = 0;
-    if (k <= kmax) {
+    const bool used = k <= kmax;
+    if (a.remap) {      // the row maximum of k' is k'(max q): trunc(phi) is monotone
+        kmax = a.remap[kmax + 128];
+        k = a.remap[k + 128];
+    }
+    if (used) {
         // exp_int(-kmax): int_exp_shift clamps at n*x0, positive arguments included (:95 torch.max)
         float em = shiftexp_f32(-kmax, a.x0, 23);
         float e = shiftexp_f32(k - kmax, a.x0, 23);
@@ -947,7 +1034,7 @@ IVIT_EXPORT int ivit_layernorm_i8_ex(const int8_t* x, int64_t ldx, int rows, int
     IVIT_REQUIRE(out_blocks == 0 || (out_blocks == 1 && C % 64 == 0 && ldo == C && ((uintptr_t)out % 16 == 0) &&
                                      ((int64_t)rows + 15) * C < 2147483648ll),
                  "ivit_layernorm_i8_ex: block-layout output needs C %% 64 == 0, ldo == C and a buffer below 2 GiB");
-    LnArgs a{x, ldx, rows, C, bias_int, s_ln, m, e, out, ldo, out_blocks};
+    LnArgs a{x, ldx, rows, C, bias_int, s_ln, m, e, out, ldo, out_blocks, nullptr, nullptr};
     hipStream_t st = ivit_stream(stream);
     // half a wave per row (constants in LDS, 3 * C floats) where it is the faster form: measured 17.5 vs 20.7 us at
     // C = 384 and 14.0 vs 14.9 us at C = 192, but 36 vs 30 us at C = 768 (rows = 50 432)
@@ -978,6 +1065,36 @@ IVIT_EXPORT int ivit_layernorm_i8_ex(const int8_t* x, int64_t ldx, int rows, int
     IVIT_CHECK_LAUNCH("ivit_layernorm_i8");
 }
 
+IVIT_EXPORT int ivit_layernorm_i8_compat(const int8_t* x, int64_t ldx, int rows, int C, const float* bias_int,
+                                         const float* s_ln, const uint32_t* m, const int32_t* e, const int8_t* remap,
+                                         const float* phi, int8_t* out, int64_t ldo, int out_blocks, ivit_stream_t stream)
+{
+    IVIT_REQUIRE(x && out && bias_int && s_ln && m && e && remap && phi, "ivit_layernorm_i8_compat: NULL operand");
+    IVIT_REQUIRE(rows > 0 && C >= 32 && C % 8 == 0 && C <= 4096, "ivit_layernorm_i8_compat: rows=%d C=%d unsupported", rows, C);
+    IVIT_REQUIRE(ldx % 4 == 0 && ldo % 4 == 0 && ldx >= C && ldo >= C && ((uintptr_t)x % 4 == 0) &&
+                     ((uintptr_t)out % 4 == 0),
+                 "ivit_layernorm_i8_compat: rows must be 4-byte aligned");
+    IVIT_REQUIRE(((uintptr_t)bias_int % 16 == 0) && ((uintptr_t)s_ln % 16 == 0) && ((uintptr_t)m % 16 == 0) &&
+                     ((uintptr_t)e % 16 == 0) && ((uintptr_t)phi % 4 == 0),
+                 "ivit_layernorm_i8_compat: per-channel tables must be 16-byte aligned");
+    IVIT_REQUIRE(out_blocks == 0 || (out_blocks == 1 && C % 64 == 0 && ldo == C && ((uintptr_t)out % 16 == 0) &&
+                                     ((int64_t)rows + 15) * C < 2147483648ll),
+                 "ivit_layernorm_i8_compat: block-layout output needs C %% 64 == 0, ldo == C and a buffer below 2 GiB");
+    LnArgs a{x, ldx, rows, C, bias_int, s_ln, m, e, out, ldo, out_blocks, remap, phi};
+    hipStream_t st = ivit_stream(stream);
+    const int nj = (C / 4 + 63) / 64;
+    const int resident = 256 * (nj <= 1 ? 6 : nj <= 3 ? 4 : nj <= 4 ? 3 : nj <= 8 ? 2 : 1);
+    int grid = grid_for_rows(rows, nj <= 3 ? 8 : nj <= 4 ? 4 : 1);
+    if (grid > resident) grid = resident;
+    if (nj <= 1) hipLaunchKernelGGL((layernorm_i8_kernel<1, true>), dim3(grid), dim3(NT), 0, st, a);
+    else if (nj <= 2) hipLaunchKernelGGL((layernorm_i8_kernel<2, true>), dim3(grid), dim3(NT), 0, st, a);
+    else if (nj <= 3) hipLaunchKernelGGL((layernorm_i8_kernel<3, true>), dim3(grid), dim3(NT), 0, st, a);
+    else if (nj <= 4) hipLaunchKernelGGL((layernorm_i8_kernel<4, true>), dim3(grid), dim3(NT), 0, st, a);
+    else if (nj <= 8) hipLaunchKernelGGL((layernorm_i8_kernel<8, true>), dim3(grid), dim3(NT), 0, st, a);
+    else hipLaunchKernelGGL((layernorm_i8_kernel<16, true>), dim3(grid), dim3(NT), 0, st, a);
+    IVIT_CHECK_LAUNCH("ivit_layernorm_i8_compat");
+}
+
 IVIT_EXPORT int ivit_layernorm_i8(const int8_t* x, int64_t ldx, int rows, int C, const float* bias_int,
                                   const float* s_ln, const uint32_t* m, const int32_t* e, int8_t* out, int64_t ldo,
                                   ivit_stream_t stream)
@@ -990,7 +1107,7 @@ IVIT_EXPORT int ivit_layernorm_i32_f32(const int32_t* x, int64_t ldx, int rows, 
 {
     IVIT_REQUIRE(x && out && bias_int && s_ln, "ivit_layernorm_i32_f32: NULL operand");
     IVIT_REQUIRE(rows > 0 && C > 0 && C <= 4096 && ldx >= C && ldo >= C, "ivit_layernorm_i32_f32: bad shape");
-    LnArgs a{x, ldx, rows, C, bias_int, s_ln, nullptr, nullptr, out, ldo, 0};
+    LnArgs a{x, ldx, rows, C, bias_int, s_ln, nullptr, nullptr, out, ldo, 0, nullptr, nullptr};
     hipLaunchKernelGGL(layernorm_i32_f32_kernel, dim3(grid_for_rows(rows)), dim3(NT), 0, ivit_stream(stream), a);
     IVIT_CHECK_LAUNCH("ivit_layernorm_i32_f32");
 }
@@ -1023,9 +1140,16 @@ IVIT_EXPORT int ivit_shiftgelu_i8_i32(const int8_t* x, int64_t ldx, int rows, in
 
 IVIT_EXPORT int ivit_shiftgelu_build_lut(float s, uint32_t m, int32_t e, int8_t* lut, ivit_stream_t stream)
 {
+    return ivit_shiftgelu_build_lut_ex(s, m, e, nullptr, lut, stream);
+}
+
+IVIT_EXPORT int ivit_shiftgelu_build_lut_ex(float s, uint32_t m, int32_t e, const int8_t* remap, int8_t* lut,
+                                            ivit_stream_t stream)
+{
     IVIT_REQUIRE(lut, "ivit_shiftgelu_build_lut: NULL table");
     GeluArgs a{};
     a.out = lut;
+    a.remap = remap;
     a.Mq = ivit_dyadic_to_double(m, e);
     IVIT_REQUIRE(a.Mq < 65536.0, "ivit_shiftgelu_build_lut: requant multiplier too large");
     int rc = gelu_x0(s, "ivit_shiftgelu_build_lut", &a.x0);

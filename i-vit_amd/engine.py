@@ -22,7 +22,7 @@ import torch
 
 from . import _lib
 from .graph import GraphReplay
-from .prepare import dyadic, f32, pad_head, quant_sym, requant_host
+from .prepare import dyadic, f32, pad_head, phi_tables, quant_sym, requant_host, shiftexp2d
 from .synth import IMG_SIZE, NUM_PATCHES, NUM_TOKENS, PATCH
 
 
@@ -62,14 +62,25 @@ class IntViTEngine(GraphReplay):
             m, e = lp.requant_to(s_out)
             return dict(W=dev(lp.W8), b=dev(lp.b32), m=dev(m.view(np.int32)), e=dev(e), K=lp.K, N=lp.W8.shape[0], Wb=None)
 
-        def ln_dev(prefix, s_out):
+        def phi_dev(s_in):
+            """natural (non power-of-two) scale of an operator's input: the reference's operator sees phi(q) = fl(fl(q*s)/s),
+            not q (prepare.py).  -> (remap int8[256], phi f32[256]) on the device, or (None, None) when phi is the identity"""
+            t = phi_tables(s_in)
+            if t is None:
+                return None, None
+            self.natural_sites += 1
+            return dev(t[0]), dev(t[1])
+
+        def ln_dev(prefix, s_out, s_in):
             lp = source.layernorm(prefix, s_out)
-            return dict(bias=dev(lp.bias_int), s=dev(lp.s_ln), m=dev(lp.m.view(np.int32)), e=dev(lp.e))
+            remap, phi = phi_dev(s_in)
+            return dict(bias=dev(lp.bias_int), s=dev(lp.s_ln), m=dev(lp.m.view(np.int32)), e=dev(lp.e), remap=remap, phi=phi)
 
         def scalar_me(pre, z):
             m, e = dyadic(pre, z)
             return int(m[0]), int(e[0])
 
+        self.natural_sites = 0     # operators whose input scale is not a power of two (compat kernels / tables)
         # ---- stem
         s0 = s("qact_input")
         self.inv_s0 = float(f32(1.0) / s0)
@@ -94,27 +105,31 @@ class IntViTEngine(GraphReplay):
             p = f"blocks.{i}."
             blk = {}
             s_q1 = s(p + "qact1")
-            blk["ln1"] = ln_dev(p + "norm1", s_q1)
+            blk["ln1"] = ln_dev(p + "norm1", s_q1, s_x)
             s_a1 = s(p + "attn.qact1")
             blk["qkv"] = lin_dev(source.linear(p + "attn.qkv", s_q1), s_a1)
             s_S = f32(f32(s_a1 * s_a1) * f32(hd ** -0.5))                 # vit_quant.py:72-75
             s_at = s(p + "attn.qact_attn1")
             s_pv = f32(f32(1.0 / 128.0) * s_a1)                           # Shiftmax scale 2^-7 x value scale
             s_a2 = s(p + "attn.qact2")
-            blk["attn"] = dict(ms=scalar_me(s_S, s_at), s_attn=float(s_at), mo=scalar_me(s_pv, s_a2))
+            blk["attn"] = dict(ms=scalar_me(s_S, s_at), s_attn=float(s_at), mo=scalar_me(s_pv, s_a2), exp2d=None)
+            if phi_tables(s_at) is not None:       # Shiftmax on phi(q): exponent tabulated over (row max, q)
+                self.natural_sites += 1
+                blk["attn"]["exp2d"] = dev(shiftexp2d(s_at).view(np.int32))
             s_a3 = s(p + "attn.qact3")
             blk["proj"] = lin_dev(source.linear(p + "attn.proj", s_a2), s_a3)
             s_b2 = s(p + "qact2")
             blk["res1"] = scalar_me(s_a3, s_b2) + scalar_me(s_x, s_b2)
             s_b3 = s(p + "qact3")
-            blk["ln2"] = ln_dev(p + "norm2", s_b3)
+            blk["ln2"] = ln_dev(p + "norm2", s_b3, s_b2)
             s_g = s(p + "mlp.qact_gelu")
             blk["fc1"] = lin_dev(source.linear(p + "mlp.fc1", s_b3), s_g)
             s_go = f32(s_g * f32(1.0 / 128.0))                             # ivit_modules.py:121,124
             s_m1 = s(p + "mlp.qact1")
             mg, eg = scalar_me(s_go, s_m1)
             lut = torch.empty(65536, dtype=torch.int8, device=self.dev)
-            _lib.call("ivit_shiftgelu_build_lut", float(s_g), mg, eg, _lib.ptr(lut), self._stream())
+            g_remap, _ = phi_dev(s_g)              # ShiftGELU sees trunc(phi(q)) (ivit_modules.py:106-107)
+            _lib.call("ivit_shiftgelu_build_lut_ex", float(s_g), mg, eg, _lib.ptr(g_remap), _lib.ptr(lut), self._stream())
             blk["gelu_lut"] = lut
             s_m2 = s(p + "mlp.qact2")
             blk["fc2"] = lin_dev(source.linear(p + "mlp.fc2", s_m1), s_m2)
@@ -125,7 +140,7 @@ class IntViTEngine(GraphReplay):
 
         # ---- tail
         s_q2 = s("qact2")
-        self.ln_f = ln_dev("norm", s_q2)
+        self.ln_f = ln_dev("norm", s_q2, s_x)
         head = source.linear("head", s_q2)
         hW, hb, hs, self.num_classes = pad_head(head.W8, head.b32, head.s_acc)    # any class count (num_classes=... of the factory)
         self.head = dict(W=dev(hW), b=dev(hb), K=head.K, N=hW.shape[0])
@@ -213,6 +228,11 @@ class IntViTEngine(GraphReplay):
 
     def _ln(self, x, ldx, rows, ln, out, st, blocks=False):
         C = self.C
+        if ln["remap"] is not None:
+            _lib.call("ivit_layernorm_i8_compat", _lib.ptr(x), ldx, rows, C, _lib.ptr(ln["bias"]), _lib.ptr(ln["s"]),
+                      _lib.ptr(ln["m"]), _lib.ptr(ln["e"]), _lib.ptr(ln["remap"]), _lib.ptr(ln["phi"]), _lib.ptr(out), C,
+                      int(blocks), st)
+            return
         _lib.call("ivit_layernorm_i8_ex", _lib.ptr(x), ldx, rows, C, _lib.ptr(ln["bias"]), _lib.ptr(ln["s"]),
                   _lib.ptr(ln["m"]), _lib.ptr(ln["e"]), _lib.ptr(out), C, int(blocks), st)
 
@@ -260,8 +280,8 @@ class IntViTEngine(GraphReplay):
                       _lib.ptr(q["m"]), _lib.ptr(q["e"]), _lib.ptr(ws["qkv"]), T, H, hd, M, 3 * C, C, qlay | int(a_ln), st)
             tap(p + "attn.qkv_headmajor", ws["qkv"], (3, B, H, T, hd))
             a = blk["attn"]
-            _lib.call("ivit_attention_fused_i8_ex", _lib.ptr(ws["qkv"]), _lib.ptr(ws["ao"]), B, H, T, hd,
-                      a["ms"][0], a["ms"][1], a["s_attn"], a["mo"][0], a["mo"][1], int(a_at), st)
+            _lib.call("ivit_attention_fused_i8_compat", _lib.ptr(ws["qkv"]), _lib.ptr(ws["ao"]), B, H, T, hd,
+                      a["ms"][0], a["ms"][1], a["s_attn"], a["mo"][0], a["mo"][1], _lib.ptr(a["exp2d"]), int(a_at), st)
             tap(p + "attn.qact2", ws["ao"], (B, T, C), a_at)
             self._gemm_res(ws["ao"], C, blk["proj"], x, blk["res1"], x2, M, st, blocks=blk_l, a_blocks=a_at)
             tap(p + "qact2", x2, (B, T, C))

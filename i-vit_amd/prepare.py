@@ -104,3 +104,52 @@ def pad_head(W8: np.ndarray, b32: np.ndarray, s_acc: np.ndarray):
         b32 = np.concatenate([b32, np.full(pad, -2 ** 31, b32.dtype)])
         s_acc = np.concatenate([s_acc, np.ones(pad, s_acc.dtype)])
     return W8, b32, s_acc, N
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Natural ("as calibrated") activation scales.  A QuantAct hands its consumer fl(q*s) (quant_modules.py:387) and the
+# consumer divides by s again (ivit_modules.py:36, 106, 165): it sees phi_s(q) = fl(fl(q*s)/s), a float32 within an ulp or
+# two of q.  round() sites recover q; I-LayerNorm (mean over phi, then trunc), ShiftGELU (trunc) and Shiftmax (phi itself
+# through the whole float32 sequence) do not.  For s = 2^p phi is the identity and none of this is needed.
+def phi_table(s) -> np.ndarray:
+    q = np.arange(-128, 128, dtype=f32)
+    s = f32(s)
+    return ((q * s).astype(f32) / s).astype(f32)
+
+
+def phi_is_identity(s) -> bool:
+    return bool(np.array_equal(phi_table(s), np.arange(-128, 128, dtype=f32)))
+
+
+def phi_tables(s):
+    """-> (remap int8[256] = trunc(phi), phi float32[256]) or None when phi is the identity"""
+    ph = phi_table(s)
+    if np.array_equal(ph, np.arange(-128, 128, dtype=f32)):
+        return None
+    remap = np.trunc(ph).astype(np.int32)
+    assert remap.min() >= -128 and remap.max() <= 127 and np.all(np.diff(remap) >= 0)
+    return remap.astype(np.int8), ph
+
+
+def shiftexp2d(s, n: int = 15) -> np.ndarray:
+    """Shiftmax's exp_int as a function of (row max q, q) at a natural input scale s: the float32 sequence of
+    ivit_modules.py:150-170 evaluated on phi(q) - phi(qmax), step by step in numpy float32 (each operation rounds exactly
+    like the torch CPU op it restates).  uint32 [256, 256], entry [qmax+128, q+128]; entries with q > qmax are unused."""
+    ph = phi_table(s)
+    with np.errstate(over="ignore"):          # the unused q > qmax half overflows in 2^(n-q); it is zeroed below
+        return _shiftexp2d(ph, f32(s), n)
+
+
+def _shiftexp2d(ph, s, n):
+    d = (ph[None, :] - ph[:, None]).astype(f32)                        # :168  x_int - x_int_max
+    x = ((d + np.floor((d / f32(2)).astype(f32))).astype(f32) - np.floor((d / f32(16)).astype(f32))).astype(f32)   # :151
+    x0 = np.floor(-(f32(1.0) / f32(s)))                                # :154  floor(-1.0 / s)
+    x = np.maximum(x, f32(f32(n) * x0))                                # :155
+    qq = np.floor((x / x0).astype(f32))                                # :157
+    r = (x - (x0 * qq).astype(f32)).astype(f32)                        # :158
+    ex = ((r / f32(2)).astype(f32) - x0).astype(f32)                   # :159
+    ex = np.floor((ex * np.ldexp(f32(1.0), (f32(n) - qq).astype(np.int32)).astype(f32)).astype(f32))   # :160
+    ex = np.maximum(ex, f32(0))
+    ex = np.where(np.arange(256)[None, :] <= np.arange(256)[:, None], ex, f32(0))
+    assert np.isfinite(ex).all() and ex.max() < 2.0 ** 32
+    return ex.astype(np.uint32)

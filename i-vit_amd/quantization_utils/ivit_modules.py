@@ -35,10 +35,14 @@ class IVITIntLayerNorm(nn.LayerNorm):
             self._cache = (key, _dev_table(lp.bias_int, x.device), _dev_table(lp.s_ln, x.device))
             self.dim_sqrt = torch.sqrt(torch.tensor(float(C)))
         _, bias_int, s_ln = self._cache
-        k = to_int32(x, scaling_factor, trunc=True)            # :36-38 x / scaling_factor, .to(int32)
+        # the literal kernel: x / scaling_factor, the float32 mean in torch's reduction order, .to(int32), ... (:36-63) for
+        # any input scale (a calibrated, non power-of-two scale makes x / s a non-integer float, see csrc/literal.hip)
+        xin = x.contiguous().float()
+        s_in = scaling_factor.reshape(-1).contiguous().float()
+        assert s_in.numel() in (1, C)
         out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
-        _lib.call("ivit_layernorm_i32_f32", _lib.ptr(k), C, k.numel() // C, C, _lib.ptr(bias_int), _lib.ptr(s_ln),
-                  _lib.ptr(out), C, _st())
+        _lib.call("ivit_layernorm_f32_f32", _lib.ptr(xin), C, xin.numel() // C, C, _lib.ptr(s_in), s_in.numel(),
+                  _lib.ptr(bias_int), _lib.ptr(s_ln), _lib.ptr(out), C, _st())
         self.bias_integer = bias_int                            # :59
         self.norm_scaling_factor = s_ln                         # :64
         return out, s_ln
@@ -90,9 +94,11 @@ class IVITIntSoftmax(nn.Module):
 
     def forward(self, x, scaling_factor):
         L = x.shape[-1]
-        k = to_int32(x, scaling_factor)   # int32: Swin's masked scores (swin_quant.py:151-156) exceed 8 bits
+        # the literal kernel: the reference discards its .to(int32) (:166) and runs the float32 sequence on x / s itself
+        # (Swin's masked scores, swin_quant.py:151-156, included), csrc/literal.hip
+        xin = x.contiguous().float()
         out8 = torch.empty(x.shape, dtype=torch.int8, device=x.device)
-        _lib.call("ivit_shiftmax_i32_i8", _lib.ptr(k), L, k.numel() // L, L, float(scaling_factor.reshape(-1)[0]),
+        _lib.call("ivit_shiftmax_f32_i8", _lib.ptr(xin), L, xin.numel() // L, L, float(scaling_factor.reshape(-1)[0]),
                   _lib.ptr(out8), L, _st())
         s = torch.tensor([1 / 2 ** (self.output_bit - 1)], dtype=torch.float32, device=x.device)  # :176
         self.act_scaling_factor = s

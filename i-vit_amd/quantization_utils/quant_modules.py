@@ -115,8 +115,13 @@ class QuantLinear(nn.Linear):
             lp = LinearParams(self.weight.detach().cpu().numpy(),
                               None if self.bias is None else self.bias.detach().cpu().numpy(), s_in)
             dev = self.weight.device
-            W8 = _dev_table(_pad_cols(lp.W8, _pad_k(lp.K)), dev)
-            b32 = None if lp.b32 is None else _dev_table(lp.b32, dev)
+            W8h, b32h = _pad_cols(lp.W8, _pad_k(lp.K)), lp.b32
+            if W8h.shape[0] % 4:          # the GEMM wants N % 4 == 0: zero rows, sliced off again in forward
+                padn = -W8h.shape[0] % 4
+                W8h = np.concatenate([W8h, np.zeros((padn, W8h.shape[1]), np.int8)])
+                b32h = None if b32h is None else np.concatenate([b32h, np.zeros(padn, b32h.dtype)])
+            W8 = _dev_table(W8h, dev)
+            b32 = None if b32h is None else _dev_table(b32h, dev)
             s_acc = _dev_table(lp.s_acc, dev)
             # buffers the reference overwrites on every call (quant_modules.py:211-220)
             self.fc_scaling_factor = _dev_table(lp.sw, dev)
@@ -130,8 +135,8 @@ class QuantLinear(nn.Linear):
         assert prev_act_scaling_factor is not None and prev_act_scaling_factor.shape == (1,)
         W8, b32, s_acc = self._params(float(prev_act_scaling_factor.item()))
         K, N = self.in_features, self.out_features
-        if K % 16 != 0 or N % 4 != 0:
-            raise NotImplementedError("ivit_gemm_i8_i32 needs in_features % 16 == 0 and out_features % 4 == 0")
+        if K % 16 != 0:
+            raise NotImplementedError("ivit_gemm_i8_i32 needs in_features % 16 == 0")
         a8 = narrow_i8(to_int32(x, prev_act_scaling_factor), "QuantLinear input")
         M = a8.numel() // K
         Kp = _pad_k(K)
@@ -139,8 +144,11 @@ class QuantLinear(nn.Linear):
             a8p = torch.zeros(M, Kp, dtype=torch.int8, device=x.device)
             a8p[:, :K] = a8.reshape(M, K)
             a8 = a8p
-        acc = torch.empty((*x.shape[:-1], N), dtype=torch.int32, device=x.device)
-        _lib.call("ivit_gemm_i8_i32", _lib.ptr(a8), Kp, _lib.ptr(W8), Kp, _lib.ptr(b32), _lib.ptr(acc), N, M, N, Kp, _st())
+        Np = W8.shape[0]
+        acc = torch.empty((*x.shape[:-1], Np), dtype=torch.int32, device=x.device)
+        _lib.call("ivit_gemm_i8_i32", _lib.ptr(a8), Kp, _lib.ptr(W8), Kp, _lib.ptr(b32), _lib.ptr(acc), Np, M, Np, Kp, _st())
+        if Np != N:
+            acc = acc[..., :N].contiguous()
         return to_float(acc, s_acc), s_acc
 
 

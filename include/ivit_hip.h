@@ -153,6 +153,15 @@ int ivit_attention_fused_i8_ex(const int8_t* qkv, int8_t* out, int batch, int he
                                uint32_t m_s, int32_t e_s, float s_attn, uint32_t m_o, int32_t e_o, int out_blocks,
                                ivit_stream_t stream);
 
+/* Natural ("as calibrated", non power-of-two) Shiftmax input scale.  The reference's Shiftmax then runs its float32
+ * sequence on phi(q) = fl(fl(q*s)/s) instead of q (ivit_modules.py:165-170: QuantAct returned q*s, quant_modules.py:387;
+ * the .to(int32) of :166 is discarded), so exp_int depends on (row max, q) jointly.  exp2d: [256][256] uint32 on the
+ * device, entry (qmax+128)*256 + (q+128) = exp_int of that pair, tabulated by the caller with the reference's float32
+ * steps (i-vit_amd/prepare.py shiftexp2d); NULL = power-of-two scale (identical to ivit_attention_fused_i8_ex). */
+int ivit_attention_fused_i8_compat(const int8_t* qkv, int8_t* out, int batch, int heads, int tokens, int head_dim,
+                                   uint32_t m_s, int32_t e_s, float s_attn, uint32_t m_o, int32_t e_o,
+                                   const uint32_t* exp2d, int out_blocks, ivit_stream_t stream);
+
 /* ---- I-LayerNorm + the QuantAct behind it ---------------------------------------------------
  * IVITIntLayerNorm.forward (ivit_modules.py:30-65) then QuantAct (fixedpoint_mul).
  *   x [rows, C] int8 (ldx), per channel: bias_int[c] = floor((beta/gamma)/(sqrt(C)/2^30)),
@@ -167,9 +176,26 @@ int ivit_layernorm_i8_ex(const int8_t* x, int64_t ldx, int rows, int C, const fl
                          const uint32_t* m, const int32_t* e, int8_t* out, int64_t ldo, int out_blocks,
                          ivit_stream_t stream);
 
+/* The same for an input carried at a natural (non power-of-two) scale s: IVITIntLayerNorm sees phi(q) = fl(fl(q*s)/s)
+ * (ivit_modules.py:36).  remap[q+128] = trunc(phi(q)) (int8, the `.to(int32)` of :38) and phi[q+128] (float32; the mean of
+ * :37 is taken over these: equal to RNE(sum q / C) except on rows whose integer sum is an exact .5 tie, where torch's CPU
+ * float32 reduction order decides -- restated in the kernel).  Both tables on the device, prepared by the caller
+ * (i-vit_amd/prepare.py phi_tables).  C % 8 == 0, C >= 32. */
+int ivit_layernorm_i8_compat(const int8_t* x, int64_t ldx, int rows, int C, const float* bias_int, const float* s_ln,
+                             const uint32_t* m, const int32_t* e, const int8_t* remap /* [256] */,
+                             const float* phi /* [256] */, int8_t* out, int64_t ldo, int out_blocks,
+                             ivit_stream_t stream);
+
 /* module-level form: int32 input (8 or 16 bit values), float32 output y*s_ln (ivit_modules.py:63) */
 int ivit_layernorm_i32_f32(const int32_t* x, int64_t ldx, int rows, int C, const float* bias_int,
                            const float* s_ln, float* out, int64_t ldo, ivit_stream_t stream);
+
+/* module-level LITERAL form, any input scale: x is the float view q*s the reference's module receives, s_in its scale
+ * (n_s = 1 per tensor, or C per channel).  Every float32 step of ivit_modules.py:36-63 as written, including the mean over
+ * x/s in torch's CPU reduction order (decides rows whose mean is an exact .5 tie when s is not a power of two) and the
+ * truncating .to(int32).  Equals ivit_layernorm_i32_f32 on round(x/s) when s is a power of two. */
+int ivit_layernorm_f32_f32(const float* x, int64_t ldx, int rows, int C, const float* s_in, int n_s,
+                           const float* bias_int, const float* s_ln, float* out, int64_t ldo, ivit_stream_t stream);
 
 /* ---- ShiftGELU -----------------------------------------------------------------------------
  * IVITIntGELU.forward (ivit_modules.py:89-126, n = 23, output_bit = 8) on rows of L int8 values
@@ -183,6 +209,10 @@ int ivit_shiftgelu_i8_i32(const int8_t* x, int64_t ldx, int rows, int L, float s
 /* Table form used by the engine: for a fixed (s, m, e) the result depends only on (row max, k):
  * lut[(kmax+128)*256 + (k+128)] = int8 result.  Build once per layer at load time ... */
 int ivit_shiftgelu_build_lut(float s, uint32_t m, int32_t e, int8_t* lut /* [256*256] */, ivit_stream_t stream);
+/* natural input scale: remap[q+128] = trunc(phi(q)) (device, [256] int8; ivit_modules.py:106-107) is applied to k and to the
+ * row maximum before the arithmetic; remap == NULL is ivit_shiftgelu_build_lut */
+int ivit_shiftgelu_build_lut_ex(float s, uint32_t m, int32_t e, const int8_t* remap, int8_t* lut /* [256*256] */,
+                                ivit_stream_t stream);
 /* ... then per call: wave-per-row max reduction + LDS-staged table row + byte gather.  L % 4 == 0. */
 int ivit_shiftgelu_lut_i8(const int8_t* x, int64_t ldx, int rows, int L, const int8_t* lut, int8_t* out,
                           int64_t ldo, ivit_stream_t stream);
@@ -195,6 +225,11 @@ int ivit_shiftgelu_lut_i8_ex(const int8_t* x, int64_t ldx, int rows, int L, cons
  * x [rows, L] int8 with scale s -> out [rows, L] int8 in [0, 127] (scale 2^-7). L <= 1024. */
 int ivit_shiftmax_i8(const int8_t* x, int64_t ldx, int rows, int L, float s, int8_t* out, int64_t ldo,
                      ivit_stream_t stream);
+/* module-level LITERAL form, any input scale: x is the float view the reference's module receives (q*s, plus Swin's float
+ * mask); every float32 step of ivit_modules.py:150-176 on x/s as written (the reference discards its .to(int32), :166),
+ * the row sum in torch's CPU reduction order. */
+int ivit_shiftmax_f32_i8(const float* x, int64_t ldx, int rows, int L, float s, int8_t* out, int64_t ldo,
+                         ivit_stream_t stream);
 /* the same on int32 inputs, |x| < 2^28: Swin adds the shift mask (-100/s, beyond 8 bits) to the scores in front of
  * the softmax (swin_quant.py:151-156) */
 int ivit_shiftmax_i32_i8(const int32_t* x, int64_t ldx, int rows, int L, float s, int8_t* out, int64_t ldo,

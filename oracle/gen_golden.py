@@ -675,6 +675,49 @@ def gen_compat_ops():
     print("compat_kat.npz written:", len(out), "arrays; compat oracle bit-equal to the reference modules on all cases")
 
 
+
+W16 = dict(patch_embed_bw=16, pos_encoding_bw=8, block_input_bw=16, attention_out_bw=16, softmax_bw=8, mlp_out_bw=16,
+           norm2_in_bw=16, att_block_out_bw=16)
+
+
+def gen_w16(tag="deit_tiny_w16"):
+    """DeiT-T with the reference's width knobs (vit_quant.py:180-187, quant_train.py:295-306) at 16 bits for the residual
+    stream and the QuantActs in front of it (softmax and the position embedding stay 8 bit): logits of the reference only.
+    The fused int8 engine does not implement these widths; the mirror must route such a model to its module path."""
+    factory, wseed, cseed, cb, iseed, nimg = "deit_tiny_patch16_224", 11, 101, 4, 1001, 4
+    model = getattr(ref_models, factory)(pretrained=False, gelu_type="ivit", softmax_type="ivit", layernorm_type="ivit", **W16)
+    fs = synth.make_float_state(factory, wseed)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in fs.items()}, strict=False)
+    model.eval()
+    model(torch.from_numpy(synth.make_images(cb, cseed)))
+    ranges, bits = {}, {}
+    for name, mod in model.named_modules():
+        if isinstance(mod, rq.QuantAct):
+            mx = float(torch.max(-mod.x_min, mod.x_max))
+            q = float(2 ** (mod.activation_bit - 1) - 1)
+            p = int(np.ceil(np.log2(mx / q)))
+            mod.x_max.fill_(q * 2.0 ** p)
+            mod.x_min.fill_(-q * 2.0 ** p)
+            ranges[name] = (np.float32(mod.x_min.item()), np.float32(mod.x_max.item()))
+            bits[name] = int(mod.activation_bit)
+    ref_models.freeze_model(model)
+    imgs = synth.make_images(nimg, iseed)
+    y = model(torch.from_numpy(imgs))
+    out = {
+        "meta": np.array(json.dumps(dict(tag=tag, factory=factory, family="ivit", weight_seed=wseed, calib_seed=cseed,
+                                         calib_batch=cb, image_seed=iseed, n_images=nimg, qkv_gain=synth.QKV_GAIN,
+                                         widths=W16, torch=torch.__version__))),
+        "range_names": np.array(list(ranges)),
+        "range_bits": np.array([bits[n] for n in ranges], np.int32),
+        "x_min": np.array([v[0] for v in ranges.values()], np.float32),
+        "x_max": np.array([v[1] for v in ranges.values()], np.float32),
+        "logits_f32_bits": y.numpy().astype(np.float32).view(np.int32),
+        "top1": y.argmax(dim=1).numpy().astype(np.int64),
+    }
+    np.savez_compressed(os.path.join(GOLD, f"{tag}.npz"), **out)
+    print(f"[{tag}] wrote fixtures; 16-bit QuantActs: {sum(b == 16 for b in bits.values())} of {len(bits)}; top1 = {out['top1'].tolist()}")
+
+
 def gen_schema():
     """state_dict keys and shapes of the reference's DeiT and Swin models (the on-disk checkpoint format)"""
     out = {}
@@ -699,6 +742,8 @@ if __name__ == "__main__":
     for w in what:
         if w == "ops":
             gen_ops()
+        elif w.endswith("_w16"):
+            gen_w16(w)
         elif w == "compat_ops":
             gen_compat_ops()
         elif w == "ibert_ops":

@@ -141,6 +141,27 @@ def test_headline_batch_256_deit_base():
     assert np.array_equal(li_b.cpu().numpy(), li)
 
 
+def test_config4_shard_batch_128_vit_base():
+    """Config 4's per-rank shard at full size (ViT-B, 1024 images over 8 GPUs = 128 per rank): golden images embedded in a
+    batch of 128 reproduce the reference's INT32 logits; permutation invariance at that size; fresh images vs the oracle."""
+    eng, fs, ranges, cfg, meta, z = build("vit_base", 128)
+    imgs_np = synth.make_images(128, 4128)
+    gold = synth.make_images(meta["n_images"], meta["image_seed"])
+    pos = [3, 126][: meta["n_images"]]
+    for p, g in zip(pos, gold):
+        imgs_np[p] = g
+    imgs = torch.from_numpy(imgs_np).to(DEV)
+    li, lf, t1 = eng.forward(imgs)
+    li = li.cpu().numpy().copy()
+    assert np.array_equal(li[pos], z["logits_int32"])
+    assert np.array_equal(t1.cpu().numpy()[pos].astype(np.int64), z["top1"])
+    perm = np.random.default_rng(4).permutation(128)
+    li2, _, _ = eng.forward(imgs[torch.from_numpy(perm).to(DEV)].contiguous())
+    assert np.array_equal(li2.cpu().numpy(), li[perm])
+    om = orc.OracleViT(fs, ranges, cfg["embed_dim"], cfg["depth"], cfg["num_heads"])
+    assert np.array_equal(li[[64]], om.forward(imgs_np[[64]])["logits_int32"])
+
+
 def test_engine_from_integer_export(tmp_path):
     """Row f2: params.npy + qconfig.npy (integer weights and scale table only) rebuild an engine whose logits equal the
     reference golden; and the module mirror's state_dict exports the same integers through the reference's route."""

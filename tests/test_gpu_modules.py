@@ -371,3 +371,91 @@ def test_ibert_model_module_path_matches_reference_golden():
         y = model(imgs)             # no fused engine for this family: module by module
     assert np.array_equal(bits(y), z["logits_f32_bits"][:2])
     assert np.array_equal(y.argmax(dim=1).cpu().numpy(), z["top1"][:2])
+
+
+# ----------------------------------------------------------------------------------- engine dispatch (dispatch.py)
+def test_non_8bit_widths_take_the_module_path_and_match_the_reference():
+    """the reference's width knobs (vit_quant.py:180-187): a DeiT-T with a 16-bit residual stream is NOT what the fused
+    int8 engine computes -- the mirror must say so and run it module by module, reproducing the reference's logits"""
+    fs, ranges, cfg, meta, z = load_synthetic_model("deit_tiny_w16")
+    model = ivit.deit_tiny_patch16_224(**meta["widths"])
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in fs.items()}, strict=False)
+    for name, mod in model.named_modules():
+        if isinstance(mod, q.QuantAct):
+            mod.x_min.fill_(float(ranges[name][0]))
+            mod.x_max.fill_(float(ranges[name][1]))
+    model.to(DEV)
+    ivit.freeze_model(model)
+    assert "16-bit" in model.engine_unsupported_reason()
+    imgs = torch.from_numpy(synth.make_images(2, meta["image_seed"])).to(DEV)
+    assert not model.takes_engine(imgs)
+    with torch.no_grad():
+        y = model(imgs)
+    assert model._engine is None
+    assert np.array_equal(bits(y), z["logits_f32_bits"][:2])
+    assert np.array_equal(y.argmax(dim=1).cpu().numpy(), z["top1"][:2])
+    # and it really is a different function from the all-8-bit model with the same weights
+    z8 = load_synthetic_model("deit_tiny")[4]
+    assert not np.array_equal(z["logits_f32_bits"][:2], z8["logits_f32_bits"][:2])
+
+
+def test_engine_follows_load_state_dict_and_range_changes():
+    """the cached engine is a snapshot: new weights, new ranges or a re-freeze must rebuild it"""
+    model, meta, z = load_model("deit_tiny")
+    imgs = torch.from_numpy(synth.make_images(2, meta["image_seed"])).to(DEV)
+    with torch.no_grad():
+        y0 = model(imgs).clone()
+        assert np.array_equal(bits(y0), z["logits_f32_bits"][:2])
+        e0 = model._engine[2]
+        assert model(imgs[:1]).shape == (1, 1000) and model._engine[2] is e0          # smaller batch: same engine
+        # 1. new weights through load_state_dict
+        sd = {k: v.clone() for k, v in model.state_dict().items()}
+        sd["head.weight"] = sd["head.weight"].flip(0)
+        sd["head.bias"] = sd["head.bias"].flip(0)
+        model.load_state_dict(sd)
+        y1 = model(imgs)
+        assert model._engine[2] is not e0
+        assert not torch.equal(y1, y0)
+        model.use_engine = False
+        assert np.array_equal(bits(model(imgs)), bits(y1))       # engine == module path on the new weights
+        model.use_engine = True
+        # 2. an in-place parameter edit (optimizer-style)
+        e1 = model._engine[2]
+        model.blocks[0].mlp.fc2.bias.mul_(2.0).add_(0.05)
+        y2 = model(imgs)
+        assert model._engine[2] is not e1 and not torch.equal(y2, y1)
+        # 3. unfreeze -> recalibrate on other data -> freeze
+        e2 = model._engine[2]
+        ivit.unfreeze_model(model)
+        model(torch.from_numpy(synth.make_images(2, 99)).to(DEV) * 3.0)
+        ivit.freeze_model(model)
+        y3 = model(imgs)
+        assert model._engine[2] is not e2 and not torch.equal(y3, y2)
+        model.use_engine = False
+        assert np.array_equal(bits(model(imgs)), bits(y3))
+
+
+@pytest.mark.parametrize("num_classes", [100, 10, 37])
+def test_engine_any_class_count(num_classes):
+    """head width comes from the model, not from a constant: engine == module path for num_classes != 1000"""
+    fs, ranges, cfg, meta, z = load_synthetic_model("deit_tiny")
+    model = ivit.deit_tiny_patch16_224(num_classes=num_classes)
+    sd = {k: torch.from_numpy(v) for k, v in fs.items()}
+    sd["head.weight"] = sd["head.weight"][:num_classes].clone()
+    sd["head.bias"] = sd["head.bias"][:num_classes].clone()
+    model.load_state_dict(sd, strict=False)
+    for name, mod in model.named_modules():
+        if isinstance(mod, q.QuantAct):
+            mod.x_min.fill_(float(ranges[name][0]))
+            mod.x_max.fill_(float(ranges[name][1]))
+    model.to(DEV)
+    ivit.freeze_model(model)
+    imgs = torch.from_numpy(synth.make_images(3, meta["image_seed"])).to(DEV)
+    with torch.no_grad():
+        ye = model(imgs)
+        assert model._engine is not None and ye.shape == (3, num_classes)
+        model.use_engine = False
+        ym = model(imgs)
+    assert np.array_equal(bits(ye), bits(ym))
+    # the per-class scale differs per row of the head, so logits of the kept classes equal the 1000-class model's
+    assert np.array_equal(bits(ye), z["logits_f32_bits"][:3, :num_classes])

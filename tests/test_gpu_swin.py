@@ -434,3 +434,28 @@ def test_swin_base_widths_calibrated_on_gpu_match_oracle():
     ref = om.forward(imgs_np)
     assert np.array_equal(y_engine.cpu().numpy().view(np.int32), ref["logits_f32"].view(np.int32))
     assert om.max_acc < 2 ** 24
+
+
+def test_config5_batch_128_swin_tiny():
+    """Config 5 at full size (batch 128: 401 408-row stage-0 GEMMs / LN16, 24 576 (window, head) pairs per attention
+    launch): the reference's golden images embedded in the batch reproduce its INT32 logits, and the batch is permutation
+    invariant at that size."""
+    eng, fs, ranges, cfg, meta, z = build_swin(128)
+    imgs_np = synth.make_images(128, 8128)
+    gold = synth.make_images(meta["n_images"], meta["image_seed"])
+    pos = [0, 63, 127][: meta["n_images"]]
+    for p, g in zip(pos, gold):
+        imgs_np[p] = g
+    imgs = torch.from_numpy(imgs_np).to(DEV)
+    li, lf, t1 = eng.forward(imgs)
+    li = li.cpu().numpy().copy()
+    t1 = t1.cpu().numpy().copy()
+    assert np.array_equal(li[pos], z["logits_int32"])
+    assert np.array_equal(t1[pos].astype(np.int64), z["top1"])
+    perm = np.random.default_rng(5).permutation(128)
+    li2, _, _ = eng.forward(imgs[torch.from_numpy(perm).to(DEV)].contiguous())
+    assert np.array_equal(li2.cpu().numpy(), li[perm])
+    # two fresh images of the batch against the CPU oracle
+    om = orc.OracleSwin(fs, ranges, cfg["embed_dim"], cfg["depths"], cfg["num_heads"], cfg["window"])
+    sub = [17, 101]
+    assert np.array_equal(li[sub], om.forward(imgs_np[sub])["logits_int32"])

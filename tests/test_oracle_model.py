@@ -103,3 +103,18 @@ def test_torch_rowsum_order_is_not_plain_left_to_right():
             seq = np.float32(seq + v)
         diff += int(orc.torch_rowsum(x) != seq)
     assert diff > 0
+
+
+def test_shiftexp2d_host_table_matches_reference_softmax(ckat):
+    """product host code (prepare.shiftexp2d, the table the attention kernel gathers from at natural scales) vs the
+    reference module's outputs: P = floor(e * factor / 2^24) rebuilt from the table equals IVITIntSoftmax"""
+    from ivit_amd.prepare import shiftexp2d
+    for ci in ckat["sm_cases"]:
+        c = f"sm{ci}_"
+        q, s = ckat[c + "q"].astype(np.int32), np.float32(ckat[c + "s"])
+        tab = shiftexp2d(s)
+        e = tab[q.max(axis=1)[:, None] + 128, q + 128].astype(np.float32)
+        S = np.array([orc.torch_rowsum(r) for r in e], np.float32)          # ivit_modules.py:171
+        factor = np.floor((np.float32(1.0) / S) * np.float32(2147483648.0))
+        P = np.floor((e * factor[:, None]).astype(np.float32) / np.float32(16777216.0)).astype(np.int32)
+        assert np.array_equal(P, ckat[c + "out"]), ci
