@@ -117,8 +117,12 @@ def phi_table(s) -> np.ndarray:
     return ((q * s).astype(f32) / s).astype(f32)
 
 
-def phi_is_identity(s) -> bool:
-    return bool(np.array_equal(phi_table(s), np.arange(-128, 128, dtype=f32)))
+def phi_is_identity(s, bits: int = 8) -> bool:
+    """True when fl(fl(q*s)/s) == q for every `bits`-bit integer q (always for s = 2^p)."""
+    if bits == 8:
+        return bool(np.array_equal(phi_table(s), np.arange(-128, 128, dtype=f32)))
+    q = np.arange(-(2 ** (bits - 1)), 2 ** (bits - 1), dtype=f32)
+    return bool(np.array_equal(((q * f32(s)).astype(f32) / f32(s)).astype(f32), q))
 
 
 def phi_tables(s):

@@ -247,6 +247,7 @@ class SwinTransformer(EngineDispatch, nn.Module):
         # the widths the constructor (= the reference's, swin_quant.py:110, 214, 222, 475) gives every QuantAct are the ones
         # the Swin kernels hard-wire; a width edited afterwards sends the model down the module path
         self._reference_widths = {n: int(m.activation_bit) for n, m in self._quant_acts()}
+        self._phi_check = None
 
     @staticmethod
     def _init_weights(m):
@@ -297,7 +298,26 @@ class SwinTransformer(EngineDispatch, nn.Module):
         for n, m in self._quant_acts():
             if int(m.activation_bit) != self._reference_widths[n]:
                 return f"QuantAct {n} is {int(m.activation_bit)}-bit (fused engine: {self._reference_widths[n]})"
-        return None
+        return self._natural_scale_reason()
+
+    def _natural_scale_reason(self):
+        """The Swin engine implements the regime in which x / s gives back the integer a QuantAct produced (every scale a
+        power of two, or any scale with fl(fl(q*s)/s) == q over its width).  With ranges as calibrated the reference's
+        LayerNorm / ShiftGELU / Shiftmax see neighbouring floats instead (prepare.py); the module path restates that
+        literally (csrc/literal.hip), the Swin engine does not yet (the DeiT / ViT engine does, through phi tables)."""
+        from .prepare import phi_is_identity, sym_scale
+        fp = self._fingerprint()
+        if self._phi_check is None or self._phi_check[0] != fp:
+            bad = None
+            for n, m in self._quant_acts():
+                lo, hi = float(m.x_min.reshape(-1)[0]), float(m.x_max.reshape(-1)[0])
+                if lo == hi == 0.0:
+                    continue
+                if not phi_is_identity(sym_scale(lo, hi, int(m.activation_bit)), int(m.activation_bit)):
+                    bad = f"QuantAct {n} has a natural (non power-of-two) scale: Swin runs module by module there"
+                    break
+            self._phi_check = (fp, bad)
+        return self._phi_check[1]
 
     def _build_engine(self, device, max_batch):
         from .swin_engine import IntSwinEngine

@@ -353,6 +353,65 @@ def _import_swin():
 
 
 def gen_swin(tag="swin_tiny"):
+    if tag.endswith("_natural"):
+        return gen_swin_natural(tag)
+    return gen_swin_pow2(tag)
+
+
+def gen_swin_natural(tag):
+    """Swin-T with its ranges AS CALIBRATED (two batches, EMA), frozen: logits / top-1 / tap digests of the reference.
+    There is no compat oracle for Swin; the fixture pins the mirror's module path (literal float kernels) on the GPU."""
+    sq = _import_swin()
+    factory, wseed, cseeds, cb, iseed, nimg = "swin_tiny_patch4_window7_224", 21, (201, 211), 2, 2001, 2
+    model = getattr(sq, factory)(pretrained=False)
+    for mod in model.modules():                                                            # shim 4
+        if isinstance(mod, rq.QuantLinear) and mod.bias is None:
+            mod.weight_function = lambda x, *a: None if x is None else SymmetricQuantFunction.apply(x, *a)
+    fs = synth.make_swin_float_state(factory, wseed)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in fs.items()}, strict=False)
+    model.eval()
+    for cs in cseeds:
+        model(torch.from_numpy(synth.make_images(cb, cs)))
+    ranges, bitsof = {}, {}
+    for name, mod in model.named_modules():
+        if isinstance(mod, rq.QuantAct) and float(torch.max(-mod.x_min, mod.x_max)) > 0:
+            ranges[name] = (np.float32(mod.x_min.item()), np.float32(mod.x_max.item()))
+            bitsof[name] = mod.activation_bit
+    ref_models.freeze_model(model)
+    taps = {}
+
+    def hook(name):
+        def fn(mod, inp, outp):
+            y, s = outp
+            taps[name] = to_int(y, s)
+        return fn
+
+    for name, mod in model.named_modules():
+        if isinstance(mod, (rq.QuantAct, rq.IVITIntSoftmax, rq.IVITIntGELU)) and name != "act_out":
+            mod.register_forward_hook(hook(name))
+    imgs = synth.make_images(nimg, iseed)
+    y = model(torch.from_numpy(imgs))
+    s_head = (model.head.fc_scaling_factor * model.qact3.act_scaling_factor).float()
+    logits_int = torch.round(y / s_head).to(torch.int64).numpy().astype(np.int32)
+    names = sorted(taps)
+    out = {
+        "meta": np.array(json.dumps(dict(tag=tag, factory=factory, weight_seed=wseed, calib_seeds=list(cseeds), calib_batch=cb,
+                                         image_seed=iseed, n_images=nimg, qkv_gain=synth.QKV_GAIN, regime="natural",
+                                         torch=torch.__version__))),
+        "range_names": np.array(list(ranges)),
+        "range_bits": np.array([bitsof[n] for n in ranges], np.int32),
+        "x_min": np.array([v[0] for v in ranges.values()], np.float32),
+        "x_max": np.array([v[1] for v in ranges.values()], np.float32),
+        "logits_int32": logits_int, "logits_f32_bits": y.numpy().astype(np.float32).view(np.int32),
+        "top1": y.argmax(dim=1).numpy().astype(np.int64),
+        "head_scale": s_head.numpy().astype(np.float32),
+        "tap_names": np.array(names), "tap_crc32": np.array([crc(taps[n]) for n in names], np.uint32),
+    }
+    np.savez_compressed(os.path.join(GOLD, f"{tag}.npz"), **out)
+    print(f"[{tag}] wrote fixtures; top1 = {out['top1'].tolist()}")
+
+
+def gen_swin_pow2(tag="swin_tiny"):
     """Swin-T (config 5).  The fork's swin_quant.py is dead code (SURVEY finding 6); it runs with the three extra
     harness-side shims of SURVEY Appendix E (tkinter stub, Int* aliases, bias-free QuantLinear weight_function) --
     reference files untouched."""
@@ -750,7 +809,7 @@ if __name__ == "__main__":
             gen_ibert_ops()
         elif w == "schema":
             gen_schema()
-        elif w.endswith("_natural"):
+        elif w.endswith("_natural") and not w.startswith("swin"):
             gen_natural(w)
         elif w.startswith("swin"):
             gen_swin(w)

@@ -459,3 +459,41 @@ def test_config5_batch_128_swin_tiny():
     om = orc.OracleSwin(fs, ranges, cfg["embed_dim"], cfg["depths"], cfg["num_heads"], cfg["window"])
     sub = [17, 101]
     assert np.array_equal(li[sub], om.forward(imgs_np[sub])["logits_int32"])
+
+
+def test_swin_natural_scales_take_the_module_path():
+    """Swin-T with its ranges as calibrated: the Swin engine implements power-of-two scales only, so the mirror must route
+    the frozen model to its module path (literal float kernels).  The taps in front of the first LayerNorm equal the
+    reference's.  (Known limit, DESIGN.md: the reference's patch-embed LayerNorm reduces over a TRANSPOSED view
+    (layers_quant.py:198-201), whose float32 reduction order depends on torch's thread partition -- its exact-tie rows, 1 in
+    96, are not reproducible between two runs of the reference itself, so no end-to-end digest is asserted here.)"""
+    import zlib
+    import ivit_amd as ivit
+    import ivit_amd.quantization_utils as qu
+    z, meta, ranges = load_fixture("swin_tiny_natural")
+    fs = synth.make_swin_float_state(meta["factory"], meta["weight_seed"])
+    model = ivit.swin_tiny_patch4_window7_224()
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in fs.items()}, strict=False)
+    for name, mod in model.named_modules():
+        if isinstance(mod, qu.QuantAct) and name in ranges:
+            mod.x_min.fill_(float(ranges[name][0]))
+            mod.x_max.fill_(float(ranges[name][1]))
+    model.to(DEV)
+    ivit.freeze_model(model)
+    assert "natural" in model.engine_unsupported_reason()
+    got = {}
+
+    def hook(name):
+        def fn(mod, inp, outp):
+            y, s = outp
+            got[name] = zlib.crc32(np.ascontiguousarray(torch.round(y / s).to(torch.int64).cpu().numpy().astype(np.int32)).tobytes())
+        return fn
+
+    for name in ("qact_input", "patch_embed.qact_before_norm"):
+        model.get_submodule(name).register_forward_hook(hook(name))
+    imgs = torch.from_numpy(synth.make_images(meta["n_images"], meta["image_seed"])).to(DEV)
+    with torch.no_grad():
+        y = model(imgs)
+    assert model._engine is None and y.shape == (meta["n_images"], 1000) and torch.isfinite(y).all()
+    gold = dict(zip([str(x) for x in z["tap_names"]], z["tap_crc32"]))
+    assert all(got[n] == int(gold[n]) for n in got) and len(got) == 2
