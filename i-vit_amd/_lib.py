@@ -38,10 +38,6 @@ SIGNATURES = {
     "ivit_gemm_i8_requant_residual_i16": [vp, i64, vp, i64, vp, vp, vp, vp, i64, u32, i32, u32, i32, vp, i64, ci, ci, ci, vp],
     "ivit_gemm_i8_requant_qkv": [vp, i64, vp, i64, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp],
     "ivit_gemm_i8_i32": [vp, i64, vp, i64, vp, vp, i64, ci, ci, ci, vp],
-    "ivit_debug_force_small_gemm": [ci],
-    "ivit_debug_set_gemm_flags": [ci],
-    "ivit_debug_ln_wave_per_row": [ci],
-    "ivit_debug_set_stamp_buffer": [vp],
     "ivit_attention_fused_i8": [vp, vp, ci, ci, ci, ci, u32, i32, f32, u32, i32, vp],
     "ivit_layernorm_i8": [vp, i64, ci, ci, vp, vp, vp, vp, vp, i64, vp],
     "ivit_layernorm_i32_f32": [vp, i64, ci, ci, vp, vp, vp, i64, vp],
@@ -78,6 +74,16 @@ SIGNATURES = {
 }
 
 
+# include/ivit_hip_debug.h: exported by libivit_hip_lab.so only (tests / scripts; the product library is stateless)
+LAB_SIGNATURES = {
+    "ivit_debug_force_small_gemm": [ci],
+    "ivit_debug_set_gemm_flags": [ci],
+    "ivit_debug_ln_wave_per_row": [ci],
+    "ivit_debug_set_stamp_buffer": [vp],
+}
+LAB_PATH = os.path.join(_HERE, "libivit_hip_lab.so")
+
+
 class IvitError(RuntimeError):
     pass
 
@@ -86,8 +92,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     """Compile csrc/*.hip -> libivit_hip.so (hipcc --offload-arch=gfx950)."""
     srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
     srcs.append(os.path.join(_HERE, "..", "include", "ivit_hip.h"))
-    stale = force or not os.path.exists(LIB_PATH) or any(
-        os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    stale = force or any(not os.path.exists(p) or any(os.path.getmtime(s) > os.path.getmtime(p) for s in srcs)
+                         for p in (LIB_PATH, LAB_PATH))
     if stale:
         cmd = ["make", "-C", CSRC, "-j4"] + ([] if verbose else ["-s"])
         subprocess.check_call(cmd)
@@ -95,28 +101,61 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 
 _lib = None
+_lab = None
+_use_lab = os.environ.get("IVIT_USE_LAB_LIBRARY") == "1"     # scripts/: measure with the lab build's knobs
+
+
+def _load(path, signatures):
+    if not os.path.exists(path):
+        raise IvitError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "(there is no CPU / PyTorch fallback for the integer ViT path)")
+    L = C.CDLL(path)
+    L.ivit_version.restype = ci
+    L.ivit_last_error_string.restype = C.c_char_p
+    for name, args in signatures.items():
+        fn = getattr(L, name)  # AttributeError if the symbol is not exported
+        fn.argtypes = args
+        fn.restype = ci
+    return L
 
 
 def lib():
-    """Load the library (never builds implicitly; never falls back)."""
+    """Load the product library (never builds implicitly; never falls back)."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise IvitError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
-                            "(there is no CPU / PyTorch fallback for the integer ViT path)")
-        L = C.CDLL(LIB_PATH)
-        L.ivit_version.restype = ci
-        L.ivit_last_error_string.restype = C.c_char_p
-        for name, args in SIGNATURES.items():
-            fn = getattr(L, name)  # AttributeError if the symbol is not exported
-            fn.argtypes = args
-            fn.restype = ci
-        _lib = L
+        _lib = _load(LIB_PATH, SIGNATURES)
     return _lib
 
 
+def lab():
+    """libivit_hip_lab.so: the same C ABI compiled with the measurement hooks of include/ivit_hip_debug.h."""
+    global _lab
+    if _lab is None:
+        _lab = _load(LAB_PATH, {**SIGNATURES, **LAB_SIGNATURES})
+    return _lab
+
+
+class lab_session:
+    """`with _lib.lab_session():` -- every `call()` inside goes to the lab build (tests of kernel forms, A/B scripts).
+    On exit the lab build's knobs are reset."""
+
+    def __enter__(self):
+        global _use_lab
+        self.prev, _use_lab = _use_lab, True
+        return lab()
+
+    def __exit__(self, *exc):
+        global _use_lab
+        L = lab()
+        L.ivit_debug_force_small_gemm(0)
+        L.ivit_debug_set_gemm_flags(0)
+        L.ivit_debug_ln_wave_per_row(0)
+        _use_lab = self.prev
+        return False
+
+
 def call(name: str, *args):
-    L = lib()
+    L = lab() if _use_lab else lib()
     rc = getattr(L, name)(*args)
     if rc != 0:
         raise IvitError(f"{name} failed ({rc}): {L.ivit_last_error_string().decode()}")

@@ -8,6 +8,11 @@
 
 #define IVIT_EXPORT extern "C" __attribute__((visibility("default")))
 
+// IVIT_LAB = 0: libivit_hip.so, the product (stateless, no measurement hooks); 1: libivit_hip_lab.so (gemm_common.h)
+#ifndef IVIT_LAB
+#define IVIT_LAB 0
+#endif
+
 // ---- host side -------------------------------------------------------------------------------
 void ivit_set_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
 

@@ -154,7 +154,9 @@ __global__ __launch_bounds__(NT) void gemm_i8_kernel(GemmArgs g)
 // ================================================================================================
 // One token per physical CU (XCC id, SE, SH, CU of HW_ID): the two co-resident workgroups of the persistent kernel take
 // turns in their DMA-bound main loops (see gemm_i8_pers_kernel).  Zero between launches: every holder releases.
+#if IVIT_LAB
 __device__ int g_cu_token[2048];
+#endif
 
 struct PersWork {
     int m0, n0, half;   // m0 < 0: none
@@ -184,9 +186,11 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_pers_kernel(GemmArgs g)
 {
     __shared__ __attribute__((aligned(16))) char smem[PERS_SMEM];
     const int tid = threadIdx.x;
+#if IVIT_LAB
     const unsigned hw_id = __builtin_amdgcn_s_getreg((16 - 1) << 11 | (0 << 6) | 4);    // HW_ID[15:0]: .. cu_id[11:8] sh_id[12] se_id[15:13]
     const unsigned xcc_id = __builtin_amdgcn_s_getreg((4 - 1) << 11 | (0 << 6) | 20);   // XCC_ID[3:0]
     int* cu_token = &g_cu_token[((xcc_id & 7u) << 8) | ((hw_id >> 8) & 0xffu)];
+#endif
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wc = wave >> 1, wt = wave & 1;
     const int h = lane >> 5, l31 = lane & 31;
@@ -356,18 +360,22 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_pers_kernel(GemmArgs g)
         // 512 cycles of MFMA), the epilogue by VALU.  Two workgroups that run their main loops at the same time just
         // halve each other's DMA rate and then sit in their epilogues together with the DMA path idle.  The per-CU token
         // makes them take turns: one streams its K loop at the full DMA rate while the other requantises and stores.
+#if IVIT_LAB
         if (g.cu_turns) {
             if (tid == 0)
                 while (atomicCAS(cu_token, 0, 1) != 0) __builtin_amdgcn_s_sleep(8);
             __syncthreads();
         }
+#endif
         load_frags(0u, 0, wf0, af0);
         int kt = 0;
         for (; kt + 2 < nk; ++kt) step(kt, T{}, F{});
         if (kt + 1 < nk) { step(kt, F{}, F{}); ++kt; }
         step(kt, F{}, T{});
         __syncthreads();   // all waves are done with every stage: buffers free
+#if IVIT_LAB
         if (g.cu_turns && tid == 0) atomicExch(cu_token, 0);
+#endif
 
         // ---- prefetch stage 0 of the next item, then this item's epilogue (staging in buffers 1-2)
         const bool more = nxt.m0 >= 0;   // uniform
@@ -462,10 +470,12 @@ int launch_gemm(GemmArgs& g, const char* name, ivit_stream_t stream)
         IVIT_REQUIRE(!g.w_blocks || g.ldw == g.K, "%s: a block-layout W operand is dense (ldw == K)", name);
     }
     if constexpr (EPI != EPI_I32) {
+#if IVIT_LAB
         if (EPI <= EPI_QKV && !blocks && (g_debug_flags & (31 | 32 | 128 | 256 | 512 | 1024 | 8192 | 4194304 | 8388608))) {   // a lab form was asked for (tests, scripts)
             int rc = IVIT_OK;
             if (ivit_gemm_lab_launch(EPI, &g, name, stream, &rc)) return rc;
         }
+#endif
         if (g.M >= 2048 && g.N >= BCH && !g_force_small) {
             g.stagger = (g_debug_flags & 64) ? 0 : 512;  // 2 workgroups x 256 CUs
             g.tiles_m = (g.M + BTOK - 1) / BTOK;

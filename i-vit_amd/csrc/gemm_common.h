@@ -6,11 +6,22 @@
 
 #include "common.h"
 
+// Two builds of the same sources (csrc/Makefile):
+//   libivit_hip.so      IVIT_LAB = 0: the product.  No process-wide state -- the knobs below are compile-time constants, the
+//                       lab kernels (gemm_lab.hip) and the ivit_debug_* hooks are not in it;
+//   libivit_hip_lab.so  IVIT_LAB = 1: the same entry points plus include/ivit_hip_debug.h (kernel-form A/B, ablations,
+//                       time stamps), for tests/ and scripts/ only.
+#if IVIT_LAB
 // test / measurement state set through include/ivit_hip_debug.h (defined in gemm_lab.hip)
 extern int g_kernel_choice;   // 0 = automatic, 1 = never the 256x256 kernel
 extern bool g_force_small;    // route every problem through the small-tile kernel
 extern void* g_stamp_buf;     // timeline buffer of the stamped builds
 extern int g_debug_flags;     // see ivit_debug_set_gemm_flags
+#else
+constexpr int g_kernel_choice = 0;
+constexpr bool g_force_small = false;
+constexpr int g_debug_flags = 0;
+#endif
 
 namespace {
 
@@ -364,4 +375,6 @@ IVIT_DEV void pers_table_write(const PersTableLoad& r, char* tab, int tid)
 }  // namespace
 
 // kernel forms of gemm_lab.hip: returns 1 if `g_debug_flags` selected one of them and it was launched (status in *rc)
+#if IVIT_LAB
 int ivit_gemm_lab_launch(int epi, void* gemm_args, const char* name, ivit_stream_t stream, int* rc);
+#endif

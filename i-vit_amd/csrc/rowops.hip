@@ -15,7 +15,11 @@
 
 // tests / A-B timing: 1 = always the wave-per-row LayerNorm kernel, 2 = the half-wave-per-row one wherever it exists
 // (ivit_debug_ln_wave_per_row)
+#if IVIT_LAB
 int g_ln_wave_per_row = 0;
+#else
+constexpr int g_ln_wave_per_row = 0;
+#endif
 
 namespace {
 
@@ -1013,11 +1017,13 @@ IVIT_EXPORT int ivit_untile_operand_i8(const int8_t* src, int64_t rows, int K, i
     IVIT_CHECK_LAUNCH("ivit_untile_operand_i8");
 }
 
+#if IVIT_LAB
 IVIT_EXPORT int ivit_debug_ln_wave_per_row(int on)
 {
     g_ln_wave_per_row = on;
     return IVIT_OK;
 }
+#endif
 
 IVIT_EXPORT int ivit_layernorm_i8_ex(const int8_t* x, int64_t ldx, int rows, int C, const float* bias_int,
                                   const float* s_ln, const uint32_t* m, const int32_t* e, int8_t* out, int64_t ldo,

@@ -10,7 +10,10 @@ What differs, deliberately:
   * the reference always instantiates `deit_tiny_patch16_224` whatever `model_config['model_name']` says (:133); here
     the name selects the factory when it is one this package provides (DeiT-T/S/B, ViT-B/L, Swin-T/S/B) and falls back
     to DeiT-T otherwise;
-  * only the 'ivit' operator family exists on this path: other gelu/softmax/layernorm types raise (layer_selection.py);
+  * operator families: 'ivit' (fused engine) and 'ibert' (module path) exist; the reference's DEFAULTS are kept -- 'ibert'
+    when the saved configuration lacks a type (:111-113), and for a checkpoint without any configuration the reference
+    picks its 'ppoly_...' GELU / softmax (:160-162), which this path does not implement: that case raises with a message
+    naming the override to pass, instead of silently substituting another operator;
   * calibration takes any iterable of image batches (no torchvision / ImageNet reader in this environment); the
     single random warm-up forward of `use_random_calibration` is kept as is.
 """
@@ -50,9 +53,18 @@ def build_model(model_config: Optional[dict] = None, num_classes: int = 1000, ge
     cfg = dict(model_config or {})
     name = cfg.get("model_name", "deit_tiny")
     factory = FACTORIES.get(name) or FACTORIES.get(f"{name}_patch16_224") or FACTORIES["deit_tiny_patch16_224"]
-    ops = dict(gelu_type=gelu_type if gelu_type is not None else cfg.get("gelu_type", "ivit"),
-               softmax_type=softmax_type if softmax_type is not None else cfg.get("softmax_type", "ivit"),
-               layernorm_type=layernorm_type if layernorm_type is not None else cfg.get("layernorm_type", "ivit"))
+    if model_config is None:
+        # inference.py:160-162: a configuration-less checkpoint gets the reference's ppoly GELU / softmax and I-BERT LayerNorm
+        if gelu_type is None or softmax_type is None:
+            raise KeyError("checkpoint without 'model_config': the reference would build its 'ppoly_deg_2_seg_16_...' GELU / "
+                           "softmax here (scripts/inference.py:160-162), which the MI355X integer path does not implement -- "
+                           "pass gelu_type= / softmax_type= ('ivit' or 'ibert') explicitly")
+        ops = dict(gelu_type=gelu_type, softmax_type=softmax_type,
+                   layernorm_type=layernorm_type if layernorm_type is not None else "ibert")
+    else:
+        ops = dict(gelu_type=gelu_type if gelu_type is not None else cfg.get("gelu_type", "ibert"),       # :111-113
+                   softmax_type=softmax_type if softmax_type is not None else cfg.get("softmax_type", "ibert"),
+                   layernorm_type=layernorm_type if layernorm_type is not None else cfg.get("layernorm_type", "ibert"))
     if factory.__name__.startswith("swin"):
         for k, v in ops.items():
             if not str(v).lower().startswith("ivit"):

@@ -1,6 +1,7 @@
 """Probe: does splitting the batch over two HIP streams (two half-batch engines launched concurrently) beat one full-batch
 forward?  (fills GEMM tail rounds / overlaps HBM-bound row kernels with MFMA-bound GEMMs, if the hardware co-schedules them)
 usage: dual_stream_probe.py [nsplit]"""
+import os; os.environ.setdefault("IVIT_USE_LAB_LIBRARY", "1")  # kernel-form knobs live in libivit_hip_lab.so
 import os
 import sys
 

@@ -1,6 +1,7 @@
 """Interleaved A/B timing of GEMM kernel variants (debug flags): every round runs each variant once, in turn, so that clock /
 thermal drift hits all variants alike; reports median and min per variant.
 usage: gemm_ab.py [--resid] [--blocks] [shape ...] -- flag flag ..."""
+import os; os.environ.setdefault("IVIT_USE_LAB_LIBRARY", "1")  # kernel-form knobs live in libivit_hip_lab.so
 import os
 import sys
 

@@ -1,4 +1,5 @@
 """Time the DeiT-B GEMM shapes (batch 256) with the ablation flags of ivit_debug_set_gemm_flags."""
+import os; os.environ.setdefault("IVIT_USE_LAB_LIBRARY", "1")  # kernel-form knobs live in libivit_hip_lab.so
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

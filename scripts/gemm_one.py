@@ -1,4 +1,5 @@
 """Run one DeiT-B GEMM shape (batch 256) a few times: for rocprofv3 --pmc passes.  usage: gemm_one.py fc1 [flags]"""
+import os; os.environ.setdefault("IVIT_USE_LAB_LIBRARY", "1")  # kernel-form knobs live in libivit_hip_lab.so
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

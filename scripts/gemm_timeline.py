@@ -1,5 +1,6 @@
 """Per-workgroup timeline of the 256x128 GEMM kernel (diagnostic stamped build): do the two workgroups of a CU
 overlap main loop with epilogue?  usage: gemm_timeline.py [fc1|qkv|proj|fc2]"""
+import os; os.environ.setdefault("IVIT_USE_LAB_LIBRARY", "1")  # kernel-form knobs live in libivit_hip_lab.so
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

@@ -1,5 +1,6 @@
 """Time stamps (s_memtime) of the ping-pong GEMM kernel's tile phases: K loop / barrier / phase 2 / copy / barrier.
 usage: pp_timeline.py qkv|fc2 [extra_flag_bits]"""
+import os; os.environ.setdefault("IVIT_USE_LAB_LIBRARY", "1")  # kernel-form knobs live in libivit_hip_lab.so
 import os
 import sys
 

@@ -1,3 +1,4 @@
+import os; os.environ.setdefault("IVIT_USE_LAB_LIBRARY", "1")  # kernel-form knobs live in libivit_hip_lab.so
 import sys, os
 sys.path.insert(0, "/root/repo")
 import numpy as np, torch

@@ -198,20 +198,22 @@ def test_gemm_both_kernels_agree():
     md, ed = me_dev(m, e)
     dA, dW, db = dev(A), dev(W), dev(b)
     outs = []
-    for force in (0, 1, 2):
-        _lib.call("ivit_debug_force_small_gemm", force)
+
+    def run():
         out = torch.empty(M, N, dtype=torch.int8, device=DEV)
         _lib.call("ivit_gemm_i8_requant", _lib.ptr(dA), K, _lib.ptr(dW), K, _lib.ptr(db), _lib.ptr(md), _lib.ptr(ed),
                   _lib.ptr(out), N, M, N, K, st())
         outs.append(out.cpu().numpy())
-    _lib.call("ivit_debug_force_small_gemm", 0)
-    for flags in (1024, 2048, 4096, 8192, 32, 4194304, 8388608):   # relaunch form; tail split; one workgroup per CU; deep ring; 256x256; persistent 256x256
-        _lib.call("ivit_debug_set_gemm_flags", flags)
-        out = torch.empty(M, N, dtype=torch.int8, device=DEV)
-        _lib.call("ivit_gemm_i8_requant", _lib.ptr(dA), K, _lib.ptr(dW), K, _lib.ptr(db), _lib.ptr(md), _lib.ptr(ed),
-                  _lib.ptr(out), N, M, N, K, st())
-        outs.append(out.cpu().numpy())
-    _lib.call("ivit_debug_set_gemm_flags", 0)
+
+    run()                                   # the product library (stateless: no knobs)
+    with _lib.lab_session():                # libivit_hip_lab.so: the same sources with the kernel-form knobs
+        for force in (0, 1, 2):
+            _lib.call("ivit_debug_force_small_gemm", force)
+            run()
+        _lib.call("ivit_debug_force_small_gemm", 0)
+        for flags in (1024, 2048, 4096, 8192, 32, 4194304, 8388608):   # relaunch form; tail split; one workgroup per CU; deep ring; 256x256; persistent 256x256
+            _lib.call("ivit_debug_set_gemm_flags", flags)
+            run()
     assert all(np.array_equal(outs[0], o) for o in outs[1:])
     assert np.array_equal(outs[0].astype(np.int32), orc.requant(orc.gemm_i8(A, W, b), m.astype(np.float64), e, 8))
 
@@ -313,11 +315,14 @@ def test_producers_write_block_layout():
     rm = torch.empty(rows, Cn, dtype=torch.int8, device=DEV)
     _lib.call("ivit_layernorm_i8", *args, _lib.ptr(rm), Cn, st())
     v = valid_bytes(rows, Cn)
-    for form in (1, 2):   # a wave per row (permlane-swapped pair stores), half a wave per row
-        _lib.call("ivit_debug_ln_wave_per_row", form)
+    for form in (0, 1, 2):   # product library; lab: a wave per row, half a wave per row
         bl = torch.zeros((rows + 15) // 16 * 16 * Cn, dtype=torch.int8, device=DEV)
-        _lib.call("ivit_layernorm_i8_ex", *args, _lib.ptr(bl), Cn, 1, st())
-        _lib.call("ivit_debug_ln_wave_per_row", 0)
+        if form == 0:
+            _lib.call("ivit_layernorm_i8_ex", *args, _lib.ptr(bl), Cn, 1, st())
+        else:
+            with _lib.lab_session():
+                _lib.call("ivit_debug_ln_wave_per_row", form)
+                _lib.call("ivit_layernorm_i8_ex", *args, _lib.ptr(bl), Cn, 1, st())
         assert np.array_equal(bl.cpu().numpy()[v], tiled_of(rm, rows, Cn).cpu().numpy()[v]), form
         assert not bl.cpu().numpy()[~v].any(), form
     # GELU table form
@@ -452,12 +457,16 @@ def test_layernorm_random_vs_oracle(rows, Cn, ln_form):
     assert np.array_equal(got, exp), f"{(got != exp).sum()} of {got.size} differ"
 
 
-@pytest.fixture(params=[2, 1], ids=["half_wave_per_row", "wave_per_row"])
+@pytest.fixture(params=[0, 2, 1], ids=["product", "lab_half_wave_per_row", "lab_wave_per_row"])
 def ln_form(request):
-    """both int8 LayerNorm kernels: half a wave per row (C <= 1536) and a wave per row"""
-    _lib.call("ivit_debug_ln_wave_per_row", request.param)
-    yield request.param
-    _lib.call("ivit_debug_ln_wave_per_row", 0)
+    """the product library's own choice of int8 LayerNorm kernel, and both forms forced through the lab build: half a wave
+    per row (C <= 1536) and a wave per row"""
+    if request.param == 0:
+        yield 0
+        return
+    with _lib.lab_session():
+        _lib.call("ivit_debug_ln_wave_per_row", request.param)
+        yield request.param
 
 
 @pytest.mark.parametrize("regime", ["tiny_gamma", "huge_gamma", "big_bias", "saturating", "vanishing", "constant_rows",

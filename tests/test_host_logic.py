@@ -2,6 +2,7 @@
 exports) against the oracle and the reference-generated fixtures.  No GPU compute."""
 import ctypes as C
 import hashlib
+import json
 import os
 import re
 
@@ -91,13 +92,19 @@ def test_images_are_order_independent():
 def test_c_abi_library_exports_every_declared_symbol():
     """include/*.h <-> libivit_hip.so <-> the ctypes table agree (loads the library, calls nothing
     that needs a GPU)."""
-    hdr = "".join(open(os.path.join(ROOT, "include", f)).read() for f in sorted(os.listdir(os.path.join(ROOT, "include"))))
-    declared = set(re.findall(r"\b(?:int|const char\*)\s+(ivit_[a-z0-9_]+)\s*\(", hdr))
+    pat = r"\b(?:int|const char\*)\s+(ivit_[a-z0-9_]+)\s*\("
+    declared = set(re.findall(pat, open(os.path.join(ROOT, "include", "ivit_hip.h")).read()))
+    hooks = set(re.findall(pat, open(os.path.join(ROOT, "include", "ivit_hip_debug.h")).read()))
     assert declared == set(_lib.SIGNATURES) | {"ivit_version", "ivit_last_error_string"}
+    assert hooks == set(_lib.LAB_SIGNATURES)
     L = _lib.lib()
     for name in declared:
         assert hasattr(L, name), name
     assert L.ivit_version() >= 100
+    # the product library is stateless as its header says: none of the measurement hooks, no lab kernels
+    assert not any(hasattr(L, name) for name in hooks)
+    LAB = _lib.lab()
+    assert all(hasattr(LAB, name) for name in declared | hooks)
     # argument validation happens before any HIP call: exercise the error path on CPU
     with pytest.raises(_lib.IvitError, match="NULL"):
         _lib.call("ivit_gemm_i8_i32", None, 64, None, 64, None, None, 64, 64, 64, 64, None)
@@ -151,11 +158,15 @@ def test_checkpoint_harness_cpu(tmp_path):
     sd["qact_input.x_min"] = sd["qact_input.x_min"].reshape(())
     bare = tmp_path / "bare.pth"
     torch.save(sd, bare)
-    m3 = inference.load_model(bare, device="cpu", strict_load=False)
+    with pytest.raises(KeyError, match="ppoly"):          # the reference's default for a config-less checkpoint (:160-162)
+        inference.load_model(bare, device="cpu", strict_load=False)
+    m3 = inference.load_model(bare, device="cpu", strict_load=False, gelu_type="ivit", softmax_type="ivit", layernorm_type="ivit")
     assert m3.qact_input.x_min.shape == (1,) and m3.is_frozen()
     # model_name selects the factory; unknown operator families are refused
-    assert type(inference.build_model({"model_name": "swin_tiny_patch4_window7_224"})).__name__ == "SwinTransformer"
-    assert inference.build_model({"model_name": "deit_small"}).embed_dim == 384
+    assert type(inference.build_model({"model_name": "swin_tiny_patch4_window7_224", "gelu_type": "ivit", "softmax_type": "ivit",
+                                       "layernorm_type": "ivit"})).__name__ == "SwinTransformer"
+    small = inference.build_model({"model_name": "deit_small"})
+    assert small.embed_dim == 384 and small.op_types == ("ibert", "ibert", "ibert")     # the reference's defaults (:111-113)
     assert type(inference.build_model({"model_name": "deit_tiny", "gelu_type": "ibert"}).blocks[0].mlp.act).__name__ == "IBERTIntGELU"
     with pytest.raises(KeyError):
         inference.build_model({"model_name": "deit_tiny", "gelu_type": "ppoly_deg_2_seg_16"})
@@ -212,3 +223,39 @@ def test_integer_export_matches_reference_integers(tmp_path):
     na, nb = a.layernorm("blocks.7.norm2", np.float32(0.03125)), b.layernorm("blocks.7.norm2", np.float32(0.03125))
     assert np.array_equal(na.bias_int, nb.bias_int) and np.array_equal(na.s_ln, nb.s_ln) and np.array_equal(na.m, nb.m)
     assert np.array_equal(a.tensor("cls_token"), b.tensor("cls_token"))
+
+
+def test_operator_signatures_match_reference_dropin_fixture(golden_dir):
+    """tests/golden/dropin_signatures.json is written by oracle/dropin_proof.py, which runs the REFERENCE's own
+    models/vit_quant.py and swin_quant.py on top of this package's modules in the build container (construction,
+    state_dict == the reference's, load_state_dict, freeze / unfreeze).  Here, without the reference: every constructor /
+    forward parameter the reference's operator classes have exists in the build's class under the same name, in the same
+    order, with the same default (the build may only add trailing parameters)."""
+    import inspect
+    import ivit_amd.layers_quant as lq
+    import ivit_amd.model_utils as mu
+    import ivit_amd.quantization_utils as qu
+    fx = json.load(open(os.path.join(golden_dir, "dropin_signatures.json")))
+    assert set(fx["reference_files_on_build_modules"]) >= {"deit_tiny_patch16_224", "deit_base_patch16_224",
+                                                           "swin_tiny_patch4_window7_224", "deit_tiny_patch16_224@ibert"}
+
+    def sig(obj):
+        return [[n, None if p.default is inspect.Parameter.empty else repr(p.default)]
+                for n, p in inspect.signature(obj).parameters.items() if n not in ("self", "args", "kwargs")]
+
+    def compatible(mine, ref, what):
+        assert len(mine) >= len(ref), what
+        for (n1, d1), (n0, d0) in zip(mine, ref):
+            assert n1 == n0, (what, n1, n0)
+            assert d1 == d0 or (d0 is not None and d1 is not None and d0.split(".")[-1] == d1.split(".")[-1]), (what, n1, d1, d0)
+
+    for name, spec in fx["signatures"].items():
+        obj = getattr(qu, name, None) or getattr(lq, name, None) or getattr(mu, name, None)
+        assert obj is not None, name
+        if "call" in spec:
+            compatible(sig(obj), spec["call"], name)
+            continue
+        compatible(sig(obj.__init__), spec["init"], name + ".__init__")
+        compatible(sig(obj.forward), spec["forward"], name + ".forward")
+        for m in spec["methods"]:
+            assert callable(getattr(obj, m, None)), (name, m)
