@@ -79,6 +79,7 @@ LAB_SIGNATURES = {
     "ivit_debug_force_small_gemm": [ci],
     "ivit_debug_set_gemm_flags": [ci],
     "ivit_debug_ln_wave_per_row": [ci],
+    "ivit_debug_ln_ablate": [ci],
     "ivit_debug_set_stamp_buffer": [vp],
 }
 LAB_PATH = os.path.join(_HERE, "libivit_hip_lab.so")
@@ -150,6 +151,7 @@ class lab_session:
         L.ivit_debug_force_small_gemm(0)
         L.ivit_debug_set_gemm_flags(0)
         L.ivit_debug_ln_wave_per_row(0)
+        L.ivit_debug_ln_ablate(0)
         _use_lab = self.prev
         return False
 

@@ -110,7 +110,9 @@ __global__ __launch_bounds__(NT, 3) void attention_kernel(AttnArgs a)
     const unsigned* lut = reinterpret_cast<const unsigned*>(smem + LUT_OFF);
     const int nqt = (T + 15) >> 4;
 
-    for (int qt = wave; qt < nqt; qt += 4) {
+    // 13 query tiles over 4 waves: one wave gets four tiles, the others three.  Which wave that is rotates with the
+    // workgroup index, so that the co-resident workgroups of a CU do not all put their extra tile on the same SIMD
+    for (int qt = (wave + bh) & 3; qt < nqt; qt += 4) {
         const int qrow = qt * 16 + l15;  // this lane's query
         const int qld = min(qrow, T - 1);
         const v4i qf = *reinterpret_cast<const v4i*>(qg + (int64_t)qld * HD + 16 * g);

@@ -17,8 +17,10 @@
 // (ivit_debug_ln_wave_per_row)
 #if IVIT_LAB
 int g_ln_wave_per_row = 0;
+int g_ln_ablate = 0;     // lab build only (ivit_debug_ln_ablate): 1 no element chain, 2 no statistics, 4 no stores, 8 no table build
 #else
 constexpr int g_ln_wave_per_row = 0;
+constexpr int g_ln_ablate = 0;
 #endif
 
 namespace {
@@ -59,6 +61,7 @@ struct LnArgs {
     // input QuantAct produced but phi(q) = fl(fl(q*s)/s) (quant_modules.py:387, ivit_modules.py:36)
     const int8_t* remap;   // [256] k'(q) = trunc(phi(q)), indexed q + 128   (ivit_modules.py:38 .to(int32))
     const float* phi;      // [256] phi(q), indexed q + 128                  (the mean, :37, is taken over these)
+    int abl;               // lab build: timing ablations (results wrong), always 0 in the product
 };
 
 // Per-row statistics exactly as ivit_modules.py:36-51 computes them.
@@ -138,7 +141,7 @@ IVIT_DEV float torch_rowsum_phi(const int8_t* qrow, int C, const float* phi_lds,
 // whose integer sum is an exact .5 tie (1 in C), where torch's float32 reduction order over the phi values decides and
 // torch_rowsum_phi restates it; everything downstream of (k', mean) is the same arithmetic.
 template <int NJ, bool COMPAT = false>
-__global__ __launch_bounds__(NT, (NJ <= 3 ? 4 : NJ <= 8 ? 2 : 1)) void layernorm_i8_kernel(LnArgs a)
+__global__ __launch_bounds__(NT, (NJ <= 3 && !COMPAT ? 3 : NJ <= 8 ? 2 : 1)) void layernorm_i8_kernel(LnArgs a)
 {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: row addresses in SALU
     const int C = a.C, nd = C >> 2;
@@ -188,20 +191,44 @@ __global__ __launch_bounds__(NT, (NJ <= 3 ? 4 : NJ <= 8 ? 2 : 1)) void layernorm
     // work that a one-row-per-wave kernel repeats in all 64 lanes; here lane r evaluates them for row r of the group
     // (G rows in parallel across lanes) and the results come back as wave-uniform values through v_readlane.
     constexpr int G = (NJ <= 3) ? 8 : (NJ <= 4) ? 4 : 1;
-    for (int row0 = (blockIdx.x * WPB + wave) * G; row0 < a.rows; row0 += gridDim.x * WPB * G) {
+    // Streaming schedule: every wave owns one CONTIGUOUS, balanced run of row groups (the former grid-stride loop left 46 %
+    // of the waves with one iteration and the rest with two at the headline shape), and the loads of group g + 1 are issued
+    // before group g is computed, so that after the first group the HBM latency sits under the element chain of the previous
+    // one instead of in front of every iteration (the launch is one resident wave set: all waves would otherwise load,
+    // compute and store in lockstep).
+    const int n_groups = (a.rows + G - 1) / G;
+    const int n_waves = gridDim.x * WPB, wave_id = blockIdx.x * WPB + wave;
+    const int gq = n_groups / n_waves, gr = n_groups - gq * n_waves;
+    const int g_begin = wave_id * gq + min(wave_id, gr), g_end = g_begin + gq + (wave_id < gr ? 1 : 0);
+    int wn[G][NJ];
+    auto load_group = [&](int row0) {
+#pragma unroll
+        for (int rr = 0; rr < G; ++rr) {
+            const int* xr = reinterpret_cast<const int*>(xin + (int64_t)min(row0 + rr, a.rows - 1) * a.ldx);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int d = lane + 64 * j;
+                wn[rr][j] = (d < nd) ? xr[d] : 0;
+            }
+        }
+    };
+    if (g_begin < g_end) load_group(g_begin * G);
+    for (int gi = g_begin; gi < g_end; ++gi) {
+        const int row0 = gi * G;
         int w[G][NJ], sum[G], var[G];   // var[]: sum of squares
         int sumq[COMPAT ? G : 1];       // COMPAT: integer sum of the un-remapped row (the mean is over phi(q) ~ q)
 #pragma unroll
+        for (int rr = 0; rr < G; ++rr)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) w[rr][j] = wn[rr][j];
+        if (gi + 1 < g_end) load_group(row0 + G);     // in flight during this group's arithmetic
+#pragma unroll
         for (int rr = 0; rr < G; ++rr) {
-            const int row = min(row0 + rr, a.rows - 1);
-            const int* xr = reinterpret_cast<const int*>(xin + (int64_t)row * a.ldx);
             sum[rr] = 0;
             var[rr] = 0;
             if constexpr (COMPAT) sumq[rr] = 0;
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                int d = lane + 64 * j;
-                w[rr][j] = (d < nd) ? xr[d] : 0;
                 if constexpr (COMPAT) {
                     sumq[rr] = __builtin_amdgcn_sdot4(w[rr][j], 0x01010101, sumq[rr], false);
                     const unsigned u = (unsigned)w[rr][j] ^ 0x80808080u;      // q + 128 per byte
@@ -488,6 +515,293 @@ __global__ __launch_bounds__(NT, NJ <= 3 ? 4 : 3) void layernorm_i8_pair_kernel(
 }
 
 // module-level form: int32 in (8- or 16-bit values), float32 out = y * s_ln (ivit_modules.py:63)
+// ------------------------------------------------------------------------------------------------
+// layernorm_i8_v2_kernel: the default int8 I-LayerNorm for C <= 1024 (NJ <= 4 dwords per lane).
+//
+// What the counters said about the kernels above at the headline shape (profiles/r02d_row_kernel_counters.json: 175 VALU
+// wave-instructions per row, of which the element chain is 90; VALU busy 48 % of the kernel): half of the instructions
+// were per-row overhead -- the 6-step all-reduce of every row's two sums (24 / row), the statistics (ten Newton steps with
+// IEEE divisions) evaluated once per 8 rows, the per-wave prologue that derives 12 * NJ bracket constants in float64.  Here:
+//   * a wave takes G = 16 rows at a time, one contiguous balanced run of rows per wave (no grid-stride remainder);
+//   * the 16 x 2 row sums are reduced by a TRANSPOSE reduction: v_permlane32_swap / v_permlane16_swap exchange the halves
+//     of two registers in one instruction, so each step halves the number of live values; 15 exchanges per sum type instead
+//     of 96 shuffles, and lane l ends up with the totals of row l >> 2;
+//   * the statistics run once per 16 rows, all lanes in parallel (lane l: row l >> 2), results broadcast by v_readlane;
+//   * per-channel constants (bias, the float32 bracket of the requantiser) are derived once per WORKGROUP into LDS and read
+//     16 bytes at a time per dword of channels and group of rows, not kept in 36 registers per wave;
+//   * channels outer, rows inner in the element chain: one set of constants serves 16 rows; results overwrite the row
+//     registers, a row with an uncertified element (~1 %) is re-read and redone literally.
+// Arithmetic identical to layernorm_i8_kernel (same certificate, same literal fallback, same COMPAT handling).
+template <int NJ, bool COMPAT, int G>
+__global__ __launch_bounds__(NT, (NJ <= 1 ? 4 : NJ <= 3 ? 3 : 2)) void layernorm_i8_v2_kernel(LnArgs a)
+{
+    static_assert(G == 8 || G == 16, "G");
+    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+    extern __shared__ __attribute__((aligned(16))) float lds_tab[];   // [C] bias | [C] lo | [C] hi
+    __shared__ unsigned char s_remap[COMPAT ? 256 : 4];
+    __shared__ float s_phi[COMPAT ? 256 : 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int C = a.C, nd = C >> 2;
+    float* t_bias = lds_tab;
+    float* t_lo = lds_tab + C;
+    float* t_hi = lds_tab + 2 * C;
+    const int abl = IVIT_LAB ? a.abl : 0;
+    for (int c = tid; c < ((abl & 8) ? 0 : C); c += NT) {
+        const double M = dyadic_mult(a.m[c], a.e[c]);
+        const double lod = M * (1.0 - 1.25 / 4194304.0), hid = M * (1.0 + 1.25 / 4194304.0);
+        float lf = (float)lod, hf = (float)hid;
+        if ((double)lf > lod) lf = __int_as_float(__float_as_int(lf) - 1);   // largest float32 <= lod (lod > 0)
+        if ((double)hf < hid) hf = __int_as_float(__float_as_int(hf) + 1);   // smallest float32 >= hid
+        const float sl = a.s_ln[c];
+        const bool ok = fabsf(sl) >= 1e-30f && fabsf(sl) <= 1e30f && lod > 1e-35 && hid < 1e30;   // see layernorm_i8_kernel
+        t_bias[c] = a.bias_int[c];
+        t_lo[c] = ok ? lf : 0.0f;
+        t_hi[c] = ok ? hf : __builtin_inff();
+    }
+    if constexpr (COMPAT) {
+        s_remap[tid] = (unsigned char)a.remap[tid];   // NT == 256
+        s_phi[tid] = a.phi[tid];
+    }
+    __syncthreads();
+    const int8_t* xin = reinterpret_cast<const int8_t*>(a.x);
+    int8_t* out = reinterpret_cast<int8_t*>(a.out);
+    BlockCol bcol[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) bcol[j] = block_col(4 * (lane + 64 * j));
+    // this wave's contiguous run of rows
+    const int n_waves = gridDim.x * WPB, wave_id = blockIdx.x * WPB + wave;
+    const int rq = a.rows / n_waves, rrm = a.rows - rq * n_waves;
+    const int r_begin = wave_id * rq + min(wave_id, rrm), r_end = r_begin + rq + (wave_id < rrm ? 1 : 0);
+    // (Tried and measured, scripts/ln_ablate.py: issuing the loads of group g + 1 before group g is computed, with groups of 8
+    // rows, does not overlap anything -- 29.5 us against 28.1 us for plain groups of 16 at the headline shape.  The phases of
+    // this kernel add up almost exactly: read + reduce 10 us, statistics 1.5 us, element chain 11.5 us, stores 6 us.)
+    auto load_group = [&](int row0, auto& dst) {
+        const int nr = min(G, r_end - row0);
+#pragma unroll
+        for (int rr = 0; rr < G; ++rr) {
+            const int* xr = reinterpret_cast<const int*>(xin + (int64_t)(row0 + min(rr, nr - 1)) * a.ldx);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                // NJ = ceil(nd / 64): only the last dword column can be partial.  Unconditional loads from a clamped address
+                // and a select, not a predicated load: branches around the loads make the compiler's s_waitcnt insertion
+                // fall back to vmcnt(0) at the first use, which also waits for the STORES of the previous group
+                const int d = lane + 64 * j;
+                if (j < NJ - 1) {
+                    dst[rr][j] = xr[d];
+                } else {
+                    const int v = xr[min(d, nd - 1)];
+                    dst[rr][j] = (d < nd) ? v : 0;
+                }
+            }
+        }
+    };
+    // De-phasing: every wave of the resident set has the same work, so without this they all read, then all compute, then
+    // all store.  Odd waves take a first group of G / 2 rows: from then on they are half a group out of step with the even
+    // waves on their SIMD, whose arithmetic then runs while the odd waves' loads and stores are in flight.
+    int step = ((wave_id & 1) && !(abl & 64)) ? G / 2 : G;
+    for (int row0 = r_begin; row0 < r_end; row0 += step, step = G) {
+        const int nrow = min(step, r_end - row0);
+        int w[G][NJ];
+        int s1[G], s2[G];
+        int sq[COMPAT ? G : 1];
+        load_group(row0, w);
+#pragma unroll
+        for (int rr = 0; rr < G; ++rr) {
+            s1[rr] = 0;
+            s2[rr] = 0;
+            if constexpr (COMPAT) sq[rr] = 0;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                if constexpr (COMPAT) {
+                    sq[rr] = __builtin_amdgcn_sdot4(w[rr][j], 0x01010101, sq[rr], false);
+                    const unsigned u = (unsigned)w[rr][j] ^ 0x80808080u;      // q + 128 per byte
+                    w[rr][j] = (int)((unsigned)s_remap[u & 255] | ((unsigned)s_remap[(u >> 8) & 255] << 8) |
+                                     ((unsigned)s_remap[(u >> 16) & 255] << 16) | ((unsigned)s_remap[u >> 24] << 24));
+                }
+                s1[rr] = __builtin_amdgcn_sdot4(w[rr][j], 0x01010101, s1[rr], false);
+                s2[rr] = __builtin_amdgcn_sdot4(w[rr][j], w[rr][j], s2[rr], false);
+            }
+        }
+        // transpose reduction: 16 values per lane -> 1; lane l ends with the totals of row (l >> 2) & 15.
+        // step "32": rows 0-7 stay in lanes 0-31, rows 8-15 go to lanes 32-63 (v_permlane32_swap exchanges the upper half
+        // of its first operand with the lower half of its second); step "16" likewise inside each half; then two steps with
+        // plain exchanges (2 values, 1 value), then the last two butterfly levels.
+        // (G = 8: one level less -- lane l ends with row (l >> 3) & 7.)
+        constexpr int LPR = 64 / G;          // lanes that end up holding one row's totals
+        auto treduce = [&](int (&v)[G]) -> int {
+            int t8[8], t4[4], t2[2];
+            if constexpr (G == 16) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const v2u r = __builtin_amdgcn_permlane32_swap((unsigned)v[i], (unsigned)v[i + 8], false, false);
+                    t8[i] = (int)(r.x + r.y);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const v2u r = __builtin_amdgcn_permlane16_swap((unsigned)t8[i], (unsigned)t8[i + 4], false, false);
+                    t4[i] = (int)(r.x + r.y);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const v2u r = __builtin_amdgcn_permlane32_swap((unsigned)v[i], (unsigned)v[i + 4], false, false);
+                    t4[i] = (int)(r.x + r.y);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const v2u r = __builtin_amdgcn_permlane16_swap((unsigned)t4[i], (unsigned)t4[i + 2], false, false);
+                    t2[i] = (int)(r.x + r.y);
+                }
+            }
+            const bool up8 = (lane & 8) != 0, up4 = (lane & 4) != 0;
+            int t;
+            if constexpr (G == 16) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int keep = up8 ? t4[i + 2] : t4[i], send = up8 ? t4[i] : t4[i + 2];
+                    t2[i] = keep + __shfl_xor(send, 8);
+                }
+                const int keep = up4 ? t2[1] : t2[0], send = up4 ? t2[0] : t2[1];
+                t = keep + __shfl_xor(send, 4);
+            } else {
+                const int keep = up8 ? t2[1] : t2[0], send = up8 ? t2[0] : t2[1];
+                t = keep + __shfl_xor(send, 8);
+                t += __shfl_xor(t, 4);
+            }
+            t += __shfl_xor(t, 2);
+            t += __shfl_xor(t, 1);
+            return t;
+        };
+        const int my_sum = treduce(s1), my_sq = treduce(s2);     // lane l: row l / LPR
+        const int my_row = (lane / LPR) & (G - 1);
+        int my_mean;
+        if constexpr (COMPAT) {
+            const int my_sumq = treduce(sq);
+            ln_mean(my_sumq, C, my_mean);      // = round(fl(sum phi / C)) unless the row is a tie (see layernorm_i8_kernel)
+            int r2 = (2 * my_sumq - C) % (2 * C);
+            r2 = r2 < 0 ? r2 + 2 * C : r2;
+            const bool tie = (r2 <= 2 || r2 >= 2 * C - 2) && (lane & (LPR - 1)) == 0 && my_row < nrow;
+            unsigned long long tm = __builtin_amdgcn_ballot_w64(tie);
+            while (tm) {                       // wave-uniform: rows decided by the float32 reduction order
+                const int tl_ = __builtin_ctzll(tm);
+                tm &= tm - 1;
+                const int rr = tl_ / LPR;
+                const float S = torch_rowsum_phi(xin + (int64_t)(row0 + rr) * a.ldx, C, s_phi, lane);
+                const int fixed = (int)rintf(S / (float)C);     // ivit_modules.py:37
+                my_mean = (my_row == rr) ? fixed : my_mean;
+            }
+        } else {
+            ln_mean(my_sum, C, my_mean);
+        }
+        const int my_var = my_sq - 2 * my_mean * my_sum + C * my_mean * my_mean;
+        const float my_hfactor = (abl & 2) ? 1.0f : ln_factor((long long)my_var) * 0.5f;   // :45-52 (the /2 of :52 is an exact scaling)
+        float mean128[G], hfac[G];      // wave-uniform (SGPRs)
+#pragma unroll
+        for (int rr = 0; rr < G; ++rr) {
+            mean128[rr] = (float)(__builtin_amdgcn_readlane(my_mean, LPR * rr) + 128);
+            hfac[rr] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_hfactor), LPR * rr));
+        }
+        unsigned unc[G];
+#pragma unroll
+        for (int rr = 0; rr < G; ++rr) unc[rr] = 0;
+        if (!(abl & 1))
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int d = min(lane + 64 * j, nd - 1);
+            const float4 b4 = *reinterpret_cast<const float4*>(t_bias + 4 * d);
+            const float4 l4 = *reinterpret_cast<const float4*>(t_lo + 4 * d);
+            const float4 h4 = *reinterpret_cast<const float4*>(t_hi + 4 * d);
+            const bool live = lane + 64 * j < nd;
+            const float bias[4] = {b4.x, b4.y, b4.z, b4.w};
+            const float lo[4] = {live ? l4.x : 0.f, live ? l4.y : 0.f, live ? l4.z : 0.f, live ? l4.w : 0.f};
+            const float hi[4] = {live ? h4.x : 0.f, live ? h4.y : 0.f, live ? h4.z : 0.f, live ? h4.w : 0.f};
+#pragma unroll
+            for (int rr = 0; rr < G; ++rr) {
+                if (rr >= nrow) continue;   // wave-uniform
+                const unsigned wu = (unsigned)w[rr][j] ^ 0x80808080u;
+                int o[4];
+                unsigned u = unc[rr];
+#pragma unroll
+                for (int c = 0; c < 4; c += 2) {
+                    const v2f xf = {(float)((wu >> (8 * c)) & 0xffu), (float)((wu >> (8 * c + 8)) & 0xffu)};
+                    const v2f dl = xf - (v2f){mean128[rr], mean128[rr]};   // x - mean, exact
+                    const v2f pr = dl * (v2f){hfac[rr], hfac[rr]};         // :52
+                    const v2f vv = {floorf(pr.x), floorf(pr.y)};
+                    const v2f y = vv + (v2f){bias[c], bias[c + 1]};        // :61
+                    const v2f tlv = __builtin_elementwise_fma(y, (v2f){lo[c], lo[c + 1]}, (v2f){12582912.0f, 12582912.0f});
+                    const v2f thv = __builtin_elementwise_fma(y, (v2f){hi[c], hi[c + 1]}, (v2f){12582912.0f, 12582912.0f});
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const int tl = __float_as_int(tlv[k]), th = __float_as_int(thv[k]);
+                        asm("v_sad_u32 %0, %1, %2, %3" : "=v"(u) : "v"(tl), "v"(th), "v"(u));
+                        o[c + k] = clamp_i32(tl, 0x4B400000 - 128, 0x4B400000 + 127);
+                    }
+                }
+                unc[rr] = u;
+                const unsigned w01 = __builtin_amdgcn_perm((unsigned)o[1], (unsigned)o[0], 0x0c0c0400u);
+                const unsigned w23 = __builtin_amdgcn_perm((unsigned)o[3], (unsigned)o[2], 0x04000c0cu);
+                w[rr][j] = (int)(w01 | w23);      // the input dword is dead from here on
+            }
+        }
+#pragma unroll
+        for (int rr = 0; rr < G; ++rr) {
+            if (rr >= nrow) continue;       // wave-uniform
+            const int row = row0 + rr;
+            if (__builtin_amdgcn_ballot_w64(unc[rr] != 0) != 0) {
+                // literal evaluation of the row (wave-uniform, ~1 % of the rows): re-read it, as layernorm_i8_kernel
+                const int* xr = reinterpret_cast<const int*>(xin + (int64_t)row * a.ldx);
+                const int mean_i = (int)mean128[rr] - 128;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const int d = lane + 64 * j;
+                    if (d >= nd) continue;
+                    int wv = xr[d];
+                    if constexpr (COMPAT) {
+                        const unsigned u = (unsigned)wv ^ 0x80808080u;
+                        wv = (int)((unsigned)s_remap[u & 255] | ((unsigned)s_remap[(u >> 8) & 255] << 8) |
+                                   ((unsigned)s_remap[(u >> 16) & 255] << 16) | ((unsigned)s_remap[u >> 24] << 24));
+                    }
+                    const float4 s4 = *reinterpret_cast<const float4*>(a.s_ln + 4 * d);
+                    const uint4 m4 = *reinterpret_cast<const uint4*>(a.m + 4 * d);
+                    const int4 e4 = *reinterpret_cast<const int4*>(a.e + 4 * d);
+                    const float4 b4 = *reinterpret_cast<const float4*>(t_bias + 4 * d);
+                    const float sl[4] = {s4.x, s4.y, s4.z, s4.w}, bias[4] = {b4.x, b4.y, b4.z, b4.w};
+                    const double Mq[4] = {dyadic_mult(m4.x, e4.x), dyadic_mult(m4.y, e4.y), dyadic_mult(m4.z, e4.z),
+                                          dyadic_mult(m4.w, e4.w)};
+                    int o[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        float dl = (float)(sx8(wv, c) - mean_i);
+                        float v = floorf(dl * hfac[rr]);                   // :52
+                        float y = v + bias[c];                             // :61
+                        float x = y * sl[c];                               // :63
+                        float qf = (float)((double)x * (1.0 / (double)sl[c]));   // quant_utils.py:220, see layernorm_i8_kernel
+                        float z = rintf(qf);
+                        double p = (double)z * Mq[c];                      // :229
+                        double t = p + IVIT_MAGIC;                         // :230
+                        o[c] = clamp_i32((int)(unsigned)__double_as_longlong(t), -128, 127);
+                    }
+                    w[rr][j] = pack4(o[0], o[1], o[2], o[3]);
+                }
+            }
+            if (abl & 4) continue;
+            if (a.out_blocks) {
+                const BlockRow br = block_row(row, C);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    if (j < NJ - 1 || lane + 64 * j < nd) *reinterpret_cast<int*>(out + block_off(br, bcol[j])) = w[rr][j];
+            } else {
+                int* orow = reinterpret_cast<int*>(out + (int64_t)row * a.ldo);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const int d = lane + 64 * j;
+                    if (j < NJ - 1 || d < nd) orow[d] = w[rr][j];
+                }
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(NT) void layernorm_i32_f32_kernel(LnArgs a)
 {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: row addresses in SALU
@@ -997,6 +1311,34 @@ __global__ void minmax_finish_kernel(unsigned* keys)
 }
 
 // ================================================================================================
+
+// layernorm_i8_v2_kernel: one resident set of workgroups, every wave a contiguous run of rows
+template <bool COMPAT>
+static int launch_ln_v2(const LnArgs& a, hipStream_t st, const char* who)
+{
+    const int nj = (a.C / 4 + 63) / 64;
+    const int resident = 256 * (nj <= 1 ? 4 : nj <= 3 ? 3 : 2);     // = the kernel's __launch_bounds__ occupancy
+    // groups of 16 rows (half the per-row cost of the statistics); groups of 8 for small launches, where twice the number of
+    // waves matters more (batch 1: 197 rows; the final LayerNorm over the class rows)
+    const bool g8 = ((a.abl >> 4) & 3) == 1 || (((a.abl >> 4) & 3) == 0 && a.rows < 16384);
+    const int gsz = g8 ? 8 : 16;
+    int grid = (int)(((int64_t)a.rows + gsz * WPB - 1) / (gsz * WPB));    // at least one full group per wave
+    if (grid > resident) grid = resident;
+    if (grid < 1) grid = 1;
+    const size_t lds = (size_t)3 * a.C * sizeof(float);
+#define IVIT_LN_V2(NJv)                                                                                              \
+    do {                                                                                                             \
+        if (g8) hipLaunchKernelGGL((layernorm_i8_v2_kernel<NJv, COMPAT, 8>), dim3(grid), dim3(NT), lds, st, a);      \
+        else hipLaunchKernelGGL((layernorm_i8_v2_kernel<NJv, COMPAT, 16>), dim3(grid), dim3(NT), lds, st, a);        \
+    } while (0)
+    if (nj <= 1) IVIT_LN_V2(1);
+    else if (nj <= 2) IVIT_LN_V2(2);
+    else if (nj <= 3) IVIT_LN_V2(3);
+    else IVIT_LN_V2(4);
+#undef IVIT_LN_V2
+    IVIT_CHECK_LAUNCH(who);
+}
+
 IVIT_EXPORT int ivit_tile_operand_i8(const int8_t* src, int64_t ld, int64_t rows, int K, int8_t* dst, ivit_stream_t stream)
 {
     IVIT_REQUIRE(src && dst && rows > 0 && K > 0 && K % 64 == 0 && ld >= K && ld % 16 == 0 && ((uintptr_t)src % 16 == 0) &&
@@ -1023,6 +1365,12 @@ IVIT_EXPORT int ivit_debug_ln_wave_per_row(int on)
     g_ln_wave_per_row = on;
     return IVIT_OK;
 }
+
+IVIT_EXPORT int ivit_debug_ln_ablate(int bits)
+{
+    g_ln_ablate = bits;
+    return IVIT_OK;
+}
 #endif
 
 IVIT_EXPORT int ivit_layernorm_i8_ex(const int8_t* x, int64_t ldx, int rows, int C, const float* bias_int,
@@ -1040,8 +1388,9 @@ IVIT_EXPORT int ivit_layernorm_i8_ex(const int8_t* x, int64_t ldx, int rows, int
     IVIT_REQUIRE(out_blocks == 0 || (out_blocks == 1 && C % 64 == 0 && ldo == C && ((uintptr_t)out % 16 == 0) &&
                                      ((int64_t)rows + 15) * C < 2147483648ll),
                  "ivit_layernorm_i8_ex: block-layout output needs C %% 64 == 0, ldo == C and a buffer below 2 GiB");
-    LnArgs a{x, ldx, rows, C, bias_int, s_ln, m, e, out, ldo, out_blocks, nullptr, nullptr};
+    LnArgs a{x, ldx, rows, C, bias_int, s_ln, m, e, out, ldo, out_blocks, nullptr, nullptr, g_ln_ablate};
     hipStream_t st = ivit_stream(stream);
+    if (C <= 1024 && g_ln_wave_per_row == 0) return launch_ln_v2<false>(a, st, "ivit_layernorm_i8");
     // half a wave per row (constants in LDS, 3 * C floats) where it is the faster form: measured 17.5 vs 20.7 us at
     // C = 384 and 14.0 vs 14.9 us at C = 192, but 36 vs 30 us at C = 768 (rows = 50 432)
     if ((C <= 384 || g_ln_wave_per_row == 2) && C <= 1536 && g_ln_wave_per_row != 1) {
@@ -1059,7 +1408,7 @@ IVIT_EXPORT int ivit_layernorm_i8_ex(const int8_t* x, int64_t ldx, int rows, int
     const int nj = (C / 4 + 63) / 64;
     // each wave sets up its per-channel constants (bias and the requant bracket, 12*NJ registers per lane) once: launch no more workgroups than
     // stay resident (256 CUs x waves/SIMD at the kernel's register count) and let them stride over the rows
-    const int resident = 256 * (nj <= 1 ? 6 : nj <= 3 ? 4 : nj <= 4 ? 3 : nj <= 8 ? 2 : 1);
+    const int resident = 256 * (nj <= 3 ? 3 : nj <= 8 ? 2 : 1);     // = the kernel's __launch_bounds__ occupancy
     int grid = grid_for_rows(rows, nj <= 3 ? 8 : nj <= 4 ? 4 : 1);   // rows per wave and iteration: G of the kernel
     if (grid > resident) grid = resident;
     if (nj <= 1) hipLaunchKernelGGL(layernorm_i8_kernel<1>, dim3(grid), dim3(NT), 0, st, a);
@@ -1086,10 +1435,11 @@ IVIT_EXPORT int ivit_layernorm_i8_compat(const int8_t* x, int64_t ldx, int rows,
     IVIT_REQUIRE(out_blocks == 0 || (out_blocks == 1 && C % 64 == 0 && ldo == C && ((uintptr_t)out % 16 == 0) &&
                                      ((int64_t)rows + 15) * C < 2147483648ll),
                  "ivit_layernorm_i8_compat: block-layout output needs C %% 64 == 0, ldo == C and a buffer below 2 GiB");
-    LnArgs a{x, ldx, rows, C, bias_int, s_ln, m, e, out, ldo, out_blocks, remap, phi};
+    LnArgs a{x, ldx, rows, C, bias_int, s_ln, m, e, out, ldo, out_blocks, remap, phi, g_ln_ablate};
     hipStream_t st = ivit_stream(stream);
+    if (C <= 1024 && g_ln_wave_per_row == 0) return launch_ln_v2<true>(a, st, "ivit_layernorm_i8_compat");
     const int nj = (C / 4 + 63) / 64;
-    const int resident = 256 * (nj <= 1 ? 6 : nj <= 3 ? 4 : nj <= 4 ? 3 : nj <= 8 ? 2 : 1);
+    const int resident = 256 * (nj <= 8 ? 2 : 1);                   // = the kernel's __launch_bounds__ occupancy
     int grid = grid_for_rows(rows, nj <= 3 ? 8 : nj <= 4 ? 4 : 1);
     if (grid > resident) grid = resident;
     if (nj <= 1) hipLaunchKernelGGL((layernorm_i8_kernel<1, true>), dim3(grid), dim3(NT), 0, st, a);
@@ -1113,7 +1463,7 @@ IVIT_EXPORT int ivit_layernorm_i32_f32(const int32_t* x, int64_t ldx, int rows, 
 {
     IVIT_REQUIRE(x && out && bias_int && s_ln, "ivit_layernorm_i32_f32: NULL operand");
     IVIT_REQUIRE(rows > 0 && C > 0 && C <= 4096 && ldx >= C && ldo >= C, "ivit_layernorm_i32_f32: bad shape");
-    LnArgs a{x, ldx, rows, C, bias_int, s_ln, nullptr, nullptr, out, ldo, 0, nullptr, nullptr};
+    LnArgs a{x, ldx, rows, C, bias_int, s_ln, nullptr, nullptr, out, ldo, 0, nullptr, nullptr, 0};
     hipLaunchKernelGGL(layernorm_i32_f32_kernel, dim3(grid_for_rows(rows)), dim3(NT), 0, ivit_stream(stream), a);
     IVIT_CHECK_LAUNCH("ivit_layernorm_i32_f32");
 }

@@ -30,6 +30,11 @@ int ivit_debug_set_stamp_buffer(void* buf);
  * wave per row, 2 = half a wave per row wherever it exists (C <= 1536): parity tests of both forms, A/B timing */
 int ivit_debug_ln_wave_per_row(int on);
 
+/* timing ablations of the default int8 LayerNorm kernel (results WRONG when non-zero): 1 no element chain, 2 no row
+ * statistics, 4 no stores, 8 no per-workgroup table build; bits 4-5 (correct results): 1 force groups of 8 rows, 2 force
+ * groups of 16; scripts/ln_ablate.py */
+int ivit_debug_ln_ablate(int bits);
+
 #ifdef __cplusplus
 }
 #endif
