@@ -43,6 +43,9 @@ SIGNATURES = {
     "ivit_layernorm_i32_f32": [vp, i64, ci, ci, vp, vp, vp, i64, vp],
     "ivit_layernorm_f32_f32": [vp, i64, ci, ci, vp, ci, vp, vp, vp, i64, vp],
     "ivit_shiftmax_f32_i8": [vp, i64, ci, ci, f32, vp, i64, vp],
+    "ivit_shiftmax_f32_i16": [vp, i64, ci, ci, f32, ci, vp, i64, vp],
+    "ivit_bgemm_pv_i16_i8": [vp, vp, vp, ci, ci, ci, ci, vp],
+    "ivit_quantize_input_f32_i32": [vp, vp, i64, f32, ci, vp],
     "ivit_shiftgelu_i8": [vp, i64, ci, ci, f32, u32, i32, vp, i64, vp],
     "ivit_shiftgelu_i8_i32": [vp, i64, ci, ci, f32, vp, i64, vp],
     "ivit_shiftgelu_build_lut": [f32, u32, i32, vp, vp],

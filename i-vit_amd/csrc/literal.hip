@@ -118,8 +118,9 @@ struct SmLitArgs {
     int64_t ldx;
     int rows, L;
     float s, x0;
-    int8_t* out;
+    void* out;       // int8 (output_bit = 8) or int16 (output_bit 9..16)
     int64_t ldo;
+    float two_sh;    // 2^(31 - output_bit + 1), ivit_modules.py:175
 };
 
 // int_exp_shift on a float32 argument, ivit_modules.py:150-162 verbatim (n = 15)
@@ -134,8 +135,9 @@ IVIT_DEV float shiftexp_lit(float d, float x0)
     return fmaxf(ex, 0.0f);
 }
 
-// IVITIntSoftmax.forward, ivit_modules.py:164-176, line by line (output_bit = 8)
-__global__ __launch_bounds__(NT) void shiftmax_f32_i8_kernel(SmLitArgs a)
+// IVITIntSoftmax.forward, ivit_modules.py:164-176, line by line
+template <typename TO>
+__global__ __launch_bounds__(NT) void shiftmax_f32_kernel(SmLitArgs a)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int row = blockIdx.x * WPB + wave; row < a.rows; row += gridDim.x * WPB) {
@@ -149,7 +151,7 @@ __global__ __launch_bounds__(NT) void shiftmax_f32_i8_kernel(SmLitArgs a)
         S = fminf(S, 2147483648.0f);                                              // :173
         const float factor = floorf((1.0f / S) * 2147483648.0f);                  // :174
         for (int i = lane; i < a.L; i += 64)
-            a.out[(int64_t)row * a.ldo + i] = (int8_t)floorf((ex(i) * factor) / 16777216.0f);   // :175
+            reinterpret_cast<TO*>(a.out)[(int64_t)row * a.ldo + i] = (TO)floorf((ex(i) * factor) / a.two_sh);   // :175
     }
 }
 
@@ -180,7 +182,19 @@ IVIT_EXPORT int ivit_shiftmax_f32_i8(const float* x, int64_t ldx, int rows, int 
     IVIT_REQUIRE(s > 0.0f, "ivit_shiftmax_f32_i8: scale must be positive");
     const float x0 = __builtin_floorf((1.0f / s) * -1.0f);      // ivit_modules.py:154
     IVIT_REQUIRE(x0 <= -1.0f && x0 >= -1048576.0f, "ivit_shiftmax_f32_i8: x0=%g out of range", (double)x0);
-    SmLitArgs a{x, ldx, rows, L, s, x0, out, ldo};
-    hipLaunchKernelGGL(shiftmax_f32_i8_kernel, dim3(rows_grid(rows)), dim3(NT), 0, ivit_stream(stream), a);
+    SmLitArgs a{x, ldx, rows, L, s, x0, out, ldo, 16777216.0f};
+    hipLaunchKernelGGL(shiftmax_f32_kernel<int8_t>, dim3(rows_grid(rows)), dim3(NT), 0, ivit_stream(stream), a);
     IVIT_CHECK_LAUNCH("ivit_shiftmax_f32_i8");
+}
+
+IVIT_EXPORT int ivit_shiftmax_f32_i16(const float* x, int64_t ldx, int rows, int L, float s, int output_bit, int16_t* out,
+                                      int64_t ldo, ivit_stream_t stream)
+{
+    IVIT_REQUIRE(x && out && rows > 0 && L > 0 && ldx >= L && ldo >= L, "ivit_shiftmax_f32_i16: bad operand");
+    IVIT_REQUIRE(s > 0.0f && output_bit >= 2 && output_bit <= 16, "ivit_shiftmax_f32_i16: scale / output_bit out of range");
+    const float x0 = __builtin_floorf((1.0f / s) * -1.0f);      // ivit_modules.py:154
+    IVIT_REQUIRE(x0 <= -1.0f && x0 >= -1048576.0f, "ivit_shiftmax_f32_i16: x0=%g out of range", (double)x0);
+    SmLitArgs a{x, ldx, rows, L, s, x0, out, ldo, __builtin_ldexpf(1.0f, 31 - output_bit + 1)};
+    hipLaunchKernelGGL(shiftmax_f32_kernel<int16_t>, dim3(rows_grid(rows)), dim3(NT), 0, ivit_stream(stream), a);
+    IVIT_CHECK_LAUNCH("ivit_shiftmax_f32_i16");
 }

@@ -1067,6 +1067,17 @@ __global__ __launch_bounds__(NT) void quantize_kernel(const float* x, int8_t* ou
         for (int64_t t = n & ~(int64_t)3; t < n; ++t) out[t] = (int8_t)quant_sym_i8(x[t], inv_scale);
 }
 
+// SymmetricQuantFunction at any width up to 32 bits (quant_utils.py:79-97): clamp(round(1/s * x), -2^(b-1), 2^(b-1) - 1)
+__global__ __launch_bounds__(NT) void quantize_i32_kernel(const float* x, int32_t* out, int64_t n, float inv_scale, float lo,
+                                                          float hi)
+{
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+        float v = rintf(inv_scale * x[i]);
+        v = fminf(fmaxf(v, lo), hi);
+        out[i] = (int32_t)fminf(v, 2147483520.0f);
+    }
+}
+
 // img [B, chans, hw, hw] -> A [B*gh*gw, chans*patch*patch]; one thread quantises 4 consecutive kw
 __global__ __launch_bounds__(NT) void patchify_kernel(const float* img, int8_t* A, int64_t lda, int batch, int chans,
                                                       int hw, int patch, float inv_scale)
@@ -1203,8 +1214,8 @@ __global__ __launch_bounds__(NT) void narrow_i32_i8_kernel(const int32_t* z, int
 
 // module-level QuantMatMul: small batched products, one output element per thread (not the hot path:
 // the engine uses the fused MFMA attention kernel)
-template <bool PV>
-__global__ __launch_bounds__(NT) void bgemm_kernel(const int8_t* X, const int8_t* Y, int32_t* O, int batch, int Tq,
+template <bool PV, typename TX = int8_t>
+__global__ __launch_bounds__(NT) void bgemm_kernel(const TX* X, const int8_t* Y, int32_t* O, int batch, int Tq,
                                                    int Tk, int D)
 {
     const int cols = PV ? D : Tk, red = PV ? Tk : D;
@@ -1214,7 +1225,7 @@ __global__ __launch_bounds__(NT) void bgemm_kernel(const int8_t* X, const int8_t
         int64_t r = idx / cols;
         int i = (int)(r % Tq);
         int b = (int)(r / Tq);
-        const int8_t* xr = X + ((int64_t)b * Tq + i) * red;
+        const TX* xr = X + ((int64_t)b * Tq + i) * red;
         int acc = 0;
         if (PV) {
             const int8_t* yb = Y + (int64_t)b * Tk * D + j;
@@ -1592,6 +1603,15 @@ IVIT_EXPORT int ivit_quantize_input_f32_i8(const float* x, int8_t* out, int64_t 
     IVIT_CHECK_LAUNCH("ivit_quantize_input_f32_i8");
 }
 
+IVIT_EXPORT int ivit_quantize_input_f32_i32(const float* x, int32_t* out, int64_t n, float inv_scale, int bits,
+                                            ivit_stream_t stream)
+{
+    IVIT_REQUIRE(x && out && n > 0 && bits >= 2 && bits <= 32, "ivit_quantize_input_f32_i32: bad operand");
+    const float lo = -__builtin_ldexpf(1.0f, bits - 1), hi = __builtin_ldexpf(1.0f, bits - 1) - 1.0f;   // float32, as torch.clamp
+    hipLaunchKernelGGL(quantize_i32_kernel, dim3(ew_grid(n)), dim3(NT), 0, ivit_stream(stream), x, out, n, inv_scale, lo, hi);
+    IVIT_CHECK_LAUNCH("ivit_quantize_input_f32_i32");
+}
+
 static int launch_patchify(const char* who, const float* img, int8_t* A, int64_t lda, int batch, int chans, int hw, int patch,
                            float inv_scale, ivit_stream_t stream)
 {
@@ -1684,6 +1704,16 @@ IVIT_EXPORT int ivit_bgemm_pv_i8(const int8_t* P, const int8_t* V, int32_t* O, i
     hipLaunchKernelGGL(bgemm_kernel<true>, dim3(ew_grid((int64_t)batch * Tq * D)), dim3(NT), 0, ivit_stream(stream), P,
                        V, O, batch, Tq, Tk, D);
     IVIT_CHECK_LAUNCH("ivit_bgemm_pv_i8");
+}
+
+IVIT_EXPORT int ivit_bgemm_pv_i16_i8(const int16_t* P, const int8_t* V, int32_t* O, int batch, int Tq, int Tk, int D,
+                                     ivit_stream_t stream)
+{
+    IVIT_REQUIRE(P && V && O && batch > 0 && Tq > 0 && Tk > 0 && D > 0, "ivit_bgemm_pv_i16_i8: bad operand");
+    IVIT_REQUIRE((int64_t)Tk * 32768 * 128 < 2147483648ll * 64, "ivit_bgemm_pv_i16_i8: Tk too large for int32 accumulation");
+    hipLaunchKernelGGL((bgemm_kernel<true, int16_t>), dim3(ew_grid((int64_t)batch * Tq * D)), dim3(NT), 0, ivit_stream(stream),
+                       P, V, O, batch, Tq, Tk, D);
+    IVIT_CHECK_LAUNCH("ivit_bgemm_pv_i16_i8");
 }
 
 IVIT_EXPORT int ivit_f32_to_i32(const float* x, int64_t rows, int C, const float* s, int n_s, int mode, int32_t* z,

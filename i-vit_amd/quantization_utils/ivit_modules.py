@@ -81,8 +81,8 @@ class IVITIntSoftmax(nn.Module):
 
     def __init__(self, output_bit=8):
         super().__init__()
-        if output_bit != 8:
-            raise NotImplementedError("the HIP Shiftmax implements output_bit=8 (the reference default)")
+        if not 2 <= output_bit <= 16:
+            raise NotImplementedError("the HIP Shiftmax implements output_bit 2..16")
         self.output_bit, self.n = output_bit, 15
         self.register_buffer("act_scaling_factor", torch.zeros(1))
 
@@ -97,9 +97,14 @@ class IVITIntSoftmax(nn.Module):
         # the literal kernel: the reference discards its .to(int32) (:166) and runs the float32 sequence on x / s itself
         # (Swin's masked scores, swin_quant.py:151-156, included), csrc/literal.hip
         xin = x.contiguous().float()
-        out8 = torch.empty(x.shape, dtype=torch.int8, device=x.device)
-        _lib.call("ivit_shiftmax_f32_i8", _lib.ptr(xin), L, xin.numel() // L, L, float(scaling_factor.reshape(-1)[0]),
-                  _lib.ptr(out8), L, _st())
+        if self.output_bit == 8:
+            out8 = torch.empty(x.shape, dtype=torch.int8, device=x.device)
+            _lib.call("ivit_shiftmax_f32_i8", _lib.ptr(xin), L, xin.numel() // L, L, float(scaling_factor.reshape(-1)[0]),
+                      _lib.ptr(out8), L, _st())
+        else:     # the softmax_bw knob (vit_quant.py:184): the same sequence with floor(. / 2^(31 - output_bit + 1)) (:175)
+            out8 = torch.empty(x.shape, dtype=torch.int16, device=x.device)
+            _lib.call("ivit_shiftmax_f32_i16", _lib.ptr(xin), L, xin.numel() // L, L, float(scaling_factor.reshape(-1)[0]),
+                      self.output_bit, _lib.ptr(out8), L, _st())
         s = torch.tensor([1 / 2 ** (self.output_bit - 1)], dtype=torch.float32, device=x.device)  # :176
         self.act_scaling_factor = s
         return to_float(out8.to(torch.int32), s), s

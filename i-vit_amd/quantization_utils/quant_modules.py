@@ -209,13 +209,16 @@ class QuantAct(nn.Module):
         bits = self.activation_bit
         if pre_act_scaling_factor is None:
             # input mode: clamp(round(1/s * x))  (SymmetricQuantFunction)
-            if bits != 8:
-                raise NotImplementedError("input-mode QuantAct is 8 bit on the HIP path")
             xin = x.contiguous().float()
-            q8 = torch.empty(xin.shape, dtype=torch.int8, device=x.device)
-            _lib.call("ivit_quantize_input_f32_i8", _lib.ptr(xin), _lib.ptr(q8), xin.numel(),
-                      float(f32(1.0) / s_out), _st())
-            q = q8.to(torch.int32)
+            if bits == 8:
+                q8 = torch.empty(xin.shape, dtype=torch.int8, device=x.device)
+                _lib.call("ivit_quantize_input_f32_i8", _lib.ptr(xin), _lib.ptr(q8), xin.numel(),
+                          float(f32(1.0) / s_out), _st())
+                q = q8.to(torch.int32)
+            else:      # e.g. pos_encoding_bw = 16 (vit_quant.py:181)
+                q = torch.empty(xin.shape, dtype=torch.int32, device=x.device)
+                _lib.call("ivit_quantize_input_f32_i32", _lib.ptr(xin), _lib.ptr(q), xin.numel(),
+                          float(f32(1.0) / s_out), int(bits), _st())
         else:
             z = to_int32(x, pre_act_scaling_factor)
             C = x.shape[-1]
@@ -254,14 +257,22 @@ class QuantMatMul(nn.Module):
         pass
 
     def forward(self, A, pre_act_scaling_factor_A, B, pre_act_scaling_factor_B):
-        a8 = narrow_i8(to_int32(A, pre_act_scaling_factor_A), "QuantMatMul A")
+        a32 = to_int32(A, pre_act_scaling_factor_A)
         b8 = narrow_i8(to_int32(B, pre_act_scaling_factor_B), "QuantMatMul B")  # to_int32 makes B contiguous [.., K, N]
         Tq, Kd = A.shape[-2], A.shape[-1]
         N = B.shape[-1]
         assert B.shape[-2] == Kd and A.shape[:-2] == B.shape[:-2]
-        batch = a8.numel() // (Tq * Kd)
+        batch = a32.numel() // (Tq * Kd)
         out = torch.empty((*A.shape[:-1], N), dtype=torch.int32, device=A.device)
-        _lib.call("ivit_bgemm_pv_i8", _lib.ptr(a8), _lib.ptr(b8), _lib.ptr(out), batch, Tq, Kd, N, _st())
+        amax = int(a32.abs().max())
+        if amax <= 127:
+            a8 = a32.to(torch.int8)
+            _lib.call("ivit_bgemm_pv_i8", _lib.ptr(a8), _lib.ptr(b8), _lib.ptr(out), batch, Tq, Kd, N, _st())
+        elif amax <= 32767:      # Shiftmax with softmax_bw = 16 feeds P . V with 16-bit probabilities
+            a16 = a32.to(torch.int16)
+            _lib.call("ivit_bgemm_pv_i16_i8", _lib.ptr(a16), _lib.ptr(b8), _lib.ptr(out), batch, Tq, Kd, N, _st())
+        else:
+            raise _lib.IvitError("QuantMatMul A: integer activations exceed 16 bits")
         s = (pre_act_scaling_factor_A * pre_act_scaling_factor_B).float()
         self.act_scaling_factor = s
         return to_float(out, s), s

@@ -49,6 +49,8 @@ int ivit_minmax_f32(const float* x, int64_t n, float* out_min_max, ivit_stream_t
  * linear_quantize :13-49):  q = clamp(round(inv_scale * x), -128, 127), inv_scale = fl(1/s)
  * computed by the caller in float32. */
 int ivit_quantize_input_f32_i8(const float* x, int8_t* out, int64_t n, float inv_scale, ivit_stream_t stream);
+/* the same at any width `bits` <= 32 (e.g. the 16-bit position embedding of pos_encoding_bw = 16), int32 out */
+int ivit_quantize_input_f32_i32(const float* x, int32_t* out, int64_t n, float inv_scale, int bits, ivit_stream_t stream);
 
 /* The same fused with the im2col of PatchEmbed's strided convolution
  * (layers_quant.py:197-198, quant_modules.py:506-511):
@@ -230,6 +232,10 @@ int ivit_shiftmax_i8(const int8_t* x, int64_t ldx, int rows, int L, float s, int
  * the row sum in torch's CPU reduction order. */
 int ivit_shiftmax_f32_i8(const float* x, int64_t ldx, int rows, int L, float s, int8_t* out, int64_t ldo,
                          ivit_stream_t stream);
+/* the same with a wider output (IVITIntSoftmax(output_bit), the reference's softmax_bw knob, vit_quant.py:184): int16 values in
+ * [0, 2^(output_bit-1) - 1], scale 2^-(output_bit-1) */
+int ivit_shiftmax_f32_i16(const float* x, int64_t ldx, int rows, int L, float s, int output_bit, int16_t* out, int64_t ldo,
+                          ivit_stream_t stream);
 /* the same on int32 inputs, |x| < 2^28: Swin adds the shift mask (-100/s, beyond 8 bits) to the scores in front of
  * the softmax (swin_quant.py:151-156) */
 int ivit_shiftmax_i32_i8(const int32_t* x, int64_t ldx, int rows, int L, float s, int8_t* out, int64_t ldo,
@@ -267,6 +273,9 @@ int ivit_bgemm_qk_i8(const int8_t* Q, const int8_t* K, int32_t* S, int batch, in
                      ivit_stream_t stream);
 int ivit_bgemm_pv_i8(const int8_t* P, const int8_t* V, int32_t* O, int batch, int Tq, int Tk, int D,
                      ivit_stream_t stream);
+/* P of more than 8 bits (Shiftmax with output_bit up to 16: values <= 32767, a row sums to ~2^15 so |acc| < 2^23) */
+int ivit_bgemm_pv_i16_i8(const int16_t* P, const int8_t* V, int32_t* O, int batch, int Tq, int Tk, int D,
+                         ivit_stream_t stream);
 
 /* ---- float <-> integer views at module edges (quant_utils.py:220; quant_modules.py:223,385-387) --
  * z = round(x / s[c]) (mode 0) or trunc(x / s[c]) (mode 1, the `.to(int32)` of ivit_modules.py:38,107);

@@ -739,12 +739,17 @@ W16 = dict(patch_embed_bw=16, pos_encoding_bw=8, block_input_bw=16, attention_ou
            norm2_in_bw=16, att_block_out_bw=16)
 
 
+W16_ALL = dict(patch_embed_bw=16, pos_encoding_bw=16, block_input_bw=16, attention_out_bw=16, softmax_bw=16, mlp_out_bw=16,
+               norm2_in_bw=16, att_block_out_bw=16)       # what `--bitwidth 16` sets (quant_train.py:299-306)
+
+
 def gen_w16(tag="deit_tiny_w16"):
     """DeiT-T with the reference's width knobs (vit_quant.py:180-187, quant_train.py:295-306) at 16 bits for the residual
     stream and the QuantActs in front of it (softmax and the position embedding stay 8 bit): logits of the reference only.
     The fused int8 engine does not implement these widths; the mirror must route such a model to its module path."""
     factory, wseed, cseed, cb, iseed, nimg = "deit_tiny_patch16_224", 11, 101, 4, 1001, 4
-    model = getattr(ref_models, factory)(pretrained=False, gelu_type="ivit", softmax_type="ivit", layernorm_type="ivit", **W16)
+    widths = W16_ALL if tag.endswith("_w16all") else W16
+    model = getattr(ref_models, factory)(pretrained=False, gelu_type="ivit", softmax_type="ivit", layernorm_type="ivit", **widths)
     fs = synth.make_float_state(factory, wseed)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in fs.items()}, strict=False)
     model.eval()
@@ -765,7 +770,7 @@ def gen_w16(tag="deit_tiny_w16"):
     out = {
         "meta": np.array(json.dumps(dict(tag=tag, factory=factory, family="ivit", weight_seed=wseed, calib_seed=cseed,
                                          calib_batch=cb, image_seed=iseed, n_images=nimg, qkv_gain=synth.QKV_GAIN,
-                                         widths=W16, torch=torch.__version__))),
+                                         widths=widths, torch=torch.__version__))),
         "range_names": np.array(list(ranges)),
         "range_bits": np.array([bits[n] for n in ranges], np.int32),
         "x_min": np.array([v[0] for v in ranges.values()], np.float32),
@@ -801,7 +806,7 @@ if __name__ == "__main__":
     for w in what:
         if w == "ops":
             gen_ops()
-        elif w.endswith("_w16"):
+        elif w.endswith("_w16") or w.endswith("_w16all"):
             gen_w16(w)
         elif w == "compat_ops":
             gen_compat_ops()

@@ -374,10 +374,13 @@ def test_ibert_model_module_path_matches_reference_golden():
 
 
 # ----------------------------------------------------------------------------------- engine dispatch (dispatch.py)
-def test_non_8bit_widths_take_the_module_path_and_match_the_reference():
-    """the reference's width knobs (vit_quant.py:180-187): a DeiT-T with a 16-bit residual stream is NOT what the fused
-    int8 engine computes -- the mirror must say so and run it module by module, reproducing the reference's logits"""
-    fs, ranges, cfg, meta, z = load_synthetic_model("deit_tiny_w16")
+@pytest.mark.parametrize("tag", ["deit_tiny_w16", "deit_tiny_w16all"])
+def test_non_8bit_widths_take_the_module_path_and_match_the_reference(tag):
+    """the reference's width knobs (vit_quant.py:180-187): a DeiT-T with a 16-bit residual stream -- and, `w16all`, what
+    `--bitwidth 16` sets (quant_train.py:299-306): every knob at 16 incl. the 16-bit Shiftmax output feeding P.V and the
+    16-bit position embedding -- is NOT what the fused int8 engine computes: the mirror must say so and run it module by
+    module, reproducing the reference's logits"""
+    fs, ranges, cfg, meta, z = load_synthetic_model(tag)
     model = ivit.deit_tiny_patch16_224(**meta["widths"])
     model.load_state_dict({k: torch.from_numpy(v) for k, v in fs.items()}, strict=False)
     for name, mod in model.named_modules():
