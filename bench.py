@@ -47,6 +47,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches in the timed region instead of HIP-graph replay")
     ap.add_argument("--probe-forwards", type=int, default=3, help="forwards of the instrumented pass (0 = skip)")
+    ap.add_argument("--natural-scales", action="store_true",
+                    help="the same model with its activation ranges AS CALIBRATED (fixture deit_base_natural) instead of "
+                         "power-of-two snapped: the regime of a real checkpoint, phi tables active (DESIGN.md section 2)")
     return ap.parse_args(argv)
 
 
@@ -173,7 +176,7 @@ def worker(args):
         dev = f"cuda:{local_rank}"
         if world > 1:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
-        fs, ranges, cfg, meta, _ = load_synthetic_model(MODEL_TAG)
+        fs, ranges, cfg, meta, _ = load_synthetic_model(MODEL_TAG + ("_natural" if args.natural_scales else ""))
         eng = IntViTEngine(fs, ranges, cfg["embed_dim"], cfg["depth"], cfg["num_heads"], device=dev, max_batch=batch)
         images = torch.from_numpy(synth.make_images(batch, 5000 + rank)).to(dev)  # resident in HBM
     dp = DataParallelTop1(eng, world, graph=not args.no_graph)
@@ -240,7 +243,8 @@ def worker(args):
                "config": {"workload": "DeiT-B INT8 integer-only forward, batch 256 per GPU, 224x224" if not stub
                           else "launcher self-test (stub engine, CPU, gloo)",
                           "global_batch": world * batch, "parallelism": f"dp{world}",
-                          "launch": "eager" if args.no_graph else "hip-graph replay"},
+                          "launch": "eager" if args.no_graph else "hip-graph replay",
+                          "activation_ranges": "as calibrated (natural scales)" if args.natural_scales else "power-of-two"},
                "mfma_util_end_to_end": round(value / world * MAC_PER_IMAGE / 2.5166e15, 4),
                "roofline": roof}
         if world == 1 and not stub and not args.no_cpu_baseline:

@@ -28,6 +28,7 @@ SIGNATURES = {
     "ivit_layernorm_i8_ex": [vp, i64, ci, ci, vp, vp, vp, vp, vp, i64, ci, vp],
     "ivit_layernorm_i8_compat": [vp, i64, ci, ci, vp, vp, vp, vp, vp, vp, vp, i64, ci, vp],
     "ivit_attention_fused_i8_compat": [vp, vp, ci, ci, ci, ci, u32, i32, f32, u32, i32, vp, ci, vp],
+    "ivit_attention_fused_i8_compat_band": [vp, vp, ci, ci, ci, ci, u32, i32, f32, u32, i32, vp, vp, ci, ci, vp],
     "ivit_shiftgelu_build_lut_ex": [f32, u32, i32, vp, vp, vp],
     "ivit_shiftgelu_lut_i8_ex": [vp, i64, ci, ci, vp, vp, i64, ci, vp],
     "ivit_tile_operand_i8": [vp, i64, i64, ci, vp, vp],

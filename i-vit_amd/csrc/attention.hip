@@ -45,7 +45,16 @@ struct AttnArgs {
     // (ivit_modules.py:165-170; the .to(int32) of :166 is discarded), so the exponent is no longer a function of qmax - q
     // alone; the host tabulates it with the reference's float32 steps (prepare.shiftexp2d).  NULL: power-of-two scale.
     const unsigned* exp2d;
+    // The same table in BAND form for the LDS path: band[(qmax + 128) * band_w + j] = exp_int of (qmax, q = qmax - j),
+    // j < band_w; band_w is a multiple of 16 and entry band_w - 1 is already the saturated value -|x0| (the argument is
+    // clamped at n * x0 from there on, ivit_modules.py:155), so index min(qmax - q, band_w - 1) covers every q.  Each wave
+    // stages the band rows of its 16 queries in LDS per query tile: 64 LDS lanes per cycle instead of one table address per
+    // cycle through the texture addresser (the full-table gather made the kernel 2.6x slower).  0: use exp2d.
+    const unsigned* band;
+    int band_w;
 };
+
+constexpr int BAND_PAD = 4;   // dwords: keeps slice rows 16-byte aligned and rotates their banks
 
 // K image: 64-byte rows; 16-byte chunk c of row r at slot (c + 2*((r>>2)&1)) & 3.  A 16x16x64 fragment read has
 // lanes 0-15 on rows 0-15 chunk 0, lanes 16-31 chunk 1, ...; with this rotation every ds_read_b128 lane group
@@ -55,6 +64,7 @@ IVIT_DEV int kswz(int r, int c) { return r * HD + (((c + 2 * ((r >> 2) & 1)) & 3
 __global__ __launch_bounds__(NT, 3) void attention_kernel(AttnArgs a)
 {
     __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
+    extern __shared__ __attribute__((aligned(16))) unsigned band_lds[];   // [4 waves][16 queries][band_w + BAND_PAD], compat only
     const int T = a.tokens;
     const int bh = blockIdx.x;
     const int b = bh / a.heads, hh = bh - b * a.heads;
@@ -146,7 +156,29 @@ __global__ __launch_bounds__(NT, 3) void attention_kernel(AttnArgs a)
         // k - max is in [-255, 0] for every real key: the 256-entry table covers it without a clamp (the entries from
         // ksat on are identical anyway); only the padding keys of the last tile carry the -1000 sentinel
         unsigned esum = 0;
-        if (a.exp2d) {      // wave-uniform; one L2-resident gather per score instead of the LDS lookup
+        if (a.band_w) {     // wave-uniform; natural input scale, band rows of this tile's 16 queries staged in LDS
+            const int W = a.band_w, stride = W + BAND_PAD;
+            unsigned* slice = band_lds + (wave * 16 + l15) * stride;
+            {
+                const uint4* src = reinterpret_cast<const uint4*>(a.band + (size_t)(rmax + 128) * W) + g * (W >> 4);
+                uint4* dst = reinterpret_cast<uint4*>(slice) + g * (W >> 4);
+                for (int i = 0; i < (W >> 4); ++i) dst[i] = src[i];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int nk = s[kt][r];
+                    unsigned e = slice[min(nk + rmax, W - 1)];     // the 1000 sentinel of the padding keys clamps, too
+                    if (kt == NKT - 1) e = (nk == 1000) ? 0u : e;
+                    s[kt][r] = (int)e;
+                    esum += e;
+                }
+            __builtin_amdgcn_wave_barrier();    // every lane has read its slice before the next tile overwrites it
+        } else if (a.exp2d) {      // wave-uniform; one L2-resident gather per score instead of the LDS lookup
             const unsigned* row2d = a.exp2d + ((rmax + 128) << 8) + 128;       // entry of q = -nk
 #pragma unroll
             for (int kt = 0; kt < NKT; ++kt)
@@ -243,6 +275,15 @@ IVIT_EXPORT int ivit_attention_fused_i8_compat(const int8_t* qkv, int8_t* out, i
                                                int head_dim, uint32_t m_s, int32_t e_s, float s_attn, uint32_t m_o,
                                                int32_t e_o, const uint32_t* exp2d, int out_blocks, ivit_stream_t stream)
 {
+    return ivit_attention_fused_i8_compat_band(qkv, out, batch, heads, tokens, head_dim, m_s, e_s, s_attn, m_o, e_o, exp2d,
+                                               nullptr, 0, out_blocks, stream);
+}
+
+IVIT_EXPORT int ivit_attention_fused_i8_compat_band(const int8_t* qkv, int8_t* out, int batch, int heads, int tokens,
+                                                    int head_dim, uint32_t m_s, int32_t e_s, float s_attn, uint32_t m_o,
+                                                    int32_t e_o, const uint32_t* exp2d, const uint32_t* band, int band_w,
+                                                    int out_blocks, ivit_stream_t stream)
+{
     IVIT_REQUIRE(qkv && out, "ivit_attention_fused_i8: NULL operand");
     IVIT_REQUIRE(batch > 0 && heads > 0, "ivit_attention_fused_i8: empty batch");
     if (head_dim != HD || tokens <= 16 * (NKT - 1) || tokens > KP) {
@@ -257,8 +298,12 @@ IVIT_EXPORT int ivit_attention_fused_i8_compat(const int8_t* qkv, int8_t* out, i
                                      ((int64_t)batch * tokens + 15) * heads * head_dim < 2147483648ll),
                  "ivit_attention_fused_i8_ex: bad output layout (block-layout buffers stay below 2 GiB)");
     IVIT_REQUIRE((uintptr_t)exp2d % 4 == 0, "ivit_attention_fused_i8_compat: misaligned exponent table");
+    IVIT_REQUIRE(band_w == 0 || (band && band_w >= 16 && band_w <= 256 && band_w % 16 == 0 && (uintptr_t)band % 16 == 0),
+                 "ivit_attention_fused_i8_compat_band: band table must be 16-byte aligned, width a multiple of 16 in [16, 256]");
     AttnArgs a;
     a.exp2d = exp2d;
+    a.band = band;
+    a.band_w = band_w;
     a.out_blocks = out_blocks;
     a.qkv = qkv; a.out = out; a.batch = batch; a.heads = heads; a.tokens = tokens;
     a.Ms = ivit_dyadic_to_double(m_s, e_s);
@@ -276,7 +321,8 @@ IVIT_EXPORT int ivit_attention_fused_i8_compat(const int8_t* qkv, int8_t* out, i
         const int x = d + (d >> 1) - (d >> 4);  // ivit_modules.py:151 (arithmetic shifts = floor)
         if (x <= 15 * a.x0) { a.ksat = i; break; }
     }
-    hipLaunchKernelGGL(attention_kernel, dim3(batch * heads), dim3(NT), 0, ivit_stream(stream), a);
+    const size_t band_lds_bytes = band_w ? (size_t)4 * 16 * (band_w + BAND_PAD) * sizeof(unsigned) : 0;
+    hipLaunchKernelGGL(attention_kernel, dim3(batch * heads), dim3(NT), band_lds_bytes, ivit_stream(stream), a);
     IVIT_CHECK_LAUNCH("ivit_attention_fused_i8");
 }
 

@@ -1401,7 +1401,9 @@ IVIT_EXPORT int ivit_layernorm_i8_ex(const int8_t* x, int64_t ldx, int rows, int
                  "ivit_layernorm_i8_ex: block-layout output needs C %% 64 == 0, ldo == C and a buffer below 2 GiB");
     LnArgs a{x, ldx, rows, C, bias_int, s_ln, m, e, out, ldo, out_blocks, nullptr, nullptr, g_ln_ablate};
     hipStream_t st = ivit_stream(stream);
-    if (C <= 1024 && g_ln_wave_per_row == 0) return launch_ln_v2<false>(a, st, "ivit_layernorm_i8");
+    // v2 where a row fills the wave (measured at 50 432 rows: C = 768 28.1 us against 30.3; C = 384 19.0 against 17.5 for the
+    // half-wave form; at C = 96 -- Swin's patch norm -- only 24 of 64 lanes would hold data)
+    if (C >= 512 && C <= 1024 && g_ln_wave_per_row == 0) return launch_ln_v2<false>(a, st, "ivit_layernorm_i8");
     // half a wave per row (constants in LDS, 3 * C floats) where it is the faster form: measured 17.5 vs 20.7 us at
     // C = 384 and 14.0 vs 14.9 us at C = 192, but 36 vs 30 us at C = 768 (rows = 50 432)
     if ((C <= 384 || g_ln_wave_per_row == 2) && C <= 1536 && g_ln_wave_per_row != 1) {
@@ -1448,7 +1450,7 @@ IVIT_EXPORT int ivit_layernorm_i8_compat(const int8_t* x, int64_t ldx, int rows,
                  "ivit_layernorm_i8_compat: block-layout output needs C %% 64 == 0, ldo == C and a buffer below 2 GiB");
     LnArgs a{x, ldx, rows, C, bias_int, s_ln, m, e, out, ldo, out_blocks, remap, phi, g_ln_ablate};
     hipStream_t st = ivit_stream(stream);
-    if (C <= 1024 && g_ln_wave_per_row == 0) return launch_ln_v2<true>(a, st, "ivit_layernorm_i8_compat");
+    if (C >= 512 && C <= 1024 && g_ln_wave_per_row == 0) return launch_ln_v2<true>(a, st, "ivit_layernorm_i8_compat");
     const int nj = (C / 4 + 63) / 64;
     const int resident = 256 * (nj <= 8 ? 2 : 1);                   // = the kernel's __launch_bounds__ occupancy
     int grid = grid_for_rows(rows, nj <= 3 ? 8 : nj <= 4 ? 4 : 1);

@@ -22,7 +22,7 @@ import torch
 
 from . import _lib
 from .graph import GraphReplay
-from .prepare import dyadic, f32, pad_head, phi_tables, quant_sym, requant_host, shiftexp2d
+from .prepare import dyadic, f32, pad_head, phi_tables, quant_sym, requant_host, shiftexp2d, shiftexp_band
 from .synth import IMG_SIZE, NUM_PATCHES, NUM_TOKENS, PATCH
 
 
@@ -112,10 +112,15 @@ class IntViTEngine(GraphReplay):
             s_at = s(p + "attn.qact_attn1")
             s_pv = f32(f32(1.0 / 128.0) * s_a1)                           # Shiftmax scale 2^-7 x value scale
             s_a2 = s(p + "attn.qact2")
-            blk["attn"] = dict(ms=scalar_me(s_S, s_at), s_attn=float(s_at), mo=scalar_me(s_pv, s_a2), exp2d=None)
+            blk["attn"] = dict(ms=scalar_me(s_S, s_at), s_attn=float(s_at), mo=scalar_me(s_pv, s_a2), exp2d=None, band=None, band_w=0)
             if phi_tables(s_at) is not None:       # Shiftmax on phi(q): exponent tabulated over (row max, q)
                 self.natural_sites += 1
-                blk["attn"]["exp2d"] = dev(shiftexp2d(s_at).view(np.int32))
+                tab = shiftexp2d(s_at)
+                band, bw = shiftexp_band(tab)
+                if bw and bw <= 128:               # band rows staged in LDS per query tile (34 KB per workgroup at width 128)
+                    blk["attn"].update(band=dev(band.view(np.int32)), band_w=bw)
+                else:                              # very fine input scale: full-table gather
+                    blk["attn"]["exp2d"] = dev(tab.view(np.int32))
             s_a3 = s(p + "attn.qact3")
             blk["proj"] = lin_dev(source.linear(p + "attn.proj", s_a2), s_a3)
             s_b2 = s(p + "qact2")
@@ -280,8 +285,9 @@ class IntViTEngine(GraphReplay):
                       _lib.ptr(q["m"]), _lib.ptr(q["e"]), _lib.ptr(ws["qkv"]), T, H, hd, M, 3 * C, C, qlay | int(a_ln), st)
             tap(p + "attn.qkv_headmajor", ws["qkv"], (3, B, H, T, hd))
             a = blk["attn"]
-            _lib.call("ivit_attention_fused_i8_compat", _lib.ptr(ws["qkv"]), _lib.ptr(ws["ao"]), B, H, T, hd,
-                      a["ms"][0], a["ms"][1], a["s_attn"], a["mo"][0], a["mo"][1], _lib.ptr(a["exp2d"]), int(a_at), st)
+            _lib.call("ivit_attention_fused_i8_compat_band", _lib.ptr(ws["qkv"]), _lib.ptr(ws["ao"]), B, H, T, hd,
+                      a["ms"][0], a["ms"][1], a["s_attn"], a["mo"][0], a["mo"][1], _lib.ptr(a["exp2d"]), _lib.ptr(a["band"]),
+                      a["band_w"], int(a_at), st)
             tap(p + "attn.qact2", ws["ao"], (B, T, C), a_at)
             self._gemm_res(ws["ao"], C, blk["proj"], x, blk["res1"], x2, M, st, blocks=blk_l, a_blocks=a_at)
             tap(p + "qact2", x2, (B, T, C))

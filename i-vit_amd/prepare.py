@@ -157,3 +157,23 @@ def _shiftexp2d(ph, s, n):
     ex = np.where(np.arange(256)[None, :] <= np.arange(256)[:, None], ex, f32(0))
     assert np.isfinite(ex).all() and ex.max() < 2.0 ** 32
     return ex.astype(np.uint32)
+
+
+def shiftexp_band(tab2d: np.ndarray):
+    """Band form of shiftexp2d for the LDS path of the attention kernel: band[qmax+128, j] = tab2d[qmax+128, qmax+128-j].
+    -> (band uint32 [256, W], W) with W the smallest multiple of 16 such that every entry at distance >= W - 1 from the row
+    maximum equals the saturated value (the exponent's argument is clamped at n*x0 there), or (None, 0) if W would exceed 256."""
+    idx = np.arange(256)
+    dist = idx[:, None] - idx[None, :]                  # qmax - q
+    valid = dist >= 0
+    sat = int(tab2d[255, 0])                            # distance 255: certainly clamped
+    unsat = valid & (tab2d != sat)
+    last = int(dist[unsat].max()) if unsat.any() else 0  # largest distance whose entry is not the saturated value
+    W = -(-(last + 2) // 16) * 16                       # entry W - 1 must itself be saturated
+    if W > 256:
+        return None, 0
+    j = np.arange(W)
+    q = idx[:, None] - j[None, :]
+    band = np.where(q >= 0, tab2d[idx[:, None], np.clip(q, 0, 255)], np.uint32(sat)).astype(np.uint32)
+    assert np.all(band[:, W - 1] == sat)
+    return np.ascontiguousarray(band), W

@@ -164,6 +164,15 @@ int ivit_attention_fused_i8_compat(const int8_t* qkv, int8_t* out, int batch, in
                                    uint32_t m_s, int32_t e_s, float s_attn, uint32_t m_o, int32_t e_o,
                                    const uint32_t* exp2d, int out_blocks, ivit_stream_t stream);
 
+/* The same with the table also in BAND form, staged per query tile in LDS (the fast path; exp2d may then be NULL):
+ * band[(qmax+128)*band_w + j] = exp_int of (qmax, q = qmax - j) for j < band_w, band_w a multiple of 16 in [16, 256] chosen
+ * by the caller such that entry band_w - 1 is already the saturated value (the exponent's argument is clamped at n*x0,
+ * ivit_modules.py:155, so every larger distance gives the same entry); i-vit_amd/prepare.py shiftexp_band. */
+int ivit_attention_fused_i8_compat_band(const int8_t* qkv, int8_t* out, int batch, int heads, int tokens, int head_dim,
+                                        uint32_t m_s, int32_t e_s, float s_attn, uint32_t m_o, int32_t e_o,
+                                        const uint32_t* exp2d, const uint32_t* band, int band_w, int out_blocks,
+                                        ivit_stream_t stream);
+
 /* ---- I-LayerNorm + the QuantAct behind it ---------------------------------------------------
  * IVITIntLayerNorm.forward (ivit_modules.py:30-65) then QuantAct (fixedpoint_mul).
  *   x [rows, C] int8 (ldx), per channel: bias_int[c] = floor((beta/gamma)/(sqrt(C)/2^30)),

@@ -567,6 +567,7 @@ NATURAL_PLAN = {
     # tag: (factory, weight seed, calibration seeds (one batch each, EMA as quant_modules.py:346-360), batch, image seed, n)
     "deit_tiny_natural": ("deit_tiny_patch16_224", 11, (101, 111, 121), 4, 1001, 8),
     "deit_small_natural": ("deit_small_patch16_224", 12, (102, 112), 4, 1002, 4),
+    "deit_base_natural": ("deit_base_patch16_224", 13, (103, 113), 2, 1003, 2),
 }
 
 

@@ -51,6 +51,11 @@ def test_compat_oracle_deit_tiny_natural_matches_reference():
     assert om.ln_tie_rows > 0          # the fixture does exercise rows decided by the float32 reduction order
 
 
+def test_compat_oracle_deit_base_natural_matches_reference():
+    """headline model, ranges as calibrated, one image (C = 768: the level-cascade branch of the reduction order)"""
+    _check_model("deit_base_natural", True, 1)
+
+
 def test_plain_integer_algorithm_is_not_the_reference_at_natural_scales():
     """what the compat restatement is for: without phi the logits differ (SURVEY finding 8)"""
     fs, ranges, cfg, meta, z = load_synthetic_model("deit_tiny_natural")
