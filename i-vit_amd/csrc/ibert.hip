@@ -11,6 +11,7 @@
 #include <limits.h>
 
 #include "common.h"
+#include "rowsum.h"
 
 namespace {
 
@@ -169,6 +170,107 @@ __global__ __launch_bounds__(NT) void ibert_layernorm_kernel(IbLnArgs a)
     }
 }
 
+// ================================================================================================
+// Literal (float view) forms: the module receives x = q * s (quant_modules.py:387) and starts with x / s
+// (ibert_modules.py:126, 226, 303), which is the integer q only for a power-of-two s.  These kernels take the float view and
+// its scale and run the reference's float32 sequence on x / s itself -- any scale -- with the row sums in torch's CPU reduction
+// order (rowsum.h).  For a power-of-two s they equal the integer-input kernels above.
+// ================================================================================================
+__global__ __launch_bounds__(NT) void ibert_gelu_f32_kernel(const float* x, int64_t n, float s, float b_int, float c_int,
+                                                            float shift_int, float s_out, float* out)
+{
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+        const float xi = x[i] / s;                                           // :226
+        const float sgn = (xi > 0.0f) ? 1.0f : ((xi < 0.0f) ? -1.0f : 0.0f); // :209
+        const float a = fminf(fabsf(xi), -b_int);                            // :210-211
+        const float t = a + b_int;
+        float y = t * t;                                                     // :212
+        y = y + c_int;
+        y = sgn * y;                                                         // :213
+        y = floorf(y / 64.0f);                                               // :215
+        const float p = xi * (y + shift_int);                                // :231
+        // :234; a zero product keeps the sign the reference's result has (its fixtures: -0.0 for the negative output scale)
+        out[i] = (p == 0.0f ? 0.0f : p) * s_out;
+    }
+}
+
+struct IbSoftmaxLitArgs {
+    const float* x;
+    int64_t ldx;
+    int rows, L;
+    float s;
+    IbSoftmaxArgs c;     // constants (k / out / exp_out of it unused)
+    float* out;          // float view exp_int * (2 / 2^output_bit)
+    float out_sf;
+    int64_t ldo;
+    float* exp_out;
+};
+
+__global__ __launch_bounds__(NT) void ibert_softmax_f32_kernel(IbSoftmaxLitArgs a)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int row = blockIdx.x * WPB + wave; row < a.rows; row += gridDim.x * WPB) {
+        const float* xr = a.x + (int64_t)row * a.ldx;
+        float xmax = -__builtin_inff();
+        for (int i = lane; i < a.L; i += 64) xmax = fmaxf(xmax, xr[i] / a.s);                 // :303-305
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) xmax = fmaxf(xmax, __shfl_xor(xmax, o));
+        if (a.exp_out) {
+            for (int i = lane; i < a.L; i += 64) a.exp_out[(int64_t)row * a.L + i] = ib_exp_int(xr[i] / a.s - xmax, a.c);
+            continue;
+        }
+        auto ex = [&](int i) {
+            const float e = ib_exp_int(xr[i] / a.s - xmax, a.c);                              // :306-307
+            const float z_int = rintf(e / a.c.exp_sf);                                        // internal QuantAct(16), :308
+            double q16 = __builtin_rint((double)z_int * a.c.M);
+            q16 = fmin(fmax(q16, -32768.0), 32767.0);
+            return ((float)q16 * a.c.act_sf) / a.c.act_sf;                                    // :309-310
+        };
+        const float ssum = torch_rowsum(ex, a.L, lane);                                       // :311
+        const float factor = floorf(4294967296.0f / ssum);                                    // :313
+        for (int i = lane; i < a.L; i += 64)
+            a.out[(int64_t)row * a.ldo + i] = floorf((ex(i) * factor) / a.c.out_div) * a.out_sf;   // :314, 319
+    }
+}
+
+struct IbLnLitArgs {
+    const float* x;
+    int64_t ldx;
+    int rows, C;
+    const float* s_in;
+    int n_s;
+    const float* bias_int;
+    const float* s_out;
+    float shift_pow2;
+    float* out;
+    int64_t ldo;
+};
+
+__global__ __launch_bounds__(NT) void ibert_layernorm_f32_kernel(IbLnLitArgs a)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int C = a.C;
+    for (int row = blockIdx.x * WPB + wave; row < a.rows; row += gridDim.x * WPB) {
+        const float* xr = a.x + (int64_t)row * a.ldx;
+        auto xint = [&](int c) { return xr[c] / a.s_in[a.n_s == 1 ? 0 : c]; };              // :126
+        const float mean_int = rintf(torch_rowsum(xint, C, lane) / (float)C);                 // :127
+        auto sq = [&](int c) {
+            const float ys = floorf((xint(c) - mean_int) / a.shift_pow2);                     // :128-129
+            return ys * ys;                                                                   // :130
+        };
+        const float var_int = torch_rowsum(sq, C, lane);                                      // :131
+        const float std_int = floorf(sqrtf(var_int)) * a.shift_pow2;                          // :142
+        const float factor = floorf(2147483648.0f / std_int);                                 // :143
+        float* orow = a.out + (int64_t)row * a.ldo;
+        for (int c = lane; c < C; c += 64) {
+            const float y = xint(c) - mean_int;
+            float v = floorf((y * factor) / 2.0f);                                            // :144
+            v = v + a.bias_int[c];                                                            // :151
+            orow[c] = v * a.s_out[c];                                                         // :153
+        }
+    }
+}
+
 }  // namespace
 
 // ================================================================================================
@@ -210,4 +312,45 @@ IVIT_EXPORT int ivit_ibert_layernorm_i32_f32(const int32_t* k, int64_t ldx, int 
     IbLnArgs a{k, ldx, rows, C, bias_int, s_out, shift_pow2, out, ldo};
     hipLaunchKernelGGL(ibert_layernorm_kernel, dim3(grid_for_rows(rows)), dim3(NT), 0, ivit_stream(stream), a);
     IVIT_CHECK_LAUNCH("ivit_ibert_layernorm_i32_f32");
+}
+
+IVIT_EXPORT int ivit_ibert_gelu_f32_f32(const float* x, int64_t n, float s, float b_int, float c_int, float shift_int,
+                                        float s_out, float* out, ivit_stream_t stream)
+{
+    IVIT_REQUIRE(x && out && n > 0 && s != 0.0f, "ivit_ibert_gelu_f32_f32: bad operand");
+    IVIT_REQUIRE(b_int < 0.0f, "ivit_ibert_gelu_f32_f32: b_int must be negative (floor(-1.769 / (s / 1.4142)))");
+    hipLaunchKernelGGL(ibert_gelu_f32_kernel, dim3(ew_grid(n)), dim3(NT), 0, ivit_stream(stream), x, n, s, b_int, c_int,
+                       shift_int, s_out, out);
+    IVIT_CHECK_LAUNCH("ivit_ibert_gelu_f32_f32");
+}
+
+IVIT_EXPORT int ivit_ibert_softmax_f32_f32(const float* x, int64_t ldx, int rows, int L, float s, float x0_int, float b_int,
+                                           float c_int, float exp_sf, float act_sf, uint32_t m_act, int32_t e_act,
+                                           int output_bit, float* out, int64_t ldo, float* exp_out, ivit_stream_t stream)
+{
+    IVIT_REQUIRE(x && (out || exp_out) && rows > 0 && L > 0 && ldx >= L && s > 0.0f, "ivit_ibert_softmax_f32_f32: bad operand");
+    IVIT_REQUIRE(!out || ldo >= L, "ivit_ibert_softmax_f32_f32: ldo < L");
+    IVIT_REQUIRE(x0_int < 0.0f && exp_sf > 0.0f && act_sf > 0.0f, "ivit_ibert_softmax_f32_f32: bad scalar constants");
+    IVIT_REQUIRE(output_bit >= 2 && output_bit <= 16, "ivit_ibert_softmax_f32_f32: output_bit=%d unsupported", output_bit);
+    IbSoftmaxLitArgs a{};
+    a.x = x; a.ldx = ldx; a.rows = rows; a.L = L; a.s = s;
+    a.c.x0_int = x0_int; a.c.b_int = b_int; a.c.c_int = c_int; a.c.exp_sf = exp_sf; a.c.act_sf = act_sf;
+    a.c.M = ivit_dyadic_to_double(m_act, e_act);
+    a.c.out_div = __builtin_ldexpf(1.0f, 32 - output_bit + 1);
+    a.out = out; a.ldo = ldo; a.exp_out = exp_out;
+    a.out_sf = 2.0f / __builtin_ldexpf(1.0f, output_bit);           // :317
+    hipLaunchKernelGGL(ibert_softmax_f32_kernel, dim3(grid_for_rows(rows)), dim3(NT), 0, ivit_stream(stream), a);
+    IVIT_CHECK_LAUNCH("ivit_ibert_softmax_f32_f32");
+}
+
+IVIT_EXPORT int ivit_ibert_layernorm_f32_f32(const float* x, int64_t ldx, int rows, int C, const float* s_in, int n_s,
+                                             const float* bias_int, const float* s_out, float shift_pow2, float* out,
+                                             int64_t ldo, ivit_stream_t stream)
+{
+    IVIT_REQUIRE(x && s_in && out && bias_int && s_out && rows > 0 && C > 0 && ldx >= C && ldo >= C && (n_s == 1 || n_s == C),
+                 "ivit_ibert_layernorm_f32_f32: bad operand");
+    IVIT_REQUIRE(shift_pow2 >= 1.0f, "ivit_ibert_layernorm_f32_f32: shift_pow2 = 2^shift must be >= 1");
+    IbLnLitArgs a{x, ldx, rows, C, s_in, n_s, bias_int, s_out, shift_pow2, out, ldo};
+    hipLaunchKernelGGL(ibert_layernorm_f32_kernel, dim3(grid_for_rows(rows)), dim3(NT), 0, ivit_stream(stream), a);
+    IVIT_CHECK_LAUNCH("ivit_ibert_layernorm_f32_f32");
 }

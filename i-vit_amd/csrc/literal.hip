@@ -11,59 +11,12 @@
 // 256-entry tables in front of its integer kernels (ivit_layernorm_i8_compat, ivit_attention_fused_i8_compat).
 // One wave per row; every arithmetic step is one IEEE float32 operation (-ffp-contract=off, correctly rounded division).
 #include "common.h"
+#include "rowsum.h"
 
 namespace {
 
 constexpr int NT = 256;
 constexpr int WPB = NT / 64;
-
-// float32 sum of elem(0..n-1) in the order of torch's CPU sum kernel (ATen native/cpu/SumKernel.cpp: vectorized_inner_sum ->
-// row_sum -> multi_row_sum, 8-float vectors x 4 accumulator rows, 4-level cascade; oracle/ivit_oracle.c
-// ivo_torch_rowsum_f32 is the checked restatement).  Whole wave calls it; the result is wave-uniform.
-template <class F>
-IVIT_DEV float torch_rowsum(F elem, int n, int lane)
-{
-    if (n < 8) {   // scalar_inner_sum: four scalar accumulators
-        float fin = 0.f;
-        if (lane == 0) {
-            float ps[4] = {0.f, 0.f, 0.f, 0.f};
-            const int size_ilp = n >> 2;
-            for (int i = 0; i < size_ilp; ++i)
-                for (int k = 0; k < 4; ++k) ps[k] += elem(i * 4 + k);
-            for (int i = size_ilp * 4; i < n; ++i) ps[0] += elem(i);
-            for (int k = 1; k < 4; ++k) ps[0] += ps[k];
-            fin = ps[0];
-        }
-        return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(fin), 0));
-    }
-    const int vec_size = n >> 3, size_ilp = vec_size >> 2;
-    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
-    if (lane < 32) {
-        int lg = 0;
-        while ((1 << lg) < size_ilp) ++lg;
-        const int lp = max(4, lg / 4), step = 1 << lp, mask = step - 1;
-        int i = 0;
-        while (i + step <= size_ilp) {
-            for (int j = 0; j < step; ++j, ++i) acc0 += elem(i * 32 + lane);
-            acc1 += acc0; acc0 = 0.f;
-            if ((i & (mask << lp)) == 0) {
-                acc2 += acc1; acc1 = 0.f;
-                if ((i & (mask << (2 * lp))) == 0) { acc3 += acc2; acc2 = 0.f; }
-            }
-        }
-        for (; i < size_ilp; ++i) acc0 += elem(i * 32 + lane);
-        acc0 += acc1; acc0 += acc2; acc0 += acc3;
-    }
-    if (lane < 8)
-        for (int i = size_ilp * 4; i < vec_size; ++i) acc0 += elem(i * 8 + lane);
-    const float p1 = __shfl(acc0, (lane + 8) & 63), p2 = __shfl(acc0, (lane + 16) & 63), p3 = __shfl(acc0, (lane + 24) & 63);
-    const float v = ((acc0 + p1) + p2) + p3;
-    float fin = 0.f;
-    for (int i = vec_size * 8; i < n; ++i) fin += elem(i);
-#pragma unroll
-    for (int l = 0; l < 8; ++l) fin += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
-    return fin;
-}
 
 struct LnLitArgs {
     const float* x;

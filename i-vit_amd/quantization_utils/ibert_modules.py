@@ -61,8 +61,11 @@ class IBERTIntLayerNorm(nn.Module):
                            _dev_table((sf * gamma).astype(np.float32), x.device))
             self.dim_sqrt = torch.sqrt(torch.tensor(float(C)))
         _, bias_int, s_out = self._cache
-        k = to_int32(x, scaling_factor)                                            # :126 (integers in the supported regime)
+        xin = x.contiguous().float()
+        s_in = scaling_factor.reshape(-1).contiguous().float()
+        assert s_in.numel() in (1, C)
         if self.overflow_handling:
+            k = to_int32(x, scaling_factor)
             # training / calibration-time guard of :134-137: raise the shift until sum(y^2) < 2^32
             y = k.double() - torch.round(k.double().mean(dim=-1, keepdim=True))
             var = (torch.floor(y / 2.0 ** float(self.shift)) ** 2).sum(dim=-1)
@@ -70,9 +73,11 @@ class IBERTIntLayerNorm(nn.Module):
                 var0 = (y ** 2).sum(dim=-1)
                 shift = torch.log2(torch.sqrt(var0 / 2 ** 32)).ceil().max()
                 self.shift = torch.max(self.shift, shift.to(self.shift).reshape(1))
+        # the literal kernel: x / scaling_factor, float32 mean and variance sums in torch's reduction order, ... (:126-153) for
+        # any input scale (csrc/ibert.hip, second half)
         out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
-        _lib.call("ivit_ibert_layernorm_i32_f32", _lib.ptr(k), C, k.numel() // C, C, _lib.ptr(bias_int), _lib.ptr(s_out),
-                  float(2.0 ** float(self.shift)), _lib.ptr(out), C, _st())
+        _lib.call("ivit_ibert_layernorm_f32_f32", _lib.ptr(xin), C, xin.numel() // C, C, _lib.ptr(s_in), s_in.numel(),
+                  _lib.ptr(bias_int), _lib.ptr(s_out), float(2.0 ** float(self.shift)), _lib.ptr(out), C, _st())
         return out, s_out
 
 
@@ -107,11 +112,12 @@ class IBERTIntGELU(nn.Module):
     def forward(self, x, scaling_factor=None):
         s = float(scaling_factor.reshape(-1)[0])
         b_int, c_int, shift_int, s_out = self.constants(s)
-        k = to_int32(x, scaling_factor)                                            # :226
-        out = torch.empty(k.shape, dtype=torch.int32, device=x.device)
-        _lib.call("ivit_ibert_gelu_i32", _lib.ptr(k), k.numel(), b_int, c_int, shift_int, _lib.ptr(out), _st())
+        xin = x.contiguous().float()
+        out = torch.empty(xin.shape, dtype=torch.float32, device=x.device)
+        _lib.call("ivit_ibert_gelu_f32_f32", _lib.ptr(xin), xin.numel(), s, b_int, c_int, shift_int, float(s_out),
+                  _lib.ptr(out), _st())                                            # literal: :226-234 on x / s itself
         so = torch.full((1,), float(s_out), dtype=torch.float32, device=x.device)
-        return to_float(out, so), so
+        return out, so
 
 
 class IBERTIntSoftmax(nn.Module):
@@ -140,21 +146,21 @@ class IBERTIntSoftmax(nn.Module):
         b_int = np.floor(f32(f32(self.coef[1]) / s))                               # :277
         c_int = np.floor(f32(f32(self.coef[2]) / f32(s * s)))                      # :278
         exp_sf = f32(f32(f32(self.coef[0]) * f32(s * s)) / f32(2 ** self.n))       # :282, 294
-        k = to_int32(x, scaling_factor)                                            # :303
-        rows = k.numel() // L
+        xin = x.contiguous().float()                                               # literal kernel: x / s itself (:303)
+        rows = xin.numel() // L
         st = _st()
         if self.act.running_stat:
             # the internal QuantAct(16) observes exp_int (:308): one extra pass that only produces exp_int
-            ex = torch.empty(k.shape, dtype=torch.float32, device=x.device)
-            _lib.call("ivit_ibert_softmax_i32", _lib.ptr(k), L, rows, L, float(x0_int), float(b_int), float(c_int),
+            ex = torch.empty(xin.shape, dtype=torch.float32, device=x.device)
+            _lib.call("ivit_ibert_softmax_f32_f32", _lib.ptr(xin), L, rows, L, float(s), float(x0_int), float(b_int), float(c_int),
                       float(exp_sf), 1.0, 1 << 30, 30, self.output_bit, None, L, _lib.ptr(ex), st)
             self.act._observe(ex)
         lo, hi = float(self.act.x_min.reshape(-1)[0]), float(self.act.x_max.reshape(-1)[0])
         act_sf = max(f32(f32(max(-f32(lo), f32(hi))) / f32(2 ** 15 - 1)), f32(EPS32))   # quant_utils.py:52-70, 16 bit
         self.act.act_scaling_factor = torch.full((1,), float(act_sf), dtype=torch.float32, device=x.device)
         m, e = dyadic(exp_sf, act_sf)
-        out = torch.empty(k.shape, dtype=torch.int32, device=x.device)
-        _lib.call("ivit_ibert_softmax_i32", _lib.ptr(k), L, rows, L, float(x0_int), float(b_int), float(c_int),
+        out = torch.empty(xin.shape, dtype=torch.float32, device=x.device)
+        _lib.call("ivit_ibert_softmax_f32_f32", _lib.ptr(xin), L, rows, L, float(s), float(x0_int), float(b_int), float(c_int),
                   float(exp_sf), float(act_sf), int(m[0]), int(e[0]), self.output_bit, _lib.ptr(out), L, None, st)
         so = torch.tensor([2 / 2 ** self.output_bit], dtype=torch.float32, device=x.device)   # :317
-        return to_float(out, so), so
+        return out, so

@@ -386,6 +386,18 @@ int ivit_ibert_softmax_i32(const int32_t* k, int64_t ldx, int rows, int L, float
 int ivit_ibert_layernorm_i32_f32(const int32_t* k, int64_t ldx, int rows, int C, const float* bias_int,
                                  const float* s_out, float shift_pow2, float* out, int64_t ldo, ivit_stream_t stream);
 
+/* LITERAL forms of the three I-BERT operators: the float view x = q*s and its scale in, the reference's float32 sequence on
+ * x / s itself (ibert_modules.py:126, 226, 303) -- any scale, not only the power-of-two ones for which x / s is the integer q;
+ * row sums in torch's CPU reduction order.  Outputs are the modules' float outputs (GELU :234, Softmax :319, LayerNorm :153). */
+int ivit_ibert_gelu_f32_f32(const float* x, int64_t n, float s, float b_int, float c_int, float shift_int, float s_out,
+                            float* out, ivit_stream_t stream);
+int ivit_ibert_softmax_f32_f32(const float* x, int64_t ldx, int rows, int L, float s, float x0_int, float b_int, float c_int,
+                               float exp_sf, float act_sf, uint32_t m_act, int32_t e_act, int output_bit, float* out,
+                               int64_t ldo, float* exp_out, ivit_stream_t stream);
+int ivit_ibert_layernorm_f32_f32(const float* x, int64_t ldx, int rows, int C, const float* s_in, int n_s,
+                                 const float* bias_int, const float* s_out, float shift_pow2, float* out, int64_t ldo,
+                                 ivit_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

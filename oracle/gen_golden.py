@@ -783,6 +783,53 @@ def gen_w16(tag="deit_tiny_w16"):
     print(f"[{tag}] wrote fixtures; 16-bit QuantActs: {sum(b == 16 for b in bits.values())} of {len(bits)}; top1 = {out['top1'].tolist()}")
 
 
+
+def gen_ibert_natural(tag="deit_tiny_ibert_natural"):
+    """DeiT-T with the fork's DEFAULT operator family (I-BERT, vit_quant.py:188-190) and its ranges AS CALIBRATED: the
+    reference's logits / top-1 / tap digests.  No CPU oracle restates I-BERT at natural scales; the fixture pins the mirror's
+    module path (literal float kernels of csrc/ibert.hip) on the GPU."""
+    factory, wseed, cseeds, cb, iseed, nimg = "deit_tiny_patch16_224", 11, (101, 111), 4, 1001, 2
+    model = getattr(ref_models, factory)(pretrained=False, gelu_type="ibert", softmax_type="ibert", layernorm_type="ibert")
+    fs = synth.make_float_state(factory, wseed)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in fs.items()}, strict=False)
+    model.eval()
+    for cs in cseeds:
+        model(torch.from_numpy(synth.make_images(cb, cs)))
+    ranges = {n: (np.float32(m.x_min.item()), np.float32(m.x_max.item()))
+              for n, m in model.named_modules() if isinstance(m, rq.QuantAct)}
+    shifts = {n: float(m.shift) for n, m in model.named_modules() if isinstance(m, rq.IBERTIntLayerNorm)}
+    ref_models.freeze_model(model)
+    taps = {}
+
+    def hook(name):
+        def fn(mod, inp, outp):
+            y, sc = outp
+            taps[name] = to_int(y, sc)
+        return fn
+
+    for name, mod in model.named_modules():
+        if isinstance(mod, rq.QuantAct) and not name.endswith("int_softmax.act"):
+            mod.register_forward_hook(hook(name))
+    imgs = synth.make_images(nimg, iseed)
+    y = model(torch.from_numpy(imgs))
+    s_head = (model.head.fc_scaling_factor * model.qact2.act_scaling_factor).float()
+    names = sorted(taps)
+    out = {
+        "meta": np.array(json.dumps(dict(tag=tag, factory=factory, family="ibert", weight_seed=wseed, calib_seeds=list(cseeds),
+                                         calib_batch=cb, image_seed=iseed, n_images=nimg, qkv_gain=synth.QKV_GAIN,
+                                         regime="natural", ln_shifts=shifts, torch=torch.__version__))),
+        "range_names": np.array(list(ranges)),
+        "x_min": np.array([v[0] for v in ranges.values()], np.float32),
+        "x_max": np.array([v[1] for v in ranges.values()], np.float32),
+        "logits_int32": torch.round(y / s_head).to(torch.int64).numpy().astype(np.int32),
+        "logits_f32_bits": y.numpy().astype(np.float32).view(np.int32),
+        "top1": y.argmax(dim=1).numpy().astype(np.int64), "head_scale": s_head.numpy().astype(np.float32),
+        "tap_names": np.array(names), "tap_crc32": np.array([crc(taps[n]) for n in names], np.uint32),
+    }
+    np.savez_compressed(os.path.join(GOLD, f"{tag}.npz"), **out)
+    print(f"[{tag}] wrote fixtures; LayerNorm shifts {sorted(set(shifts.values()))}; top1 = {out['top1'].tolist()}")
+
+
 def gen_schema():
     """state_dict keys and shapes of the reference's DeiT and Swin models (the on-disk checkpoint format)"""
     out = {}
@@ -815,6 +862,8 @@ if __name__ == "__main__":
             gen_ibert_ops()
         elif w == "schema":
             gen_schema()
+        elif w == "deit_tiny_ibert_natural":
+            gen_ibert_natural(w)
         elif w.endswith("_natural") and not w.startswith("swin"):
             gen_natural(w)
         elif w.startswith("swin"):

@@ -462,3 +462,32 @@ def test_engine_any_class_count(num_classes):
     assert np.array_equal(bits(ye), bits(ym))
     # the per-class scale differs per row of the head, so logits of the kept classes equal the 1000-class model's
     assert np.array_equal(bits(ye), z["logits_f32_bits"][:3, :num_classes])
+
+
+def test_ibert_natural_scale_module_path_matches_reference():
+    """the fork's default operator family with ranges AS CALIBRATED (the regime of its authors' checkpoints): the I-BERT
+    modules run the literal float kernels (x / s itself, torch's reduction order) and reproduce the reference's INT32 logits,
+    top-1 and every QuantAct tap"""
+    import zlib
+    model, meta, z = load_model("deit_tiny_ibert_natural")
+    assert meta["family"] == "ibert" and meta["regime"] == "natural"
+    got = {}
+
+    def hook(name):
+        def fn(mod, inp, outp):
+            y, s = outp
+            got[name] = zlib.crc32(np.ascontiguousarray(torch.round(y / s).to(torch.int64).cpu().numpy().astype(np.int32)).tobytes())
+        return fn
+
+    for name, mod in model.named_modules():
+        if isinstance(mod, q.QuantAct) and not name.endswith("int_softmax.act"):
+            mod.register_forward_hook(hook(name))
+    imgs = torch.from_numpy(synth.make_images(meta["n_images"], meta["image_seed"])).to(DEV)
+    with torch.no_grad():
+        y = model(imgs)
+    gold = dict(zip([str(x) for x in z["tap_names"]], z["tap_crc32"]))
+    bad = [n for n in got if n in gold and got[n] != int(gold[n])]
+    assert not bad, bad[:6]
+    li = np.rint(y.cpu().numpy().astype(np.float64) / z["head_scale"].astype(np.float64)).astype(np.int32)
+    assert np.array_equal(li, z["logits_int32"])
+    assert np.array_equal(y.argmax(dim=1).cpu().numpy(), z["top1"])
