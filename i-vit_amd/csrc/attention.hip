@@ -30,7 +30,7 @@ constexpr int VT_ROW = NKS * 64;       // 256 B per d row: one bank row, chunk j
 constexpr int K_BYTES = KP * HD;       // 13312
 constexpr int VT_BYTES = HD * VT_ROW;  // 16384
 constexpr int LUT_OFF = K_BYTES + VT_BYTES;
-constexpr int SMEM_BYTES = LUT_OFF + 256 * 4;
+constexpr int SMEM_BYTES = LUT_OFF + 2 * 256 * 4;   // exponent table as u32 (exact row sum) and as float32 (the product of :175)
 
 struct AttnArgs {
     const int8_t* qkv;
@@ -61,6 +61,8 @@ constexpr int BAND_PAD = 4;   // dwords: keeps slice rows 16-byte aligned and ro
 // ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ...) touches 16 distinct 16-byte slots of the 256-byte bank row.
 IVIT_DEV int kswz(int r, int c) { return r * HD + (((c + 2 * ((r >> 2) & 1)) & 3) << 4); }
 
+// MODE 0: power-of-two input scale (256-entry table); 1: natural scale, band rows in LDS; 2: natural scale, full-table gather
+template <int MODE>
 __global__ __launch_bounds__(NT, 3) void attention_kernel(AttnArgs a)
 {
     __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
@@ -76,7 +78,11 @@ __global__ __launch_bounds__(NT, 3) void attention_kernel(AttnArgs a)
     const int8_t* vg = qg + 2 * plane;
 
     // ---- Shiftmax exponent table: lut[i] = int_exp_shift(-i), i = kmax - k in [0,255]
-    reinterpret_cast<unsigned*>(smem + LUT_OFF)[tid] = shiftexp_int(-tid, a.x0, 15);
+    {
+        const unsigned e0 = shiftexp_int(-tid, a.x0, 15);
+        reinterpret_cast<unsigned*>(smem + LUT_OFF)[tid] = e0;
+        reinterpret_cast<float*>(smem + LUT_OFF)[256 + tid] = (float)e0;   // same address + 1 KB: one more ds_read, one cvt fewer per score
+    }
 
     // ---- K tile [key][64]; rows >= T are never consumed unmasked
     for (int q = tid; q < T * 4; q += NT) {
@@ -156,7 +162,7 @@ __global__ __launch_bounds__(NT, 3) void attention_kernel(AttnArgs a)
         // k - max is in [-255, 0] for every real key: the 256-entry table covers it without a clamp (the entries from
         // ksat on are identical anyway); only the padding keys of the last tile carry the -1000 sentinel
         unsigned esum = 0;
-        if (a.band_w) {     // wave-uniform; natural input scale, band rows of this tile's 16 queries staged in LDS
+        if constexpr (MODE == 1) {     // natural input scale, band rows of this tile's 16 queries staged in LDS
             const int W = a.band_w, stride = W + BAND_PAD;
             unsigned* slice = band_lds + (wave * 16 + l15) * stride;
             {
@@ -178,7 +184,7 @@ __global__ __launch_bounds__(NT, 3) void attention_kernel(AttnArgs a)
                     esum += e;
                 }
             __builtin_amdgcn_wave_barrier();    // every lane has read its slice before the next tile overwrites it
-        } else if (a.exp2d) {      // wave-uniform; one L2-resident gather per score instead of the LDS lookup
+        } else if constexpr (MODE == 2) {      // one L2-resident gather per score instead of the LDS lookup
             const unsigned* row2d = a.exp2d + ((rmax + 128) << 8) + 128;       // entry of q = -nk
 #pragma unroll
             for (int kt = 0; kt < NKT; ++kt)
@@ -195,16 +201,22 @@ __global__ __launch_bounds__(NT, 3) void attention_kernel(AttnArgs a)
         for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                unsigned e;
+                unsigned e, ef;
                 if (kt == NKT - 1) {
-                    e = lut[min(rmax + s[kt][r], 255)];
-                    e = (s[kt][r] == 1000) ? 0u : e;
+                    const int idx = min(rmax + s[kt][r], 255);
+                    e = lut[idx];
+                    ef = lut[256 + idx];
+                    const bool pad = s[kt][r] == 1000;
+                    e = pad ? 0u : e;
+                    ef = pad ? 0u : ef;
                 } else {
                     e = lut[rmax + s[kt][r]];
+                    ef = lut[256 + rmax + s[kt][r]];
                 }
-                s[kt][r] = (int)e;
+                s[kt][r] = (int)ef;       // float32 bit pattern of the exponent
                 esum += e;
             }
+        constexpr bool ef_is_float = MODE == 0;
         esum += __shfl_xor(esum, 16);
         esum += __shfl_xor(esum, 32);
         float S = (float)esum;                                     // exp_int.sum (:171)
@@ -221,8 +233,10 @@ __global__ __launch_bounds__(NT, 3) void attention_kernel(AttnArgs a)
                 if (4 * ks + t < NKT) {
                     unsigned p[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        p[r] = (unsigned)((float)(unsigned)s[4 * ks + t][r] * factor);  // float32 product (:175), < 2^31
+                    for (int r = 0; r < 4; ++r) {
+                        const float ev = ef_is_float ? __int_as_float(s[4 * ks + t][r]) : (float)(unsigned)s[4 * ks + t][r];
+                        p[r] = (unsigned)(ev * factor);  // float32 product (:175), < 2^31
+                    }
                     // floor(. / 2^24) = the top byte of each product: gather the four top bytes with two byte permutes
                     const unsigned lo = __builtin_amdgcn_perm(p[1], p[0], 0x0c0c0703u);  // [p0.b3, p1.b3, 0, 0]
                     const unsigned hi = __builtin_amdgcn_perm(p[3], p[2], 0x07030c0cu);  // [0, 0, p2.b3, p3.b3]
@@ -322,7 +336,9 @@ IVIT_EXPORT int ivit_attention_fused_i8_compat_band(const int8_t* qkv, int8_t* o
         if (x <= 15 * a.x0) { a.ksat = i; break; }
     }
     const size_t band_lds_bytes = band_w ? (size_t)4 * 16 * (band_w + BAND_PAD) * sizeof(unsigned) : 0;
-    hipLaunchKernelGGL(attention_kernel, dim3(batch * heads), dim3(NT), band_lds_bytes, ivit_stream(stream), a);
+    if (band_w) hipLaunchKernelGGL(attention_kernel<1>, dim3(batch * heads), dim3(NT), band_lds_bytes, ivit_stream(stream), a);
+    else if (exp2d) hipLaunchKernelGGL(attention_kernel<2>, dim3(batch * heads), dim3(NT), 0, ivit_stream(stream), a);
+    else hipLaunchKernelGGL(attention_kernel<0>, dim3(batch * heads), dim3(NT), 0, ivit_stream(stream), a);
     IVIT_CHECK_LAUNCH("ivit_attention_fused_i8");
 }
 
