@@ -34,6 +34,7 @@ MODEL_CONFIGS = {
     "deit_small_patch16_224": dict(embed_dim=384, depth=12, num_heads=6),
     "deit_base_patch16_224": dict(embed_dim=768, depth=12, num_heads=12),
     "vit_base_patch16_224": dict(embed_dim=768, depth=12, num_heads=12),
+    "vit_large_patch16_224": dict(embed_dim=1024, depth=24, num_heads=16),
 }
 
 IMG_SIZE = 224

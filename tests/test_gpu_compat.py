@@ -268,3 +268,36 @@ def test_natural_scale_headline_batch_256_deit_base():
     assert np.array_equal(t1.cpu().numpy()[pos].astype(np.int64), z["top1"])
     lg, _, _ = eng.forward_graph(x, resident=True)
     assert np.array_equal(lg.cpu().numpy(), li)
+
+
+def test_vit_large_width_calibrated_on_gpu_three_way():
+    """ViT-L channel width (C = 1024, 16 heads; 3 blocks to keep it short): the ranges come from two calibration forwards of
+    the module mirror on the GPU (running min/max + EMA, i.e. NATURAL scales, no snapping); then the fused engine (phi
+    tables, LayerNorm v2 with four dwords per lane), the module-by-module path (literal float kernels) and the CPU compat
+    oracle -- three independent implementations -- agree on the INT32 logits."""
+    import ivit_amd.quantization_utils as qu
+    from ivit_amd.vit_quant import VisionTransformer
+    depth = 3
+    fs = synth.make_float_state("vit_large_patch16_224", 44, depth=depth)
+    model = VisionTransformer(embed_dim=1024, depth=depth, num_heads=16)
+    missing, unexpected = model.load_state_dict({k: torch.from_numpy(v) for k, v in fs.items()}, strict=False)
+    assert not unexpected
+    model.to(DEV).eval()
+    with torch.no_grad():
+        model(torch.from_numpy(synth.make_images(2, 771)).to(DEV))
+        model(torch.from_numpy(synth.make_images(2, 772)).to(DEV))
+    ivit.freeze_model(model)
+    ranges = {n: (np.float32(float(m.x_min)), np.float32(float(m.x_max))) for n, m in model.named_modules()
+              if isinstance(m, qu.QuantAct)}
+    imgs_np = synth.make_images(2, 773)
+    imgs = torch.from_numpy(imgs_np).to(DEV)
+    with torch.no_grad():
+        ye = model(imgs)
+        eng = model._engine[2]
+        assert eng.natural_sites > 0 and eng.C == 1024
+        li_e = eng.forward(imgs)[0].cpu().numpy().copy()
+        model.use_engine = False
+        ym = model(imgs)
+    assert np.array_equal(ye.cpu().numpy().view(np.int32), ym.cpu().numpy().view(np.int32))
+    om = orc.OracleViT(fs, ranges, 1024, depth, 16, compat=True)
+    assert np.array_equal(li_e, om.forward(imgs_np)["logits_int32"])
