@@ -74,9 +74,10 @@ class EngineDispatch:
         raise NotImplementedError
 
     def _width_mismatch(self, expected: dict):
-        """first QuantAct whose activation_bit differs from what the fused kernels hard-wire (default 8)"""
+        """first QuantAct whose activation_bit differs from what the fused kernels hard-wire (`expected`: full module name ->
+        width; every QuantAct not listed is 8 bit)"""
         for n, m in self._quant_acts():
-            want = expected.get(n.split(".")[-1] if n.split(".")[-1] in expected else n, 8)
+            want = expected.get(n, 8)
             if int(m.activation_bit) != want:
                 return f"QuantAct {n} is {int(m.activation_bit)}-bit (fused engine: {want})"
         return None
