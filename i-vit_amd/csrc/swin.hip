@@ -5,6 +5,7 @@
 // The fork's swin_quant.py does not run as shipped (SURVEY.md finding 6); semantics are SURVEY Appendix A.8, pinned by
 // tests/golden/swin_tiny.npz (generated from the reference with harness-side shims).
 #include "common.h"
+#include "rowsum.h"
 
 namespace {
 
@@ -157,6 +158,55 @@ __global__ __launch_bounds__(NT) void layernorm_i16_i8_kernel(Ln16Args a)
             float z = rintf(x / s);                                   // quant_utils.py:220 (correctly rounded quotient)
             double p = (double)z * dyadic_mult(a.m[c], a.e[c]);       // :229
             double tt = p + IVIT_MAGIC;                               // :230
+            orow[c] = (int8_t)clamp_i32((int)(unsigned)__double_as_longlong(tt), -128, 127);
+        }
+    }
+}
+
+// Natural (non power-of-two) scale of the 16-bit input: IVITIntLayerNorm sees phi(q) = fl(fl(q*s)/s) (QuantAct hands on q*s,
+// quant_modules.py:387; ivit_modules.py:36 divides by s again).  Literal: the float32 mean over the phi values in torch's
+// CPU reduction order (rowsum.h), `.to(int32)` truncation, then the usual chain.  One wave per row.
+struct Ln16LitArgs {
+    Ln16Args b;
+    float s_in;
+};
+
+__global__ __launch_bounds__(NT) void layernorm_i16_i8_literal_kernel(Ln16LitArgs al)
+{
+    const Ln16Args& a = al.b;
+    const float s_in = al.s_in;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int C = a.C;
+    for (int row = blockIdx.x * WPB + wave; row < a.rows; row += gridDim.x * WPB) {
+        const int16_t* xr = a.x + (int64_t)row * C;
+        auto xint = [&](int c) { return ((float)xr[c] * s_in) / s_in; };       // :36 on the float view q * s
+        const float S = torch_rowsum(xint, C, lane);
+        const int mean_int = (int)rintf(S / (float)C);                         // :37
+        long long var = 0;
+        for (int c = lane; c < C; c += 64) {
+            const long long d = (long long)(int)truncf(xint(c)) - mean_int;    // :38-40
+            var += d * d;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            int vlo = __shfl_xor((int)(var & 0xffffffffll), o);
+            int vhi = __shfl_xor((int)(var >> 32), o);
+            var += ((long long)vhi << 32) | (unsigned)vlo;
+        }
+        float varf = (float)var, t = 65536.0f;                                 // :45-49
+#pragma unroll 1
+        for (int it = 0; it < 10; ++it) t = floorf((t + floorf(varf / t)) * 0.5f);
+        const float factor = floorf((1.0f / t) * 2147483648.0f);               // :51
+        int8_t* orow = a.out + win_row(a.map, row) * a.ldo;
+        for (int c = lane; c < C; c += 64) {
+            float dl = (float)((int)truncf(xint(c)) - mean_int);
+            float v = floorf((dl * factor) * 0.5f);                             // :52
+            float y = v + a.bias_int[c];                                        // :61
+            float s = a.s_ln[c];
+            float x = y * s;                                                    // :63
+            float z = rintf(x / s);                                             // quant_utils.py:220
+            double p = (double)z * dyadic_mult(a.m[c], a.e[c]);                 // :229
+            double tt = p + IVIT_MAGIC;                                         // :230
             orow[c] = (int8_t)clamp_i32((int)(unsigned)__double_as_longlong(tt), -128, 127);
         }
     }
@@ -371,6 +421,11 @@ struct WinAttnArgs {
     int nwin, heads, T, nW;
     double Ms, Mb, Mo;      // qact_attn1; qact2 main operand; qact3
     int x0, ksat;
+    // natural Shiftmax input scale: phi[q + 128] = fl(fl(q*s)/s) for unmasked scores and phim[q + 128] =
+    // fl(fl(fl(q*s) - 100)/s) for scores under the shift mask (swin_quant.py:151-156 adds float -100 to q*s before the softmax
+    // divides by s), both float32 [256] on the device; NULL: power-of-two scale
+    const float* phi;
+    const float* phim;
 };
 
 constexpr int WHD = 32;
@@ -381,10 +436,16 @@ constexpr int WLUT_OFF = WPB * WVT_BYTES;
 __global__ __launch_bounds__(NT) void window_attention_kernel(WinAttnArgs a)
 {
     __shared__ __attribute__((aligned(16))) char smem[WLUT_OFF + 256 * 4];
+    __shared__ float s_phi[2][256];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, l15 = lane & 15;
     const int T = a.T;
     reinterpret_cast<unsigned*>(smem + WLUT_OFF)[tid] = shiftexp_int(-tid, a.x0, 15);
+    const bool compat = a.phi != nullptr;      // uniform
+    if (compat) {
+        s_phi[0][tid] = a.phi[tid];
+        s_phi[1][tid] = a.phim[tid];
+    }
     __syncthreads();
     const unsigned* lut = reinterpret_cast<const unsigned*>(smem + WLUT_OFF);
     char* vt = smem + wave * WVT_BYTES;
@@ -445,6 +506,7 @@ __global__ __launch_bounds__(NT) void window_attention_kernel(WinAttnArgs a)
             const unsigned qreg = regrow ? regrow[qld] : 0u;
             int s[4][4];
             int rmax = -100000;
+            float xv[4][4], xmax = -__builtin_inff();     // compat: the float view x / s of every score
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
                 v4i acc = {0, 0, 0, 0};
@@ -455,18 +517,45 @@ __global__ __launch_bounds__(NT) void window_attention_kernel(WinAttnArgs a)
                 for (int r = 0; r < 4; ++r) {
                     const int key = 16 * kt + 4 * g + r;
                     int ka = -100000;
+                    xv[kt][r] = -__builtin_inff();
                     if (key < T) {
                         const int kS = clamp_i32(requant_exact(acc[r], a.Ms), -128, 127);        // qact_attn1
                         ka = clamp_i32(requant_exact(kS, a.Mb) + bv[r], -128, 127);              // qact2 (two operands)
-                        if (((kreg[kt] >> (8 * r)) & 0xffu) != qreg) ka += a.mask_value;         // shift mask, after the clamp
+                        const bool masked = ((kreg[kt] >> (8 * r)) & 0xffu) != qreg;
+                        if (compat) xv[kt][r] = s_phi[masked ? 1 : 0][ka + 128];
+                        if (masked) ka += a.mask_value;                                          // shift mask, after the clamp
                     }
                     s[kt][r] = ka;
                     rmax = max(rmax, ka);
+                    xmax = fmaxf(xmax, xv[kt][r]);
                 }
             }
             rmax = max(rmax, __shfl_xor(rmax, 16));
             rmax = max(rmax, __shfl_xor(rmax, 32));
             unsigned esum = 0;
+            if (compat) {
+                // Shiftmax's float32 sequence on the phi values themselves (ivit_modules.py:150-170), per score
+                xmax = fmaxf(xmax, __shfl_xor(xmax, 16));
+                xmax = fmaxf(xmax, __shfl_xor(xmax, 32));
+                const float x0f = (float)a.x0;
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        unsigned e = 0u;
+                        if (s[kt][r] != -100000) {
+                            const float d = xv[kt][r] - xmax;                                    // :168
+                            float x = (d + floorf(d / 2.0f)) - floorf(d / 16.0f);                // :151
+                            x = fmaxf(x, 15.0f * x0f);                                           // :155
+                            const float qq = floorf(x / x0f);                                    // :157
+                            const float rr = x - x0f * qq;                                       // :158
+                            const float ex = floorf((rr / 2.0f - x0f) * ldexpf(1.0f, 15 - (int)qq));   // :159-160
+                            e = (unsigned)fmaxf(ex, 0.0f);
+                        }
+                        s[kt][r] = (int)e;
+                        esum += e;
+                    }
+            } else
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
@@ -597,6 +686,19 @@ IVIT_EXPORT int ivit_layernorm_i16_i8(const int16_t* x, int rows, int C, const f
     IVIT_CHECK_LAUNCH("ivit_layernorm_i16_i8");
 }
 
+IVIT_EXPORT int ivit_layernorm_i16_i8_compat(const int16_t* x, int rows, int C, float s_in, const float* bias_int,
+                                             const float* s_ln, const uint32_t* m, const int32_t* e, int8_t* out, int64_t ldo,
+                                             int H, int W, int ws, int shift, ivit_stream_t stream)
+{
+    IVIT_REQUIRE(x && out && bias_int && s_ln && m && e && rows > 0 && C > 0 && C <= 4096 && ldo >= C && s_in > 0.0f,
+                 "ivit_layernorm_i16_i8_compat: bad operand");
+    int rc = check_map("ivit_layernorm_i16_i8_compat", rows, H, W, ws, shift);
+    if (rc) return rc;
+    Ln16LitArgs a{Ln16Args{x, rows, C, bias_int, s_ln, m, e, out, ldo, WinMap{H, W, ws, shift}}, s_in};
+    hipLaunchKernelGGL(layernorm_i16_i8_literal_kernel, dim3(grid_for_rows(rows)), dim3(NT), 0, ivit_stream(stream), a);
+    IVIT_CHECK_LAUNCH("ivit_layernorm_i16_i8_compat");
+}
+
 IVIT_EXPORT int ivit_patch_merge_i16(const int16_t* x, int16_t* out, int batch, int H, int W, int C, ivit_stream_t stream)
 {
     IVIT_REQUIRE(x && out && batch > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C % 4 == 0,
@@ -623,6 +725,16 @@ IVIT_EXPORT int ivit_window_attention_i8(const int8_t* qkv, int8_t* out, int64_t
                                          int heads, int tokens, int head_dim, uint32_t m_s, int32_t e_s, uint32_t m_b,
                                          int32_t e_b, float s_attn, uint32_t m_o, int32_t e_o, ivit_stream_t stream)
 {
+    return ivit_window_attention_i8_compat(qkv, out, ldo, bias_add, mask_region, mask_value, windows, windows_per_image, heads,
+                                           tokens, head_dim, m_s, e_s, m_b, e_b, s_attn, m_o, e_o, nullptr, nullptr, stream);
+}
+
+IVIT_EXPORT int ivit_window_attention_i8_compat(const int8_t* qkv, int8_t* out, int64_t ldo, const int16_t* bias_add,
+                                                const uint8_t* mask_region, int mask_value, int windows, int windows_per_image,
+                                                int heads, int tokens, int head_dim, uint32_t m_s, int32_t e_s, uint32_t m_b,
+                                                int32_t e_b, float s_attn, uint32_t m_o, int32_t e_o, const float* phi,
+                                                const float* phi_masked, ivit_stream_t stream)
+{
     IVIT_REQUIRE(qkv && out && bias_add, "ivit_window_attention_i8: NULL operand");
     IVIT_REQUIRE(windows > 0 && heads > 0 && windows_per_image > 0 && windows % windows_per_image == 0,
                  "ivit_window_attention_i8: bad window counts");
@@ -635,7 +747,9 @@ IVIT_EXPORT int ivit_window_attention_i8(const int8_t* qkv, int8_t* out, int64_t
     IVIT_REQUIRE(((uintptr_t)bias_add % 8 == 0) && ((uintptr_t)mask_region % 4 == 0), "ivit_window_attention_i8: misaligned table");
     IVIT_REQUIRE(mask_value <= 0 && mask_value >= -32768, "ivit_window_attention_i8: mask_value=%d outside [-32768, 0]", mask_value);
     IVIT_REQUIRE(s_attn > 0.0f, "ivit_window_attention_i8: scale must be positive");
+    IVIT_REQUIRE((phi == nullptr) == (phi_masked == nullptr), "ivit_window_attention_i8_compat: phi and phi_masked go together");
     WinAttnArgs a;
+    a.phi = phi; a.phim = phi_masked;
     a.qkv = qkv; a.out = out; a.ldo = ldo; a.bias = bias_add; a.region = mask_region; a.mask_value = mask_value;
     a.nwin = windows; a.heads = heads; a.T = tokens; a.nW = windows_per_image;
     a.Ms = ivit_dyadic_to_double(m_s, e_s);

@@ -22,7 +22,8 @@ import torch
 
 from . import _lib
 from .graph import GraphReplay
-from .prepare import LayerNormParams, LinearParams, dyadic, f32, pad_head, quant_sym, requant_host, sym_scale
+from .prepare import (LayerNormParams, LinearParams, dyadic, f32, pad_head, phi_is_identity, phi_table, phi_tables, quant_sym,
+                      requant_host, sym_scale)
 from .synth import IMG_SIZE
 
 PATCH = 4
@@ -105,9 +106,21 @@ class IntSwinEngine(GraphReplay):
             d.update(m=dev(m.view(np.int32)), e=dev(e))
             return d
 
-        def ln_dev(prefix, s_out):
+        self.natural_sites = 0     # operators whose input scale is not a power of two: literal / table-driven kernels
+
+        def ln_dev(prefix, s_out, s_in, bits_in=16):
+            """s_in: scale of the LayerNorm's input.  If fl(fl(q*s_in)/s_in) != q for some q of that width, the reference's
+            LayerNorm sees those neighbouring floats (ivit_modules.py:36-38): 16-bit inputs take the literal kernel, the 8-bit
+            patch norm the table form of the DeiT engine."""
             lp = LayerNormParams(P[prefix + ".weight"], P[prefix + ".bias"], s_out)
-            return dict(bias=dev(lp.bias_int), s=dev(lp.s_ln), m=dev(lp.m.view(np.int32)), e=dev(lp.e))
+            d = dict(bias=dev(lp.bias_int), s=dev(lp.s_ln), m=dev(lp.m.view(np.int32)), e=dev(lp.e), s_in=None, remap=None, phi=None)
+            if not phi_is_identity(s_in, bits_in):
+                self.natural_sites += 1
+                d["s_in"] = float(s_in)
+                if bits_in == 8:
+                    remap, phi = phi_tables(s_in)
+                    d.update(remap=dev(remap), phi=dev(phi))
+            return d
 
         def sme(pre, z):
             m, e = dyadic(pre, z)
@@ -119,7 +132,7 @@ class IntSwinEngine(GraphReplay):
         s_bn = s("patch_embed.qact_before_norm")
         self.patch = lin_dev("patch_embed.proj", s0, s_bn)
         s_pq = s("patch_embed.qact")
-        self.patch_ln = ln_dev("patch_embed.norm", s_pq)
+        self.patch_ln = ln_dev("patch_embed.norm", s_pq, s_bn, 8)
         s_x = s("qact1", 16)
         self.stem_me = sme(s_pq, s_x)
 
@@ -139,7 +152,7 @@ class IntSwinEngine(GraphReplay):
                 N = win * win
                 blk = dict(win=win, shift=shift)
                 s_q1 = s(p + "qact1")
-                blk["ln1"] = ln_dev(p + "norm1", s_q1)
+                blk["ln1"] = ln_dev(p + "norm1", s_q1, s_x)
                 s_a1 = s(p + "attn.qact1")
                 blk["qkv"] = lin_dev(p + "attn.qkv", s_q1, s_a1)
                 s_S = f32(f32(s_a1 * s_a1) * f32(HEAD_DIM ** -0.5))            # swin_quant.py:139-141
@@ -154,18 +167,29 @@ class IntSwinEngine(GraphReplay):
                 bias_pad = np.zeros((nH, N, 64), np.int16)
                 bias_pad[:, :, :N] = bias_add
                 region, mask_value = None, 0
+                # Shiftmax input: phi(q) = fl(fl(q*s)/s) for a plain score, fl(fl(fl(q*s) - 100)/s) for one under the shift
+                # mask (:149-156 adds float -100 to q*s, ivit_modules.py:165 divides by s).  Integer kernel when phi is the
+                # identity and -100/s an integer; else the literal float sequence on the two 256-entry tables
+                qv = np.arange(-128, 128, dtype=f32)
+                phi_m = ((((qv * s_A).astype(f32) + f32(-100.0)).astype(f32)) / s_A).astype(f32)
+                att_nat = not phi_is_identity(s_A)
                 if shift:
                     mval = f32(-100.0) / s_A                                    # :149-155: (k*s + (-100)) / s
                     if mval != np.rint(mval) or abs(mval) >= 32768:
-                        raise ValueError("shift mask / attention scale is not a 16-bit integer (outside the pow2 regime)")
-                    mask_value = int(mval)
+                        att_nat = True
+                        mask_value = -1                                         # unused by the literal form
+                    else:
+                        mask_value = int(mval)
                     region = np.zeros(((H // win) * (W // win), 64), np.uint8)
                     region[:, :N] = shift_mask_regions(H, W, win, shift)
+                if att_nat:
+                    self.natural_sites += 1
                 s_pv = f32(f32(1.0 / 128.0) * s_a1)
                 s_a3 = s(p + "attn.qact3")
                 blk["attn"] = dict(ms=sme(s_S, s_at), mb=sme(s_at, s_A), s_attn=float(s_A), mo=sme(s_pv, s_a3),
                                    bias=dev(bias_pad), region=None if region is None else dev(region),
-                                   mask_value=mask_value, nW=(H // win) * (W // win))
+                                   mask_value=mask_value, nW=(H // win) * (W // win),
+                                   phi=dev(phi_table(s_A)) if att_nat else None, phim=dev(phi_m) if att_nat else None)
                 lp, d = lin_host(p + "attn.proj", s_a3)
                 s_a4 = s(p + "attn.qact4", 16)
                 mp, ep = dyadic(lp.s_acc, s_a4)
@@ -174,14 +198,19 @@ class IntSwinEngine(GraphReplay):
                 s_b2 = s(p + "qact2", 16)
                 blk["res1"] = sme(s_a4, s_b2) + sme(s_x, s_b2)
                 s_b3 = s(p + "qact3")
-                blk["ln2"] = ln_dev(p + "norm2", s_b3)
+                blk["ln2"] = ln_dev(p + "norm2", s_b3, s_b2)
                 s_g = s(p + "mlp.qact_gelu")
                 blk["fc1"] = lin_dev(p + "mlp.fc1", s_b3, s_g)
                 s_go = f32(s_g * f32(1.0 / 128.0))
                 s_m1 = s(p + "mlp.qact1")
                 mg, eg = sme(s_go, s_m1)
                 lut = torch.empty(65536, dtype=torch.int8, device=self.dev)
-                _lib.call("ivit_shiftgelu_build_lut", float(s_g), mg, eg, _lib.ptr(lut), self._stream())
+                g_tabs = phi_tables(s_g)            # ShiftGELU sees trunc(phi(q)) (ivit_modules.py:106-107)
+                g_remap = None
+                if g_tabs is not None:
+                    self.natural_sites += 1
+                    g_remap = dev(g_tabs[0])
+                _lib.call("ivit_shiftgelu_build_lut_ex", float(s_g), mg, eg, _lib.ptr(g_remap), _lib.ptr(lut), self._stream())
                 blk["gelu_lut"] = lut
                 s_m2 = s(p + "mlp.qact2")
                 blk["fc2"] = lin_dev(p + "mlp.fc2", s_m1, s_m2)
@@ -193,7 +222,7 @@ class IntSwinEngine(GraphReplay):
                 p = f"layers.{li}.downsample."
                 s_d1 = s(p + "qact1")
                 s_d2 = s(p + "qact2")
-                st["down"] = dict(ln=ln_dev(p + "norm", s_d1), red=lin_dev(p + "reduction", s_d1, s_d2))
+                st["down"] = dict(ln=ln_dev(p + "norm", s_d1, s_x), red=lin_dev(p + "reduction", s_d1, s_d2))
                 s_x = s_d2
             self.stages.append(st)
             if st["down"] is not None:
@@ -202,7 +231,7 @@ class IntSwinEngine(GraphReplay):
 
         # ---- tail (swin_quant.py:552-563)
         s_q2 = s("qact2")
-        self.ln_f = ln_dev("norm", s_q2)
+        self.ln_f = ln_dev("norm", s_q2, s_x)
         s_q3 = s("qact3")
         self.pool_me = sme(s_q2, s_q3)
         lp = LinearParams(P["head.weight"], P.get("head.bias"), s_q3)
@@ -268,6 +297,10 @@ class IntSwinEngine(GraphReplay):
                   _lib.ptr(lin["m"]), _lib.ptr(lin["e"]), _lib.ptr(out), ldo, M, lin["N"], lin["K"], lay, st)
 
     def _ln16(self, x, rows, C, ln, out, ldo, st, H=0, W=0, ws=0, shift=0):
+        if ln["s_in"] is not None:       # natural input scale: the literal kernel (csrc/swin.hip)
+            _lib.call("ivit_layernorm_i16_i8_compat", _lib.ptr(x), rows, C, ln["s_in"], _lib.ptr(ln["bias"]), _lib.ptr(ln["s"]),
+                      _lib.ptr(ln["m"]), _lib.ptr(ln["e"]), _lib.ptr(out), ldo, H, W, ws, shift, st)
+            return
         _lib.call("ivit_layernorm_i16_i8", _lib.ptr(x), rows, C, _lib.ptr(ln["bias"]), _lib.ptr(ln["s"]),
                   _lib.ptr(ln["m"]), _lib.ptr(ln["e"]), _lib.ptr(out), ldo, H, W, ws, shift, st)
 
@@ -299,8 +332,13 @@ class IntSwinEngine(GraphReplay):
         self._gemm(ws["a0"], 64, self.patch, ws["pe"], C0, M, st)
         tap("patch_embed.qact_before_norm", ws["pe"], M, C0)
         ln = self.patch_ln
-        _lib.call("ivit_layernorm_i8", _lib.ptr(ws["pe"]), C0, M, C0, _lib.ptr(ln["bias"]), _lib.ptr(ln["s"]),
-                  _lib.ptr(ln["m"]), _lib.ptr(ln["e"]), _lib.ptr(ws["pn"]), C0, st)
+        if ln["remap"] is not None:
+            _lib.call("ivit_layernorm_i8_compat", _lib.ptr(ws["pe"]), C0, M, C0, _lib.ptr(ln["bias"]), _lib.ptr(ln["s"]),
+                      _lib.ptr(ln["m"]), _lib.ptr(ln["e"]), _lib.ptr(ln["remap"]), _lib.ptr(ln["phi"]), _lib.ptr(ws["pn"]), C0,
+                      0, st)
+        else:
+            _lib.call("ivit_layernorm_i8", _lib.ptr(ws["pe"]), C0, M, C0, _lib.ptr(ln["bias"]), _lib.ptr(ln["s"]),
+                      _lib.ptr(ln["m"]), _lib.ptr(ln["e"]), _lib.ptr(ws["pn"]), C0, st)
         tap("patch_embed.qact", ws["pn"], M, C0)
         x, x2 = ws["x"], ws["x2"]
         _lib.call("ivit_requant_i8_i16", _lib.ptr(ws["pn"]), self.stem_me[0], self.stem_me[1], _lib.ptr(x), M * C0, st)
@@ -328,9 +366,9 @@ class IntSwinEngine(GraphReplay):
                     hm = ws["qkv"][: 3 * M * C].view(3, nwin, nH, N, HEAD_DIM)
                     taps[p + "attn.qact1"] = hm.permute(1, 3, 0, 2, 4).reshape(nwin, N, 3 * C).clone()
                 a = blk["attn"]
-                _lib.call("ivit_window_attention_i8", _lib.ptr(ws["qkv"]), _lib.ptr(ws["ao"]), ld, _lib.ptr(a["bias"]),
+                _lib.call("ivit_window_attention_i8_compat", _lib.ptr(ws["qkv"]), _lib.ptr(ws["ao"]), ld, _lib.ptr(a["bias"]),
                           _lib.ptr(a["region"]), a["mask_value"], nwin, a["nW"], nH, N, HEAD_DIM, a["ms"][0], a["ms"][1], a["mb"][0],
-                          a["mb"][1], a["s_attn"], a["mo"][0], a["mo"][1], st)
+                          a["mb"][1], a["s_attn"], a["mo"][0], a["mo"][1], _lib.ptr(a["phi"]), _lib.ptr(a["phim"]), st)
                 tap(p + "attn.qact3", ws["ao"], M, C, ld)
                 pj = blk["proj"]
                 _lib.call("ivit_gemm_i8_i32", _lib.ptr(ws["ao"]), ld, _lib.ptr(pj["W"]), pj["K"], _lib.ptr(pj["b"]),

@@ -298,13 +298,17 @@ class SwinTransformer(EngineDispatch, nn.Module):
         for n, m in self._quant_acts():
             if int(m.activation_bit) != self._reference_widths[n]:
                 return f"QuantAct {n} is {int(m.activation_bit)}-bit (fused engine: {self._reference_widths[n]})"
-        return self._natural_scale_reason()
+        last = self.patch_grid[0] // 2 ** (self.num_layers - 1)
+        if (last * last) % 2 == 0:
+            # the token pooling of the tail (swin_quant.py:554) is a float mean over last^2 tokens: with an even count an exact
+            # .5 tie is possible and, at natural scales, decided by float fuzz the engine does not restate -> module path
+            return self._natural_scale_reason()
+        return None
 
     def _natural_scale_reason(self):
-        """The Swin engine implements the regime in which x / s gives back the integer a QuantAct produced (every scale a
-        power of two, or any scale with fl(fl(q*s)/s) == q over its width).  With ranges as calibrated the reference's
-        LayerNorm / ShiftGELU / Shiftmax see neighbouring floats instead (prepare.py); the module path restates that
-        literally (csrc/literal.hip), the Swin engine does not yet (the DeiT / ViT engine does, through phi tables)."""
+        """Non-None when some QuantAct scale is natural (fl(fl(q*s)/s) != q for some q of its width).  The Swin engine handles
+        natural scales (literal LayerNorm on the 16-bit stream, literal Shiftmax on phi tables, remapped ShiftGELU table,
+        swin_engine.py); this check is only consulted for geometries whose tail pooling could tie (see the caller)."""
         from .prepare import phi_is_identity, sym_scale
         fp = self._fingerprint()
         if self._phi_check is None or self._phi_check[0] != fp:

@@ -328,6 +328,11 @@ int ivit_residual_requant_i16(const void* a, int a_bits, const uint32_t* m_pre, 
 int ivit_layernorm_i16_i8(const int16_t* x, int rows, int C, const float* bias_int, const float* s_ln,
                           const uint32_t* m, const int32_t* e, int8_t* out, int64_t ldo, int H, int W, int ws, int shift,
                           ivit_stream_t stream);
+/* the same for a 16-bit input carried at a natural scale s_in: the reference's LayerNorm sees fl(fl(q*s_in)/s_in); literal
+ * form (float32 mean over those values in torch's CPU reduction order, truncating .to(int32), ivit_modules.py:36-38) */
+int ivit_layernorm_i16_i8_compat(const int16_t* x, int rows, int C, float s_in, const float* bias_int, const float* s_ln,
+                                 const uint32_t* m, const int32_t* e, int8_t* out, int64_t ldo, int H, int W, int ws,
+                                 int shift, ivit_stream_t stream);
 
 /* PatchMerging gather (swin_quant.py:337-344): x [B, H*W, C] int16 -> out [B, (H/2)*(W/2), 4C],
  * channel blocks (even y, even x), (odd y, even x), (even y, odd x), (odd y, odd x). */
@@ -355,6 +360,16 @@ int ivit_window_attention_i8(const int8_t* qkv, int8_t* out, int64_t ldo, const 
                              const uint8_t* mask_region, int mask_value, int windows, int windows_per_image, int heads,
                              int tokens, int head_dim, uint32_t m_s, int32_t e_s, uint32_t m_b, int32_t e_b,
                              float s_attn, uint32_t m_o, int32_t e_o, ivit_stream_t stream);
+/* Natural (non power-of-two) scale s_attn of the Shiftmax input: phi[q+128] = fl(fl(q*s)/s) is what the reference's Shiftmax
+ * sees of an unmasked score q, phi_masked[q+128] = fl(fl(fl(q*s) - 100)/s) of a score under the shift mask
+ * (swin_quant.py:151-156 adds float -100 to q*s; ivit_modules.py:165 divides by s); the kernel runs the float32 sequence of
+ * ivit_modules.py:150-170 on those values per score.  Both tables float32 [256] on the device (prepare.py); both NULL =
+ * ivit_window_attention_i8. */
+int ivit_window_attention_i8_compat(const int8_t* qkv, int8_t* out, int64_t ldo, const int16_t* bias_add,
+                                    const uint8_t* mask_region, int mask_value, int windows, int windows_per_image, int heads,
+                                    int tokens, int head_dim, uint32_t m_s, int32_t e_s, uint32_t m_b, int32_t e_b,
+                                    float s_attn, uint32_t m_o, int32_t e_o, const float* phi, const float* phi_masked,
+                                    ivit_stream_t stream);
 
 /* =================================================================================================
  * I-BERT operator family (models/quantization_utils/ibert_modules.py; registry key 'ibert', the fork's default,

@@ -731,6 +731,53 @@ def gen_compat_ops():
         c = f"sm{ci}_"
         out[c + "q"], out[c + "s"], out[c + "out"] = q.reshape(rows, L).astype(np.int8), s, ref
     out["sm_cases"] = np.arange(5, dtype=np.int32)
+    # --- IVITIntLayerNorm on a 16-bit stream at a natural scale (Swin's residual stream)
+    for ci, (rows, Cn, s) in enumerate([(24, 96, np.float32(0.000913)), (16, 384, np.float32(0.0004471)), (12, 768, np.float32(0.00171))]):
+        ln = rq.IVITIntLayerNorm(Cn)
+        gamma = rng.uniform(0.5, 1.5, size=Cn).astype(np.float32)
+        beta = rng.normal(0, 0.1, size=Cn).astype(np.float32)
+        ln.weight.data, ln.bias.data = torch.from_numpy(gamma), torch.from_numpy(beta)
+        q = np.clip(np.rint(rng.normal(0, 6000, size=(1, rows, Cn))), -32768, 32767).astype(np.int32)
+        for r in range(0, rows, 2):            # every other row: an exact .5 tie of the mean
+            tgt = Cn // 2 + Cn * int(rng.integers(-200, 200))
+            for _ in range(100000):
+                d = tgt - int(q[0, r].sum())
+                if d == 0:
+                    break
+                c = int(rng.integers(0, Cn))
+                q[0, r, c] = int(np.clip(q[0, r, c] + np.clip(d, -5000, 5000), -32768, 32767))
+            assert int(q[0, r].sum()) == tgt
+        x = (torch.from_numpy(q.astype(np.float32)) * torch.tensor([s])).float()
+        yl, sl = ln(x, torch.tensor([s]))
+        qa = rq.QuantAct()
+        hi = float(np.abs(yl.numpy()).max()) * 0.93
+        qa.x_min.fill_(-hi)
+        qa.x_max.fill_(hi)
+        qa.fix()
+        yq, sq = qa(yl, sl)
+        y, s_ln, _ = orc.layernorm_scaled(q.reshape(rows, Cn), s, gamma, beta)
+        assert np.array_equal((y * s_ln).astype(np.float32).view(np.int32), yl.numpy().reshape(rows, Cn).view(np.int32)), ci
+        c = f"ln16_{ci}_"
+        out[c + "q"], out[c + "s"] = q.reshape(rows, Cn).astype(np.int16), s
+        out[c + "gamma"], out[c + "beta"] = gamma, beta
+        out[c + "range"] = np.array([-hi, hi], np.float32)
+        out[c + "q_out"] = torch.round(yq / sq).numpy().reshape(rows, Cn).astype(np.int32)
+    out["ln16_cases"] = np.arange(3, dtype=np.int32)
+    # --- IVITIntSoftmax behind Swin's shift mask: x = q*s + mask, mask in {0, -100.0} (swin_quant.py:151-156)
+    for ci, (rows, L, s, sd) in enumerate([(49, 49, np.float32(0.271), 30), (49, 49, np.float32(0.1173), 45), (49, 49, np.float32(1.3), 20)]):
+        sm = rq.IVITIntSoftmax()
+        q = np.clip(np.rint(rng.normal(0, sd, size=(1, 1, rows, L))), -128, 127).astype(np.int32)
+        mask = (rng.random(size=(rows, L)) < 0.35)
+        mask[np.arange(rows), np.arange(L)] = False                      # a token always attends to itself
+        mf = np.where(mask, np.float32(-100.0), np.float32(0.0)).astype(np.float32)
+        x = (torch.from_numpy(q.astype(np.float32)) * torch.tensor([s])).float() + torch.from_numpy(mf)[None, None]
+        ys, ss = sm(x, torch.tensor([s]))
+        ref = torch.round(ys / ss).numpy().reshape(rows, L).astype(np.int32)
+        xint = (x / torch.tensor([s])).numpy().reshape(rows, L).astype(np.float32)
+        assert np.array_equal(orc.shiftmax_xint(xint, s), ref), ci
+        c = f"smm{ci}_"
+        out[c + "q"], out[c + "s"], out[c + "mask"], out[c + "out"] = q.reshape(rows, L).astype(np.int8), s, mask, ref
+    out["smm_cases"] = np.arange(3, dtype=np.int32)
     np.savez_compressed(os.path.join(GOLD, "compat_kat.npz"), **out)
     print("compat_kat.npz written:", len(out), "arrays; compat oracle bit-equal to the reference modules on all cases")
 

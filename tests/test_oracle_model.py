@@ -123,3 +123,19 @@ def test_shiftexp2d_host_table_matches_reference_softmax(ckat):
         factor = np.floor((np.float32(1.0) / S) * np.float32(2147483648.0))
         P = np.floor((e * factor[:, None]).astype(np.float32) / np.float32(16777216.0)).astype(np.int32)
         assert np.array_equal(P, ckat[c + "out"]), ci
+
+
+def test_compat_ln16_and_masked_shiftmax_kat(ckat):
+    """Swin's natural-scale operators: I-LayerNorm on the 16-bit stream (every other row an exact tie of the mean) and
+    Shiftmax behind the float shift mask, against the reference modules' outputs"""
+    for ci in ckat["ln16_cases"]:
+        c = f"ln16_{ci}_"
+        y, s_ln, _ = orc.layernorm_scaled(ckat[c + "q"].astype(np.int32), ckat[c + "s"], ckat[c + "gamma"], ckat[c + "beta"])
+        lo, hi = ckat[c + "range"]
+        m, e = orc.dyadic(s_ln, orc.sym_scale(lo, hi, 8))
+        assert np.array_equal(orc.requant(orc.roundtrip(y, s_ln), m, e, 8), ckat[c + "q_out"]), ci
+    for ci in ckat["smm_cases"]:
+        c = f"smm{ci}_"
+        q, s, mask = ckat[c + "q"].astype(np.float32), np.float32(ckat[c + "s"]), ckat[c + "mask"]
+        x = ((q * s).astype(np.float32) + np.where(mask, np.float32(-100.0), np.float32(0.0))).astype(np.float32)
+        assert np.array_equal(orc.shiftmax_xint((x / s).astype(np.float32), s), ckat[c + "out"]), ci
