@@ -68,7 +68,7 @@ SIGNATURES = {
     "ivit_requant_i8_i16": [vp, u32, i32, vp, i64, vp],
     "ivit_residual_requant_i16": [vp, ci, vp, vp, u32, i32, vp, u32, i32, vp, i64, ci, ci, ci, ci, ci, vp],
     "ivit_layernorm_i16_i8": [vp, ci, ci, vp, vp, vp, vp, vp, i64, ci, ci, ci, ci, vp],
-    "ivit_layernorm_i16_i8_compat": [vp, ci, ci, f32, vp, vp, vp, vp, vp, i64, ci, ci, ci, ci, vp],
+    "ivit_layernorm_i16_i8_compat": [vp, ci, ci, f32, ci, vp, vp, vp, vp, vp, i64, ci, ci, ci, ci, vp],
     "ivit_patch_merge_i16": [vp, vp, ci, ci, ci, ci, vp],
     "ivit_avgpool_requant_i8": [vp, vp, ci, ci, ci, u32, i32, vp],
     # I-BERT operator family (include/ivit_hip.h, last section)

@@ -365,6 +365,230 @@ __global__ __launch_bounds__(NT) void layernorm_i16_i8_tiled_kernel(Ln16Args a)
     }
 }
 
+// The tiled kernel for a 16-bit input carried at a NATURAL scale s_in (ivit_layernorm_i16_i8_compat): per element
+//   phi = fl(fl(q * s_in) / s_in)   -- the float the reference's LayerNorm sees (quant_modules.py:387, ivit_modules.py:36); the
+//       quotient by the invariant s_in is the 3-instruction form q0 = x * r, e = fma(-s, q0, x), phi = fma(e, r, q0) with
+//       r = RN(1 / s_in), correctly rounded for every 16-bit q at this s_in (checked exhaustively on the host,
+//       prepare.markstein_division_ok; the literal kernel above is the fallback);
+//   k' = trunc(phi) replaces q in everything downstream (ivit_modules.py:38);
+//   the mean is round(fl(S / C)) with S the float32 sum of the phi values in torch's CPU reduction order: the phi values of
+//   the wave's rows go through LDS once and two rows at a time are summed by the two halves of the wave (rowsum32 below).
+template <class F>
+IVIT_DEV float rowsum32(F elem, int n, int l32, int base)
+{
+    // rowsum.h torch_rowsum on 32 lanes (lanes base .. base + 31 of the wave): same partial sums, same order
+    const int vec_size = n >> 3, size_ilp = vec_size >> 2;
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+    {
+        int lg = 0;
+        while ((1 << lg) < size_ilp) ++lg;
+        const int lp = max(4, lg / 4), step = 1 << lp, mask = step - 1;
+        int i = 0;
+        while (i + step <= size_ilp) {
+            for (int j = 0; j < step; ++j, ++i) acc0 += elem(i * 32 + l32);
+            acc1 += acc0; acc0 = 0.f;
+            if ((i & (mask << lp)) == 0) {
+                acc2 += acc1; acc1 = 0.f;
+                if ((i & (mask << (2 * lp))) == 0) { acc3 += acc2; acc2 = 0.f; }
+            }
+        }
+        for (; i < size_ilp; ++i) acc0 += elem(i * 32 + l32);
+        acc0 += acc1; acc0 += acc2; acc0 += acc3;
+    }
+    if (l32 < 8)
+        for (int i = size_ilp * 4; i < vec_size; ++i) acc0 += elem(i * 8 + l32);
+    const float p1 = __shfl(acc0, base + ((l32 + 8) & 31)), p2 = __shfl(acc0, base + ((l32 + 16) & 31)),
+                p3 = __shfl(acc0, base + ((l32 + 24) & 31));
+    const float v = ((acc0 + p1) + p2) + p3;    // lanes base .. base + 7: the 8 vector lanes
+    float fin = 0.f;
+    for (int i = vec_size * 8; i < n; ++i) fin += elem(i);
+#pragma unroll
+    for (int l = 0; l < 8; ++l) fin += __shfl(v, base + l);
+    return fin;
+}
+
+template <int LPR, int NJ>
+__global__ __launch_bounds__(NT) void layernorm_i16_i8_tiled_compat_kernel(Ln16Args a, float s_in, float r_in)
+{
+    __shared__ float s_phi[WPB][64 * 8 * NJ];      // [wave][row of the wave][channel]
+    __shared__ float s_sum[WPB][64];
+    constexpr int RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane & (LPR - 1), grp = lane / LPR;
+    const int C = a.C, nd = C >> 3;
+    // bias and the float32 bracket (lo, hi) of each channel's QuantAct multiplier: see layernorm_i8_kernel (rowops.hip) for
+    // the certificate that replaces the literal float64 tail of the chain; uncertified wave-iterations are redone literally
+    float bias[NJ][8], lo[NJ][8], hi[NJ][8];
+    {
+        // all table loads first (vector loads, independent), then the arithmetic: the waves of this kernel have little
+        // else in flight to hide a chain of dependent global-load latencies behind
+        float4 bq[NJ][2], sq[NJ][2];
+        uint4 mq[NJ][2];
+        int4 eq[NJ][2];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int d = min(sub + LPR * j, nd - 1);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                bq[j][h] = *reinterpret_cast<const float4*>(a.bias_int + 8 * d + 4 * h);
+                sq[j][h] = *reinterpret_cast<const float4*>(a.s_ln + 8 * d + 4 * h);
+                mq[j][h] = *reinterpret_cast<const uint4*>(a.m + 8 * d + 4 * h);
+                eq[j][h] = *reinterpret_cast<const int4*>(a.e + 8 * d + 4 * h);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float bb[4] = {bq[j][h].x, bq[j][h].y, bq[j][h].z, bq[j][h].w};
+                const float ss[4] = {sq[j][h].x, sq[j][h].y, sq[j][h].z, sq[j][h].w};
+                const unsigned mm[4] = {mq[j][h].x, mq[j][h].y, mq[j][h].z, mq[j][h].w};
+                const int ee[4] = {eq[j][h].x, eq[j][h].y, eq[j][h].z, eq[j][h].w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    bias[j][4 * h + c] = bb[c];
+                    const double M = dyadic_mult(mm[c], ee[c]);
+                    const double lod = M * (1.0 - 1.25 / 4194304.0), hid = M * (1.0 + 1.25 / 4194304.0);
+                    float lf = (float)lod, hf = (float)hid;
+                    if ((double)lf > lod) lf = __int_as_float(__float_as_int(lf) - 1);
+                    if ((double)hf < hid) hf = __int_as_float(__float_as_int(hf) + 1);
+                    const bool ok = fabsf(ss[c]) >= 1e-30f && fabsf(ss[c]) <= 1e30f && lod > 1e-35 && hid < 1e30;
+                    lo[j][4 * h + c] = ok ? lf : 0.0f;
+                    hi[j][4 * h + c] = ok ? hf : __builtin_inff();
+                }
+            }
+    }
+    const float fC = (float)C;
+    for (int row0 = (blockIdx.x * WPB + wave) * RPW; row0 < a.rows; row0 += gridDim.x * WPB * RPW) {
+        const int row = row0 + grp;
+        const bool live = row < a.rows;
+        const int16_t* xr = a.x + (int64_t)min(row, a.rows - 1) * C;
+        v4i w[NJ];
+        float* prow = s_phi[wave] + grp * C;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int d = sub + LPR * j;
+            w[j] = (d < nd) ? *reinterpret_cast<const v4i*>(xr + 8 * d) : v4i{0, 0, 0, 0};
+            float ph[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int qv = (c & 1) ? (w[j][c >> 1] >> 16) : (int)(int16_t)w[j][c >> 1];
+                const float x = (float)qv * s_in;                                   // quant_modules.py:387
+                const float q0 = x * r_in;                                          // :36  x / s_in (Markstein, see above)
+                const float e = __builtin_fmaf(-s_in, q0, x);
+                ph[c] = __builtin_fmaf(e, r_in, q0);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {                                           // :38 .to(int32) truncates
+                const int k0 = (int)ph[2 * q], k1 = (int)ph[2 * q + 1];
+                w[j][q] = (k0 & 0xffff) | (k1 << 16);
+            }
+            if (d < nd) {
+                *reinterpret_cast<float4*>(prow + 8 * d) = make_float4(ph[0], ph[1], ph[2], ph[3]);
+                *reinterpret_cast<float4*>(prow + 8 * d + 4) = make_float4(ph[4], ph[5], ph[6], ph[7]);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        {   // float32 row sums in torch's order: the two halves of the wave take two rows per round
+            const int half = lane >> 5, l32 = lane & 31;
+#pragma unroll 1
+            for (int r0 = 0; r0 < RPW; r0 += 2) {
+                const int rr = min(r0 + half, RPW - 1);
+                const float* pr = s_phi[wave] + rr * C;
+                const float S = rowsum32([&](int i) { return pr[i]; }, C, l32, 32 * half);
+                if (l32 == 0 && r0 + half < RPW) s_sum[wave][rr] = S;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int mean_int = (int)rintf(s_sum[wave][grp] / fC);                 // :37
+        __builtin_amdgcn_wave_barrier();                                        // before the next iteration overwrites s_phi
+        unsigned long long var = 0;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            if (sub + LPR * j < nd) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned d0 = (unsigned)abs((int)(int16_t)w[j][q] - mean_int);
+                    const unsigned d1 = (unsigned)abs((w[j][q] >> 16) - mean_int);
+                    var += (unsigned long long)d0 * d0;
+                    var += (unsigned long long)d1 * d1;
+                }
+            }
+        }
+#pragma unroll
+        for (int o = LPR / 2; o > 0; o >>= 1) {
+            const unsigned vlo = (unsigned)__shfl_xor((int)(unsigned)var, o);
+            const unsigned vhi = (unsigned)__shfl_xor((int)(var >> 32), o);
+            var += ((unsigned long long)vhi << 32) | vlo;
+        }
+        float varf = (float)var, t = 65536.0f;                                  // :45-49
+#pragma unroll 1
+        for (int it = 0; it < 10; ++it) t = floorf((t + floorf(varf / t)) * 0.5f);
+        const float hfactor = floorf((1.0f / t) * 2147483648.0f) * 0.5f;        // :51; the /2 of :52 commutes (exact scaling)
+        int8_t* orow = a.out + win_row(a.map, min(row, a.rows - 1)) * a.ldo;
+        int2 res[NJ];
+        unsigned unc = 0;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            int o[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int xv = (c & 1) ? (w[j][c >> 1] >> 16) : (int)(int16_t)w[j][c >> 1];
+                const float dl = (float)(xv - mean_int);
+                const float v = floorf(dl * hfactor);                           // :52
+                const float y = v + bias[j][c];                                 // :61
+                const int tl = __float_as_int(__builtin_fmaf(y, lo[j][c], 12582912.0f));
+                const int th = __float_as_int(__builtin_fmaf(y, hi[j][c], 12582912.0f));
+                asm("v_sad_u32 %0, %1, %2, %3" : "=v"(unc) : "v"(tl), "v"(th), "v"(unc));
+                o[c] = clamp_i32(tl, 0x4B400000 - 128, 0x4B400000 + 127);       // low byte = int8 result
+            }
+            res[j].x = pack4(o[0], o[1], o[2], o[3]);
+            res[j].y = pack4(o[4], o[5], o[6], o[7]);
+        }
+        if (__builtin_amdgcn_ballot_w64(unc != 0) != 0) {
+            // literal evaluation (wave-uniform branch): x = y * s_ln (:63), z = round(x / s_ln) (quant_utils.py:220),
+            // RNE(float64(z) * M) (:229-230)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int d = min(sub + LPR * j, nd - 1);
+                int o[8];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const float4 s4 = *reinterpret_cast<const float4*>(a.s_ln + 8 * d + 4 * h);
+                    const uint4 m4 = *reinterpret_cast<const uint4*>(a.m + 8 * d + 4 * h);
+                    const int4 e4 = *reinterpret_cast<const int4*>(a.e + 8 * d + 4 * h);
+                    const float ss[4] = {s4.x, s4.y, s4.z, s4.w};
+                    const double MM[4] = {dyadic_mult(m4.x, e4.x), dyadic_mult(m4.y, e4.y), dyadic_mult(m4.z, e4.z),
+                                          dyadic_mult(m4.w, e4.w)};
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) {
+                        const int c = 4 * h + cc;
+                        const int xv = (c & 1) ? (w[j][c >> 1] >> 16) : (int)(int16_t)w[j][c >> 1];
+                        const float dl = (float)(xv - mean_int);
+                        const float v = floorf(dl * hfactor);
+                        const float y = v + bias[j][c];
+                        const float x = y * ss[cc];
+                        const float z = rintf((float)((double)x * (1.0 / (double)ss[cc])));   // see layernorm_i8_kernel
+                        const double tt = (double)z * MM[cc] + IVIT_MAGIC;
+                        o[c] = clamp_i32((int)(unsigned)__double_as_longlong(tt), -128, 127);
+                    }
+                }
+                res[j].x = pack4(o[0], o[1], o[2], o[3]);
+                res[j].y = pack4(o[4], o[5], o[6], o[7]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int d = sub + LPR * j;
+            if (live && d < nd) *reinterpret_cast<int2*>(orow + 8 * d) = res[j];
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // PatchMerging gather (swin_quant.py:337-344): [B, H*W, C] int16 -> [B, H/2*W/2, 4C], channel blocks
 // (0::2,0::2), (1::2,0::2), (0::2,1::2), (1::2,1::2)
@@ -686,16 +910,43 @@ IVIT_EXPORT int ivit_layernorm_i16_i8(const int16_t* x, int rows, int C, const f
     IVIT_CHECK_LAUNCH("ivit_layernorm_i16_i8");
 }
 
-IVIT_EXPORT int ivit_layernorm_i16_i8_compat(const int16_t* x, int rows, int C, float s_in, const float* bias_int,
-                                             const float* s_ln, const uint32_t* m, const int32_t* e, int8_t* out, int64_t ldo,
-                                             int H, int W, int ws, int shift, ivit_stream_t stream)
+IVIT_EXPORT int ivit_layernorm_i16_i8_compat(const int16_t* x, int rows, int C, float s_in, int fast_division,
+                                             const float* bias_int, const float* s_ln, const uint32_t* m, const int32_t* e,
+                                             int8_t* out, int64_t ldo, int H, int W, int ws, int shift, ivit_stream_t stream)
 {
     IVIT_REQUIRE(x && out && bias_int && s_ln && m && e && rows > 0 && C > 0 && C <= 4096 && ldo >= C && s_in > 0.0f,
                  "ivit_layernorm_i16_i8_compat: bad operand");
     int rc = check_map("ivit_layernorm_i16_i8_compat", rows, H, W, ws, shift);
     if (rc) return rc;
-    Ln16LitArgs a{Ln16Args{x, rows, C, bias_int, s_ln, m, e, out, ldo, WinMap{H, W, ws, shift}}, s_in};
-    hipLaunchKernelGGL(layernorm_i16_i8_literal_kernel, dim3(grid_for_rows(rows)), dim3(NT), 0, ivit_stream(stream), a);
+    Ln16Args b{x, rows, C, bias_int, s_ln, m, e, out, ldo, WinMap{H, W, ws, shift}};
+    hipStream_t st = ivit_stream(stream);
+    const bool tiled = fast_division && C % 8 == 0 && C <= 1536 && ldo % 8 == 0 && ((uintptr_t)x % 16 == 0) &&
+                       ((uintptr_t)out % 8 == 0) && ((uintptr_t)bias_int % 16 == 0) && ((uintptr_t)s_ln % 16 == 0) &&
+                       ((uintptr_t)m % 16 == 0) && ((uintptr_t)e % 16 == 0);
+    if (tiled) {
+        const int nd = C / 8;
+        int lpr = 4;
+        while ((nd + lpr - 1) / lpr > 3) lpr *= 2;
+        const int nj = (nd + lpr - 1) / lpr;
+        int nblk = grid_for_rows(rows, 64 / lpr);
+        if (nblk > 512) nblk = 512;
+        const float r_in = 1.0f / s_in;
+        bool launched = false;
+#define LN16C_CASE(L, J)                                                                                                  \
+    if (lpr == L && nj == J) {                                                                                            \
+        hipLaunchKernelGGL((layernorm_i16_i8_tiled_compat_kernel<L, J>), dim3(nblk), dim3(NT), 0, st, b, s_in, r_in);     \
+        launched = true;                                                                                                  \
+    }
+        LN16C_CASE(4, 1); LN16C_CASE(4, 2); LN16C_CASE(4, 3);
+        LN16C_CASE(8, 2); LN16C_CASE(8, 3);
+        LN16C_CASE(16, 2); LN16C_CASE(16, 3);
+        LN16C_CASE(32, 2); LN16C_CASE(32, 3);
+        LN16C_CASE(64, 2); LN16C_CASE(64, 3);
+#undef LN16C_CASE
+        if (launched) IVIT_CHECK_LAUNCH("ivit_layernorm_i16_i8_compat");
+    }
+    Ln16LitArgs a{b, s_in};
+    hipLaunchKernelGGL(layernorm_i16_i8_literal_kernel, dim3(grid_for_rows(rows)), dim3(NT), 0, st, a);
     IVIT_CHECK_LAUNCH("ivit_layernorm_i16_i8_compat");
 }
 

@@ -177,3 +177,23 @@ def shiftexp_band(tab2d: np.ndarray):
     band = np.where(q >= 0, tab2d[idx[:, None], np.clip(q, 0, 255)], np.uint32(sat)).astype(np.uint32)
     assert np.all(band[:, W - 1] == sat)
     return np.ascontiguousarray(band), W
+
+
+def markstein_division_ok(s, bits: int = 16) -> bool:
+    """Is the 3-instruction quotient by the invariant s -- q0 = fl(x*r), e = fma(-s, q0, x), fma(e, r, q0), r = fl(1/s) -- the
+    correctly rounded fl(x / s) for EVERY x = fl(q*s), q a `bits`-bit integer?  (Markstein's theorem says yes unless the
+    significand of s is all ones; this checks the actual inputs exhaustively, emulating the two fmas in float64: both are an
+    exact product plus one addend, rounded once.)  Enables the tiled natural-scale LayerNorm of the Swin engine."""
+    s = f32(s)
+    q = np.arange(-(2 ** (bits - 1)), 2 ** (bits - 1), dtype=f32)
+    x = (q * s).astype(f32)
+    ref = (x / s).astype(f32)
+    r = f32(f32(1.0) / s)
+    q0 = (x * r).astype(f32)
+    e = (x.astype(np.float64) - np.float64(s) * q0.astype(np.float64)).astype(f32)          # exact difference, one rounding
+    got = (q0.astype(np.float64) + e.astype(np.float64) * np.float64(r))
+    # the float64 sum above can itself round (q0 is ~2^15, e*r ~2^-10): accept only when rounding it to float32 is unambiguous
+    got32 = got.astype(f32)
+    near_mid = np.abs(got - (got32.astype(np.float64) + np.spacing(got32).astype(np.float64) * np.where(got > got32, 0.5, -0.5))) \
+        < np.abs(got) * 2.0 ** -50
+    return bool(np.array_equal(got32, ref) and not near_mid.any())

@@ -22,7 +22,8 @@ import torch
 
 from . import _lib
 from .graph import GraphReplay
-from .prepare import (LayerNormParams, LinearParams, dyadic, f32, pad_head, phi_is_identity, phi_table, phi_tables, quant_sym,
+from .prepare import (LayerNormParams, LinearParams, dyadic, f32, markstein_division_ok, pad_head, phi_is_identity, phi_table,
+                      phi_tables, quant_sym,
                       requant_host, sym_scale)
 from .synth import IMG_SIZE
 
@@ -113,10 +114,12 @@ class IntSwinEngine(GraphReplay):
             LayerNorm sees those neighbouring floats (ivit_modules.py:36-38): 16-bit inputs take the literal kernel, the 8-bit
             patch norm the table form of the DeiT engine."""
             lp = LayerNormParams(P[prefix + ".weight"], P[prefix + ".bias"], s_out)
-            d = dict(bias=dev(lp.bias_int), s=dev(lp.s_ln), m=dev(lp.m.view(np.int32)), e=dev(lp.e), s_in=None, remap=None, phi=None)
+            d = dict(bias=dev(lp.bias_int), s=dev(lp.s_ln), m=dev(lp.m.view(np.int32)), e=dev(lp.e), s_in=None, remap=None, phi=None,
+                     fast_div=0)
             if not phi_is_identity(s_in, bits_in):
                 self.natural_sites += 1
                 d["s_in"] = float(s_in)
+                d["fast_div"] = int(bits_in == 16 and markstein_division_ok(s_in, 16))
                 if bits_in == 8:
                     remap, phi = phi_tables(s_in)
                     d.update(remap=dev(remap), phi=dev(phi))
@@ -298,7 +301,7 @@ class IntSwinEngine(GraphReplay):
 
     def _ln16(self, x, rows, C, ln, out, ldo, st, H=0, W=0, ws=0, shift=0):
         if ln["s_in"] is not None:       # natural input scale: the literal kernel (csrc/swin.hip)
-            _lib.call("ivit_layernorm_i16_i8_compat", _lib.ptr(x), rows, C, ln["s_in"], _lib.ptr(ln["bias"]), _lib.ptr(ln["s"]),
+            _lib.call("ivit_layernorm_i16_i8_compat", _lib.ptr(x), rows, C, ln["s_in"], ln["fast_div"], _lib.ptr(ln["bias"]), _lib.ptr(ln["s"]),
                       _lib.ptr(ln["m"]), _lib.ptr(ln["e"]), _lib.ptr(out), ldo, H, W, ws, shift, st)
             return
         _lib.call("ivit_layernorm_i16_i8", _lib.ptr(x), rows, C, _lib.ptr(ln["bias"]), _lib.ptr(ln["s"]),

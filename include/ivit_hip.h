@@ -328,11 +328,14 @@ int ivit_residual_requant_i16(const void* a, int a_bits, const uint32_t* m_pre, 
 int ivit_layernorm_i16_i8(const int16_t* x, int rows, int C, const float* bias_int, const float* s_ln,
                           const uint32_t* m, const int32_t* e, int8_t* out, int64_t ldo, int H, int W, int ws, int shift,
                           ivit_stream_t stream);
-/* the same for a 16-bit input carried at a natural scale s_in: the reference's LayerNorm sees fl(fl(q*s_in)/s_in); literal
- * form (float32 mean over those values in torch's CPU reduction order, truncating .to(int32), ivit_modules.py:36-38) */
-int ivit_layernorm_i16_i8_compat(const int16_t* x, int rows, int C, float s_in, const float* bias_int, const float* s_ln,
-                                 const uint32_t* m, const int32_t* e, int8_t* out, int64_t ldo, int H, int W, int ws,
-                                 int shift, ivit_stream_t stream);
+/* the same for a 16-bit input carried at a natural scale s_in: the reference's LayerNorm sees fl(fl(q*s_in)/s_in) (float32 mean
+ * over those values in torch's CPU reduction order, truncating .to(int32), ivit_modules.py:36-38).  fast_division = 1: the
+ * caller has verified (exhaustively over the 65 536 inputs, prepare.markstein_division_ok) that the 3-instruction quotient by
+ * the invariant s_in -- q0 = x*r, e = fma(-s, q0, x), fma(e, r, q0) with r = RN(1/s_in) -- is the correctly rounded one for this
+ * s_in, which enables the tiled kernel; 0: the literal one-wave-per-row kernel with IEEE divisions. */
+int ivit_layernorm_i16_i8_compat(const int16_t* x, int rows, int C, float s_in, int fast_division, const float* bias_int,
+                                 const float* s_ln, const uint32_t* m, const int32_t* e, int8_t* out, int64_t ldo, int H, int W,
+                                 int ws, int shift, ivit_stream_t stream);
 
 /* PatchMerging gather (swin_quant.py:337-344): x [B, H*W, C] int16 -> out [B, (H/2)*(W/2), 4C],
  * channel blocks (even y, even x), (odd y, even x), (even y, odd x), (odd y, odd x). */

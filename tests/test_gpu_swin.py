@@ -511,11 +511,14 @@ def test_layernorm_i16_natural_scale_kat(golden_dir):
         rows, Cn = q.shape
         lo, hi = ck[c + "range"]
         lp = LayerNormParams(ck[c + "gamma"], ck[c + "beta"], sym_scale(lo, hi, 8))
-        out = torch.empty(rows, Cn, dtype=torch.int8, device=DEV)
-        _lib.call("ivit_layernorm_i16_i8_compat", _lib.ptr(dev(q)), rows, Cn, float(ck[c + "s"]), _lib.ptr(dev(lp.bias_int)),
-                  _lib.ptr(dev(lp.s_ln)), _lib.ptr(dev(lp.m.view(np.int32))), _lib.ptr(dev(lp.e)), _lib.ptr(out), Cn,
-                  0, 0, 0, 0, st())
-        assert np.array_equal(out.cpu().numpy().astype(np.int32), ck[c + "q_out"]), ci
+        from ivit_amd.prepare import markstein_division_ok
+        assert markstein_division_ok(ck[c + "s"], 16)
+        for fast in (0, 1):      # the literal one-wave-per-row kernel; the tiled kernel with the 3-instruction quotient
+            out = torch.empty(rows, Cn, dtype=torch.int8, device=DEV)
+            _lib.call("ivit_layernorm_i16_i8_compat", _lib.ptr(dev(q)), rows, Cn, float(ck[c + "s"]), fast, _lib.ptr(dev(lp.bias_int)),
+                      _lib.ptr(dev(lp.s_ln)), _lib.ptr(dev(lp.m.view(np.int32))), _lib.ptr(dev(lp.e)), _lib.ptr(out), Cn,
+                      0, 0, 0, 0, st())
+            assert np.array_equal(out.cpu().numpy().astype(np.int32), ck[c + "q_out"]), (ci, fast)
 
 
 @pytest.mark.parametrize("B_,nW,nH,N,s_attn,masked", [(8, 4, 3, 49, 0.271, True), (6, 1, 6, 49, 0.1173, False),
@@ -605,3 +608,36 @@ def test_swin_natural_scales_engine_equals_module_path():
             a, b = taps[name].cpu().numpy().astype(np.int32).reshape(-1), got[name].cpu().numpy().reshape(-1)
             assert a.size == b.size and np.array_equal(a, b), f"tap {name}: {(a != b).sum()} of {a.size} differ"
     assert np.array_equal(ye.cpu().numpy().view(np.int32), ym.cpu().numpy().view(np.int32))
+
+
+@pytest.mark.parametrize("rows,Cn,s", [(5000, 96, 0.000913), (3001, 192, 0.0004471), (999, 384, 0.00171), (777, 768, 0.000613),
+                                       (130, 1536, 0.0009), (64, 3072, 0.0011)])
+def test_layernorm_i16_natural_scale_random_vs_oracle(rows, Cn, s):
+    """every LPR / NJ instantiation of the tiled natural-scale kernel (and the literal kernel for C > 1536) against the oracle,
+    whose restatement is pinned by the reference KATs; a third of the rows are exact ties of the mean"""
+    from ivit_amd.prepare import LayerNormParams, markstein_division_ok
+    rng = np.random.default_rng(rows + Cn)
+    s = np.float32(s)
+    q = np.clip(np.rint(rng.normal(rng.normal(0, 2000, size=(rows, 1)), rng.uniform(500, 8000, size=(rows, 1)), size=(rows, Cn))),
+                -32768, 32767).astype(np.int32)
+    for r in range(0, rows, 3):
+        d = Cn // 2 + Cn * int(rng.integers(-100, 100)) - int(q[r].sum())
+        for c in rng.permutation(Cn):
+            if d == 0:
+                break
+            nv = int(np.clip(q[r, c] + d, -32768, 32767))
+            d -= nv - q[r, c]
+            q[r, c] = nv
+    gamma = rng.uniform(0.5, 1.5, size=Cn).astype(np.float32)
+    beta = rng.normal(0, 0.1, size=Cn).astype(np.float32)
+    y, s_ln, _ = orc.layernorm_scaled(q, s, gamma, beta)
+    s_out = np.float32(np.abs(y * s_ln).max() / 127 * 0.83)
+    m, e = orc.dyadic(s_ln, s_out)
+    exp = orc.requant(orc.roundtrip(y, s_ln), m, e, 8)
+    lp = LayerNormParams(gamma, beta, s_out)
+    assert markstein_division_ok(s, 16)
+    out = torch.empty(rows, Cn, dtype=torch.int8, device=DEV)
+    _lib.call("ivit_layernorm_i16_i8_compat", _lib.ptr(dev(q.astype(np.int16))), rows, Cn, float(s), 1, _lib.ptr(dev(lp.bias_int)),
+              _lib.ptr(dev(lp.s_ln)), _lib.ptr(dev(lp.m.view(np.int32))), _lib.ptr(dev(lp.e)), _lib.ptr(out), Cn, 0, 0, 0, 0, st())
+    got = out.cpu().numpy().astype(np.int32)
+    assert np.array_equal(got, exp), f"{(got != exp).sum()} of {got.size} differ"
