@@ -565,6 +565,12 @@ __global__ __launch_bounds__(NT, (NJ <= 1 ? 4 : NJ <= 3 ? 3 : 2)) void layernorm
     __syncthreads();
     const int8_t* xin = reinterpret_cast<const int8_t*>(a.x);
     int8_t* out = reinterpret_cast<int8_t*>(a.out);
+#if IVIT_LAB
+    if ((abl & 128) && (blockIdx.x & 1)) {      // lab: start every other workgroup late (phase-overlap experiment)
+        const int units = (abl >> 8) & 15;
+        for (int it = 0; it < units; ++it) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
     BlockCol bcol[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) bcol[j] = block_col(4 * (lane + 64 * j));
