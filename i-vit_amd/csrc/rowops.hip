@@ -533,7 +533,7 @@ __global__ __launch_bounds__(NT, NJ <= 3 ? 4 : 3) void layernorm_i8_pair_kernel(
 //     registers, a row with an uncertified element (~1 %) is re-read and redone literally.
 // Arithmetic identical to layernorm_i8_kernel (same certificate, same literal fallback, same COMPAT handling).
 template <int NJ, bool COMPAT, int G>
-__global__ __launch_bounds__(NT, (NJ <= 1 ? 4 : NJ <= 3 ? 3 : 2)) void layernorm_i8_v2_kernel(LnArgs a)
+__global__ __launch_bounds__(NT, (G == 8 && NJ <= 3 ? 4 : NJ <= 1 ? 4 : NJ <= 3 ? 3 : 2)) void layernorm_i8_v2_kernel(LnArgs a)
 {
     static_assert(G == 8 || G == 16, "G");
     typedef unsigned v2u __attribute__((ext_vector_type(2)));
@@ -601,10 +601,7 @@ __global__ __launch_bounds__(NT, (NJ <= 1 ? 4 : NJ <= 3 ? 3 : 2)) void layernorm
             }
         }
     };
-    // De-phasing: every wave of the resident set has the same work, so without this they all read, then all compute, then
-    // all store.  Odd waves take a first group of G / 2 rows: from then on they are half a group out of step with the even
-    // waves on their SIMD, whose arithmetic then runs while the odd waves' loads and stores are in flight.
-    int step = ((wave_id & 1) && !(abl & 64)) ? G / 2 : G;
+    int step = ((wave_id & 1) && (abl & 64)) ? G / 2 : G;     // lab bit 6: the de-phasing experiment (no gain)
     for (int row0 = r_begin; row0 < r_end; row0 += step, step = G) {
         const int nrow = min(step, r_end - row0);
         int w[G][NJ];
@@ -1335,12 +1332,15 @@ static int launch_ln_v2(const LnArgs& a, hipStream_t st, const char* who)
 {
     const int nj = (a.C / 4 + 63) / 64;
     const int resident = 256 * (nj <= 1 ? 4 : nj <= 3 ? 3 : 2);     // = the kernel's __launch_bounds__ occupancy
-    // groups of 16 rows (half the per-row cost of the statistics); groups of 8 for small launches, where twice the number of
-    // waves matters more (batch 1: 197 rows; the final LayerNorm over the class rows)
-    const bool g8 = ((a.abl >> 4) & 3) == 1 || (((a.abl >> 4) & 3) == 0 && a.rows < 16384);
+    // One group of 8 rows per wave and more workgroups than fit at once (measured at the headline shape, scripts/ln_ablate.py:
+    // 25.5 us; groups of 16 rows on one resident set of workgroups 28-30 us, groups of 8 on a resident set 27.8 us): a wave's
+    // timeline is serial -- first loads, arithmetic, store drain -- so shorter waves that start as others finish overlap those
+    // phases across waves, which neither prefetching nor de-phasing a resident set achieved.
+    // Lab bits 4-5: 2 = groups of 16 on a resident set (the former default).
+    const bool g8 = ((a.abl >> 4) & 3) != 2;
     const int gsz = g8 ? 8 : 16;
-    int grid = (int)(((int64_t)a.rows + gsz * WPB - 1) / (gsz * WPB));    // at least one full group per wave
-    if (grid > resident) grid = resident;
+    int grid = (int)(((int64_t)a.rows + gsz * WPB - 1) / (gsz * WPB));    // one full group per wave
+    if (grid > resident && !g8) grid = resident;
     if (grid < 1) grid = 1;
     const size_t lds = (size_t)3 * a.C * sizeof(float);
 #define IVIT_LN_V2(NJv)                                                                                              \
