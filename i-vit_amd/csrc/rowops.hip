@@ -533,9 +533,9 @@ __global__ __launch_bounds__(NT, NJ <= 3 ? 4 : 3) void layernorm_i8_pair_kernel(
 //     registers, a row with an uncertified element (~1 %) is re-read and redone literally.
 // Arithmetic identical to layernorm_i8_kernel (same certificate, same literal fallback, same COMPAT handling).
 template <int NJ, bool COMPAT, int G>
-__global__ __launch_bounds__(NT, (G == 8 && NJ <= 3 ? 4 : NJ <= 1 ? 4 : NJ <= 3 ? 3 : 2)) void layernorm_i8_v2_kernel(LnArgs a)
+__global__ __launch_bounds__(NT, (G == 4 && NJ <= 3 ? 5 : G == 8 && NJ <= 3 ? 4 : NJ <= 1 ? 4 : NJ <= 3 ? 3 : 2)) void layernorm_i8_v2_kernel(LnArgs a)
 {
-    static_assert(G == 8 || G == 16, "G");
+    static_assert(G == 4 || G == 8 || G == 16, "G");
     typedef unsigned v2u __attribute__((ext_vector_type(2)));
     extern __shared__ __attribute__((aligned(16))) float lds_tab[];   // [C] bias | [C] lo | [C] hi
     __shared__ unsigned char s_remap[COMPAT ? 256 : 4];
@@ -633,7 +633,19 @@ __global__ __launch_bounds__(NT, (G == 8 && NJ <= 3 ? 4 : NJ <= 1 ? 4 : NJ <= 3 
         constexpr int LPR = 64 / G;          // lanes that end up holding one row's totals
         auto treduce = [&](int (&v)[G]) -> int {
             int t8[8], t4[4], t2[2];
-            if constexpr (G == 16) {
+            if constexpr (G == 4) {
+                for (int i = 0; i < 2; ++i) {
+                    const v2u r = __builtin_amdgcn_permlane32_swap((unsigned)v[i], (unsigned)v[i + 2], false, false);
+                    t2[i] = (int)(r.x + r.y);
+                }
+                const v2u r = __builtin_amdgcn_permlane16_swap((unsigned)t2[0], (unsigned)t2[1], false, false);
+                int t = (int)(r.x + r.y);
+                t += __shfl_xor(t, 8);
+                t += __shfl_xor(t, 4);
+                t += __shfl_xor(t, 2);
+                t += __shfl_xor(t, 1);
+                return t;
+            } else if constexpr (G == 16) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const v2u r = __builtin_amdgcn_permlane32_swap((unsigned)v[i], (unsigned)v[i + 8], false, false);
@@ -657,8 +669,9 @@ __global__ __launch_bounds__(NT, (G == 8 && NJ <= 3 ? 4 : NJ <= 1 ? 4 : NJ <= 3 
                 }
             }
             const bool up8 = (lane & 8) != 0, up4 = (lane & 4) != 0;
-            int t;
-            if constexpr (G == 16) {
+            int t = 0;
+            if constexpr (G == 4) {
+            } else if constexpr (G == 16) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const int keep = up8 ? t4[i + 2] : t4[i], send = up8 ? t4[i] : t4[i + 2];
@@ -1336,16 +1349,20 @@ static int launch_ln_v2(const LnArgs& a, hipStream_t st, const char* who)
     // 25.5 us; groups of 16 rows on one resident set of workgroups 28-30 us, groups of 8 on a resident set 27.8 us): a wave's
     // timeline is serial -- first loads, arithmetic, store drain -- so shorter waves that start as others finish overlap those
     // phases across waves, which neither prefetching nor de-phasing a resident set achieved.
-    // Lab bits 4-5: 2 = groups of 16 on a resident set (the former default).
-    const bool g8 = ((a.abl >> 4) & 3) != 2;
-    const int gsz = g8 ? 8 : 16;
+    // At four times the rows the order flips (90.9 vs 87.6 us: the statistics are paid once per 16 rows and a resident set then
+    // has several groups per wave anyway); groups of 4 rows: 27.0 us.  Lab bits 4-5: 1 / 2 / 3 force groups of 8 / 16 / 4.
+    const int force = (a.abl >> 4) & 3;
+    const bool g8 = force == 1 || force == 3 || (force == 0 && a.rows <= 131072);
+    const bool g4 = force == 3;
+    const int gsz = g4 ? 4 : g8 ? 8 : 16;
     int grid = (int)(((int64_t)a.rows + gsz * WPB - 1) / (gsz * WPB));    // one full group per wave
     if (grid > resident && !g8) grid = resident;
     if (grid < 1) grid = 1;
     const size_t lds = (size_t)3 * a.C * sizeof(float);
 #define IVIT_LN_V2(NJv)                                                                                              \
     do {                                                                                                             \
-        if (g8) hipLaunchKernelGGL((layernorm_i8_v2_kernel<NJv, COMPAT, 8>), dim3(grid), dim3(NT), lds, st, a);      \
+        if (g4) hipLaunchKernelGGL((layernorm_i8_v2_kernel<NJv, COMPAT, 4>), dim3(grid), dim3(NT), lds, st, a);      \
+        else if (g8) hipLaunchKernelGGL((layernorm_i8_v2_kernel<NJv, COMPAT, 8>), dim3(grid), dim3(NT), lds, st, a); \
         else hipLaunchKernelGGL((layernorm_i8_v2_kernel<NJv, COMPAT, 16>), dim3(grid), dim3(NT), lds, st, a);        \
     } while (0)
     if (nj <= 1) IVIT_LN_V2(1);

@@ -31,8 +31,8 @@ int ivit_debug_set_stamp_buffer(void* buf);
 int ivit_debug_ln_wave_per_row(int on);
 
 /* timing ablations of the default int8 LayerNorm kernel (results WRONG when non-zero): 1 no element chain, 2 no row
- * statistics, 4 no stores, 8 no per-workgroup table build; correct results: bits 4-5 = 2 groups of 16 rows on one resident
- * set of workgroups (the former default), bit 6 odd waves start with half a group, bit 7 + bits 8-11 delayed start of every
+ * statistics, 4 no stores, 8 no per-workgroup table build; correct results: bits 4-5 = 1 / 2 / 3 force groups of 8 rows (oversubscribed
+ * grid) / 16 rows (one resident set of workgroups) / 4 rows, bit 6 odd waves start with half a group, bit 7 + bits 8-11 delayed start of every
  * other workgroup; scripts/ln_ablate.py */
 int ivit_debug_ln_ablate(int bits);
 
