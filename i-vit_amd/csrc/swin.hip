@@ -7,6 +7,12 @@
 #include "common.h"
 #include "rowsum.h"
 
+#if IVIT_LAB
+extern int g_ln_ablate;     // rowops.hip; bits 16-19: workgroup cap of the tiled 16-bit LayerNorm in units of 256 (0 = default)
+#else
+constexpr int g_ln_ablate = 0;
+#endif
+
 namespace {
 
 constexpr int NT = 256;
@@ -897,7 +903,8 @@ IVIT_EXPORT int ivit_layernorm_i16_i8(const int16_t* x, int rows, int C, const f
     // persistent-style launch: the per-channel constants (24 f64 reciprocals per lane) are set up once per wave, so keep
     // the grid at the number of resident workgroups (2 per CU at ~195 VGPRs) and let each wave stride over many rows
     int nblk = grid_for_rows(rows, 64 / lpr);
-    if (nblk > 512) nblk = 512;
+    const int cap = ((g_ln_ablate >> 16) & 15) ? 256 * ((g_ln_ablate >> 16) & 15) : 512;
+    if (nblk > cap) nblk = cap;
     const dim3 grid(nblk), blk(NT);
 #define LN16_CASE(L, J) \
     if (lpr == L && nj == J) hipLaunchKernelGGL((layernorm_i16_i8_tiled_kernel<L, J>), grid, blk, 0, st, a)
