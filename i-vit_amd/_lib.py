@@ -31,6 +31,7 @@ SIGNATURES = {
     "ivit_attention_fused_i8_compat_band": [vp, vp, ci, ci, ci, ci, u32, i32, f32, u32, i32, vp, vp, ci, ci, vp],
     "ivit_shiftgelu_build_lut_ex": [f32, u32, i32, vp, vp, vp],
     "ivit_shiftgelu_lut_i8_ex": [vp, i64, ci, ci, vp, vp, i64, ci, vp],
+    "ivit_pack_weight_frags_i8": [vp, i64, ci, ci, vp, vp],
     "ivit_tile_operand_i8": [vp, i64, i64, ci, vp, vp],
     "ivit_untile_operand_i8": [vp, i64, ci, vp, i64, vp],
     "ivit_gemm_i8_requant_ex": [vp, i64, vp, i64, vp, vp, vp, vp, i64, ci, ci, ci, ci, vp],

@@ -343,11 +343,18 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_pers_kernel(GemmArgs g)
         }
         __builtin_amdgcn_s_barrier();                                     // everyone's stage 0; table visible
         asm volatile("" ::: "memory");
+        v4i bq[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                lds_read16_async(bq[i][q], lds_addr(tab) + (unsigned)(BCH * 8 + 4 * (64 * wc + 32 * i + 8 * q + 4 * h)));
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int4 b4 = *reinterpret_cast<const int4*>(tab + BCH * 8 + 4 * (64 * wc + 32 * i + 8 * q + 4 * h));
+                lds_wait(bq[i][q]);
+                const v4i b4 = bq[i][q];
 #pragma unroll
                 for (int j = 0; j < TJ; ++j) {
                     acc[i][j][4 * q + 0] = b4.x;
@@ -424,6 +431,280 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_pers_kernel(GemmArgs g)
     }
 }
 
+// ================================================================================================
+// Weights-in-registers form: tile 128 tokens x 256 channels, 4 waves, wave w owns channels [64w, 64w + 64) x all 128 tokens
+// (the same 2 x 4 MFMA tiles = 128 accumulators per lane as above).  A wave's weight fragments are read by no other wave of
+// the workgroup, so they bypass the LDS: W comes pre-packed in MFMA-fragment order (ivit_pack_weight_frags_i8: one K step of
+// a wave = 4 KB contiguous = four 1 KB global_load_dwordx4) and lands in registers two K steps ahead (three rotating
+// buffers, nk % 3 == 0).  Only the token tile goes through the LDS (8 KB DMA per K step, read by all four waves):
+//   LDS traffic per K step and workgroup   72 KB (24 written by DMA + 48 of fragment reads)  ->  40 KB (8 + 32)
+//   bytes through the CU's vector-memory path: 24 KB either way
+// The 256 x 128 kernel above keeps the LDS pipe busier (1152 of 128-B cycles per pair of co-resident K steps) than the
+// MFMA pipe (1024); this one 640.  The epilogue is the shared one (staging tile in its own LDS region, so the next tile's
+// first stage and first weight buffer are already in flight while it runs).
+// ================================================================================================
+constexpr int WR_TOK = 128, WR_CH = 256, WR_STAGES = 3;
+constexpr int WR_STAGE = WR_TOK * BK;                       // 8 KiB
+constexpr int WR_RING = WR_STAGES * WR_STAGE;               // 24 KiB
+constexpr int WR_CS = WR_TOK * (WR_CH + 4);                 // 32.5 KiB epilogue staging
+constexpr int WR_TAB = WR_CH * 12;                          // float2 lohi[256]; int bias[256]
+constexpr int WR_SMEM = WR_RING + WR_CS + 2 * WR_TAB;       // 62.5 KiB: two workgroups per CU
+
+struct WrTile { int m0, n0; };   // m0 < 0: none
+
+IVIT_DEV WrTile wr_tile(const GemmArgs& g, int t)
+{
+    const int nblk = g.tiles_m * g.tiles_n;
+    if (t >= nblk) return WrTile{-1, 0};
+    const int q8 = nblk >> 3, r8 = nblk & 7, xcd = t & 7;
+    const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (t >> 3);
+    const int tm = lid / g.tiles_n, tn = lid - tm * g.tiles_n;
+    return WrTile{tm * WR_TOK, tn * WR_CH};
+}
+
+// ABL (lab build only): 1 no epilogue, 2 no weight loads in the loop, 4 no DMA in the loop, 8 no MFMA
+template <int EPI, int ABL = 0>
+__global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_wreg_kernel(GemmArgs g)
+{
+    __shared__ __attribute__((aligned(16))) char smem[WR_SMEM];
+    char* const cs = smem + WR_RING;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, l31 = lane & 31;
+    const int lrow = lane >> 2, lslot = lane & 3;
+    const int nk = g.K / BK;
+    using T = std::true_type;
+    using F = std::false_type;
+
+    // ---- sources: 8 DMA pieces of 16 token rows per stage (wave w: pieces w, w + 4); this wave's 64 weight rows
+    const int8_t* asrc[2];
+    const int8_t* wsrc = g.W;      // wave-uniform
+    const unsigned lane16 = (unsigned)lane * 16u;
+    auto set_sources = [&](const WrTile& w) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int piece = wave + 4 * i;
+            const int row = 16 * piece + lrow;
+            const int c = lslot ^ ((row >> 2) & 3);
+            asrc[i] = g.A + (int64_t)min(w.m0 + row, g.M - 1) * g.lda + 16 * c;
+            if (g.a_blocks) {   // uniform block origin + lane * 16, recomputed per tile (no per-lane 64-bit value kept across the main loop)
+                unsigned l16 = lane16;
+                asm volatile("" : "+v"(l16));
+                asrc[i] = g.A + (int64_t)min((w.m0 >> 4) + piece, ((g.M + 15) >> 4) - 1) * (g.K >> 6) * 1024 + l16;
+            }
+        }
+        wsrc = g.W + (int64_t)min((w.n0 >> 6) + wave, ((g.N + 63) >> 6) - 1) * nk * 4096;
+    };
+    const int kstep_a = g.a_blocks ? 1024 : BK;
+    auto issue_dma = [&](int kt, int i) {
+        __builtin_amdgcn_global_load_lds((gptr_t)(asrc[i] + kt * kstep_a),
+                                         (lptr_t)(smem + (kt % WR_STAGES) * WR_STAGE + 1024 * (wave + 4 * i)), 16, 0, 0);
+    };
+    // weight fragments of K step kt into buffer wr[.]: piece p = 2 i + ks (channel sub-tile i, K half ks) is 1 KB at p * 1024
+    v4i wr0[4], wr1[4], wr2[4];
+    auto issue_w = [&](v4i (&wr)[4], int kt, int p) {
+        const int8_t* src = wsrc + (int64_t)kt * 4096;
+        if (p == 0) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(wr[0]) : "v"(lane16), "s"(src));
+        if (p == 1) asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(wr[1]) : "v"(lane16), "s"(src));
+        if (p == 2) asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "=v"(wr[2]) : "v"(lane16), "s"(src));
+        if (p == 3) asm volatile("global_load_dwordx4 %0, %1, %2 offset:3072" : "=v"(wr[3]) : "v"(lane16), "s"(src));
+    };
+    auto issue_all = [&](v4i (&wr)[4], int kt) {
+        issue_dma(kt, 0);
+        issue_dma(kt, 1);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) issue_w(wr, kt, p);
+    };
+
+    const unsigned smem_base = (unsigned)(__UINTPTR_TYPE__)(lptr_t)smem;
+    const unsigned abase[2] = {smem_base + (unsigned)swz(l31, h), smem_base + (unsigned)swz(l31, 2 + h)};
+    v4i af0[4], af1[4];
+    auto load_frags = [&](unsigned stage_off, int ks, v4i (&af)[4]) {
+        const unsigned aa = abase[ks] + stage_off;
+        asm volatile("ds_read_b128 %0, %1" : "=v"(af[0]) : "v"(aa));
+        asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(af[1]) : "v"(aa));
+        asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(af[2]) : "v"(aa));
+        asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(af[3]) : "v"(aa));
+    };
+    auto wait_frags = [&](v4i (&af)[4]) {   // at most the newest group of four reads outstanding
+        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3])::"memory");
+    };
+    // own DMA pieces and weight registers of the NEXT K step have landed (the 6 operations of the step after it may be in
+    // flight), and every LDS read of this wave has returned
+    auto wait_next = [&](auto inflight_tag, v4i (&af)[4], v4i (&wn)[4]) {
+        if constexpr (ABL & 6)
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
+                         : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]), "+v"(wn[0]), "+v"(wn[1]), "+v"(wn[2]), "+v"(wn[3])::"memory");
+        else if constexpr (decltype(inflight_tag)::value)
+            asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)"
+                         : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]), "+v"(wn[0]), "+v"(wn[1]), "+v"(wn[2]), "+v"(wn[3])::"memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
+                         : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]), "+v"(wn[0]), "+v"(wn[1]), "+v"(wn[2]), "+v"(wn[3])::"memory");
+    };
+
+    v16i acc[2][4];
+    // K step kt on weight buffer wc (current), wn (next: waited for here), wf (the one after: loaded here)
+    unsigned long long* stamp = nullptr;   // ABL & 16: [block][tile < 4][16]: tile start, loop start, loop end, epilogue end, step starts
+    auto step = [&](int kt, v4i (&wc)[4], v4i (&wn)[4], v4i (&wf)[4], auto issue_tag, auto last_tag) {
+        constexpr bool ISSUE = decltype(issue_tag)::value;
+        constexpr bool LAST = decltype(last_tag)::value;
+        if constexpr (ABL & 16)
+            if (stamp && kt < 12) stamp[4 + kt] = __builtin_amdgcn_s_memtime();
+        load_frags((unsigned)((kt % WR_STAGES) * WR_STAGE), 1, af1);
+        wait_frags(af0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if constexpr (!(ABL & 8)) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wc[2 * i], af0[j], acc[i][j], 0, 0, 0);
+                else asm volatile("" : "+v"(acc[i][j]) : "v"(wc[2 * i]), "v"(af0[j]));
+                if constexpr (ISSUE) {
+                    const int n = 4 * i + j;
+                    if (n < 2) { if constexpr (!(ABL & 4)) issue_dma(kt + 2, n); }
+                    else if (n < 6) { if constexpr (!(ABL & 2)) issue_w(wf, kt + 2, n - 2); }
+                }
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        wait_next(issue_tag, af1, wn);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if constexpr (!LAST) load_frags((unsigned)(((kt + 1) % WR_STAGES) * WR_STAGE), 0, af0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if constexpr (!(ABL & 8)) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wc[2 * i + 1], af1[j], acc[i][j], 0, 0, 0);
+                else asm volatile("" : "+v"(acc[i][j]) : "v"(wc[2 * i + 1]), "v"(af1[j]));
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    auto table_issue = [&](int n0) {
+        PersTableLoad r{0u, 0, 0, false};
+        const int c = n0 + tid;
+        if (c < g.N) {
+            r.m = g.m[c];
+            r.e = g.e[c];
+            r.bias = g.bias ? g.bias[c] : 0;
+            r.valid = true;
+        }
+        return r;
+    };
+    auto table_write = [&](const PersTableLoad& r, char* tab) {
+        float2 lh = make_float2(0.f, 0.f);
+        if (r.valid) {
+            const double M = dyadic_mult(r.m, r.e);
+            const float mf = (float)M;
+            const int bits = __float_as_int(mf);
+            lh.x = ((double)mf > M) ? __int_as_float(bits - 1) : mf;
+            lh.y = ((double)mf < M) ? __int_as_float(bits + 1) : mf;
+        }
+        reinterpret_cast<float2*>(tab)[tid] = lh;
+        reinterpret_cast<int*>(tab + WR_CH * 8)[tid] = r.bias;
+    };
+
+    const int G = gridDim.x, b = blockIdx.x;
+    WrTile cur = wr_tile(g, b);
+    if (cur.m0 < 0) return;   // uniform
+    table_write(table_issue(cur.n0), smem + WR_RING + WR_CS);
+    set_sources(cur);
+    issue_all(wr0, 0);
+    issue_dma(1, 0);
+    issue_dma(1, 1);
+
+    for (int it = 0; cur.m0 >= 0; ++it) {
+        char* tab = smem + WR_RING + WR_CS + (it & 1) * WR_TAB;
+        char* tab_next = smem + WR_RING + WR_CS + ((it + 1) & 1) * WR_TAB;
+        const WrTile nxt = wr_tile(g, b + (it + 1) * G);
+        if constexpr (ABL & 16) {
+            stamp = (tid == 0 && it < 4) ? reinterpret_cast<unsigned long long*>(const_cast<int8_t*>(g.res)) + (blockIdx.x * 4 + it) * 16 : nullptr;
+            if (stamp) stamp[0] = __builtin_amdgcn_s_memtime();
+        }
+        // stage 0 and weight buffer 0 of this tile are in flight (or landed); the table was written during the last epilogue
+#pragma unroll
+        for (int p = 0; p < 4; ++p) issue_w(wr1, 1, p);
+        // Stage 0 and weight buffer 0 were issued before the last epilogue, whose __syncthreads drained them; only the first tile
+        // has to wait here.  (An unconditional counted wait would also drain the epilogue's stores: vmcnt counts them too.)
+        if (it == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        asm volatile("" : "+v"(wr0[0]), "+v"(wr0[1]), "+v"(wr0[2]), "+v"(wr0[3])::"memory");
+        __builtin_amdgcn_s_barrier();     // everyone's stage 0; table visible
+        asm volatile("" ::: "memory");
+        v4i bq[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                lds_read16_async(bq[i][q], lds_addr(tab) + (unsigned)(WR_CH * 8 + 4 * (64 * wave + 32 * i + 8 * q + 4 * h)));
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                lds_wait(bq[i][q]);
+                const v4i b4 = bq[i][q];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[i][j][4 * q + 0] = b4.x;
+                    acc[i][j][4 * q + 1] = b4.y;
+                    acc[i][j][4 * q + 2] = b4.z;
+                    acc[i][j][4 * q + 3] = b4.w;
+                }
+            }
+        load_frags(0u, 0, af0);
+        if constexpr (ABL & 16)
+            if (stamp) stamp[1] = __builtin_amdgcn_s_memtime();
+        int kt = 0;
+        for (; kt + 3 < nk; kt += 3) {
+            step(kt, wr0, wr1, wr2, T{}, F{});
+            step(kt + 1, wr1, wr2, wr0, T{}, F{});
+            step(kt + 2, wr2, wr0, wr1, T{}, F{});
+        }
+        step(kt, wr0, wr1, wr2, T{}, F{});
+        step(kt + 1, wr1, wr2, wr0, F{}, F{});
+        step(kt + 2, wr2, wr0, wr1, F{}, T{});
+        if constexpr (ABL & 16)
+            if (stamp) stamp[2] = __builtin_amdgcn_s_memtime();
+        // every wave's reads of every stage returned before the barrier of the last step: the ring is free
+        const bool more = nxt.m0 >= 0;   // uniform
+        if (more) {
+            set_sources(nxt);
+            issue_all(wr0, 0);
+            issue_dma(1, 0);
+            issue_dma(1, 1);
+        }
+        struct Hook {
+            decltype(table_issue)& ti;
+            decltype(table_write)& tw;
+            int n0;
+            char* dst;
+            bool more;
+            mutable PersTableLoad ld;
+            IVIT_DEV void issue() const { if (more) ld = ti(n0); }
+            IVIT_DEV void consume() const { if (more) tw(ld, dst); }
+        };
+        Hook hook{table_issue, table_write, nxt.n0, tab_next, more, PersTableLoad{0u, 0, 0, false}};
+        if constexpr (ABL & 1) {
+            int sum = 0;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sum ^= acc[i][j][r];
+            if (sum == 0x12345679) reinterpret_cast<int*>(g.out)[tid] = sum;
+            hook.issue();
+            hook.consume();
+        } else {
+            epilogue_i8<EPI, 2, 4, WR_TOK, BIG_NT, 0, WR_CH, Hook>(acc, g, cs, tab, cur.m0, cur.n0, 64 * wave, 0, tid, h, l31, hook);
+        }
+        if constexpr (ABL & 16)
+            if (stamp) stamp[3] = __builtin_amdgcn_s_memtime();
+        cur = nxt;
+    }
+}
+
 template <int EPI>
 int launch_gemm(GemmArgs& g, const char* name, ivit_stream_t stream)
 {
@@ -463,11 +744,35 @@ int launch_gemm(GemmArgs& g, const char* name, ivit_stream_t stream)
     }
     g.flags = g_debug_flags & (31 | 128 | 256 | 512);
     const bool blocks = g.a_blocks || g.w_blocks;
-    if (blocks) {
+    if (blocks && !g.w_frags) {
         IVIT_REQUIRE(EPI != EPI_I32 && g.M >= 2048 && g.N >= BCH && !g_force_small,
                      "%s: block-layout operands need the persistent kernel (M >= 2048, N >= 128, requantising epilogue)", name);
         IVIT_REQUIRE(!g.a_blocks || g.lda == g.K, "%s: a block-layout A operand is dense (lda == K)", name);
         IVIT_REQUIRE(!g.w_blocks || g.ldw == g.K, "%s: a block-layout W operand is dense (ldw == K)", name);
+    }
+    if (g.w_frags) IVIT_REQUIRE(!g.a_blocks || g.lda == g.K, "%s: a block-layout A operand is dense (lda == K)", name);
+    if (g.w_frags) {
+        IVIT_REQUIRE(EPI != EPI_I32 && g.M >= 2048 && g.N >= 128 && g.N % 64 == 0 && (g.K / BK) % 3 == 0 && !g.w_blocks && !g_force_small,
+                     "%s: the fragment-packed weight needs M >= 2048, N >= 128, N %% 64 == 0, K %% 192 == 0 and a requantising epilogue", name);
+        if constexpr (EPI != EPI_I32) {
+            g.tiles_m = (g.M + WR_TOK - 1) / WR_TOK;
+            g.tiles_n = (g.N + WR_CH - 1) / WR_CH;
+            const int ntiles = g.tiles_m * g.tiles_n;
+            const dim3 grid(ntiles < 512 ? ntiles : 512);
+#if IVIT_LAB
+            if constexpr (EPI == EPI_RQ) {   // ablations (scripts/gemm_ab.py --frags): what each stream of the kernel costs
+                switch (g_debug_flags & 31) {
+#define IVIT_WR_ABL(v) case v: hipLaunchKernelGGL((gemm_i8_wreg_kernel<EPI_RQ, v>), grid, dim3(BIG_NT), 0, ivit_stream(stream), g); IVIT_CHECK_LAUNCH(name)
+                    case 16: g.res = (const int8_t*)g_stamp_buf; hipLaunchKernelGGL((gemm_i8_wreg_kernel<EPI_RQ, 16>), (g_debug_flags & 4096) ? dim3(256) : grid, dim3(BIG_NT), (g_debug_flags & 4096) ? 40960 : 0, ivit_stream(stream), g); IVIT_CHECK_LAUNCH(name);
+                    IVIT_WR_ABL(1); IVIT_WR_ABL(2); IVIT_WR_ABL(4); IVIT_WR_ABL(6); IVIT_WR_ABL(8); IVIT_WR_ABL(14); IVIT_WR_ABL(15); IVIT_WR_ABL(7);
+#undef IVIT_WR_ABL
+                    default: break;
+                }
+            }
+#endif
+            hipLaunchKernelGGL((gemm_i8_wreg_kernel<EPI>), grid, dim3(BIG_NT), 0, ivit_stream(stream), g);
+            IVIT_CHECK_LAUNCH(name);
+        }
     }
     if constexpr (EPI != EPI_I32) {
 #if IVIT_LAB
@@ -515,7 +820,31 @@ int launch_gemm(GemmArgs& g, const char* name, ivit_stream_t stream)
     IVIT_CHECK_LAUNCH(name);
 }
 
+// W[N][K] row-major -> MFMA-fragment order (include/ivit_hip.h IVIT_W_FRAGS), one 16-byte chunk per thread; rows >= N are zero
+__global__ __launch_bounds__(256) void pack_weight_frags_kernel(const int8_t* W, int64_t ldw, int N, int K, int8_t* dst)
+{
+    const int c16 = K >> 4, n64 = (N + 63) & ~63;
+    const int64_t total = (int64_t)n64 * c16;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (int64_t)gridDim.x * 256) {
+        const int n = (int)(q / c16), k = (int)(q - (int64_t)n * c16) << 4;
+        int4 v = make_int4(0, 0, 0, 0);
+        if (n < N) v = *reinterpret_cast<const int4*>(W + (int64_t)n * ldw + k);
+        const int64_t off = ((int64_t)(n >> 6) * (K >> 6) + (k >> 6)) * 4096 + ((((n >> 5) & 1) * 2 + ((k >> 5) & 1)) * 2 + ((k >> 4) & 1)) * 512 + (n & 31) * 16;
+        *reinterpret_cast<int4*>(dst + off) = v;
+    }
+}
+
 }  // namespace
+
+IVIT_EXPORT int ivit_pack_weight_frags_i8(const int8_t* W, int64_t ldw, int N, int K, int8_t* dst, ivit_stream_t stream)
+{
+    IVIT_REQUIRE(W && dst && N > 0 && K > 0 && K % 64 == 0 && ldw >= K && ldw % 16 == 0 && ((uintptr_t)W % 16 == 0) && ((uintptr_t)dst % 16 == 0),
+                 "ivit_pack_weight_frags_i8: bad operand (K must be a multiple of 64, rows 16-byte aligned)");
+    const int64_t total = (int64_t)((N + 63) & ~63) * (K >> 4);
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(pack_weight_frags_kernel, dim3(grid), dim3(256), 0, ivit_stream(stream), W, ldw, N, K, dst);
+    IVIT_CHECK_LAUNCH("ivit_pack_weight_frags_i8");
+}
 
 IVIT_EXPORT int ivit_gemm_i8_requant_ex(const int8_t* A, int64_t lda, const int8_t* W, int64_t ldw, const int32_t* bias,
                                      const uint32_t* m, const int32_t* e, int8_t* out, int64_t ldo, int M, int N,
@@ -524,8 +853,8 @@ IVIT_EXPORT int ivit_gemm_i8_requant_ex(const int8_t* A, int64_t lda, const int8
     GemmArgs g{};
     g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.m = m; g.e = e;
     g.out = out; g.ldo = ldo; g.M = M; g.N = N; g.K = K;
-    g.a_blocks = layouts & 1; g.w_blocks = (layouts >> 1) & 1; g.out_blocks = (layouts >> 2) & 1;
-    IVIT_REQUIRE((layouts & ~7) == 0, "ivit_gemm_i8_requant_ex: unknown layout bits");
+    g.a_blocks = layouts & 1; g.w_blocks = (layouts >> 1) & 1; g.out_blocks = (layouts >> 2) & 1; g.w_frags = (layouts >> 3) & 1;
+    IVIT_REQUIRE((layouts & ~15) == 0, "ivit_gemm_i8_requant_ex: unknown layout bits");
     IVIT_REQUIRE(!g.out_blocks || (N % 64 == 0 && ldo == N && ((int64_t)M + 15) * N < 2147483648ll),
                  "ivit_gemm_i8_requant_ex: block-layout output needs N %% 64 == 0, ldo == N and a buffer below 2 GiB");
     return launch_gemm<EPI_RQ>(g, "ivit_gemm_i8_requant_ex", stream);
@@ -551,8 +880,8 @@ IVIT_EXPORT int ivit_gemm_i8_requant_residual_ex(const int8_t* A, int64_t lda, c
     g.M_res = ivit_dyadic_to_double(m_res, e_res);
     IVIT_REQUIRE(g.M_main < 1048576.0 && g.M_res < 1048576.0,
                  "ivit_gemm_i8_requant_residual_ex: residual multiplier >= 2^20 is outside the int8 fast path");
-    g.a_blocks = layouts & 1; g.w_blocks = (layouts >> 1) & 1;
-    IVIT_REQUIRE((layouts & ~3) == 0, "ivit_gemm_i8_requant_residual_ex: unknown layout bits");
+    g.a_blocks = layouts & 1; g.w_blocks = (layouts >> 1) & 1; g.w_frags = (layouts >> 3) & 1;
+    IVIT_REQUIRE((layouts & ~11) == 0, "ivit_gemm_i8_requant_residual_ex: unknown layout bits");
     return launch_gemm<EPI_RESID>(g, "ivit_gemm_i8_requant_residual_ex", stream);
 }
 
@@ -590,8 +919,8 @@ IVIT_EXPORT int ivit_gemm_i8_requant_qkv_ex(const int8_t* A, int64_t lda, const 
     g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.m = m; g.e = e;
     g.out = qkv; g.ldo = 0; g.M = M; g.N = N; g.K = K;
     g.tokens = tokens; g.heads = heads; g.head_dim = head_dim;
-    g.a_blocks = layouts & 1; g.w_blocks = (layouts >> 1) & 1;
-    IVIT_REQUIRE((layouts & ~3) == 0, "ivit_gemm_i8_requant_qkv_ex: unknown layout bits");
+    g.a_blocks = layouts & 1; g.w_blocks = (layouts >> 1) & 1; g.w_frags = (layouts >> 3) & 1;
+    IVIT_REQUIRE((layouts & ~11) == 0, "ivit_gemm_i8_requant_qkv_ex: unknown layout bits");
     return launch_gemm<EPI_QKV>(g, "ivit_gemm_i8_requant_qkv_ex", stream);
 }
 

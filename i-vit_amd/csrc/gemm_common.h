@@ -61,12 +61,28 @@ struct GemmArgs {
     int split_from;  // persistent kernel: tiles [split_from, tiles_m*tiles_n) are processed as two half tiles each
     int a_blocks, w_blocks;   // operand in the block layout (common.h: ivit_block_offset); persistent kernel only
     int out_blocks;           // EPI_RQ: the int8 output in the block layout (row length N): it is the next GEMM's A operand
+    int w_frags;              // W is the MFMA-fragment copy (ivit_pack_weight_frags_i8): the weights-in-registers kernel
 };
 
 IVIT_DEV int nk_of(const GemmArgs& g) { return g.K / 64; }
 
 // byte offset of 16-byte chunk c (0..3) of tile row r; rows are 64 B, four rows per 256-B bank row.
 IVIT_DEV int swz(int r, int c) { return r * BK + ((c ^ ((r >> 2) & 3)) << 4); }
+
+// LDS reads the compiler does not see.  A kernel that has an LDS-DMA (global_load_lds) in flight pays `s_waitcnt vmcnt(0)` in
+// front of every LDS read the compiler knows about (it cannot prove that the read does not alias the DMA's destination), i.e.
+// the whole latency of a prefetch issued just before.  These reads are for data that the kernel's own barriers already
+// ordered; completion is waited for with lds_wait(), whose "+v" operands tie every later use behind the wait.
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef int v2i __attribute__((ext_vector_type(2)));
+IVIT_DEV unsigned lds_addr(const void* p) { return (unsigned)(__UINTPTR_TYPE__)(lds_ptr_t)p; }
+IVIT_DEV void lds_read16_async(v4f& d, unsigned a) { asm volatile("ds_read_b128 %0, %1" : "=v"(d) : "v"(a)); }
+IVIT_DEV void lds_read16_async(v4i& d, unsigned a) { asm volatile("ds_read_b128 %0, %1" : "=v"(d) : "v"(a)); }
+IVIT_DEV void lds_read8x2_async(v2i& d, unsigned a) { asm volatile("ds_read2_b32 %0, %1 offset1:1" : "=v"(d) : "v"(a)); }
+IVIT_DEV void lds_wait(v4f& a, v4f& b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b)); }
+IVIT_DEV void lds_wait(v4i& a) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a)); }
+IVIT_DEV void lds_wait(v2i& a, v2i& b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b)); }
 
 IVIT_DEV int pack4_i8(int a, int b, int c, int d)
 {
@@ -120,14 +136,24 @@ IVIT_DEV void epilogue_i8(v16i (&acc)[TI][TJ], const GemmArgs& g, char* smem, co
     // t_lo == t_hi certifies RNE(acc*M) -- including exact ties, which straddle and fail the test.
     // Valid while acc is exact in float32 and |acc*hi| < 2^22 (M <= 1 is part of the contract), i.e.
     // |acc| < 2^22; anything else, and any failed certificate, takes the float64 path for that quad.
-    const float2* rq = reinterpret_cast<const float2*>(rq_lds);
+    // (lo, hi) of the quad's four channels: read one batch ahead (double-buffered), invisible to the compiler (see lds_read16_async)
+    const unsigned rq_a = lds_addr(rq_lds) + 8u * (unsigned)(wch + 4 * h);
+    v4f lhbuf[2][2];
+    lds_read16_async(lhbuf[0][0], rq_a);
+    lds_read16_async(lhbuf[0][1], rq_a + 16u);
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int cl = wch + 32 * i + 8 * q + 4 * h;  // local channel of the quad
-            const float4 lh01 = *reinterpret_cast<const float4*>(rq + cl);      // lo0 hi0 lo1 hi1
-            const float4 lh23 = *reinterpret_cast<const float4*>(rq + cl + 2);  // lo2 hi2 lo3 hi3
+            v4f& lh01 = lhbuf[(4 * i + q) & 1][0];      // lo0 hi0 lo1 hi1
+            v4f& lh23 = lhbuf[(4 * i + q) & 1][1];      // lo2 hi2 lo3 hi3
+            lds_wait(lh01, lh23);
+            if (4 * i + q + 1 < 4 * TI) {
+                const int nb = 4 * i + q + 1;
+                lds_read16_async(lhbuf[nb & 1][0], rq_a + 8u * (unsigned)(32 * (nb >> 2) + 8 * (nb & 3)));
+                lds_read16_async(lhbuf[nb & 1][1], rq_a + 8u * (unsigned)(32 * (nb >> 2) + 8 * (nb & 3)) + 16u);
+            }
             const float lo[4] = {lh01.x, lh01.z, lh23.x, lh23.z};
             const float hi[4] = {lh01.y, lh01.w, lh23.y, lh23.w};
             // one branch-free batch of TJ*4 independent chains (instruction-level parallelism: the wave that
@@ -201,6 +227,7 @@ IVIT_DEV void epilogue_i8(v16i (&acc)[TI][TJ], const GemmArgs& g, char* smem, co
     int8_t* out = reinterpret_cast<int8_t*>(g.out);
     constexpr int NIT = TOK * CPR / NTHREADS;
     int v[NIT][4];
+    v2i vv[NIT][2];
     int4 rv[NIT];
     int4 rw[EPI == EPI_RESID16 ? NIT : 1][2];   // 16 int16 residual values per chunk
     hook.issue();    // persistent kernel: next tile's table loads go out before this tile's stores
@@ -208,8 +235,8 @@ IVIT_DEV void epilogue_i8(v16i (&acc)[TI][TJ], const GemmArgs& g, char* smem, co
     for (int it = 0; it < NIT; ++it) {
         const int q = tid + NTHREADS * it;
         const int tl = q / CPR, cc = q % CPR;
-        const int* src = reinterpret_cast<const int*>(smem + tl * CSS + 16 * cc);
-        v[it][0] = src[0]; v[it][1] = src[1]; v[it][2] = src[2]; v[it][3] = src[3];
+        lds_read8x2_async(vv[it][0], lds_addr(smem) + (unsigned)(tl * CSS + 16 * cc));
+        lds_read8x2_async(vv[it][1], lds_addr(smem) + (unsigned)(tl * CSS + 16 * cc + 8));
         if constexpr (EPI == EPI_RESID) {
             const int t = min(m0 + tl, g.M - 1), cn = min(n0 + 16 * cc, g.N - 16);
             rv[it] = *reinterpret_cast<const int4*>(g.res + (int64_t)t * g.ldr + cn);
@@ -220,6 +247,11 @@ IVIT_DEV void epilogue_i8(v16i (&acc)[TI][TJ], const GemmArgs& g, char* smem, co
             rw[it][0] = rp[0];
             rw[it][1] = rp[1];
         }
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        lds_wait(vv[it][0], vv[it][1]);
+        v[it][0] = vv[it][0].x; v[it][1] = vv[it][0].y; v[it][2] = vv[it][1].x; v[it][3] = vv[it][1].y;
     }
     hook.consume();
     // EPI_QKV addressing state (see below)

@@ -82,6 +82,14 @@ int ivit_quantize_patchify_ld_f32_i8(const float* img, int8_t* A, int64_t lda, i
 #define IVIT_A_BLOCKS 1
 #define IVIT_W_BLOCKS 2
 #define IVIT_OUT_BLOCKS 4   /* ivit_gemm_i8_requant_ex only: the int8 output in the block layout (ldo == N, N % 64 == 0) */
+/* IVIT_W_FRAGS: `W` is the copy made by ivit_pack_weight_frags_i8 -- the weights in the order the MFMA consumes them, so that
+ * a wave loads its fragments straight into registers (1 KB contiguous per instruction) and only the token tile goes through
+ * the LDS: channel n, byte k at ((n / 64) * (K / 64) + k / 64) * 4096 + (((n / 32) % 2 * 2 + (k / 32) % 2) * 2 + (k / 16) % 2) * 512
+ * + (n % 32) * 16 + k % 16, channels padded with zero rows to a multiple of 64 (ceil(N / 64) * 64 * K bytes).  Needs M >= 2048,
+ * N >= 128, N % 64 == 0, K % 192 == 0; combines with IVIT_A_BLOCKS / IVIT_OUT_BLOCKS, not with IVIT_W_BLOCKS.  `ldw` is
+ * ignored.  Results are identical to every other form. */
+#define IVIT_W_FRAGS 8
+int ivit_pack_weight_frags_i8(const int8_t* W, int64_t ldw, int N, int K, int8_t* dst, ivit_stream_t stream);
 int ivit_tile_operand_i8(const int8_t* src, int64_t ld, int64_t rows, int K, int8_t* dst, ivit_stream_t stream);
 int ivit_untile_operand_i8(const int8_t* src, int64_t rows, int K, int8_t* dst, int64_t ld, ivit_stream_t stream);
 

@@ -18,7 +18,9 @@ SHAPES = {"qkv": (2304, 768), "proj": (768, 768), "fc1": (3072, 768), "fc2": (76
 RESID = "--resid" in sys.argv
 QKV = "--qkv" in sys.argv         # head-major q/k/v epilogue (qkv shape only)
 BLOCKS = "--blocks" in sys.argv   # both operands in the block layout (persistent kernel only)
-args = [a for a in sys.argv[1:] if a not in ("--resid", "--blocks", "--qkv")]
+FRAGS = "--frags" in sys.argv     # A in the block layout, W fragment-packed: the weights-in-registers kernel
+BOTH = "--both" in sys.argv       # blocks and frags, interleaved
+args = [a for a in sys.argv[1:] if a not in ("--resid", "--blocks", "--qkv", "--frags", "--both")]
 split = args.index("--") if "--" in args else 0
 names = args[:split] or list(SHAPES)
 flags = [int(x) for x in args[split + 1:]] if "--" in args else [0]
@@ -33,41 +35,46 @@ for name in names:
     e = torch.full((N,), 42, dtype=torch.int32, device=DEV)
     out = torch.empty(M, N, dtype=torch.int8, device=DEV)
 
-    if BLOCKS:
-        At, Wt = torch.empty_like(A), torch.empty_like(W)
-        _lib.call("ivit_tile_operand_i8", _lib.ptr(A), K, M, K, _lib.ptr(At), _lib.stream_ptr())
-        _lib.call("ivit_tile_operand_i8", _lib.ptr(W), K, N, K, _lib.ptr(Wt), _lib.stream_ptr())
-        A, W = At, Wt
-    LAY = 3 if BLOCKS else 0
+    # variants: ("rows" | "blocks" | "frags", debug flag); --both times the block-layout persistent kernel against the
+    # weights-in-registers kernel in the same process, interleaved
+    At, Wt, Wf = torch.empty_like(A), torch.empty_like(W), torch.empty_like(W)
+    _lib.call("ivit_tile_operand_i8", _lib.ptr(A), K, M, K, _lib.ptr(At), _lib.stream_ptr())
+    _lib.call("ivit_tile_operand_i8", _lib.ptr(W), K, N, K, _lib.ptr(Wt), _lib.stream_ptr())
+    _lib.call("ivit_pack_weight_frags_i8", _lib.ptr(W), K, N, K, _lib.ptr(Wf), _lib.stream_ptr())
+    OPS = {"rows": (A, W, 0), "blocks": (At, Wt, 3), "frags": (At, Wf, 9)}
     resid_t = torch.from_numpy(rng.integers(-128, 128, size=(M, N)).astype(np.int8)).to(DEV)
 
-    def run():
+    def run(kind):
+        a_, w_, LAY = OPS[kind]
         if QKV and N % 192 == 0:
-            _lib.call("ivit_gemm_i8_requant_qkv_ex", _lib.ptr(A), K, _lib.ptr(W), K, _lib.ptr(b), _lib.ptr(m), _lib.ptr(e),
+            _lib.call("ivit_gemm_i8_requant_qkv_ex", _lib.ptr(a_), K, _lib.ptr(w_), K, _lib.ptr(b), _lib.ptr(m), _lib.ptr(e),
                       _lib.ptr(out), 197, N // 192, 64, M, N, K, LAY, _lib.stream_ptr())
         elif RESID:   # the fused residual QuantAct form (attn.proj, mlp.fc2)
-            _lib.call("ivit_gemm_i8_requant_residual_ex", _lib.ptr(A), K, _lib.ptr(W), K, _lib.ptr(b), _lib.ptr(m), _lib.ptr(e),
+            _lib.call("ivit_gemm_i8_requant_residual_ex", _lib.ptr(a_), K, _lib.ptr(w_), K, _lib.ptr(b), _lib.ptr(m), _lib.ptr(e),
                       _lib.ptr(resid_t), N, 1503238554, 31, 1073741824, 32, _lib.ptr(out), N, M, N, K, LAY, _lib.stream_ptr())
         else:
-            _lib.call("ivit_gemm_i8_requant_ex", _lib.ptr(A), K, _lib.ptr(W), K, _lib.ptr(b), _lib.ptr(m), _lib.ptr(e), _lib.ptr(out),
+            _lib.call("ivit_gemm_i8_requant_ex", _lib.ptr(a_), K, _lib.ptr(w_), K, _lib.ptr(b), _lib.ptr(m), _lib.ptr(e), _lib.ptr(out),
                       N, M, N, K, LAY, _lib.stream_ptr())
-    for _ in range(10):
-        run()
-    res = {f: [] for f in flags}
+    kinds = ["blocks", "frags"] if BOTH else ["frags"] if FRAGS else ["blocks"] if BLOCKS else ["rows"]
+    variants = [(k, f) for k in kinds for f in flags]
+    for k in kinds:
+        for _ in range(5):
+            run(k)
+    res = {v: [] for v in variants}
     for r in range(ROUNDS):
-        for f in (flags if r % 2 == 0 else flags[::-1]):
-            _lib.call("ivit_debug_set_gemm_flags", f)
-            run()
+        for v in (variants if r % 2 == 0 else variants[::-1]):
+            _lib.call("ivit_debug_set_gemm_flags", v[1])
+            run(v[0])
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(ITERS):
-                run()
+                run(v[0])
             e1.record()
             torch.cuda.synchronize()
-            res[f].append(e0.elapsed_time(e1) / ITERS * 1e3)
+            res[v].append(e0.elapsed_time(e1) / ITERS * 1e3)
     _lib.call("ivit_debug_set_gemm_flags", 0)
-    for f in flags:
-        v = sorted(res[f])
-        med, mn = v[len(v) // 2], v[0]
-        print(f"{name:5s} flags={f:8d}  median {med:7.1f} us ({2 * M * N * K / med / 1e6:7.1f} TOPS)   min {mn:7.1f} us", flush=True)
+    for v in variants:
+        t = sorted(res[v])
+        med, mn = t[len(t) // 2], t[0]
+        print(f"{name:5s} {v[0]:6s} flags={v[1]:8d}  median {med:7.1f} us ({2 * M * N * K / med / 1e6:7.1f} TOPS)   min {mn:7.1f} us", flush=True)

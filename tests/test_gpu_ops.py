@@ -292,6 +292,71 @@ def test_gemm_block_layout_operands(M, N, K):
                   _lib.ptr(out), N, 512, N, K, 1, st())
 
 
+def _frag_layout_host(W):
+    """include/ivit_hip.h IVIT_W_FRAGS, by its documented formula"""
+    N, K = W.shape
+    n64 = (N + 63) // 64 * 64
+    out = np.zeros(n64 * K, dtype=np.int8)
+    n = np.arange(N)[:, None]
+    k = np.arange(K)[None, :]
+    off = ((n // 64) * (K // 64) + k // 64) * 4096 + (((n // 32) % 2 * 2 + (k // 32) % 2) * 2 + (k // 16) % 2) * 512 + (n % 32) * 16 + k % 16
+    out[off.reshape(-1)] = W.reshape(-1)
+    return out
+
+
+@pytest.mark.parametrize("M,N,K", [(2600, 512, 384), (197 * 16, 768, 768), (2049, 192, 192), (4000, 320, 576), (197 * 12, 2304, 768)])
+def test_gemm_weight_fragment_layout(M, N, K):
+    """ivit_pack_weight_frags_i8 == the documented layout; the weights-in-registers kernel (IVIT_W_FRAGS) == the oracle for
+    all epilogues, row-major and block-layout A, block-layout output, partial token and channel tiles"""
+    rng = np.random.default_rng(M + K + 1)
+    A = rng.integers(-128, 128, size=(M, K)).astype(np.int8)
+    W = rng.integers(-128, 128, size=(N, K)).astype(np.int8)
+    b = rng.integers(-50000, 50000, size=N).astype(np.int32)
+    m, e = rand_me(rng, N, -16, -9)
+    md, ed = me_dev(m, e)
+    dA, dW, db = dev(A), dev(W), dev(b)
+    R16 = (M + 15) // 16 * 16
+    At = torch.zeros(R16 * K, dtype=torch.int8, device=DEV)
+    _lib.call("ivit_tile_operand_i8", _lib.ptr(dA), K, M, K, _lib.ptr(At), st())
+    Wf = torch.full(((N + 63) // 64 * 64 * K,), 77, dtype=torch.int8, device=DEV)
+    _lib.call("ivit_pack_weight_frags_i8", _lib.ptr(dW), K, N, K, _lib.ptr(Wf), st())
+    assert np.array_equal(Wf.cpu().numpy(), _frag_layout_host(W))
+    exp = orc.requant(orc.gemm_i8(A, W, b), m.astype(np.float64), e, 8)
+    res = rng.integers(-128, 128, size=(M, N)).astype(np.int8)
+    dres = dev(res)
+    m1, e1 = dyadic(np.float32(0.7 * 2 ** -4), np.float32(2 ** -4))
+    m2, e2 = dyadic(np.float32(2 ** -5), np.float32(2 ** -4))
+    exp_res = orc.requant(exp, m1.astype(np.float64), e1, 8, z2=res.astype(np.int32), m2=m2.astype(np.float64), e2=e2)
+    for lay in (8, 9):
+        a_op = At if lay & 1 else dA
+        out = torch.zeros(M, N, dtype=torch.int8, device=DEV)
+        _lib.call("ivit_gemm_i8_requant_ex", _lib.ptr(a_op), K, _lib.ptr(Wf), K, _lib.ptr(db), _lib.ptr(md), _lib.ptr(ed),
+                  _lib.ptr(out), N, M, N, K, lay, st())
+        assert np.array_equal(out.cpu().numpy().astype(np.int32), exp), lay
+        out = torch.zeros(M, N, dtype=torch.int8, device=DEV)
+        _lib.call("ivit_gemm_i8_requant_residual_ex", _lib.ptr(a_op), K, _lib.ptr(Wf), K, _lib.ptr(db), _lib.ptr(md),
+                  _lib.ptr(ed), _lib.ptr(dres), N, int(m1[0]), int(e1[0]), int(m2[0]), int(e2[0]), _lib.ptr(out), N, M, N, K,
+                  lay, st())
+        assert np.array_equal(out.cpu().numpy().astype(np.int32), exp_res), lay
+    if M % 197 == 0 and N % 192 == 0:     # head-major q/k/v epilogue
+        T, hd = 197, 64
+        H = N // (3 * hd)
+        outs = []
+        for lay in (0, 9):
+            out = torch.zeros(3 * M * H * hd, dtype=torch.int8, device=DEV)
+            _lib.call("ivit_gemm_i8_requant_qkv_ex", _lib.ptr(At if lay else dA), K, _lib.ptr(Wf if lay else dW), K, _lib.ptr(db),
+                      _lib.ptr(md), _lib.ptr(ed), _lib.ptr(out), T, H, hd, M, N, K, lay, st())
+            outs.append(out.cpu().numpy())
+        assert np.array_equal(outs[0], outs[1])
+    outb = torch.zeros(R16 * N, dtype=torch.int8, device=DEV)
+    _lib.call("ivit_gemm_i8_requant_ex", _lib.ptr(At), K, _lib.ptr(Wf), K, _lib.ptr(db), _lib.ptr(md), _lib.ptr(ed),
+              _lib.ptr(outb), N, M, N, K, 13, st())
+    assert np.array_equal(outb.cpu().numpy(), _block_layout_host(exp.astype(np.int8)))
+    with pytest.raises(_lib.IvitError, match="fragment-packed"):   # K / 64 must be a multiple of 3
+        _lib.call("ivit_gemm_i8_requant_ex", _lib.ptr(dA), K, _lib.ptr(Wf), K, _lib.ptr(db), _lib.ptr(md), _lib.ptr(ed),
+                  _lib.ptr(out), N, M, N, 128, 8, st())
+
+
 def test_producers_write_block_layout():
     """LayerNorm, fused attention and the GELU table kernel with out_blocks = 1 == ivit_tile_operand_i8 of their
     row-major output (ragged row counts: the last 16-row block is partly padding)"""
