@@ -222,8 +222,8 @@ def worker(args):
         macs = [float(M) * N * K for _, _, (M, N, K), _ in rows]
         avg_ms = sum(ms) / len(ms)
         achieved = 2.0 * sum(macs) / (sum(ms) * 1e-3) / 1e12
-        traffic, traffic_src = pmc_traffic(("gemm_i8_pers_kernel<1, 0>", "gemm_i8_pers_kernel<1>"))   # names as profiled
-        roof = {"bound": "mfma", "kernel": "gemm_i8_pers_kernel<EPI_RESID> (attn.proj + mlp.fc2, residual QuantAct fused)",
+        traffic, traffic_src = pmc_traffic(("gemm_i8_wreg_kernel<1, 0>", "gemm_i8_wreg_kernel<1>", "gemm_i8_pers_kernel<1, 0>", "gemm_i8_pers_kernel<1>"))   # names as profiled
+        roof = {"bound": "mfma", "kernel": "gemm_i8_wreg_kernel<EPI_RESID> (attn.proj + mlp.fc2, residual QuantAct fused)",
                 "achieved": round(achieved, 1), "peak": INT8_PEAK_TOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / INT8_PEAK_TOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "launches": len(ms), "avg_launch_ms": round(avg_ms, 4),

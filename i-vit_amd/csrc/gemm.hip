@@ -545,7 +545,7 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_wreg_kernel(GemmArgs g)
 
     v16i acc[2][4];
     // K step kt on weight buffer wc (current), wn (next: waited for here), wf (the one after: loaded here)
-    unsigned long long* stamp = nullptr;   // ABL & 16: [block][tile < 4][16]: tile start, loop start, loop end, epilogue end, step starts
+    unsigned long long* stamp = nullptr;   // ABL & 16: [block][tile < 4][32]: tile start, loop start, loop end, epilogue end, step starts
     auto step = [&](int kt, v4i (&wc)[4], v4i (&wn)[4], v4i (&wf)[4], auto issue_tag, auto last_tag) {
         constexpr bool ISSUE = decltype(issue_tag)::value;
         constexpr bool LAST = decltype(last_tag)::value;
@@ -620,8 +620,11 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_wreg_kernel(GemmArgs g)
         char* tab_next = smem + WR_RING + WR_CS + ((it + 1) & 1) * WR_TAB;
         const WrTile nxt = wr_tile(g, b + (it + 1) * G);
         if constexpr (ABL & 16) {
-            stamp = (tid == 0 && it < 4) ? reinterpret_cast<unsigned long long*>(const_cast<int8_t*>(g.res)) + (blockIdx.x * 4 + it) * 16 : nullptr;
-            if (stamp) stamp[0] = __builtin_amdgcn_s_memtime();
+            stamp = (tid == 0 && it < 4) ? reinterpret_cast<unsigned long long*>(const_cast<int8_t*>(g.res)) + (blockIdx.x * 4 + it) * 32 : nullptr;
+            if (stamp) {
+                stamp[0] = __builtin_amdgcn_s_memtime();
+                stamp[16] = __builtin_amdgcn_s_memrealtime();   // constant 100 MHz: the shader clock follows from the pair
+            }
         }
         // stage 0 and weight buffer 0 of this tile are in flight (or landed); the table was written during the last epilogue
 #pragma unroll
@@ -682,7 +685,15 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_wreg_kernel(GemmArgs g)
             bool more;
             mutable PersTableLoad ld;
             IVIT_DEV void issue() const { if (more) ld = ti(n0); }
-            IVIT_DEV void consume() const { if (more) tw(ld, dst); }
+            // also this wave's share of the next tile's first stage and weight buffer (issued before the epilogue; every load
+            // outstanding here is older than the stores that follow): landed before the barrier at the next tile's start
+            IVIT_DEV void consume() const
+            {
+                if (more) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    tw(ld, dst);
+                }
+            }
         };
         Hook hook{table_issue, table_write, nxt.n0, tab_next, more, PersTableLoad{0u, 0, 0, false}};
         if constexpr (ABL & 1) {
@@ -894,13 +905,15 @@ IVIT_EXPORT int ivit_gemm_i8_requant_residual(const int8_t* A, int64_t lda, cons
     return ivit_gemm_i8_requant_residual_ex(A, lda, W, ldw, bias, m, e, res, ldr, m_main, e_main, m_res, e_res, out, ldo, M, N, K, 0, stream);
 }
 
-IVIT_EXPORT int ivit_gemm_i8_requant_residual_i16(const int8_t* A, int64_t lda, const int8_t* W, int64_t ldw,
+IVIT_EXPORT int ivit_gemm_i8_requant_residual_i16_ex(const int8_t* A, int64_t lda, const int8_t* W, int64_t ldw,
                                                   const int32_t* bias, const uint32_t* m, const int32_t* e,
                                                   const int16_t* res, int64_t ldr, uint32_t m_main, int32_t e_main,
                                                   uint32_t m_res, int32_t e_res, int16_t* out, int64_t ldo, int M, int N,
-                                                  int K, ivit_stream_t stream)
+                                                  int K, int layouts, ivit_stream_t stream)
 {
     GemmArgs g{};
+    g.a_blocks = layouts & 1; g.w_blocks = (layouts >> 1) & 1; g.w_frags = (layouts >> 3) & 1;
+    IVIT_REQUIRE((layouts & ~11) == 0, "ivit_gemm_i8_requant_residual_i16_ex: unknown layout bits");
     g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.m = m; g.e = e;
     g.res = reinterpret_cast<const int8_t*>(res); g.ldr = ldr;
     g.out = out; g.ldo = ldo; g.M = M; g.N = N; g.K = K;
@@ -908,6 +921,15 @@ IVIT_EXPORT int ivit_gemm_i8_requant_residual_i16(const int8_t* A, int64_t lda, 
     g.M_res = ivit_dyadic_to_double(m_res, e_res);
     IVIT_REQUIRE(g.M_main < 32768.0 && g.M_res < 32768.0, "ivit_gemm_i8_requant_residual_i16: residual multiplier too large");
     return launch_gemm<EPI_RESID16>(g, "ivit_gemm_i8_requant_residual_i16", stream);
+}
+
+IVIT_EXPORT int ivit_gemm_i8_requant_residual_i16(const int8_t* A, int64_t lda, const int8_t* W, int64_t ldw,
+                                                  const int32_t* bias, const uint32_t* m, const int32_t* e,
+                                                  const int16_t* res, int64_t ldr, uint32_t m_main, int32_t e_main,
+                                                  uint32_t m_res, int32_t e_res, int16_t* out, int64_t ldo, int M, int N,
+                                                  int K, ivit_stream_t stream)
+{
+    return ivit_gemm_i8_requant_residual_i16_ex(A, lda, W, ldw, bias, m, e, res, ldr, m_main, e_main, m_res, e_res, out, ldo, M, N, K, 0, stream);
 }
 
 IVIT_EXPORT int ivit_gemm_i8_requant_qkv_ex(const int8_t* A, int64_t lda, const int8_t* W, int64_t ldw,

@@ -126,6 +126,7 @@ IVIT_DEV void epilogue_i8(v16i (&acc)[TI][TJ], const GemmArgs& g, char* smem, co
     // The epilogue is a short VALU burst next to the co-resident workgroup's MFMA stream: give it issue priority
     // so its dependent chains do not wait behind queued MFMAs (which run in the matrix pipe once issued).
     __builtin_amdgcn_s_setprio(2);
+    hook.issue();    // persistent kernels: the next tile's table loads have all of phase 1 to land
     constexpr int CSS = CH + 4;       // LDS row stride: (CH/4 + 1) dwords, odd -> conflict-free dword writes
     constexpr int CPR = CH / 16;      // 16-byte chunks per row
     // Phase 1.  out = clamp8(RNE(acc * M)), M = m * 2^-e, must equal the reference's float64
@@ -214,7 +215,32 @@ IVIT_DEV void epilogue_i8(v16i (&acc)[TI][TJ], const GemmArgs& g, char* smem, co
     }
     unsigned long long t_p1 = 0, t_sync = 0;
     if constexpr (ABL & 512) t_p1 = __builtin_amdgcn_s_memtime();
-    __syncthreads();
+    // Phase 2 work items of this thread: NIT chunks (token row tl, 16-byte column chunk cc).  The residual loads go out BEFORE the
+    // barrier (the accumulators are dead, their registers free), so their latency runs under the barrier wait and the LDS reads.
+    constexpr int NIT = TOK * CPR / NTHREADS;
+    int4 rv[NIT];
+    int4 rw[EPI == EPI_RESID16 ? NIT : 1][2];   // 16 int16 residual values per chunk
+    if constexpr (EPI == EPI_RESID || EPI == EPI_RESID16) {
+        if constexpr (!(ABL & 16)) {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int q = tid + NTHREADS * it;
+                const int tl = q / CPR, cc = q % CPR;
+                const int t = min(m0 + tl, g.M - 1), cn = min(n0 + 16 * cc, g.N - 16);
+                if constexpr (EPI == EPI_RESID) {
+                    rv[it] = *reinterpret_cast<const int4*>(g.res + (int64_t)t * g.ldr + cn);
+                } else {
+                    const int4* rp = reinterpret_cast<const int4*>(reinterpret_cast<const int16_t*>(g.res) + (int64_t)t * g.ldr + cn);
+                    rw[it][0] = rp[0];
+                    rw[it][1] = rp[1];
+                }
+            }
+        }
+    }
+    // barrier without the vmcnt(0) drain of __syncthreads(): only this wave's LDS writes have to be complete
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
     if constexpr (ABL & 512) {
         t_sync = __builtin_amdgcn_s_memtime();
         if (tid == 0 && g.res != nullptr) {
@@ -225,28 +251,14 @@ IVIT_DEV void epilogue_i8(v16i (&acc)[TI][TJ], const GemmArgs& g, char* smem, co
     if constexpr (ABL & 16) return;
 
     int8_t* out = reinterpret_cast<int8_t*>(g.out);
-    constexpr int NIT = TOK * CPR / NTHREADS;
     int v[NIT][4];
     v2i vv[NIT][2];
-    int4 rv[NIT];
-    int4 rw[EPI == EPI_RESID16 ? NIT : 1][2];   // 16 int16 residual values per chunk
-    hook.issue();    // persistent kernel: next tile's table loads go out before this tile's stores
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int q = tid + NTHREADS * it;
         const int tl = q / CPR, cc = q % CPR;
         lds_read8x2_async(vv[it][0], lds_addr(smem) + (unsigned)(tl * CSS + 16 * cc));
         lds_read8x2_async(vv[it][1], lds_addr(smem) + (unsigned)(tl * CSS + 16 * cc + 8));
-        if constexpr (EPI == EPI_RESID) {
-            const int t = min(m0 + tl, g.M - 1), cn = min(n0 + 16 * cc, g.N - 16);
-            rv[it] = *reinterpret_cast<const int4*>(g.res + (int64_t)t * g.ldr + cn);
-        }
-        if constexpr (EPI == EPI_RESID16) {
-            const int t = min(m0 + tl, g.M - 1), cn = min(n0 + 16 * cc, g.N - 16);
-            const int4* rp = reinterpret_cast<const int4*>(reinterpret_cast<const int16_t*>(g.res) + (int64_t)t * g.ldr + cn);
-            rw[it][0] = rp[0];
-            rw[it][1] = rp[1];
-        }
     }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {

@@ -159,6 +159,15 @@ class IntViTEngine(GraphReplay):
                 lin["Wb"] = torch.empty_like(lin["W"])
                 _lib.call("ivit_tile_operand_i8", _lib.ptr(lin["W"]), lin["K"], lin["N"], lin["K"], _lib.ptr(lin["Wb"]),
                           self._stream())
+        # MFMA-fragment copies (IVIT_W_FRAGS): the weights-in-registers GEMM, 14-21 % faster than the LDS-DMA kernel on block-layout
+        # weights; needs K % 192 == 0, and its 256-channel tiles must not waste more than an eighth of their columns
+        for lin in [self.patch] + [b[k] for b in self.blocks for k in ("qkv", "proj", "fc1", "fc2")]:
+            N, K = lin["N"], lin["K"]
+            lin["Wf"] = None
+            if K % 192 == 0 and N % 64 == 0 and N >= 128 and (N + 255) // 256 * 256 * 8 <= N * 9:
+                lin["Wf"] = torch.empty((N + 63) // 64 * 64 * K, dtype=torch.int8, device=self.dev)
+                _lib.call("ivit_pack_weight_frags_i8", _lib.ptr(lin["W"]), K, N, K, _lib.ptr(lin["Wf"]), self._stream())
+        self.weight_frags = True      # False: block-layout weights through the LDS-DMA kernel (A/B timing)
         self.block_operands = True    # False: row-major activations / weights everywhere (tests, A/B timing)
         # which producers write their output (a GEMM A operand) in the block layout.  Measured per producer / consumer pair
         # (DESIGN.md section 5): the GEMM gains 4-6 % from a block-layout A, the producer pays for 64-byte row segments
@@ -192,6 +201,8 @@ class IntViTEngine(GraphReplay):
 
     def _w(self, lin, blocks):
         """(weight pointer, layout bit) -- the block-layout copy when the call goes to the persistent kernel"""
+        if blocks and self.weight_frags and lin.get("Wf") is not None:
+            return _lib.ptr(lin["Wf"]), 8
         if blocks and lin["Wb"] is not None:
             return _lib.ptr(lin["Wb"]), 2
         return _lib.ptr(lin["W"]), 0

@@ -99,6 +99,12 @@ class IntSwinEngine(GraphReplay):
                 # block-layout copy (include/ivit_hip.h IVIT_LAYOUT_BLOCKS) for the calls that reach the persistent GEMM
                 d["Wb"] = torch.empty_like(d["W"])
                 _lib.call("ivit_tile_operand_i8", _lib.ptr(d["W"]), Kp, d["N"], Kp, _lib.ptr(d["Wb"]), _lib.stream_ptr())
+            d["Wf"] = None
+            N = d["N"]
+            if Kp % 192 == 0 and N % 64 == 0 and N >= 128 and (N + 255) // 256 * 256 * 8 <= N * 9:
+                # MFMA-fragment copy (IVIT_W_FRAGS): the weights-in-registers GEMM (stage 1 fc1, stage 2 qkv / fc1, all of stage 3)
+                d["Wf"] = torch.empty((N + 63) // 64 * 64 * Kp, dtype=torch.int8, device=self.dev)
+                _lib.call("ivit_pack_weight_frags_i8", _lib.ptr(d["W"]), Kp, N, Kp, _lib.ptr(d["Wf"]), _lib.stream_ptr())
             return lp, d
 
         def lin_dev(name, s_in, s_out):
@@ -290,6 +296,8 @@ class IntSwinEngine(GraphReplay):
     @staticmethod
     def _w(lin, M):
         """(weight pointer, layouts) -- the block-layout copy when the call goes to the persistent kernel"""
+        if lin.get("Wf") is not None and M >= 2048:
+            return _lib.ptr(lin["Wf"]), 8
         if lin["Wb"] is not None and M >= 2048:
             return _lib.ptr(lin["Wb"]), 2
         return _lib.ptr(lin["W"]), 0
@@ -393,9 +401,10 @@ class IntSwinEngine(GraphReplay):
                     self._gemm(ws["g"], 4 * C, f2, ws["f2"], C, M, st)
                     tap(p + "mlp.qact2", ws["f2"], M, C)
                 # mlp.fc2 + mlp.qact2 + the 16-bit residual QuantAct qact4 in one kernel (swin_quant.py:297-299)
-                _lib.call("ivit_gemm_i8_requant_residual_i16", _lib.ptr(ws["g"]), 4 * C, _lib.ptr(f2["W"]), f2["K"],
+                f2w, f2lay = self._w(f2, M)
+                _lib.call("ivit_gemm_i8_requant_residual_i16_ex", _lib.ptr(ws["g"]), 4 * C, f2w, f2["K"],
                           _lib.ptr(f2["b"]), _lib.ptr(f2["m"]), _lib.ptr(f2["e"]), _lib.ptr(x2), C, r[0], r[1], r[2], r[3],
-                          _lib.ptr(x), C, M, f2["N"], f2["K"], st)
+                          _lib.ptr(x), C, M, f2["N"], f2["K"], f2lay, st)
                 tap(p + "qact4", x, M, C)
             dn = stg["down"]
             if dn is not None:

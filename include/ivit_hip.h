@@ -129,6 +129,11 @@ int ivit_gemm_i8_requant_residual_i16(const int8_t* A, int64_t lda, const int8_t
                                       const int16_t* res, int64_t ldr, uint32_t m_main, int32_t e_main,
                                       uint32_t m_res, int32_t e_res, int16_t* out, int64_t ldo,
                                       int M, int N, int K, ivit_stream_t stream);
+int ivit_gemm_i8_requant_residual_i16_ex(const int8_t* A, int64_t lda, const int8_t* W, int64_t ldw,
+                                         const int32_t* bias, const uint32_t* m, const int32_t* e,
+                                         const int16_t* res, int64_t ldr, uint32_t m_main, int32_t e_main,
+                                         uint32_t m_res, int32_t e_res, int16_t* out, int64_t ldo,
+                                         int M, int N, int K, int layouts, ivit_stream_t stream);
 
 /* as ivit_gemm_i8_requant but the output is written head-major for the attention kernel:
  * N = 3 * heads * head_dim, row t = b * tokens + tok  ->

@@ -33,6 +33,8 @@ def run(cid, steps=20, warmup=5, graph=False):
         eng = IntViTEngine(fs, ranges, cfg["embed_dim"], cfg["depth"], cfg["num_heads"], device=DEV, max_batch=B)
     if os.environ.get("IVIT_BLOCK_A") and hasattr(eng, "block_a"):   # A/B: e.g. IVIT_BLOCK_A=gelu or IVIT_BLOCK_A=none
         eng.block_a = {k: k in os.environ["IVIT_BLOCK_A"].split(",") for k in eng.block_a}
+    if os.environ.get("IVIT_WEIGHT_FRAGS") and hasattr(eng, "weight_frags"):   # A/B: 0 = block-layout weights, LDS-DMA kernel
+        eng.weight_frags = os.environ["IVIT_WEIGHT_FRAGS"] != "0"
     if os.environ.get("IVIT_COMPACT_WS") and hasattr(eng, "_compact"):   # A/B: 0 = every intermediate in its own buffer
         eng._compact(os.environ["IVIT_COMPACT_WS"] != "0")
     if os.environ.get("IVIT_GELU_INPLACE") and hasattr(eng, "gelu_in_place"):   # A/B: 0 = GELU into its own buffer
