@@ -400,8 +400,10 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_pers_kernel(GemmArgs g)
             IVIT_DEV void consume() const { if (more) pers_table_write(ld, dst, tid); }
         };
         Hook hook{g, nxt.n0, tid, tab_next, more, PersTableLoad{0u, 0, 0, false}};
+        int tid_o = tid;   // opaque: the epilogue's per-thread addresses are computed here, not carried through the main loop
+        asm volatile("" : "+v"(tid_o));
         epilogue_i8<EPI, 2, TJ, (HALF ? 128 : BTOK), BIG_NT, EABL, BCH, Hook>(acc, g, smem + BIG_STAGE, tab, cur.m0, cur.n0,
-                                                                           64 * wc, WTOK * wt, tid, h, l31, hook);
+                                                                           64 * wc, WTOK * wt, tid_o, (tid_o >> 5) & 1, tid_o & 31, hook);
         __syncthreads();   // staging reads done before the next item's stage 1 DMA overwrites buffer 1
     };
 
@@ -450,19 +452,36 @@ constexpr int WR_CS = WR_TOK * (WR_CH + 4);                 // 32.5 KiB epilogue
 constexpr int WR_TAB = WR_CH * 12;                          // float2 lohi[256]; int bias[256]
 constexpr int WR_SMEM = WR_RING + WR_CS + 2 * WR_TAB;       // 62.5 KiB: two workgroups per CU
 
-struct WrTile { int m0, n0; };   // m0 < 0: none
+struct WrWork { int m0, n0, half; };   // m0 < 0: none
 
-IVIT_DEV WrTile wr_tile(const GemmArgs& g, int t)
+IVIT_DEV WrWork wr_tile(const GemmArgs& g, int t)
 {
     const int nblk = g.tiles_m * g.tiles_n;
-    if (t >= nblk) return WrTile{-1, 0};
     const int q8 = nblk >> 3, r8 = nblk & 7, xcd = t & 7;
     const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (t >> 3);
     const int tm = lid / g.tiles_n, tn = lid - tm * g.tiles_n;
-    return WrTile{tm * WR_TOK, tn * WR_CH};
+    return WrWork{tm * WR_TOK, tn * WR_CH, 0};
 }
 
-// ABL (lab build only): 1 no epilogue, 2 no weight loads in the loop, 4 no DMA in the loop, 8 no MFMA
+// Work item i of workgroup b (grid G).  Tiles [0, split_from) are full tiles, tile t with workgroup t % G.  The remaining R
+// tiles -- a last round that would leave most workgroups idle -- are processed as 2R half tiles of 64 tokens, one per
+// workgroup 0 .. 2R-1, after that workgroup's full tiles: the tail then costs about half a tile time on twice the CUs.
+IVIT_DEV WrWork wr_work(const GemmArgs& g, int i, int b, int G)
+{
+    const int F = g.tiles_m * g.tiles_n;
+    const int t = b + i * G;
+    if (t < g.split_from) return wr_tile(g, t);
+    const int nfull = b < g.split_from ? (g.split_from - b + G - 1) / G : 0;   // full tiles of workgroup b
+    if (i == nfull && g.split_from + (b >> 1) < F) {
+        WrWork w = wr_tile(g, g.split_from + (b >> 1));
+        w.m0 += 64 * (b & 1);
+        w.half = 1;
+        if (w.m0 < g.M) return w;
+    }
+    return WrWork{-1, 0, 0};
+}
+
+// ABL (lab build only): 1 no epilogue, 2 no weight loads in the loop, 4 no DMA in the loop, 8 no MFMA, 16 time stamps
 template <int EPI, int ABL = 0>
 __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_wreg_kernel(GemmArgs g)
 {
@@ -471,116 +490,62 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_wreg_kernel(GemmArgs g)
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, l31 = lane & 31;
-    const int lrow = lane >> 2, lslot = lane & 3;
     const int nk = g.K / BK;
     using T = std::true_type;
     using F = std::false_type;
 
-    // ---- sources: 8 DMA pieces of 16 token rows per stage (wave w: pieces w, w + 4); this wave's 64 weight rows
+    // ---- sources: 8 DMA pieces of 16 token rows per stage (wave w: pieces w, w + 4; a half tile has pieces 0..3 only);
+    //      this wave's 64 weight rows
     const int8_t* asrc[2];
-    const int8_t* wsrc = g.W;      // wave-uniform
-    const unsigned lane16 = (unsigned)lane * 16u;
-    auto set_sources = [&](const WrTile& w) {
+    const int8_t* wsrc = g.W;      // this lane's 16 bytes of the wave's weight piece 0, K step 0
+    auto set_sources = [&](const WrWork& w) {
+        // per-lane address parts are recomputed from an opaque copy of the lane id for every work item: hoisted out of the tile
+        // loop they would occupy registers through the main loop (and were spilled)
+        int lane_o = lane;
+        asm volatile("" : "+v"(lane_o));
+        const int lrow_o = lane_o >> 2, lslot_o = lane_o & 3;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int piece = wave + 4 * i;
-            const int row = 16 * piece + lrow;
-            const int c = lslot ^ ((row >> 2) & 3);
+            const int row = 16 * piece + lrow_o;
+            const int c = lslot_o ^ ((row >> 2) & 3);
             asrc[i] = g.A + (int64_t)min(w.m0 + row, g.M - 1) * g.lda + 16 * c;
-            if (g.a_blocks) {   // uniform block origin + lane * 16, recomputed per tile (no per-lane 64-bit value kept across the main loop)
-                unsigned l16 = lane16;
-                asm volatile("" : "+v"(l16));
-                asrc[i] = g.A + (int64_t)min((w.m0 >> 4) + piece, ((g.M + 15) >> 4) - 1) * (g.K >> 6) * 1024 + l16;
-            }
+            if (g.a_blocks)   // uniform block origin + lane * 16
+                asrc[i] = g.A + (int64_t)min((w.m0 >> 4) + piece, ((g.M + 15) >> 4) - 1) * (g.K >> 6) * 1024 + (unsigned)lane_o * 16u;
         }
-        wsrc = g.W + (int64_t)min((w.n0 >> 6) + wave, ((g.N + 63) >> 6) - 1) * nk * 4096;
+        const int cg = min((w.n0 >> 6) + wave, ((g.N + 63) >> 6) - 1);
+        wsrc = g.W + (int64_t)cg * nk * 4096 + (unsigned)lane_o * 16u;
     };
     const int kstep_a = g.a_blocks ? 1024 : BK;
     auto issue_dma = [&](int kt, int i) {
         __builtin_amdgcn_global_load_lds((gptr_t)(asrc[i] + kt * kstep_a),
                                          (lptr_t)(smem + (kt % WR_STAGES) * WR_STAGE + 1024 * (wave + 4 * i)), 16, 0, 0);
     };
-    // weight fragments of K step kt into buffer wr[.]: piece p = 2 i + ks (channel sub-tile i, K half ks) is 1 KB at p * 1024
+    // weight fragments of K step kt into buffer wr[.]: piece p = 2 i + ks (channel sub-tile i, K half ks) is 1 KB at p * 1024.
+    // Per-lane 64-bit addresses (an SGPR base + lane offset form depends on the compiler keeping the base in SGPRs, which it
+    // does not under register pressure)
     v4i wr0[4], wr1[4], wr2[4];
     auto issue_w = [&](v4i (&wr)[4], int kt, int p) {
         const int8_t* src = wsrc + (int64_t)kt * 4096;
-        if (p == 0) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(wr[0]) : "v"(lane16), "s"(src));
-        if (p == 1) asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(wr[1]) : "v"(lane16), "s"(src));
-        if (p == 2) asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "=v"(wr[2]) : "v"(lane16), "s"(src));
-        if (p == 3) asm volatile("global_load_dwordx4 %0, %1, %2 offset:3072" : "=v"(wr[3]) : "v"(lane16), "s"(src));
+        if (p == 0) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(wr[0]) : "v"(src));
+        if (p == 1) asm volatile("global_load_dwordx4 %0, %1, off offset:1024" : "=v"(wr[1]) : "v"(src));
+        if (p == 2) asm volatile("global_load_dwordx4 %0, %1, off offset:2048" : "=v"(wr[2]) : "v"(src));
+        if (p == 3) asm volatile("global_load_dwordx4 %0, %1, off offset:3072" : "=v"(wr[3]) : "v"(src));
     };
-    auto issue_all = [&](v4i (&wr)[4], int kt) {
-        issue_dma(kt, 0);
-        issue_dma(kt, 1);
+    // what goes out ahead of a work item: stage 0, weight buffer 0, stage 1 (the item's own first step issues weight buffer 1)
+    auto prefetch = [&](const WrWork& w) {
+        set_sources(w);
+        issue_dma(0, 0);
+        if (!w.half) issue_dma(0, 1);
 #pragma unroll
-        for (int p = 0; p < 4; ++p) issue_w(wr, kt, p);
+        for (int p = 0; p < 4; ++p) issue_w(wr0, 0, p);
+        issue_dma(1, 0);
+        if (!w.half) issue_dma(1, 1);
     };
 
     const unsigned smem_base = (unsigned)(__UINTPTR_TYPE__)(lptr_t)smem;
     const unsigned abase[2] = {smem_base + (unsigned)swz(l31, h), smem_base + (unsigned)swz(l31, 2 + h)};
-    v4i af0[4], af1[4];
-    auto load_frags = [&](unsigned stage_off, int ks, v4i (&af)[4]) {
-        const unsigned aa = abase[ks] + stage_off;
-        asm volatile("ds_read_b128 %0, %1" : "=v"(af[0]) : "v"(aa));
-        asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(af[1]) : "v"(aa));
-        asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(af[2]) : "v"(aa));
-        asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(af[3]) : "v"(aa));
-    };
-    auto wait_frags = [&](v4i (&af)[4]) {   // at most the newest group of four reads outstanding
-        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3])::"memory");
-    };
-    // own DMA pieces and weight registers of the NEXT K step have landed (the 6 operations of the step after it may be in
-    // flight), and every LDS read of this wave has returned
-    auto wait_next = [&](auto inflight_tag, v4i (&af)[4], v4i (&wn)[4]) {
-        if constexpr (ABL & 6)
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
-                         : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]), "+v"(wn[0]), "+v"(wn[1]), "+v"(wn[2]), "+v"(wn[3])::"memory");
-        else if constexpr (decltype(inflight_tag)::value)
-            asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)"
-                         : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]), "+v"(wn[0]), "+v"(wn[1]), "+v"(wn[2]), "+v"(wn[3])::"memory");
-        else
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
-                         : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]), "+v"(wn[0]), "+v"(wn[1]), "+v"(wn[2]), "+v"(wn[3])::"memory");
-    };
-
-    v16i acc[2][4];
-    // K step kt on weight buffer wc (current), wn (next: waited for here), wf (the one after: loaded here)
     unsigned long long* stamp = nullptr;   // ABL & 16: [block][tile < 4][32]: tile start, loop start, loop end, epilogue end, step starts
-    auto step = [&](int kt, v4i (&wc)[4], v4i (&wn)[4], v4i (&wf)[4], auto issue_tag, auto last_tag) {
-        constexpr bool ISSUE = decltype(issue_tag)::value;
-        constexpr bool LAST = decltype(last_tag)::value;
-        if constexpr (ABL & 16)
-            if (stamp && kt < 12) stamp[4 + kt] = __builtin_amdgcn_s_memtime();
-        load_frags((unsigned)((kt % WR_STAGES) * WR_STAGE), 1, af1);
-        wait_frags(af0);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if constexpr (!(ABL & 8)) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wc[2 * i], af0[j], acc[i][j], 0, 0, 0);
-                else asm volatile("" : "+v"(acc[i][j]) : "v"(wc[2 * i]), "v"(af0[j]));
-                if constexpr (ISSUE) {
-                    const int n = 4 * i + j;
-                    if (n < 2) { if constexpr (!(ABL & 4)) issue_dma(kt + 2, n); }
-                    else if (n < 6) { if constexpr (!(ABL & 2)) issue_w(wf, kt + 2, n - 2); }
-                }
-            }
-        __builtin_amdgcn_sched_barrier(0);
-        wait_next(issue_tag, af1, wn);
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if constexpr (!LAST) load_frags((unsigned)(((kt + 1) % WR_STAGES) * WR_STAGE), 0, af0);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if constexpr (!(ABL & 8)) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wc[2 * i + 1], af1[j], acc[i][j], 0, 0, 0);
-                else asm volatile("" : "+v"(acc[i][j]) : "v"(wc[2 * i + 1]), "v"(af1[j]));
-            }
-        __builtin_amdgcn_sched_barrier(0);
-    };
 
     auto table_issue = [&](int n0) {
         PersTableLoad r{0u, 0, 0, false};
@@ -606,32 +571,95 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_wreg_kernel(GemmArgs g)
         reinterpret_cast<int*>(tab + WR_CH * 8)[tid] = r.bias;
     };
 
-    const int G = gridDim.x, b = blockIdx.x;
-    WrTile cur = wr_tile(g, b);
-    if (cur.m0 < 0) return;   // uniform
-    table_write(table_issue(cur.n0), smem + WR_RING + WR_CS);
-    set_sources(cur);
-    issue_all(wr0, 0);
-    issue_dma(1, 0);
-    issue_dma(1, 1);
-
-    for (int it = 0; cur.m0 >= 0; ++it) {
-        char* tab = smem + WR_RING + WR_CS + (it & 1) * WR_TAB;
-        char* tab_next = smem + WR_RING + WR_CS + ((it + 1) & 1) * WR_TAB;
-        const WrTile nxt = wr_tile(g, b + (it + 1) * G);
-        if constexpr (ABL & 16) {
-            stamp = (tid == 0 && it < 4) ? reinterpret_cast<unsigned long long*>(const_cast<int8_t*>(g.res)) + (blockIdx.x * 4 + it) * 32 : nullptr;
-            if (stamp) {
-                stamp[0] = __builtin_amdgcn_s_memtime();
-                stamp[16] = __builtin_amdgcn_s_memrealtime();   // constant 100 MHz: the shader clock follows from the pair
+    // One work item: a full tile (128 tokens: 4 token sub-tiles per wave) or a half tile (64 tokens: 2).
+    auto run = [&](auto half_tag, const WrWork& cur, const WrWork& nxt, char* tab, char* tab_next, bool first) {
+        constexpr bool HALF = decltype(half_tag)::value;
+        constexpr int TJ = HALF ? 2 : 4;
+        constexpr int NP = HALF ? 1 : 2;          // DMA pieces per wave and K step
+        v4i af0[TJ], af1[TJ];
+        auto load_frags = [&](unsigned stage_off, int ks, v4i (&af)[TJ]) {
+            const unsigned aa = abase[ks] + stage_off;
+            asm volatile("ds_read_b128 %0, %1" : "=v"(af[0]) : "v"(aa));
+            asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(af[1]) : "v"(aa));
+            if constexpr (TJ == 4) {
+                asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(af[2]) : "v"(aa));
+                asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(af[3]) : "v"(aa));
             }
-        }
-        // stage 0 and weight buffer 0 of this tile are in flight (or landed); the table was written during the last epilogue
+        };
+        auto wait_frags = [&](v4i (&af)[TJ]) {   // at most the newest group of reads outstanding
+            if constexpr (TJ == 4) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3])::"memory");
+            else asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(af[0]), "+v"(af[1])::"memory");
+        };
+        // own DMA pieces and weight registers of the NEXT K step have landed (the NP + 4 operations of the step after it may be
+        // in flight), and every LDS read of this wave has returned
+        auto wait_next = [&](auto inflight_tag, v4i (&af)[TJ], v4i (&wn)[4]) {
+            constexpr bool INFLIGHT = decltype(inflight_tag)::value && !(ABL & 6);
+            if constexpr (TJ == 4) {
+                if constexpr (INFLIGHT)
+                    asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)"
+                                 : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]), "+v"(wn[0]), "+v"(wn[1]), "+v"(wn[2]), "+v"(wn[3])::"memory");
+                else
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
+                                 : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]), "+v"(wn[0]), "+v"(wn[1]), "+v"(wn[2]), "+v"(wn[3])::"memory");
+            } else {
+                if constexpr (INFLIGHT)
+                    asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" : "+v"(af[0]), "+v"(af[1]), "+v"(wn[0]), "+v"(wn[1]), "+v"(wn[2]), "+v"(wn[3])::"memory");
+                else
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(af[0]), "+v"(af[1]), "+v"(wn[0]), "+v"(wn[1]), "+v"(wn[2]), "+v"(wn[3])::"memory");
+            }
+        };
+        v16i acc[2][TJ];
+        // K step kt on weight buffer wc (current), wn (next: waited for here), wf (the one after: loaded here)
+        auto step = [&](int kt, v4i (&wc)[4], v4i (&wn)[4], v4i (&wf)[4], auto issue_tag, auto last_tag) {
+            constexpr bool ISSUE = decltype(issue_tag)::value;
+            constexpr bool LAST = decltype(last_tag)::value;
+            if constexpr (ABL & 16)
+                if (stamp && kt < 12) stamp[4 + kt] = __builtin_amdgcn_s_memtime();
+            load_frags((unsigned)((kt % WR_STAGES) * WR_STAGE), 1, af1);
+            wait_frags(af0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) {
+                    if constexpr (!(ABL & 8)) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wc[2 * i], af0[j], acc[i][j], 0, 0, 0);
+                    else asm volatile("" : "+v"(acc[i][j]) : "v"(wc[2 * i]), "v"(af0[j]));
+                    if constexpr (ISSUE) {   // NP + 4 loads of K step kt + 2 spread over the MFMAs of this half step
+                        const int n = TJ * i + j;
+                        if constexpr (HALF) {    // four MFMAs, five loads: DMA piece and weight piece 0 behind the first
+                            if (n == 0) { if constexpr (!(ABL & 4)) issue_dma(kt + 2, 0); }
+                            if constexpr (!(ABL & 2)) issue_w(wf, kt + 2, n);
+                        } else {
+                            if (n < NP) { if constexpr (!(ABL & 4)) issue_dma(kt + 2, n); }
+                            else if (n < NP + 4) { if constexpr (!(ABL & 2)) issue_w(wf, kt + 2, n - NP); }
+                        }
+                    }
+                }
+            __builtin_amdgcn_sched_barrier(0);
+            wait_next(issue_tag, af1, wn);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if constexpr (!LAST) load_frags((unsigned)(((kt + 1) % WR_STAGES) * WR_STAGE), 0, af0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) {
+                    if constexpr (!(ABL & 8)) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wc[2 * i + 1], af1[j], acc[i][j], 0, 0, 0);
+                    else asm volatile("" : "+v"(acc[i][j]) : "v"(wc[2 * i + 1]), "v"(af1[j]));
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+
+        // stage 0, weight buffer 0 and stage 1 of this item are in flight (or landed); the table was written during the last epilogue
 #pragma unroll
         for (int p = 0; p < 4; ++p) issue_w(wr1, 1, p);
-        // Stage 0 and weight buffer 0 were issued before the last epilogue, whose __syncthreads drained them; only the first tile
-        // has to wait here.  (An unconditional counted wait would also drain the epilogue's stores: vmcnt counts them too.)
-        if (it == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        // They were issued before the last epilogue, which waited for them (Hook::consume); only a workgroup's first item has to
+        // wait here.  (An unconditional counted wait would also drain the epilogue's stores: vmcnt counts them too.)
+        if (first) {
+            if constexpr (HALF) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        }
         asm volatile("" : "+v"(wr0[0]), "+v"(wr0[1]), "+v"(wr0[2]), "+v"(wr0[3])::"memory");
         __builtin_amdgcn_s_barrier();     // everyone's stage 0; table visible
         asm volatile("" ::: "memory");
@@ -648,7 +676,7 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_wreg_kernel(GemmArgs g)
                 lds_wait(bq[i][q]);
                 const v4i b4 = bq[i][q];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < TJ; ++j) {
                     acc[i][j][4 * q + 0] = b4.x;
                     acc[i][j][4 * q + 1] = b4.y;
                     acc[i][j][4 * q + 2] = b4.z;
@@ -671,12 +699,7 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_wreg_kernel(GemmArgs g)
             if (stamp) stamp[2] = __builtin_amdgcn_s_memtime();
         // every wave's reads of every stage returned before the barrier of the last step: the ring is free
         const bool more = nxt.m0 >= 0;   // uniform
-        if (more) {
-            set_sources(nxt);
-            issue_all(wr0, 0);
-            issue_dma(1, 0);
-            issue_dma(1, 1);
-        }
+        if (more) prefetch(nxt);
         struct Hook {
             decltype(table_issue)& ti;
             decltype(table_write)& tw;
@@ -685,8 +708,8 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_wreg_kernel(GemmArgs g)
             bool more;
             mutable PersTableLoad ld;
             IVIT_DEV void issue() const { if (more) ld = ti(n0); }
-            // also this wave's share of the next tile's first stage and weight buffer (issued before the epilogue; every load
-            // outstanding here is older than the stores that follow): landed before the barrier at the next tile's start
+            // also this wave's share of the next item's first stages and weight buffer (issued before the epilogue; every load
+            // outstanding here is older than the stores that follow): landed before the barrier at the next item's start
             IVIT_DEV void consume() const
             {
                 if (more) {
@@ -701,15 +724,39 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_wreg_kernel(GemmArgs g)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < TJ; ++j)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) sum ^= acc[i][j][r];
             if (sum == 0x12345679) reinterpret_cast<int*>(g.out)[tid] = sum;
             hook.issue();
             hook.consume();
         } else {
-            epilogue_i8<EPI, 2, 4, WR_TOK, BIG_NT, 0, WR_CH, Hook>(acc, g, cs, tab, cur.m0, cur.n0, 64 * wave, 0, tid, h, l31, hook);
+            int tid_o = tid;   // opaque: the epilogue's per-thread addresses are computed here, not carried through the main loop
+            asm volatile("" : "+v"(tid_o));
+            epilogue_i8<EPI, 2, TJ, 32 * TJ, BIG_NT, 0, WR_CH, Hook>(acc, g, cs, tab, cur.m0, cur.n0, 64 * wave, 0, tid_o, (tid_o >> 5) & 1,
+                                                                      tid_o & 31, hook);
         }
+    };
+
+    const int G = gridDim.x, b = blockIdx.x;
+    WrWork cur = wr_work(g, 0, b, G);
+    if (cur.m0 < 0) return;   // uniform
+    table_write(table_issue(cur.n0), smem + WR_RING + WR_CS);
+    prefetch(cur);
+
+    for (int it = 0; cur.m0 >= 0; ++it) {
+        char* tab = smem + WR_RING + WR_CS + (it & 1) * WR_TAB;
+        char* tab_next = smem + WR_RING + WR_CS + ((it + 1) & 1) * WR_TAB;
+        const WrWork nxt = wr_work(g, it + 1, b, G);
+        if constexpr (ABL & 16) {
+            stamp = (tid == 0 && it < 4) ? reinterpret_cast<unsigned long long*>(const_cast<int8_t*>(g.res)) + (blockIdx.x * 4 + it) * 32 : nullptr;
+            if (stamp) {
+                stamp[0] = __builtin_amdgcn_s_memtime();
+                stamp[16] = __builtin_amdgcn_s_memrealtime();   // constant 100 MHz: the shader clock follows from the pair
+            }
+        }
+        if (cur.half) run(T{}, cur, nxt, tab, tab_next, it == 0);
+        else run(F{}, cur, nxt, tab, tab_next, it == 0);
         if constexpr (ABL & 16)
             if (stamp) stamp[3] = __builtin_amdgcn_s_memtime();
         cur = nxt;
@@ -769,6 +816,13 @@ int launch_gemm(GemmArgs& g, const char* name, ivit_stream_t stream)
             g.tiles_m = (g.M + WR_TOK - 1) / WR_TOK;
             g.tiles_n = (g.N + WR_CH - 1) / WR_CH;
             const int ntiles = g.tiles_m * g.tiles_n;
+            // A sparse last round (R tiles on 512 slots) runs as 2R half tiles of 64 tokens (wr_work) when every half tile still
+            // finds a CU of its own (2R <= 256): fc1 at the headline shape, R = 120, 144 -> 136 us.  Beyond that two half tiles
+            // share a CU while a lone full tile has one to itself and runs nearly twice as fast: measured slower (N = 768,
+            // R = 158: proj 53.8 -> 60.5 us, fc2 124 -> 135 us with the residual epilogue).  Lab bit 27: off, bit 11: up to 2R <= 512.
+            const int rounds = ntiles / 512, R = ntiles - rounds * 512;
+            const bool split = rounds > 0 && R > 0 && 2 * R <= ((g_debug_flags & 2048) ? 512 : 256) && !(g_debug_flags & 134217728);
+            g.split_from = split ? rounds * 512 : ntiles;
             const dim3 grid(ntiles < 512 ? ntiles : 512);
 #if IVIT_LAB
             if constexpr (EPI == EPI_RQ) {   // ablations (scripts/gemm_ab.py --frags): what each stream of the kernel costs
