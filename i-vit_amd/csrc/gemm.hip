@@ -41,7 +41,7 @@ __global__ __launch_bounds__(NT) void gemm_i8_kernel(GemmArgs g)
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int h = lane >> 5, l31 = lane & 31;
-    if constexpr (EPI != EPI_I32) fill_rq_table(g, smem + SMEM_BYTES, n0, BN, tid);
+    if constexpr (EPI != EPI_I32 && EPI != EPI_RQ16) fill_rq_table(g, smem + SMEM_BYTES, n0, BN, tid);
 
     // ---- staging: thread moves chunks (row = tid/4 + 64 i, c = tid%4) of both tiles
     const int srow = tid >> 2, sc = tid & 3;
@@ -136,6 +136,37 @@ __global__ __launch_bounds__(NT) void gemm_i8_kernel(GemmArgs g)
                         v4i v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
                         *reinterpret_cast<v4i*>(out + (int64_t)t * g.ldo + c0) = v;
                     }
+                }
+            }
+        return;
+    } else if constexpr (EPI == EPI_RQ16) {
+        // 16-bit per-channel QuantAct from the registers: a lane holds 4 consecutive channels of one token per register quad,
+        // i.e. one 8-byte store.  quant_utils.py:229-230 literally: float64 product (53-bit rounding), then RNE.
+        int16_t* out = reinterpret_cast<int16_t*>(g.out);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c0 = n0 + 64 * wn + 32 * i + 8 * q + 4 * h;
+                if (c0 >= g.N) continue;
+                const uint4 m4 = *reinterpret_cast<const uint4*>(g.m + c0);
+                const int4 e4 = *reinterpret_cast<const int4*>(g.e + c0);
+                const double Mc[4] = {dyadic_mult(m4.x, e4.x), dyadic_mult(m4.y, e4.y), dyadic_mult(m4.z, e4.z), dyadic_mult(m4.w, e4.w)};
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int t = m0 + 64 * wm + 32 * j + l31;
+                    if (t >= g.M) continue;
+                    int o[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const double p = (double)acc[i][j][4 * q + r] * Mc[r];
+                        const double tt = p + IVIT_MAGIC;
+                        o[r] = clamp_i32((int)(unsigned)__double_as_longlong(tt), -32768, 32767);
+                    }
+                    int2 ow;
+                    ow.x = (o[0] & 0xffff) | (o[1] << 16);
+                    ow.y = (o[2] & 0xffff) | (o[3] << 16);
+                    *reinterpret_cast<int2*>(out + (int64_t)t * g.ldo + c0) = ow;
                 }
             }
         return;
@@ -773,9 +804,12 @@ int launch_gemm(GemmArgs& g, const char* name, ivit_stream_t stream)
                  "%s: lda=%lld ldw=%lld must be >= K and multiples of 16", name, (long long)g.lda, (long long)g.ldw);
     IVIT_REQUIRE(((uintptr_t)g.A % 16 == 0) && ((uintptr_t)g.W % 16 == 0) && ((uintptr_t)g.out % 16 == 0),
                  "%s: operands must be 16-byte aligned", name);
-    if (EPI == EPI_I32) {
+    if (EPI == EPI_I32 || EPI == EPI_RQ16) {
         IVIT_REQUIRE(g.N % 4 == 0 && g.ldo % 4 == 0 && g.ldo >= g.N, "%s: N=%d ldo=%lld must be multiples of 4", name,
                      g.N, (long long)g.ldo);
+        if (EPI == EPI_RQ16)
+            IVIT_REQUIRE(g.m && g.e && ((uintptr_t)g.m % 16 == 0) && ((uintptr_t)g.e % 16 == 0) && ((uintptr_t)g.out % 8 == 0),
+                         "%s: requantiser tables missing or misaligned", name);
     } else {
         IVIT_REQUIRE(g.m && g.e, "%s: NULL requantiser table", name);
         IVIT_REQUIRE(((uintptr_t)g.bias % 16 == 0), "%s: bias must be 16-byte aligned", name);
@@ -803,16 +837,16 @@ int launch_gemm(GemmArgs& g, const char* name, ivit_stream_t stream)
     g.flags = g_debug_flags & (31 | 128 | 256 | 512);
     const bool blocks = g.a_blocks || g.w_blocks;
     if (blocks && !g.w_frags) {
-        IVIT_REQUIRE(EPI != EPI_I32 && g.M >= 2048 && g.N >= BCH && !g_force_small,
+        IVIT_REQUIRE(EPI != EPI_I32 && EPI != EPI_RQ16 && g.M >= 2048 && g.N >= BCH && !g_force_small,
                      "%s: block-layout operands need the persistent kernel (M >= 2048, N >= 128, requantising epilogue)", name);
         IVIT_REQUIRE(!g.a_blocks || g.lda == g.K, "%s: a block-layout A operand is dense (lda == K)", name);
         IVIT_REQUIRE(!g.w_blocks || g.ldw == g.K, "%s: a block-layout W operand is dense (ldw == K)", name);
     }
     if (g.w_frags) IVIT_REQUIRE(!g.a_blocks || g.lda == g.K, "%s: a block-layout A operand is dense (lda == K)", name);
     if (g.w_frags) {
-        IVIT_REQUIRE(EPI != EPI_I32 && g.M >= 2048 && g.N >= 128 && g.N % 64 == 0 && (g.K / BK) % 3 == 0 && !g.w_blocks && !g_force_small,
+        IVIT_REQUIRE(EPI != EPI_I32 && EPI != EPI_RQ16 && g.M >= 2048 && g.N >= 128 && g.N % 64 == 0 && (g.K / BK) % 3 == 0 && !g.w_blocks && !g_force_small,
                      "%s: the fragment-packed weight needs M >= 2048, N >= 128, N %% 64 == 0, K %% 192 == 0 and a requantising epilogue", name);
-        if constexpr (EPI != EPI_I32) {
+        if constexpr (EPI != EPI_I32 && EPI != EPI_RQ16) {
             g.tiles_m = (g.M + WR_TOK - 1) / WR_TOK;
             g.tiles_n = (g.N + WR_CH - 1) / WR_CH;
             const int ntiles = g.tiles_m * g.tiles_n;
@@ -839,7 +873,7 @@ int launch_gemm(GemmArgs& g, const char* name, ivit_stream_t stream)
             IVIT_CHECK_LAUNCH(name);
         }
     }
-    if constexpr (EPI != EPI_I32) {
+    if constexpr (EPI != EPI_I32 && EPI != EPI_RQ16) {
 #if IVIT_LAB
         if (EPI <= EPI_QKV && !blocks && (g_debug_flags & (31 | 32 | 128 | 256 | 512 | 1024 | 8192 | 4194304 | 8388608))) {   // a lab form was asked for (tests, scripts)
             int rc = IVIT_OK;
@@ -1006,6 +1040,16 @@ IVIT_EXPORT int ivit_gemm_i8_requant_qkv(const int8_t* A, int64_t lda, const int
                                          ivit_stream_t stream)
 {
     return ivit_gemm_i8_requant_qkv_ex(A, lda, W, ldw, bias, m, e, qkv, tokens, heads, head_dim, M, N, K, 0, stream);
+}
+
+IVIT_EXPORT int ivit_gemm_i8_requant_i16(const int8_t* A, int64_t lda, const int8_t* W, int64_t ldw, const int32_t* bias,
+                                         const uint32_t* m, const int32_t* e, int16_t* out, int64_t ldo, int M, int N, int K,
+                                         ivit_stream_t stream)
+{
+    GemmArgs g{};
+    g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.m = m; g.e = e;
+    g.out = out; g.ldo = ldo; g.M = M; g.N = N; g.K = K;
+    return launch_gemm<EPI_RQ16>(g, "ivit_gemm_i8_requant_i16", stream);
 }
 
 IVIT_EXPORT int ivit_gemm_i8_i32(const int8_t* A, int64_t lda, const int8_t* W, int64_t ldw, const int32_t* bias,

@@ -35,7 +35,9 @@ constexpr int SMEM_BYTES = 2 * STAGE_BYTES;  // 32 KiB >= 128 * 132
 
 // EPI_RESID16 (Swin mlp.fc2 + the 16-bit residual QuantAct): int8 requant as EPI_RQ, then
 //   out16 = clamp16(RNE(k8 * M_main) + RNE(res16 * M_res)) with res / out int16 (res, out of GemmArgs reinterpreted)
-enum { EPI_RQ = 0, EPI_RESID = 1, EPI_QKV = 2, EPI_I32 = 3, EPI_RESID16 = 4 };
+// EPI_RQ16 (Swin attn.proj + attn.qact4): out16 = clamp16(RNE(acc * M[n])), int16 rows, straight from the accumulator registers
+// (small-tile kernel only)
+enum { EPI_RQ = 0, EPI_RESID = 1, EPI_QKV = 2, EPI_I32 = 3, EPI_RESID16 = 4, EPI_RQ16 = 5 };
 
 
 struct GemmArgs {

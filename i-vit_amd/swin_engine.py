@@ -113,6 +113,7 @@ class IntSwinEngine(GraphReplay):
             d.update(m=dev(m.view(np.int32)), e=dev(e))
             return d
 
+        self.proj_i16 = True       # attn.proj writes the 16-bit attn.qact4 output instead of raw accumulators
         self.natural_sites = 0     # operators whose input scale is not a power of two: literal / table-driven kernels
 
         def ln_dev(prefix, s_out, s_in, bits_in=16):
@@ -382,11 +383,19 @@ class IntSwinEngine(GraphReplay):
                           a["mb"][1], a["s_attn"], a["mo"][0], a["mo"][1], _lib.ptr(a["phi"]), _lib.ptr(a["phim"]), st)
                 tap(p + "attn.qact3", ws["ao"], M, C, ld)
                 pj = blk["proj"]
-                _lib.call("ivit_gemm_i8_i32", _lib.ptr(ws["ao"]), ld, _lib.ptr(pj["W"]), pj["K"], _lib.ptr(pj["b"]),
-                          _lib.ptr(ws["acc"]), C, M, C, pj["K"], st)
                 r = blk["res1"]
-                _lib.call("ivit_residual_requant_i16", _lib.ptr(ws["acc"]), 32, _lib.ptr(pj["m"]), _lib.ptr(pj["e"]),
-                          r[0], r[1], _lib.ptr(x), r[2], r[3], _lib.ptr(x2), M, C, H, W, win, shift, st)
+                if self.proj_i16:
+                    # attn.proj + the 16-bit attn.qact4 in the GEMM epilogue (int16 [M, C] in window order, half the bytes of
+                    # raw accumulators), then window reverse / un-shift + the residual QuantAct
+                    _lib.call("ivit_gemm_i8_requant_i16", _lib.ptr(ws["ao"]), ld, _lib.ptr(pj["W"]), pj["K"], _lib.ptr(pj["b"]),
+                              _lib.ptr(pj["m"]), _lib.ptr(pj["e"]), _lib.ptr(ws["acc"]), C, M, C, pj["K"], st)
+                    _lib.call("ivit_residual_requant_i16", _lib.ptr(ws["acc"]), 16, None, None,
+                              r[0], r[1], _lib.ptr(x), r[2], r[3], _lib.ptr(x2), M, C, H, W, win, shift, st)
+                else:      # A/B: raw int32 accumulators, attn.qact4 inside the residual kernel
+                    _lib.call("ivit_gemm_i8_i32", _lib.ptr(ws["ao"]), ld, _lib.ptr(pj["W"]), pj["K"], _lib.ptr(pj["b"]),
+                              _lib.ptr(ws["acc"]), C, M, C, pj["K"], st)
+                    _lib.call("ivit_residual_requant_i16", _lib.ptr(ws["acc"]), 32, _lib.ptr(pj["m"]), _lib.ptr(pj["e"]),
+                              r[0], r[1], _lib.ptr(x), r[2], r[3], _lib.ptr(x2), M, C, H, W, win, shift, st)
                 tap(p + "qact2", x2, M, C)
                 self._ln16(x2, M, C, blk["ln2"], ws["h"], ld, st)
                 tap(p + "qact3", ws["h"], M, C, ld)

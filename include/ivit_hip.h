@@ -146,6 +146,14 @@ int ivit_gemm_i8_requant_qkv_ex(const int8_t* A, int64_t lda, const int8_t* W, i
                                 const uint32_t* m, const int32_t* e, int8_t* qkv, int tokens, int heads,
                                 int head_dim, int M, int N, int K, int layouts, ivit_stream_t stream);
 
+/* 16-bit per-channel QuantAct of the accumulators (Swin attn.proj + attn.qact4, swin_quant.py:164-166):
+ *   out[t][n] = clamp16(RNE(acc * m[n] / 2^e[n])),  out int16 [M, N] (ldo in elements), N % 4 == 0, ldo % 4 == 0.
+ * Followed by ivit_residual_requant_i16(a_bits = 16) it replaces ivit_gemm_i8_i32 + ivit_residual_requant_i16(a_bits = 32)
+ * with half the intermediate bytes. */
+int ivit_gemm_i8_requant_i16(const int8_t* A, int64_t lda, const int8_t* W, int64_t ldw, const int32_t* bias,
+                             const uint32_t* m, const int32_t* e, int16_t* out, int64_t ldo, int M, int N, int K,
+                             ivit_stream_t stream);
+
 /* raw accumulators (classifier head; module-level QuantLinear): out int32 [M, N], N % 4 == 0 */
 int ivit_gemm_i8_i32(const int8_t* A, int64_t lda, const int8_t* W, int64_t ldw, const int32_t* bias,
                      int32_t* out, int64_t ldo, int M, int N, int K, ivit_stream_t stream);

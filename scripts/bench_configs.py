@@ -35,6 +35,8 @@ def run(cid, steps=20, warmup=5, graph=False):
         eng.block_a = {k: k in os.environ["IVIT_BLOCK_A"].split(",") for k in eng.block_a}
     if os.environ.get("IVIT_WEIGHT_FRAGS") and hasattr(eng, "weight_frags"):   # A/B: 0 = block-layout weights, LDS-DMA kernel
         eng.weight_frags = os.environ["IVIT_WEIGHT_FRAGS"] != "0"
+    if os.environ.get("IVIT_PROJ_I16") and hasattr(eng, "proj_i16"):   # A/B (Swin): 0 = raw int32 accumulators out of attn.proj
+        eng.proj_i16 = os.environ["IVIT_PROJ_I16"] != "0"
     if os.environ.get("IVIT_COMPACT_WS") and hasattr(eng, "_compact"):   # A/B: 0 = every intermediate in its own buffer
         eng._compact(os.environ["IVIT_COMPACT_WS"] != "0")
     if os.environ.get("IVIT_GELU_INPLACE") and hasattr(eng, "gelu_in_place"):   # A/B: 0 = GELU into its own buffer

@@ -124,6 +124,26 @@ def test_gemm_i32_and_bias_none():
         assert np.array_equal(out.cpu().numpy(), orc.gemm_i8(A, W, bias))
 
 
+@pytest.mark.parametrize("M,N,K", [(70, 96, 128), (3000, 192, 192), (401, 384, 384), (2500, 768, 768)])
+def test_gemm_requant_i16(M, N, K):
+    """16-bit per-channel QuantAct from the accumulators (Swin attn.proj + attn.qact4), incl. saturation at +-32767/8"""
+    rng = np.random.default_rng(M + N)
+    A = rng.integers(-128, 128, size=(M, K)).astype(np.int8)
+    W = rng.integers(-128, 128, size=(N, K)).astype(np.int8)
+    b = rng.integers(-50000, 50000, size=N).astype(np.int32)
+    m, e = rand_me(rng, N, -8, 1)           # multipliers 2^-9 .. 1: results span and exceed the int16 range
+    md, ed = me_dev(m, e)
+    exp = orc.requant(orc.gemm_i8(A, W, b), m.astype(np.float64), e, 16)
+    for bias in (b, None):
+        out = torch.zeros(M, N, dtype=torch.int16, device=DEV)
+        _lib.call("ivit_gemm_i8_requant_i16", _lib.ptr(dev(A)), K, _lib.ptr(dev(W)), K, None if bias is None else _lib.ptr(dev(bias)),
+                  _lib.ptr(md), _lib.ptr(ed), _lib.ptr(out), N, M, N, K, st())
+        want = exp if bias is not None else orc.requant(orc.gemm_i8(A, W, None), m.astype(np.float64), e, 16)
+        assert np.array_equal(out.cpu().numpy().astype(np.int32), want)
+    assert (np.abs(exp) == 32767).any() or (exp == -32768).any()
+    assert (np.abs(exp) < 30000).any()
+
+
 def test_gemm_mfma_layout_identity():
     """A = I-like selector with an asymmetric W catches any row/column swap of the MFMA maps."""
     K = 128
