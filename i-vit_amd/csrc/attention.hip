@@ -52,6 +52,9 @@ struct AttnArgs {
     // cycle through the texture addresser (the full-table gather made the kernel 2.6x slower).  0: use exp2d.
     const unsigned* band;
     int band_w;
+    // I-BERT softmax (MODE 3): exp_int after the internal QuantAct(16), as the float32 the reference sums and multiplies, for
+    // every (row max, q): [256][256], built by ivit_ibert_softmax_build_table
+    const float* ib_table;
 };
 
 constexpr int BAND_PAD = 4;   // dwords: keeps slice rows 16-byte aligned and rotates their banks
@@ -61,7 +64,8 @@ constexpr int BAND_PAD = 4;   // dwords: keeps slice rows 16-byte aligned and ro
 // ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ...) touches 16 distinct 16-byte slots of the 256-byte bank row.
 IVIT_DEV int kswz(int r, int c) { return r * HD + (((c + 2 * ((r >> 2) & 1)) & 3) << 4); }
 
-// MODE 0: power-of-two input scale (256-entry table); 1: natural scale, band rows in LDS; 2: natural scale, full-table gather
+// MODE 0: power-of-two input scale (256-entry table); 1: natural scale, band rows in LDS; 2: natural scale, full-table gather;
+// 3: the I-BERT softmax (ibert_modules.py:237-319) from its (row max, q) table, row sum in torch's float32 reduction order
 template <int MODE>
 __global__ __launch_bounds__(NT, 3) void attention_kernel(AttnArgs a)
 {
@@ -78,7 +82,7 @@ __global__ __launch_bounds__(NT, 3) void attention_kernel(AttnArgs a)
     const int8_t* vg = qg + 2 * plane;
 
     // ---- Shiftmax exponent table: lut[i] = int_exp_shift(-i), i = kmax - k in [0,255]
-    {
+    if constexpr (MODE != 3) {
         const unsigned e0 = shiftexp_int(-tid, a.x0, 15);
         reinterpret_cast<unsigned*>(smem + LUT_OFF)[tid] = e0;
         reinterpret_cast<float*>(smem + LUT_OFF)[256 + tid] = (float)e0;   // same address + 1 KB: one more ds_read, one cvt fewer per score
@@ -184,6 +188,66 @@ __global__ __launch_bounds__(NT, 3) void attention_kernel(AttnArgs a)
                     esum += e;
                 }
             __builtin_amdgcn_wave_barrier();    // every lane has read its slice before the next tile overwrites it
+        } else if constexpr (MODE == 3) {
+            // IBERTIntSoftmax: e = table[row max][q] (float32), S = e.sum() in float32 IN TORCH'S ORDER (ATen SumKernel, rowsum.h:
+            // for 192 <= T < 208 the 32 partials p = key % 32 take their six elements key = p, p + 32, .. in turn, vectors of
+            // keys 192.. join partials 0..7, the scalar tail goes first into the final accumulator, then the eight lane sums
+            // ((P[l] + P[l+8]) + P[l+16]) + P[l+24] are added left to right).  With key = 16 kt + 4 g + r a lane holds the whole
+            // sequence of its eight partials (hi = kt & 1, r): they are summed in registers, exchanged among the four lanes of
+            // a query and combined by every lane alike.  The values are integers for a power-of-two range of the internal
+            // QuantAct and fl(fl(k * s) / s) otherwise: the order matters then.
+            const float* row2d = a.ib_table + ((rmax + 128) << 8) + 128;       // entry of q = -nk
+            float e12[4];
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int nk = s[kt][r];
+                    float e = row2d[-min(nk, 128)];
+                    if (kt == NKT - 1) {
+                        e = (nk == 1000) ? 0.0f : e;
+                        e12[r] = e;
+                    }
+                    s[kt][r] = __float_as_int(e);
+                }
+            const int nv = T >> 3;                 // 8-float vectors: 24 or 25 (the launcher keeps T < 208)
+            float Pp[2][4];
+#pragma unroll
+            for (int hi = 0; hi < 2; ++hi)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float acc = 0.0f;
+#pragma unroll
+                    for (int m = 0; m < 6; ++m) acc += __int_as_float(s[2 * m + hi][r]);
+                    Pp[hi][r] = acc;
+                }
+            if (nv > 24 && g < 2) {                // vector 24 = keys 192 .. 199 -> partials 0 .. 7 (lanes g = 0, 1; hi = 0)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Pp[0][r] += e12[r];
+            }
+            float fin = 0.0f;
+#pragma unroll
+            for (int gp = 0; gp < 4; ++gp)         // scalar tail: keys 8 nv .. T - 1 in order
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = 192 + 4 * gp + r;
+                    const float val = __shfl(e12[r], (gp << 4) | l15);
+                    if (key >= 8 * nv && key < T) fin += val;
+                }
+            float A[4][2][4];
+#pragma unroll
+            for (int gp = 0; gp < 4; ++gp)
+#pragma unroll
+                for (int hi = 0; hi < 2; ++hi)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) A[gp][hi][r] = __shfl(Pp[hi][r], (gp << 4) | l15);
+#pragma unroll
+            for (int l = 0; l < 8; ++l) {
+                const int gm = l >> 2, r = l & 3;
+                const float v = ((A[gm][0][r] + A[2 + gm][0][r]) + A[gm][1][r]) + A[2 + gm][1][r];
+                fin += v;
+            }
+            esum = (unsigned)__float_as_int(fin);   // carried as bits to the common code below
         } else if constexpr (MODE == 2) {      // one L2-resident gather per score instead of the LDS lookup
             const unsigned* row2d = a.exp2d + ((rmax + 128) << 8) + 128;       // entry of q = -nk
 #pragma unroll
@@ -216,26 +280,45 @@ __global__ __launch_bounds__(NT, 3) void attention_kernel(AttnArgs a)
                 s[kt][r] = (int)ef;       // float32 bit pattern of the exponent
                 esum += e;
             }
-        constexpr bool ef_is_float = MODE == 0;
-        esum += __shfl_xor(esum, 16);
-        esum += __shfl_xor(esum, 32);
-        float S = (float)esum;                                     // exp_int.sum (:171)
-        S = fminf(S, 2147483648.0f);                               // clamp_max_(2**31-1) in float32 (:173)
-        const float factor = floorf((1.0f / S) * 2147483648.0f);   // (:174)
+        constexpr bool ef_is_float = MODE == 0 || MODE == 3;
+        float factor;
+        if constexpr (MODE == 3) {
+            factor = floorf(4294967296.0f / __int_as_float((int)esum));        // ibert_modules.py:313
+        } else {
+            esum += __shfl_xor(esum, 16);
+            esum += __shfl_xor(esum, 32);
+            float S = (float)esum;                                     // exp_int.sum (:171)
+            S = fminf(S, 2147483648.0f);                               // clamp_max_(2**31-1) in float32 (:173)
+            factor = floorf((1.0f / S) * 2147483648.0f);               // (:174)
+        }
 
         // packed probabilities: dword t of key step ks = bytes r = 0..3 of key tile 4ks + t
         v4i pk[NKS];
+        v4i pkh[MODE == 3 ? NKS : 1];      // I-BERT: probabilities reach 128 (a one-hot row): 128 = 127 + 1, the 1 in a second operand
+        bool any_hi = false;
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 unsigned w = 0;
+                if constexpr (MODE == 3) pkh[ks][t] = 0;
                 if (4 * ks + t < NKT) {
                     unsigned p[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float ev = ef_is_float ? __int_as_float(s[4 * ks + t][r]) : (float)(unsigned)s[4 * ks + t][r];
-                        p[r] = (unsigned)(ev * factor);  // float32 product (:175), < 2^31
+                        if constexpr (MODE == 3) {
+                            // floor(fl32(e * factor) / 2^25) in [0, 128] (ibert_modules.py:314, output_bit = 8), kept in the
+                            // top byte like the Shiftmax form below: min(., 127) << 24, the overflow bit separately
+                            const unsigned pi = (unsigned)((ev * factor) * 2.98023223876953125e-08f);
+                            p[r] = min(pi, 127u) << 24;
+                            if (pi > 127u) {
+                                any_hi = true;
+                                pkh[ks][t] |= 1 << (8 * r);
+                            }
+                        } else {
+                            p[r] = (unsigned)(ev * factor);  // float32 product (:175), < 2^31
+                        }
                     }
                     // floor(. / 2^24) = the top byte of each product: gather the four top bytes with two byte permutes
                     const unsigned lo = __builtin_amdgcn_perm(p[1], p[0], 0x0c0c0703u);  // [p0.b3, p1.b3, 0, 0]
@@ -245,6 +328,7 @@ __global__ __launch_bounds__(NT, 3) void attention_kernel(AttnArgs a)
                 pk[ks][t] = (int)w;
             }
 
+        const bool hi_pass = MODE == 3 && __builtin_amdgcn_ballot_w64(any_hi) != 0;   // wave-uniform, almost never
         // ---- O^T = Vt . P^T, requantised (attn.qact2), 4 consecutive d per dword
         const int64_t orow_idx = (int64_t)b * T + qrow;
         const BlockRow obrow = block_row((int)orow_idx, a.heads * HD);
@@ -257,6 +341,8 @@ __global__ __launch_bounds__(NT, 3) void attention_kernel(AttnArgs a)
             for (int ks = 0; ks < NKS; ++ks) {
                 const v4i vf = *reinterpret_cast<const v4i*>(smem + K_BYTES + d * VT_ROW + (((4 * ks + g) ^ (d & 15)) << 4));
                 acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(vf, pk[ks], acc, 0, 0, 0);
+                if constexpr (MODE == 3)
+                    if (hi_pass) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(vf, pkh[ks], acc, 0, 0, 0);
             }
             if (qrow < T) {
                 unsigned w = 0;
@@ -314,7 +400,7 @@ IVIT_EXPORT int ivit_attention_fused_i8_compat_band(const int8_t* qkv, int8_t* o
     IVIT_REQUIRE((uintptr_t)exp2d % 4 == 0, "ivit_attention_fused_i8_compat: misaligned exponent table");
     IVIT_REQUIRE(band_w == 0 || (band && band_w >= 16 && band_w <= 256 && band_w % 16 == 0 && (uintptr_t)band % 16 == 0),
                  "ivit_attention_fused_i8_compat_band: band table must be 16-byte aligned, width a multiple of 16 in [16, 256]");
-    AttnArgs a;
+    AttnArgs a{};
     a.exp2d = exp2d;
     a.band = band;
     a.band_w = band_w;
@@ -340,6 +426,31 @@ IVIT_EXPORT int ivit_attention_fused_i8_compat_band(const int8_t* qkv, int8_t* o
     else if (exp2d) hipLaunchKernelGGL(attention_kernel<2>, dim3(batch * heads), dim3(NT), 0, ivit_stream(stream), a);
     else hipLaunchKernelGGL(attention_kernel<0>, dim3(batch * heads), dim3(NT), 0, ivit_stream(stream), a);
     IVIT_CHECK_LAUNCH("ivit_attention_fused_i8");
+}
+
+IVIT_EXPORT int ivit_attention_fused_i8_ibert(const int8_t* qkv, int8_t* out, int batch, int heads, int tokens, int head_dim,
+                                              uint32_t m_s, int32_t e_s, uint32_t m_o, int32_t e_o, const float* table,
+                                              int out_blocks, ivit_stream_t stream)
+{
+    IVIT_REQUIRE(qkv && out && table && batch > 0 && heads > 0, "ivit_attention_fused_i8_ibert: bad operand");
+    if (head_dim != HD || tokens <= 16 * (NKT - 1) || tokens >= KP) {
+        ivit_set_error("ivit_attention_fused_i8_ibert: unsupported geometry head_dim=%d tokens=%d (need 64, 193..207)", head_dim, tokens);
+        return IVIT_ERR_UNSUPPORTED;
+    }
+    IVIT_REQUIRE(((uintptr_t)qkv % 16 == 0) && ((uintptr_t)out % 4 == 0) && ((uintptr_t)table % 4 == 0),
+                 "ivit_attention_fused_i8_ibert: misaligned operand");
+    IVIT_REQUIRE(out_blocks == 0 || (out_blocks == 1 && ((uintptr_t)out % 16 == 0) &&
+                                     ((int64_t)batch * tokens + 15) * heads * head_dim < 2147483648ll),
+                 "ivit_attention_fused_i8_ibert: bad output layout (block-layout buffers stay below 2 GiB)");
+    AttnArgs a{};
+    a.ib_table = table;
+    a.out_blocks = out_blocks;
+    a.qkv = qkv; a.out = out; a.batch = batch; a.heads = heads; a.tokens = tokens;
+    a.Ms = ivit_dyadic_to_double(m_s, e_s);
+    a.Mo = ivit_dyadic_to_double(m_o, e_o);
+    IVIT_REQUIRE(a.Ms < 2048.0 && a.Mo < 512.0, "ivit_attention_fused_i8_ibert: requant multiplier too large");
+    hipLaunchKernelGGL(attention_kernel<3>, dim3(batch * heads), dim3(NT), 0, ivit_stream(stream), a);
+    IVIT_CHECK_LAUNCH("ivit_attention_fused_i8_ibert");
 }
 
 IVIT_EXPORT int ivit_attention_fused_i8(const int8_t* qkv, int8_t* out, int batch, int heads, int tokens,

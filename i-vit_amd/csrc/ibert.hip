@@ -233,6 +233,103 @@ __global__ __launch_bounds__(NT) void ibert_softmax_f32_kernel(IbSoftmaxLitArgs 
     }
 }
 
+// ------------------------------------------------------------------------------------------------ fused-engine forms
+// The integer engine (engine.py, family "ibert") keeps int8 activations between kernels.  Every value the reference's float
+// tensors hold at an operator's input is fl(q * s) for the int8 q the engine carries, so each operator below performs the
+// literal float32 sequence of the *_f32 kernels above on fl(q * s) -- any scale, power of two or as calibrated -- and fuses
+// the QuantAct that follows (quant_utils.py:220-245: z = round(x / s_pre), RNE(float64(z) * m / 2^e), clamp).
+
+// GELU + mlp.qact1 is a function of q alone: 256 entries, written as all 256 rows of the (row max, q) table that
+// ivit_shiftgelu_lut_i8 reads, so the same gather kernel applies it.
+__global__ __launch_bounds__(NT) void ibert_gelu_lut_kernel(float s, float b_int, float c_int, float shift_int, float s_out, double Mq,
+                                                            int8_t* lut)
+{
+    const int q = (int)threadIdx.x - 128;                 // NT == 256
+    const float x = (float)q * s;                         // the float the reference's tensor holds
+    const float xi = x / s;                               // :226
+    const float sgn = (xi > 0.0f) ? 1.0f : ((xi < 0.0f) ? -1.0f : 0.0f);
+    const float a = fminf(fabsf(xi), -b_int);
+    const float t = a + b_int;
+    float y = t * t;
+    y = y + c_int;
+    y = sgn * y;
+    y = floorf(y / 64.0f);
+    const float p = xi * (y + shift_int);
+    const float g = (p == 0.0f ? 0.0f : p) * s_out;       // IBERTIntGELU output (float view)
+    const float z = rintf(g / s_out);                     // QuantAct: quant_utils.py:220
+    // s_out is negative (coeff[0] < 0, :213): requant(z, s) == requant(-z, -s) exactly, Mq is the multiplier of |s_out|
+    double r = __builtin_rint((s_out < 0.0f ? -(double)z : (double)z) * Mq);
+    r = fmin(fmax(r, -128.0), 127.0);
+    const int8_t v = (int8_t)(int)r;
+    for (int row = 0; row < 256; ++row) lut[row * 256 + threadIdx.x] = v;
+}
+
+// Softmax: exp_int after the internal QuantAct(16), as the float the reference sums and multiplies (:306-310), for every
+// (row max qm, q <= qm): table[(qm + 128) * 256 + (q + 128)]; 0 for q > qm.
+__global__ __launch_bounds__(NT) void ibert_softmax_table_kernel(float s, IbSoftmaxArgs c, float* table)
+{
+    const int idx = blockIdx.x * NT + threadIdx.x;     // 65536 entries
+    const int qm = (idx >> 8) - 128, q = (idx & 255) - 128;
+    float ef = 0.0f;
+    if (q <= qm) {
+        const float xm = ((float)qm * s) / s, xq = ((float)q * s) / s;       // :303
+        const float e = ib_exp_int(xq - xm, c);                              // :305-307
+        const float z_int = rintf(e / c.exp_sf);                             // :308
+        double q16 = __builtin_rint((double)z_int * c.M);
+        q16 = fmin(fmax(q16, -32768.0), 32767.0);
+        ef = ((float)q16 * c.act_sf) / c.act_sf;                             // :309-310
+    }
+    table[idx] = ef;
+}
+
+// LayerNorm (ibert_modules.py:126-153) on int8 rows at scale s_in + the QuantAct behind it; one wave per row.
+struct IbLnI8Args {
+    const int8_t* x;
+    int64_t ldx;
+    int rows, C;
+    float s_in;
+    const float* bias_int;
+    const float* s_out;     // sf * gamma[c]
+    float shift_pow2;
+    const uint32_t* m;      // QuantAct: dyadic(s_out[c] / s_next)
+    const int32_t* e;
+    int8_t* out;
+    int64_t ldo;
+    int out_blocks;
+};
+
+__global__ __launch_bounds__(NT) void ibert_layernorm_i8_kernel(IbLnI8Args a)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int C = a.C;
+    for (int row = blockIdx.x * WPB + wave; row < a.rows; row += gridDim.x * WPB) {
+        const int8_t* xr = a.x + (int64_t)row * a.ldx;
+        auto xint = [&](int c) { return ((float)xr[c] * a.s_in) / a.s_in; };                  // :126 on fl(q * s)
+        const float mean_int = rintf(torch_rowsum(xint, C, lane) / (float)C);                 // :127
+        auto sq = [&](int c) {
+            const float ys = floorf((xint(c) - mean_int) / a.shift_pow2);                     // :128-129
+            return ys * ys;                                                                   // :130
+        };
+        const float var_int = torch_rowsum(sq, C, lane);                                      // :131
+        const float std_int = floorf(sqrtf(var_int)) * a.shift_pow2;                          // :142
+        const float factor = floorf(2147483648.0f / std_int);                                 // :143
+        const BlockRow brow = block_row(row, C);
+        for (int c = lane; c < C; c += 64) {
+            const float y = xint(c) - mean_int;
+            float v = floorf((y * factor) / 2.0f);                                            // :144
+            v = v + a.bias_int[c];                                                            // :151
+            const float so = a.s_out[c];
+            const float xo = v * so;                                                          // :153
+            const float z = rintf(xo / so);                                                   // quant_utils.py:220
+            double r = __builtin_rint((double)z * dyadic_mult(a.m[c], a.e[c]));               // :229-230
+            r = fmin(fmax(r, -128.0), 127.0);
+            const int8_t o = (int8_t)(int)r;
+            if (a.out_blocks) a.out[block_off(brow, block_col(c))] = o;
+            else a.out[(int64_t)row * a.ldo + c] = o;
+        }
+    }
+}
+
 struct IbLnLitArgs {
     const float* x;
     int64_t ldx;
@@ -353,4 +450,38 @@ IVIT_EXPORT int ivit_ibert_layernorm_f32_f32(const float* x, int64_t ldx, int ro
     IbLnLitArgs a{x, ldx, rows, C, s_in, n_s, bias_int, s_out, shift_pow2, out, ldo};
     hipLaunchKernelGGL(ibert_layernorm_f32_kernel, dim3(grid_for_rows(rows)), dim3(NT), 0, ivit_stream(stream), a);
     IVIT_CHECK_LAUNCH("ivit_ibert_layernorm_f32_f32");
+}
+
+IVIT_EXPORT int ivit_ibert_gelu_build_lut(float s, float b_int, float c_int, float shift_int, float s_out, uint32_t m_q, int32_t e_q,
+                                          int8_t* lut, ivit_stream_t stream)
+{
+    IVIT_REQUIRE(lut && s != 0.0f && s_out != 0.0f && b_int < 0.0f, "ivit_ibert_gelu_build_lut: bad operand");
+    hipLaunchKernelGGL(ibert_gelu_lut_kernel, dim3(1), dim3(NT), 0, ivit_stream(stream), s, b_int, c_int, shift_int, s_out,
+                       ivit_dyadic_to_double(m_q, e_q), lut);
+    IVIT_CHECK_LAUNCH("ivit_ibert_gelu_build_lut");
+}
+
+IVIT_EXPORT int ivit_ibert_softmax_build_table(float s, float x0_int, float b_int, float c_int, float exp_sf, float act_sf,
+                                               uint32_t m_act, int32_t e_act, float* table, ivit_stream_t stream)
+{
+    IVIT_REQUIRE(table && s > 0.0f && x0_int < 0.0f && exp_sf > 0.0f && act_sf > 0.0f, "ivit_ibert_softmax_build_table: bad operand");
+    IbSoftmaxArgs c{};
+    c.x0_int = x0_int; c.b_int = b_int; c.c_int = c_int; c.exp_sf = exp_sf; c.act_sf = act_sf;
+    c.M = ivit_dyadic_to_double(m_act, e_act);
+    hipLaunchKernelGGL(ibert_softmax_table_kernel, dim3(65536 / NT), dim3(NT), 0, ivit_stream(stream), s, c, table);
+    IVIT_CHECK_LAUNCH("ivit_ibert_softmax_build_table");
+}
+
+IVIT_EXPORT int ivit_ibert_layernorm_i8(const int8_t* x, int64_t ldx, int rows, int C, float s_in, const float* bias_int,
+                                        const float* s_out, float shift_pow2, const uint32_t* m, const int32_t* e, int8_t* out,
+                                        int64_t ldo, int out_blocks, ivit_stream_t stream)
+{
+    IVIT_REQUIRE(x && out && bias_int && s_out && m && e && rows > 0 && C > 0 && ldx >= C && ldo >= C && s_in > 0.0f,
+                 "ivit_ibert_layernorm_i8: bad operand");
+    IVIT_REQUIRE(shift_pow2 >= 1.0f, "ivit_ibert_layernorm_i8: shift_pow2 = 2^shift must be >= 1");
+    IVIT_REQUIRE(out_blocks == 0 || (out_blocks == 1 && C % 64 == 0 && ldo == C && ((int64_t)rows + 15) * C < 2147483648ll),
+                 "ivit_ibert_layernorm_i8: block-layout output needs C %% 64 == 0, ldo == C and a buffer below 2 GiB");
+    IbLnI8Args a{x, ldx, rows, C, s_in, bias_int, s_out, shift_pow2, m, e, out, ldo, out_blocks};
+    hipLaunchKernelGGL(ibert_layernorm_i8_kernel, dim3(grid_for_rows(rows)), dim3(NT), 0, ivit_stream(stream), a);
+    IVIT_CHECK_LAUNCH("ivit_ibert_layernorm_i8");
 }

@@ -34,11 +34,16 @@ def _np(v):
 
 class IntViTEngine(GraphReplay):
     def __init__(self, float_state=None, ranges=None, embed_dim: int = 768, depth: int = 12, num_heads: int = 12,
-                 device="cuda:0", max_batch: int = 256, source=None):
+                 device="cuda:0", max_batch: int = 256, source=None, family: str = "ivit"):
         """float_state: name -> float32 array (the reference's state_dict names, SURVEY Appendix D);
         ranges: QuantAct name -> (x_min, x_max) of the frozen model.  Alternatively `source`: any object with the
         FloatSource interface of export.py (e.g. export.ExportSource: integer parameters + scale table, no floats)."""
         self.C, self.D, self.H = embed_dim, depth, num_heads
+        # operator family of LayerNorm / Softmax / GELU: "ivit" (I-ViT: IVITIntLayerNorm, Shiftmax, ShiftGELU) or "ibert" (the
+        # fork's default, ibert_modules.py: literal float32 sequences on fl(q * s), any activation scale)
+        if family not in ("ivit", "ibert"):
+            raise ValueError(f"operator family {family!r}: the fused engine implements 'ivit' and 'ibert'")
+        self.family = family
         self.hd = embed_dim // num_heads
         if self.hd != 64:
             raise ValueError("fused attention kernel supports head_dim 64 only")
@@ -73,12 +78,26 @@ class IntViTEngine(GraphReplay):
 
         def ln_dev(prefix, s_out, s_in):
             lp = source.layernorm(prefix, s_out)
+            if family == "ibert":
+                # IBERTIntLayerNorm has the same per-channel constants (bias_int, s_out = sqrt(C) / 2^30 * gamma,
+                # ibert_modules.py:145-153) and an overflow shift buffer (:134-137); the kernel works on fl(q * s_in) literally
+                try:
+                    shift = float(np.asarray(source.tensor(prefix + ".shift")).reshape(-1)[0])
+                except KeyError:
+                    shift = 0.0
+                return dict(kind="ibert", bias=dev(lp.bias_int), s=dev(lp.s_ln), m=dev(lp.m.view(np.int32)), e=dev(lp.e),
+                            s_in=float(s_in), shift_pow2=float(2.0 ** shift), remap=None, phi=None)
             remap, phi = phi_dev(s_in)
             return dict(bias=dev(lp.bias_int), s=dev(lp.s_ln), m=dev(lp.m.view(np.int32)), e=dev(lp.e), remap=remap, phi=phi)
 
         def scalar_me(pre, z):
             m, e = dyadic(pre, z)
             return int(m[0]), int(e[0])
+
+        def ranges_of(name):
+            if ranges is None or name not in ranges:
+                raise KeyError(f"the 'ibert' engine needs the range of {name} (the softmax's internal 16-bit QuantAct)")
+            return float(ranges[name][0]), float(ranges[name][1])
 
         self.natural_sites = 0     # operators whose input scale is not a power of two (compat kernels / tables)
         # ---- stem
@@ -113,7 +132,17 @@ class IntViTEngine(GraphReplay):
             s_pv = f32(f32(1.0 / 128.0) * s_a1)                           # Shiftmax scale 2^-7 x value scale
             s_a2 = s(p + "attn.qact2")
             blk["attn"] = dict(ms=scalar_me(s_S, s_at), s_attn=float(s_at), mo=scalar_me(s_pv, s_a2), exp2d=None, band=None, band_w=0)
-            if phi_tables(s_at) is not None:       # Shiftmax on phi(q): exponent tabulated over (row max, q)
+            if family == "ibert":
+                # IBERTIntSoftmax (output_bit 8, scale 2 / 2^8 = 2^-7 like Shiftmax's): exp_int after its internal 16-bit
+                # QuantAct, tabulated over (row max, q) with the reference's float32 sequence (csrc/ibert.hip)
+                from .quantization_utils.ibert_modules import softmax_constants
+                lo, hi = ranges_of(p + "attn.int_softmax.act")
+                x0i, bi, ci, exp_sf, act_sf, ma, ea = softmax_constants(s_at, lo, hi)
+                tab = torch.empty(65536, dtype=torch.float32, device=self.dev)
+                _lib.call("ivit_ibert_softmax_build_table", float(s_at), x0i, bi, ci, float(exp_sf), float(act_sf), ma, ea,
+                          _lib.ptr(tab), self._stream())
+                blk["attn"]["ib_table"] = tab
+            elif phi_tables(s_at) is not None:       # Shiftmax on phi(q): exponent tabulated over (row max, q)
                 self.natural_sites += 1
                 tab = shiftexp2d(s_at)
                 band, bw = shiftexp_band(tab)
@@ -129,12 +158,20 @@ class IntViTEngine(GraphReplay):
             blk["ln2"] = ln_dev(p + "norm2", s_b3, s_b2)
             s_g = s(p + "mlp.qact_gelu")
             blk["fc1"] = lin_dev(source.linear(p + "mlp.fc1", s_b3), s_g)
-            s_go = f32(s_g * f32(1.0 / 128.0))                             # ivit_modules.py:121,124
             s_m1 = s(p + "mlp.qact1")
-            mg, eg = scalar_me(s_go, s_m1)
             lut = torch.empty(65536, dtype=torch.int8, device=self.dev)
-            g_remap, _ = phi_dev(s_g)              # ShiftGELU sees trunc(phi(q)) (ivit_modules.py:106-107)
-            _lib.call("ivit_shiftgelu_build_lut_ex", float(s_g), mg, eg, _lib.ptr(g_remap), _lib.ptr(lut), self._stream())
+            if family == "ibert":
+                # IBERTIntGELU + mlp.qact1 depend on q alone: one 256-entry map, replicated over the table's row-max axis.  Its
+                # output scale is negative (ibert_modules.py:213, 232): requant(z, s) == requant(-z, -s) (quant_modules.QuantAct)
+                from .quantization_utils.ibert_modules import gelu_constants
+                gb, gc, gsh, gso = gelu_constants(s_g)
+                mg, eg = scalar_me(abs(f32(gso)), s_m1)
+                _lib.call("ivit_ibert_gelu_build_lut", float(s_g), gb, gc, gsh, float(gso), mg, eg, _lib.ptr(lut), self._stream())
+            else:
+                s_go = f32(s_g * f32(1.0 / 128.0))                             # ivit_modules.py:121,124
+                mg, eg = scalar_me(s_go, s_m1)
+                g_remap, _ = phi_dev(s_g)              # ShiftGELU sees trunc(phi(q)) (ivit_modules.py:106-107)
+                _lib.call("ivit_shiftgelu_build_lut_ex", float(s_g), mg, eg, _lib.ptr(g_remap), _lib.ptr(lut), self._stream())
             blk["gelu_lut"] = lut
             s_m2 = s(p + "mlp.qact2")
             blk["fc2"] = lin_dev(source.linear(p + "mlp.fc2", s_m1), s_m2)
@@ -244,6 +281,10 @@ class IntViTEngine(GraphReplay):
 
     def _ln(self, x, ldx, rows, ln, out, st, blocks=False):
         C = self.C
+        if ln.get("kind") == "ibert":
+            _lib.call("ivit_ibert_layernorm_i8", _lib.ptr(x), ldx, rows, C, ln["s_in"], _lib.ptr(ln["bias"]), _lib.ptr(ln["s"]),
+                      ln["shift_pow2"], _lib.ptr(ln["m"]), _lib.ptr(ln["e"]), _lib.ptr(out), C, int(blocks), st)
+            return
         if ln["remap"] is not None:
             _lib.call("ivit_layernorm_i8_compat", _lib.ptr(x), ldx, rows, C, _lib.ptr(ln["bias"]), _lib.ptr(ln["s"]),
                       _lib.ptr(ln["m"]), _lib.ptr(ln["e"]), _lib.ptr(ln["remap"]), _lib.ptr(ln["phi"]), _lib.ptr(out), C,
@@ -296,9 +337,13 @@ class IntViTEngine(GraphReplay):
                       _lib.ptr(q["m"]), _lib.ptr(q["e"]), _lib.ptr(ws["qkv"]), T, H, hd, M, 3 * C, C, qlay | int(a_ln), st)
             tap(p + "attn.qkv_headmajor", ws["qkv"], (3, B, H, T, hd))
             a = blk["attn"]
-            _lib.call("ivit_attention_fused_i8_compat_band", _lib.ptr(ws["qkv"]), _lib.ptr(ws["ao"]), B, H, T, hd,
-                      a["ms"][0], a["ms"][1], a["s_attn"], a["mo"][0], a["mo"][1], _lib.ptr(a["exp2d"]), _lib.ptr(a["band"]),
-                      a["band_w"], int(a_at), st)
+            if self.family == "ibert":
+                _lib.call("ivit_attention_fused_i8_ibert", _lib.ptr(ws["qkv"]), _lib.ptr(ws["ao"]), B, H, T, hd,
+                          a["ms"][0], a["ms"][1], a["mo"][0], a["mo"][1], _lib.ptr(a["ib_table"]), int(a_at), st)
+            else:
+                _lib.call("ivit_attention_fused_i8_compat_band", _lib.ptr(ws["qkv"]), _lib.ptr(ws["ao"]), B, H, T, hd,
+                          a["ms"][0], a["ms"][1], a["s_attn"], a["mo"][0], a["mo"][1], _lib.ptr(a["exp2d"]), _lib.ptr(a["band"]),
+                          a["band_w"], int(a_at), st)
             tap(p + "attn.qact2", ws["ao"], (B, T, C), a_at)
             self._gemm_res(ws["ao"], C, blk["proj"], x, blk["res1"], x2, M, st, blocks=blk_l, a_blocks=a_at)
             tap(p + "qact2", x2, (B, T, C))

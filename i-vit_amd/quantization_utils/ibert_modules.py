@@ -19,6 +19,37 @@ from ..prepare import EPS32, dyadic, f32
 from .quant_modules import QuantAct, _dev_table, _st, to_float, to_int32
 
 
+# ---- host-side scalar constants of the operators, float32 with the reference's own sequence of operations; shared by the
+#      modules below and by the fused engine (engine.py, family "ibert")
+_GELU_K, _GELU_N = 1.4142, 6
+_GELU_COEFF = (-0.2888, -1.769, 1 / -0.2888)          # :172-175 (coeff[2] /= coeff[0])
+_SM_X0, _SM_N = -0.6931, 30
+_SM_COEF = (0.35815147, 0.96963238 / 0.35815147, 1.0 / 0.35815147)   # :253-257
+
+
+def gelu_constants(s):
+    """(b_int, c_int, shift_int, s_out) in float32, ibert_modules.py:205-206, 214-216, 229, 232."""
+    s = f32(s)
+    sf = f32(s / f32(_GELU_K))
+    b_int = np.floor(f32(f32(_GELU_COEFF[1]) / sf))
+    c_int = np.floor(f32(f32(_GELU_COEFF[2]) / f32(sf * sf)))
+    sf2 = f32(f32(f32(sf * sf) * f32(_GELU_COEFF[0])) * f32(2 ** _GELU_N))
+    shift_int = np.floor(f32(f32(1.0) / sf2))
+    return float(b_int), float(c_int), float(shift_int), f32(f32(s * sf2) / f32(2))
+
+
+def softmax_constants(s, lo, hi):
+    """(x0_int, b_int, c_int, exp_sf, act_sf, m, e): :277-294 and the internal 16-bit QuantAct (range lo..hi) of :308."""
+    s = f32(s)
+    x0_int = np.floor(f32(f32(_SM_X0) / s))                                    # :287
+    b_int = np.floor(f32(f32(_SM_COEF[1]) / s))                                # :277
+    c_int = np.floor(f32(f32(_SM_COEF[2]) / f32(s * s)))                       # :278
+    exp_sf = f32(f32(f32(_SM_COEF[0]) * f32(s * s)) / f32(2 ** _SM_N))         # :282, 294
+    act_sf = max(f32(f32(max(-f32(lo), f32(hi))) / f32(2 ** 15 - 1)), f32(EPS32))   # quant_utils.py:52-70, 16 bit
+    m, e = dyadic(exp_sf, act_sf)
+    return float(x0_int), float(b_int), float(c_int), exp_sf, act_sf, int(m[0]), int(e[0])
+
+
 def _check_mode(quant_mode, force_dequant, what):
     if quant_mode != "symmetric" or force_dequant in ("nonlinear", what):
         raise NotImplementedError(f"IBERT {what}: only the integer (quant_mode='symmetric') form runs on the MI355X path")

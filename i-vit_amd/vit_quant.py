@@ -153,15 +153,17 @@ class VisionTransformer(EngineDispatch, nn.Module):
     # ---------------------------------------------------------------- fused engine path (dispatch.py)
     def engine_unsupported_reason(self):
         """None when the fused int8 engine computes exactly what this module tree would; else why not."""
-        if any(t != "ivit" for t in self.op_types):
-            return f"operator family {self.op_types} (fused engine: I-ViT operators)"
+        if len(set(self.op_types)) != 1 or self.op_types[0] not in ("ivit", "ibert"):
+            return f"operator family {self.op_types} (fused engine: all three operators 'ivit', or all three 'ibert')"
         if self.embed_dim // self.num_heads != 64 or self.embed_dim % 64:
             return "head_dim != 64"
         if self.geometry != (224, 16, 3, 4.0, True, None):
             return f"geometry {self.geometry} (fused engine: 224x224, patch 16, 3 channels, mlp_ratio 4, qkv bias)"
         if self.num_classes <= 0:
             return "no classification head"
-        bad = self._width_mismatch({})          # every QuantAct of the DeiT / ViT engine is 8 bit
+        # every QuantAct of the DeiT / ViT engine is 8 bit, except the 16-bit one inside IBERTIntSoftmax (ibert_modules.py:247)
+        inner = {f"blocks.{i}.attn.int_softmax.act": 16 for i in range(self.depth)} if self.op_types[0] == "ibert" else {}
+        bad = self._width_mismatch(inner)
         if bad:
             return bad
         a, m = self.blocks[0].attn.int_softmax, self.blocks[0].mlp.act
@@ -172,7 +174,7 @@ class VisionTransformer(EngineDispatch, nn.Module):
     def _build_engine(self, device, max_batch):
         from .engine import IntViTEngine
         return IntViTEngine(dict(self.state_dict()), self.ranges(), self.embed_dim, self.depth, self.num_heads,
-                            device=device, max_batch=max_batch)
+                            device=device, max_batch=max_batch, family=self.op_types[0])
 
     def forward(self, x):
         if self.takes_engine(x):

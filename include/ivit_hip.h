@@ -437,6 +437,27 @@ int ivit_ibert_layernorm_f32_f32(const float* x, int64_t ldx, int rows, int C, c
                                  const float* bias_int, const float* s_out, float shift_pow2, float* out, int64_t ldo,
                                  ivit_stream_t stream);
 
+/* ---- the I-BERT family inside the fused int8 engine (engine.py, family "ibert"; ibert_modules.py:12-319) ---------------
+ * int8 activations in and out; every operator runs the reference's float32 sequence on fl(q * s) (what its float tensors hold)
+ * and fuses the QuantAct behind it, so power-of-two scales and scales as calibrated are covered alike.
+ *  - ivit_ibert_gelu_build_lut: IBERTIntGELU (:203-235) + the 8-bit QuantAct `mlp.qact1` as a function of q, written as all
+ *    256 rows of a (row max, q) table: ivit_shiftgelu_lut_i8(_ex) applies it.  (m_q, e_q) = dyadic(s_out / s_next).
+ *  - ivit_ibert_softmax_build_table: exp_int after the softmax's internal 16-bit QuantAct (:303-310) as the float32 the
+ *    reference sums and multiplies, for every (row max qm, q <= qm): table[(qm + 128) * 256 + q + 128], 65 536 floats.
+ *  - ivit_attention_fused_i8_ibert: ivit_attention_fused_i8 with that softmax: row sum in float32 in torch's CPU reduction
+ *    order, factor = floor(2^32 / sum), p = floor(fl(e * factor) / 2^25) in [0, 128] (output_bit 8, scale 2^-7).  tokens 193..207.
+ *  - ivit_ibert_layernorm_i8: IBERTIntLayerNorm (:126-153; mean and variance sums in torch's order) + the QuantAct behind it.
+ *    bias_int / s_out / (m, e) as for ivit_layernorm_i8; shift_pow2 = 2^shift (the module's overflow buffer). */
+int ivit_ibert_gelu_build_lut(float s, float b_int, float c_int, float shift_int, float s_out, uint32_t m_q, int32_t e_q,
+                              int8_t* lut, ivit_stream_t stream);
+int ivit_ibert_softmax_build_table(float s, float x0_int, float b_int, float c_int, float exp_sf, float act_sf, uint32_t m_act,
+                                   int32_t e_act, float* table, ivit_stream_t stream);
+int ivit_attention_fused_i8_ibert(const int8_t* qkv, int8_t* out, int batch, int heads, int tokens, int head_dim, uint32_t m_s,
+                                  int32_t e_s, uint32_t m_o, int32_t e_o, const float* table, int out_blocks, ivit_stream_t stream);
+int ivit_ibert_layernorm_i8(const int8_t* x, int64_t ldx, int rows, int C, float s_in, const float* bias_int, const float* s_out,
+                            float shift_pow2, const uint32_t* m, const int32_t* e, int8_t* out, int64_t ldo, int out_blocks,
+                            ivit_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

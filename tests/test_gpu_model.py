@@ -49,6 +49,28 @@ def test_golden_logits_and_taps(tag):
     assert np.array_equal(t1.cpu().numpy().astype(np.int64), z["top1"])
 
 
+@pytest.mark.parametrize("tag", ["deit_tiny_ibert", "deit_tiny_ibert_natural"])
+def test_ibert_engine_golden_logits_and_taps(tag):
+    """the fork's default operator family (I-BERT GELU / Softmax / LayerNorm) in the fused engine, power-of-two ranges and
+    ranges as calibrated: every QuantAct tap, INT32 logits and top-1 of the REFERENCE"""
+    fs, ranges, cfg, meta, z = load_synthetic_model(tag)
+    eng = IntViTEngine(fs, ranges, cfg["embed_dim"], cfg["depth"], cfg["num_heads"], device=DEV, max_batch=4, family="ibert")
+    n = meta["n_images"]
+    imgs = torch.from_numpy(synth.make_images(n, meta["image_seed"])).to(DEV)
+    taps = {}
+    li, lf, t1 = eng.forward(imgs, taps)
+    torch.cuda.synchronize()
+    gold = dict(zip([str(x) for x in z["tap_names"]], z["tap_crc32"]))
+    bad = [name for name, t in taps.items() if name in gold and crc(t.cpu().numpy().astype(np.int32)) != int(gold[name])]
+    checked = sum(1 for name in taps if name in gold)
+    assert not bad, (bad[:5], checked)
+    assert checked == 7 * cfg["depth"] + 3
+    assert np.array_equal(li.cpu().numpy(), z["logits_int32"]), f"{tag}: INT32 logits differ"
+    assert np.array_equal(t1.cpu().numpy().astype(np.int64), z["top1"])
+    if "regime" not in meta:
+        assert np.array_equal(lf.cpu().numpy().view(np.int32), z["logits_f32_bits"])
+
+
 def meta_batch(tag):
     return {"deit_tiny": 8, "deit_small": 4, "deit_base": 4, "vit_base": 2}[tag]
 

@@ -367,10 +367,44 @@ def test_ibert_model_module_path_matches_reference_golden():
     model, meta, z = load_model("deit_tiny_ibert")
     assert meta["family"] == "ibert" and type(model.blocks[0].attn.int_softmax).__name__ == "IBERTIntSoftmax"
     imgs = torch.from_numpy(synth.make_images(2, meta["image_seed"])).to(DEV)
+    assert model.engine_unsupported_reason() is None and model.takes_engine(imgs)
     with torch.no_grad():
-        y = model(imgs)             # no fused engine for this family: module by module
+        ye = model(imgs)            # default: the fused engine (family "ibert")
+        model.use_engine = False
+        y = model(imgs)             # module by module
     assert np.array_equal(bits(y), z["logits_f32_bits"][:2])
     assert np.array_equal(y.argmax(dim=1).cpu().numpy(), z["top1"][:2])
+    assert np.array_equal(bits(ye), bits(y))
+
+
+@pytest.mark.parametrize("regime", ["pow2", "natural"])
+def test_ibert_engine_equals_module_path_deit_small_width(regime):
+    """a wider I-BERT model than the reference fixtures cover (DeiT-S: C = 384, 6 heads; 12 fresh images; ranges calibrated
+    here, snapped to powers of two or left as calibrated): fused engine == module-by-module path, float logits bitwise"""
+    fs = synth.make_float_state("deit_small_patch16_224", 23)
+    model = ivit.deit_small_patch16_224(gelu_type="ibert", softmax_type="ibert", layernorm_type="ibert")
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in fs.items()}, strict=False)
+    model.to(DEV).eval()
+    with torch.no_grad():
+        model(torch.from_numpy(synth.make_images(4, 77)).to(DEV))         # calibration forward (running min / max)
+    if regime == "pow2":
+        for mod in model.modules():
+            if isinstance(mod, q.QuantAct):
+                qmax = 2 ** (mod.activation_bit - 1) - 1
+                a = max(-float(mod.x_min), float(mod.x_max)) / qmax
+                p = 2.0 ** np.ceil(np.log2(a))
+                mod.x_max.fill_(qmax * p)
+                mod.x_min.fill_(-qmax * p)
+    ivit.freeze_model(model)
+    imgs = torch.from_numpy(synth.make_images(12, 78)).to(DEV)
+    assert model.takes_engine(imgs), model.engine_unsupported_reason()
+    with torch.no_grad():
+        ye = model(imgs)
+        assert model.engine(12).family == "ibert"
+        model.use_engine = False
+        ym = model(imgs)
+    assert np.array_equal(bits(ye), bits(ym))
+    assert len(set(ym.argmax(dim=1).cpu().tolist())) > 1
 
 
 # ----------------------------------------------------------------------------------- engine dispatch (dispatch.py)
@@ -471,6 +505,7 @@ def test_ibert_natural_scale_module_path_matches_reference():
     import zlib
     model, meta, z = load_model("deit_tiny_ibert_natural")
     assert meta["family"] == "ibert" and meta["regime"] == "natural"
+    model.use_engine = False          # (the fused engine on this fixture: test_gpu_model.py)
     got = {}
 
     def hook(name):
