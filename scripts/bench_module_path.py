@@ -34,6 +34,11 @@ for fam in ("ivit", "ibert"):
     model.use_engine = False
     ms = timed(model)
     print(f"{fam:5s} module path  batch {B}: {ms:8.2f} ms / forward  ({B / ms * 1e3:8.0f} img/s)", flush=True)
-    if fam == "ivit":
-        model.use_engine = True
-        print(f"{fam:5s} engine       batch {B}: {timed(model):8.2f} ms / forward  (reason if not taken: {model.engine_unsupported_reason()})", flush=True)
+    model.use_engine = True
+    print(f"{fam:5s} engine       batch {B}: {timed(model, 10):8.2f} ms / forward  (reason if not taken: {model.engine_unsupported_reason()})", flush=True)
+    if os.environ.get("IVIT_KERNEL_SPLIT"):   # per-kernel time of the engine forward (torch profiler)
+        from torch.profiler import profile, ProfilerActivity
+        with torch.no_grad(), profile(activities=[ProfilerActivity.CUDA]) as prof:
+            model(imgs)
+            torch.cuda.synchronize()
+        print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=10, max_name_column_width=60), flush=True)
