@@ -65,7 +65,8 @@ constexpr int BAND_PAD = 4;   // dwords: keeps slice rows 16-byte aligned and ro
 IVIT_DEV int kswz(int r, int c) { return r * HD + (((c + 2 * ((r >> 2) & 1)) & 3) << 4); }
 
 // MODE 0: power-of-two input scale (256-entry table); 1: natural scale, band rows in LDS; 2: natural scale, full-table gather;
-// 3: the I-BERT softmax (ibert_modules.py:237-319) from its (row max, q) table, row sum in torch's float32 reduction order
+// 3 / 4: the I-BERT softmax (ibert_modules.py:237-319) from its (row max, q) table (3: gathered from global memory, 4: band rows
+// staged in LDS like mode 1), row sum in torch's float32 reduction order
 template <int MODE>
 __global__ __launch_bounds__(NT, 3) void attention_kernel(AttnArgs a)
 {
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(NT, 3) void attention_kernel(AttnArgs a)
     const int8_t* vg = qg + 2 * plane;
 
     // ---- Shiftmax exponent table: lut[i] = int_exp_shift(-i), i = kmax - k in [0,255]
-    if constexpr (MODE != 3) {
+    if constexpr (MODE < 3) {
         const unsigned e0 = shiftexp_int(-tid, a.x0, 15);
         reinterpret_cast<unsigned*>(smem + LUT_OFF)[tid] = e0;
         reinterpret_cast<float*>(smem + LUT_OFF)[256 + tid] = (float)e0;   // same address + 1 KB: one more ds_read, one cvt fewer per score
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(NT, 3) void attention_kernel(AttnArgs a)
                     esum += e;
                 }
             __builtin_amdgcn_wave_barrier();    // every lane has read its slice before the next tile overwrites it
-        } else if constexpr (MODE == 3) {
+        } else if constexpr (MODE >= 3) {
             // IBERTIntSoftmax: e = table[row max][q] (float32), S = e.sum() in float32 IN TORCH'S ORDER (ATen SumKernel, rowsum.h:
             // for 192 <= T < 208 the 32 partials p = key % 32 take their six elements key = p, p + 32, .. in turn, vectors of
             // keys 192.. join partials 0..7, the scalar tail goes first into the final accumulator, then the eight lane sums
@@ -196,20 +197,33 @@ __global__ __launch_bounds__(NT, 3) void attention_kernel(AttnArgs a)
             // sequence of its eight partials (hi = kt & 1, r): they are summed in registers, exchanged among the four lanes of
             // a query and combined by every lane alike.  The values are integers for a power-of-two range of the internal
             // QuantAct and fl(fl(k * s) / s) otherwise: the order matters then.
-            const float* row2d = a.ib_table + ((rmax + 128) << 8) + 128;       // entry of q = -nk
+            const float* row2d = a.ib_table + ((rmax + 128) << 8) + 128;       // mode 3: entry of q = -nk
+            const int W = a.band_w, stride = W + BAND_PAD;
+            const unsigned* slice = band_lds + (wave * 16 + l15) * stride;     // mode 4: this query's band row
+            if constexpr (MODE == 4) {
+                const uint4* src = reinterpret_cast<const uint4*>(a.band + (size_t)(rmax + 128) * W) + g * (W >> 4);
+                uint4* dst = reinterpret_cast<uint4*>(band_lds + (wave * 16 + l15) * stride) + g * (W >> 4);
+                for (int i = 0; i < (W >> 4); ++i) dst[i] = src[i];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
             float e12[4];
 #pragma unroll
             for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int nk = s[kt][r];
-                    float e = row2d[-min(nk, 128)];
+                    float e;
+                    if constexpr (MODE == 4) e = __int_as_float((int)slice[min(nk + rmax, W - 1)]);   // the 1000 sentinel clamps, too
+                    else e = row2d[-min(nk, 128)];
                     if (kt == NKT - 1) {
                         e = (nk == 1000) ? 0.0f : e;
                         e12[r] = e;
                     }
                     s[kt][r] = __float_as_int(e);
                 }
+            if constexpr (MODE == 4) __builtin_amdgcn_wave_barrier();    // every lane has read its slice before the next tile overwrites it
             const int nv = T >> 3;                 // 8-float vectors: 24 or 25 (the launcher keeps T < 208)
             float Pp[2][4];
 #pragma unroll
@@ -280,9 +294,9 @@ __global__ __launch_bounds__(NT, 3) void attention_kernel(AttnArgs a)
                 s[kt][r] = (int)ef;       // float32 bit pattern of the exponent
                 esum += e;
             }
-        constexpr bool ef_is_float = MODE == 0 || MODE == 3;
+        constexpr bool ef_is_float = MODE == 0 || MODE >= 3;
         float factor;
-        if constexpr (MODE == 3) {
+        if constexpr (MODE >= 3) {
             factor = floorf(4294967296.0f / __int_as_float((int)esum));        // ibert_modules.py:313
         } else {
             esum += __shfl_xor(esum, 16);
@@ -294,20 +308,20 @@ __global__ __launch_bounds__(NT, 3) void attention_kernel(AttnArgs a)
 
         // packed probabilities: dword t of key step ks = bytes r = 0..3 of key tile 4ks + t
         v4i pk[NKS];
-        v4i pkh[MODE == 3 ? NKS : 1];      // I-BERT: probabilities reach 128 (a one-hot row): 128 = 127 + 1, the 1 in a second operand
+        v4i pkh[MODE >= 3 ? NKS : 1];      // I-BERT: probabilities reach 128 (a one-hot row): 128 = 127 + 1, the 1 in a second operand
         bool any_hi = false;
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 unsigned w = 0;
-                if constexpr (MODE == 3) pkh[ks][t] = 0;
+                if constexpr (MODE >= 3) pkh[ks][t] = 0;
                 if (4 * ks + t < NKT) {
                     unsigned p[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float ev = ef_is_float ? __int_as_float(s[4 * ks + t][r]) : (float)(unsigned)s[4 * ks + t][r];
-                        if constexpr (MODE == 3) {
+                        if constexpr (MODE >= 3) {
                             // floor(fl32(e * factor) / 2^25) in [0, 128] (ibert_modules.py:314, output_bit = 8), kept in the
                             // top byte like the Shiftmax form below: min(., 127) << 24, the overflow bit separately
                             const unsigned pi = (unsigned)((ev * factor) * 2.98023223876953125e-08f);
@@ -328,7 +342,7 @@ __global__ __launch_bounds__(NT, 3) void attention_kernel(AttnArgs a)
                 pk[ks][t] = (int)w;
             }
 
-        const bool hi_pass = MODE == 3 && __builtin_amdgcn_ballot_w64(any_hi) != 0;   // wave-uniform, almost never
+        const bool hi_pass = MODE >= 3 && __builtin_amdgcn_ballot_w64(any_hi) != 0;   // wave-uniform, almost never
         // ---- O^T = Vt . P^T, requantised (attn.qact2), 4 consecutive d per dword
         const int64_t orow_idx = (int64_t)b * T + qrow;
         const BlockRow obrow = block_row((int)orow_idx, a.heads * HD);
@@ -341,7 +355,7 @@ __global__ __launch_bounds__(NT, 3) void attention_kernel(AttnArgs a)
             for (int ks = 0; ks < NKS; ++ks) {
                 const v4i vf = *reinterpret_cast<const v4i*>(smem + K_BYTES + d * VT_ROW + (((4 * ks + g) ^ (d & 15)) << 4));
                 acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(vf, pk[ks], acc, 0, 0, 0);
-                if constexpr (MODE == 3)
+                if constexpr (MODE >= 3)
                     if (hi_pass) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(vf, pkh[ks], acc, 0, 0, 0);
             }
             if (qrow < T) {
@@ -430,9 +444,11 @@ IVIT_EXPORT int ivit_attention_fused_i8_compat_band(const int8_t* qkv, int8_t* o
 
 IVIT_EXPORT int ivit_attention_fused_i8_ibert(const int8_t* qkv, int8_t* out, int batch, int heads, int tokens, int head_dim,
                                               uint32_t m_s, int32_t e_s, uint32_t m_o, int32_t e_o, const float* table,
-                                              int out_blocks, ivit_stream_t stream)
+                                              const float* band, int band_w, int out_blocks, ivit_stream_t stream)
 {
     IVIT_REQUIRE(qkv && out && table && batch > 0 && heads > 0, "ivit_attention_fused_i8_ibert: bad operand");
+    IVIT_REQUIRE(band_w == 0 || (band && band_w >= 16 && band_w <= 256 && band_w % 16 == 0 && (uintptr_t)band % 16 == 0),
+                 "ivit_attention_fused_i8_ibert: band table must be 16-byte aligned, width a multiple of 16 in [16, 256]");
     if (head_dim != HD || tokens <= 16 * (NKT - 1) || tokens >= KP) {
         ivit_set_error("ivit_attention_fused_i8_ibert: unsupported geometry head_dim=%d tokens=%d (need 64, 193..207)", head_dim, tokens);
         return IVIT_ERR_UNSUPPORTED;
@@ -449,7 +465,11 @@ IVIT_EXPORT int ivit_attention_fused_i8_ibert(const int8_t* qkv, int8_t* out, in
     a.Ms = ivit_dyadic_to_double(m_s, e_s);
     a.Mo = ivit_dyadic_to_double(m_o, e_o);
     IVIT_REQUIRE(a.Ms < 2048.0 && a.Mo < 512.0, "ivit_attention_fused_i8_ibert: requant multiplier too large");
-    hipLaunchKernelGGL(attention_kernel<3>, dim3(batch * heads), dim3(NT), 0, ivit_stream(stream), a);
+    a.band = reinterpret_cast<const unsigned*>(band);
+    a.band_w = band_w;
+    const size_t band_lds_bytes = band_w ? (size_t)4 * 16 * (band_w + BAND_PAD) * sizeof(unsigned) : 0;
+    if (band_w) hipLaunchKernelGGL(attention_kernel<4>, dim3(batch * heads), dim3(NT), band_lds_bytes, ivit_stream(stream), a);
+    else hipLaunchKernelGGL(attention_kernel<3>, dim3(batch * heads), dim3(NT), 0, ivit_stream(stream), a);
     IVIT_CHECK_LAUNCH("ivit_attention_fused_i8_ibert");
 }
 

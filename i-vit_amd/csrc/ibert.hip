@@ -298,11 +298,11 @@ struct IbLnI8Args {
     int out_blocks;
 };
 
-__global__ __launch_bounds__(NT) void ibert_layernorm_i8_kernel(IbLnI8Args a)
+// one row, literally (whole wave)
+IVIT_DEV void ib_ln_row_literal(const IbLnI8Args& a, int row, int lane)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int C = a.C;
-    for (int row = blockIdx.x * WPB + wave; row < a.rows; row += gridDim.x * WPB) {
+    {
         const int8_t* xr = a.x + (int64_t)row * a.ldx;
         auto xint = [&](int c) { return ((float)xr[c] * a.s_in) / a.s_in; };                  // :126 on fl(q * s)
         const float mean_int = rintf(torch_rowsum(xint, C, lane) / (float)C);                 // :127
@@ -326,6 +326,122 @@ __global__ __launch_bounds__(NT) void ibert_layernorm_i8_kernel(IbLnI8Args a)
             const int8_t o = (int8_t)(int)r;
             if (a.out_blocks) a.out[block_off(brow, block_col(c))] = o;
             else a.out[(int64_t)row * a.ldo + c] = o;
+        }
+    }
+}
+
+__global__ __launch_bounds__(NT) void ibert_layernorm_i8_kernel(IbLnI8Args a)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int row = blockIdx.x * WPB + wave; row < a.rows; row += gridDim.x * WPB) ib_ln_row_literal(a, row, lane);
+}
+
+// The same result without evaluating the two float32 row sums term by term.  Both sums only feed a rounding:
+//   mean_int = rint(fl(S1 / C)):  S1 (torch order) lies within 0.3 of the real sum R = sum q + sum (phi(q) - q) (32 partials of
+//     <= C / 32 terms below 2^12, then ~40 additions below 2^17: worst-case rounding 0.26 for C <= 1024), so rint(R / C) is the
+//     answer unless frac(R / C) is within 2e-3 of 0.5;
+//   std_int = floor(sqrt(S2)) * 2^shift:  the terms floor(y / 2^shift)^2 are integers; V = their exact integer sum.  V < 2^24: every
+//     partial sum is exact in float32, S2 == V in any order.  Otherwise |S2 - V| <= 3e-6 V (non-negative terms, < 48 roundings
+//     deep): floor(sqrt) is decided unless sqrt(V) is that close to an integer.
+// Undecided rows (and std = 0) take ib_ln_row_literal.  Element steps are the literal float32 operations on phi(q) from a
+// 256-entry table; the QuantAct's z = round(fl(fl(v * s) / s)) equals v for |v| < 2^21 (two roundings: error < 0.25).
+template <int NJ>
+__global__ __launch_bounds__(NT) void ibert_layernorm_i8_fast_kernel(IbLnI8Args a)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    const int C = a.C, nd = C >> 2;
+    double* tM = reinterpret_cast<double*>(lds_raw);
+    float* tbias = reinterpret_cast<float*>(tM + C);
+    float* tphi = tbias + C;
+    float* tdphi = tphi + 256;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int c = tid; c < C; c += NT) {
+        tM[c] = dyadic_mult(a.m[c], a.e[c]);
+        tbias[c] = a.bias_int[c];
+    }
+    {
+        const float qf = (float)(tid - 128);              // NT == 256
+        const float ph = (qf * a.s_in) / a.s_in;          // :126 on fl(q * s)
+        tphi[tid] = ph;
+        tdphi[tid] = ph - qf;                             // exact (both within an ulp of q)
+    }
+    __syncthreads();
+    const bool shift1 = a.shift_pow2 == 1.0f;
+    for (int row = blockIdx.x * WPB + wave; row < a.rows; row += gridDim.x * WPB) {
+        const int* xr = reinterpret_cast<const int*>(a.x + (int64_t)row * a.ldx);
+        int w[NJ];
+        int sq = 0;
+        float dsum = 0.0f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int d = lane + 64 * j;
+            const int v = xr[min(d, nd - 1)];
+            w[j] = d < nd ? v : 0;
+            sq = __builtin_amdgcn_sdot4(w[j], 0x01010101, sq, false);
+            if (d < nd) {
+                const unsigned u = (unsigned)w[j] ^ 0x80808080u;
+                dsum += (tdphi[u & 255] + tdphi[(u >> 8) & 255]) + (tdphi[(u >> 16) & 255] + tdphi[u >> 24]);
+            }
+        }
+        sq = wave_reduce_sum_i32(sq);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) dsum += __shfl_xor(dsum, o);
+        const double m0 = ((double)sq + (double)dsum) / (double)C;
+        const double fr = m0 - __builtin_floor(m0);
+        if (__builtin_fabs(fr - 0.5) < 2e-3) {            // wave-uniform
+            ib_ln_row_literal(a, row, lane);
+            continue;
+        }
+        const float mean_int = (float)__builtin_rint(m0);
+        float y0[NJ][4];
+        int V = 0;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const unsigned u = (unsigned)w[j] ^ 0x80808080u;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float y = tphi[(u >> (8 * k)) & 255] - mean_int;            // :128
+                y0[j][k] = y;
+                const float ys = shift1 ? floorf(y) : floorf(y / a.shift_pow2);   // :129
+                const int yi = (lane + 64 * j < nd) ? (int)ys : 0;
+                V += yi * yi;                                                     // :130-131, exact
+            }
+        }
+        V = wave_reduce_sum_i32(V);
+        bool ok = V > 0;
+        if (V >= (1 << 24)) {
+            const double r = __builtin_sqrt((double)V);
+            ok = __builtin_floor(r * (1.0 - 3e-6)) == __builtin_floor(r * (1.0 + 3e-6));
+        }
+        if (!ok) {
+            ib_ln_row_literal(a, row, lane);
+            continue;
+        }
+        const float std_int = floorf(sqrtf((float)V)) * a.shift_pow2;             // :142
+        const float factor = floorf(2147483648.0f / std_int);                    // :143
+        const BlockRow brow = block_row(row, C);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int d = lane + 64 * j;
+            if (d >= nd) continue;
+            int o[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c = 4 * d + k;
+                float v = floorf((y0[j][k] * factor) / 2.0f);                     // :144
+                v = v + tbias[c];                                                 // :151
+                float z = v;
+                if (!(fabsf(v) < 2097152.0f)) {                                   // rare: the QuantAct's quotient literally
+                    const float so = a.s_out[c];
+                    z = rintf((v * so) / so);
+                }
+                double r = __builtin_rint((double)z * tM[c]);
+                r = fmin(fmax(r, -128.0), 127.0);
+                o[k] = (int)r;
+            }
+            const int pw = (o[0] & 0xff) | ((o[1] & 0xff) << 8) | ((o[2] & 0xff) << 16) | ((o[3] & 0xff) << 24);
+            if (a.out_blocks) *reinterpret_cast<int*>(a.out + block_off(brow, block_col(4 * d))) = pw;
+            else *reinterpret_cast<int*>(a.out + (int64_t)row * a.ldo + 4 * d) = pw;
         }
     }
 }
@@ -482,6 +598,19 @@ IVIT_EXPORT int ivit_ibert_layernorm_i8(const int8_t* x, int64_t ldx, int rows, 
     IVIT_REQUIRE(out_blocks == 0 || (out_blocks == 1 && C % 64 == 0 && ldo == C && ((int64_t)rows + 15) * C < 2147483648ll),
                  "ivit_ibert_layernorm_i8: block-layout output needs C %% 64 == 0, ldo == C and a buffer below 2 GiB");
     IbLnI8Args a{x, ldx, rows, C, s_in, bias_int, s_out, shift_pow2, m, e, out, ldo, out_blocks};
+    // the fast form (sums decided without term-by-term float32 additions) needs dword rows and C <= 1024 (its error bound)
+    const bool fast = C % 4 == 0 && C <= 1024 && ldx % 4 == 0 && ldo % 4 == 0 && ((uintptr_t)x % 4 == 0) && ((uintptr_t)out % 4 == 0);
+    if (fast) {
+        const size_t lds = (size_t)C * 12 + 2048;
+        const int nj = (C / 4 + 63) / 64;
+        const dim3 grid(grid_for_rows(rows)), blk(NT);
+        hipStream_t st = ivit_stream(stream);
+        if (nj <= 1) hipLaunchKernelGGL(ibert_layernorm_i8_fast_kernel<1>, grid, blk, lds, st, a);
+        else if (nj <= 2) hipLaunchKernelGGL(ibert_layernorm_i8_fast_kernel<2>, grid, blk, lds, st, a);
+        else if (nj <= 3) hipLaunchKernelGGL(ibert_layernorm_i8_fast_kernel<3>, grid, blk, lds, st, a);
+        else hipLaunchKernelGGL(ibert_layernorm_i8_fast_kernel<4>, grid, blk, lds, st, a);
+        IVIT_CHECK_LAUNCH("ivit_ibert_layernorm_i8");
+    }
     hipLaunchKernelGGL(ibert_layernorm_i8_kernel, dim3(grid_for_rows(rows)), dim3(NT), 0, ivit_stream(stream), a);
     IVIT_CHECK_LAUNCH("ivit_ibert_layernorm_i8");
 }

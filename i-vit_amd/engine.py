@@ -142,6 +142,10 @@ class IntViTEngine(GraphReplay):
                 _lib.call("ivit_ibert_softmax_build_table", float(s_at), x0i, bi, ci, float(exp_sf), float(act_sf), ma, ea,
                           _lib.ptr(tab), self._stream())
                 blk["attn"]["ib_table"] = tab
+                # band form (LDS path) when the exponent saturates within 128 steps of the row maximum
+                band, bw = shiftexp_band(tab.cpu().numpy().view(np.uint32).reshape(256, 256))
+                if bw and bw <= 128:
+                    blk["attn"].update(band=dev(band.view(np.float32)), band_w=bw)
             elif phi_tables(s_at) is not None:       # Shiftmax on phi(q): exponent tabulated over (row max, q)
                 self.natural_sites += 1
                 tab = shiftexp2d(s_at)
@@ -339,7 +343,8 @@ class IntViTEngine(GraphReplay):
             a = blk["attn"]
             if self.family == "ibert":
                 _lib.call("ivit_attention_fused_i8_ibert", _lib.ptr(ws["qkv"]), _lib.ptr(ws["ao"]), B, H, T, hd,
-                          a["ms"][0], a["ms"][1], a["mo"][0], a["mo"][1], _lib.ptr(a["ib_table"]), int(a_at), st)
+                          a["ms"][0], a["ms"][1], a["mo"][0], a["mo"][1], _lib.ptr(a["ib_table"]), _lib.ptr(a["band"]), a["band_w"],
+                          int(a_at), st)
             else:
                 _lib.call("ivit_attention_fused_i8_compat_band", _lib.ptr(ws["qkv"]), _lib.ptr(ws["ao"]), B, H, T, hd,
                           a["ms"][0], a["ms"][1], a["s_attn"], a["mo"][0], a["mo"][1], _lib.ptr(a["exp2d"]), _lib.ptr(a["band"]),

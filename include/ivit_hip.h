@@ -446,6 +446,8 @@ int ivit_ibert_layernorm_f32_f32(const float* x, int64_t ldx, int rows, int C, c
  *    reference sums and multiplies, for every (row max qm, q <= qm): table[(qm + 128) * 256 + q + 128], 65 536 floats.
  *  - ivit_attention_fused_i8_ibert: ivit_attention_fused_i8 with that softmax: row sum in float32 in torch's CPU reduction
  *    order, factor = floor(2^32 / sum), p = floor(fl(e * factor) / 2^25) in [0, 128] (output_bit 8, scale 2^-7).  tokens 193..207.
+ *    band / band_w: the table in the band form of ivit_attention_fused_i8_compat_band (band[(qm + 128) * band_w + j] = entry of
+ *    q = qm - j, entry band_w - 1 already the saturated value), staged in LDS per query tile; band_w = 0: gather from `table`.
  *  - ivit_ibert_layernorm_i8: IBERTIntLayerNorm (:126-153; mean and variance sums in torch's order) + the QuantAct behind it.
  *    bias_int / s_out / (m, e) as for ivit_layernorm_i8; shift_pow2 = 2^shift (the module's overflow buffer). */
 int ivit_ibert_gelu_build_lut(float s, float b_int, float c_int, float shift_int, float s_out, uint32_t m_q, int32_t e_q,
@@ -453,7 +455,8 @@ int ivit_ibert_gelu_build_lut(float s, float b_int, float c_int, float shift_int
 int ivit_ibert_softmax_build_table(float s, float x0_int, float b_int, float c_int, float exp_sf, float act_sf, uint32_t m_act,
                                    int32_t e_act, float* table, ivit_stream_t stream);
 int ivit_attention_fused_i8_ibert(const int8_t* qkv, int8_t* out, int batch, int heads, int tokens, int head_dim, uint32_t m_s,
-                                  int32_t e_s, uint32_t m_o, int32_t e_o, const float* table, int out_blocks, ivit_stream_t stream);
+                                  int32_t e_s, uint32_t m_o, int32_t e_o, const float* table, const float* band, int band_w,
+                                  int out_blocks, ivit_stream_t stream);
 int ivit_ibert_layernorm_i8(const int8_t* x, int64_t ldx, int rows, int C, float s_in, const float* bias_int, const float* s_out,
                             float shift_pow2, const uint32_t* m, const int32_t* e, int8_t* out, int64_t ldo, int out_blocks,
                             ivit_stream_t stream);

@@ -12,6 +12,7 @@ pytestmark = pytest.mark.gpu
 ivit = pytest.importorskip("ivit_amd")
 from ivit_amd import _lib, synth  # noqa: E402
 from ivit_amd.checkpoint import load_synthetic_model  # noqa: E402
+from ivit_amd.prepare import LayerNormParams  # noqa: E402
 import ivit_amd.quantization_utils as q  # noqa: E402
 
 DEV = "cuda:0"
@@ -359,6 +360,58 @@ def test_ibert_layernorm_module_kat(ikat):
         nan = np.isnan(want)                       # the constant row: std = 0 -> 0 * inf (NaN payload / sign is not compared)
         assert np.array_equal(np.isnan(got), nan) and nan.sum() == C
         assert np.array_equal(got[~nan].view(np.int32), want[~nan].view(np.int32))
+
+
+@pytest.mark.parametrize("C,s_in", [(192, 2.0 ** -4), (768, 0.0371), (384, 0.05), (1024, 0.0213), (100, 0.0371), (198, 0.0371)])
+def test_ibert_layernorm_i8_engine_kernel_equals_modules(C, s_in):
+    """ivit_ibert_layernorm_i8 (the fused engine's kernel: sums decided from exact integers, undecided rows literally) ==
+    IBERTIntLayerNorm (literal float32 kernel) followed by a QuantAct, on random rows, rows whose mean is an exact tie
+    (sum q = C * k + C / 2: the float32 reduction order decides), constant rows + one outlier, saturating rows"""
+    rng = np.random.default_rng(C)
+    rows = 257
+    qv = rng.integers(-128, 128, size=(rows, C)).astype(np.int8)
+    qv[0] = 5
+    qv[0, 3] = 90                                        # tiny variance
+    for r in range(1, 40):                               # exact mean ties
+        row = rng.integers(-100, 100, size=C).astype(np.int64)
+        want = C * int(rng.integers(-20, 20)) + C // 2
+        row[0] += want - int(row.sum())
+        while abs(row[0]) > 127:                         # spread the correction
+            i = int(rng.integers(1, C))
+            step = int(np.clip(row[0], -60, 60))
+            if -128 <= row[i] + step <= 127:
+                row[i] += step
+                row[0] -= step
+        assert row.sum() == want and np.abs(row).max() <= 128
+        qv[r] = np.clip(row, -128, 127)
+    qv[40] = 127
+    qv[40, ::2] = -128
+    gamma = rng.uniform(0.5, 1.5, size=C).astype(np.float32)
+    beta = rng.uniform(-1, 1, size=C).astype(np.float32)
+    ln = q.IBERTIntLayerNorm(C).to(DEV)
+    ln.weight.data = torch.from_numpy(gamma).to(DEV)
+    ln.bias.data = torch.from_numpy(beta).to(DEV)
+    ln.fix()
+    act = q.QuantAct().to(DEV)
+    act.x_min.fill_(-2.9)
+    act.x_max.fill_(3.1)
+    act.fix()
+    s_t = torch.tensor([s_in], dtype=torch.float32, device=DEV)
+    x = (torch.from_numpy(qv.astype(np.float32)).to(DEV) * s_t)
+    with torch.no_grad():
+        y, s_ln = ln(x, s_t)
+        z, s_z = act(y, s_ln)
+    exp = torch.round(z / s_z).to(torch.int32).cpu().numpy()
+    lp = LayerNormParams(gamma, beta, float(s_z))
+    out = torch.zeros(rows, C, dtype=torch.int8, device=DEV)
+    dq, db, dsl = torch.from_numpy(qv).to(DEV), torch.from_numpy(lp.bias_int).to(DEV), torch.from_numpy(lp.s_ln).to(DEV)
+    dm, de = torch.from_numpy(lp.m.view(np.int32)).to(DEV), torch.from_numpy(lp.e).to(DEV)
+    _lib.call("ivit_ibert_layernorm_i8", _lib.ptr(dq), C, rows, C, float(s_in), _lib.ptr(db), _lib.ptr(dsl), 1.0, _lib.ptr(dm),
+              _lib.ptr(de), _lib.ptr(out), C, 0, _lib.stream_ptr())
+    got = out.cpu().numpy().astype(np.int32)
+    bad = np.argwhere(got != exp)
+    assert bad.size == 0, (len(bad), bad[:5], got[tuple(bad[0])], exp[tuple(bad[0])])
+    assert np.abs(exp).max() > 50
 
 
 def test_ibert_model_module_path_matches_reference_golden():
