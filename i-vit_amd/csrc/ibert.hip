@@ -348,16 +348,20 @@ __global__ __launch_bounds__(NT) void ibert_layernorm_i8_kernel(IbLnI8Args a)
 template <int NJ>
 __global__ __launch_bounds__(NT) void ibert_layernorm_i8_fast_kernel(IbLnI8Args a)
 {
-    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    __shared__ float tphi[256], tdphi[256];
     const int C = a.C, nd = C >> 2;
-    double* tM = reinterpret_cast<double*>(lds_raw);
-    float* tbias = reinterpret_cast<float*>(tM + C);
-    float* tphi = tbias + C;
-    float* tdphi = tphi + 256;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int c = tid; c < C; c += NT) {
-        tM[c] = dyadic_mult(a.m[c], a.e[c]);
-        tbias[c] = a.bias_int[c];
+    // a lane always works on the same channels (dwords lane + 64 j): their requantisers and biases stay in registers
+    double Mreg[NJ][4];
+    float breg[NJ][4];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int d = min(lane + 64 * j, nd - 1);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            Mreg[j][k] = dyadic_mult(a.m[4 * d + k], a.e[4 * d + k]);
+            breg[j][k] = a.bias_int[4 * d + k];
+        }
     }
     {
         const float qf = (float)(tid - 128);              // NT == 256
@@ -372,16 +376,18 @@ __global__ __launch_bounds__(NT) void ibert_layernorm_i8_fast_kernel(IbLnI8Args 
         int w[NJ];
         int sq = 0;
         float dsum = 0.0f;
+        // all loads of the row first (unconditional, clamped address + select: a branch around a load serialises load -> use ->
+        // next load, three memory latencies per row instead of one)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) w[j] = xr[min(lane + 64 * j, nd - 1)];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            const int d = lane + 64 * j;
-            const int v = xr[min(d, nd - 1)];
-            w[j] = d < nd ? v : 0;
+            const bool live = lane + 64 * j < nd;
+            w[j] = live ? w[j] : 0;
             sq = __builtin_amdgcn_sdot4(w[j], 0x01010101, sq, false);
-            if (d < nd) {
-                const unsigned u = (unsigned)w[j] ^ 0x80808080u;
-                dsum += (tdphi[u & 255] + tdphi[(u >> 8) & 255]) + (tdphi[(u >> 16) & 255] + tdphi[u >> 24]);
-            }
+            const unsigned u = (unsigned)w[j] ^ 0x80808080u;
+            const float dd = (tdphi[u & 255] + tdphi[(u >> 8) & 255]) + (tdphi[(u >> 16) & 255] + tdphi[u >> 24]);
+            dsum += live ? dd : 0.0f;
         }
         sq = wave_reduce_sum_i32(sq);
 #pragma unroll
@@ -423,25 +429,26 @@ __global__ __launch_bounds__(NT) void ibert_layernorm_i8_fast_kernel(IbLnI8Args 
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int d = lane + 64 * j;
-            if (d >= nd) continue;
             int o[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int c = 4 * d + k;
                 float v = floorf((y0[j][k] * factor) / 2.0f);                     // :144
-                v = v + tbias[c];                                                 // :151
+                v = v + breg[j][k];                                               // :151
                 float z = v;
-                if (!(fabsf(v) < 2097152.0f)) {                                   // rare: the QuantAct's quotient literally
+                if (!(fabsf(v) < 2097152.0f) && d < nd) {                         // rare: the QuantAct's quotient literally
                     const float so = a.s_out[c];
                     z = rintf((v * so) / so);
                 }
-                double r = __builtin_rint((double)z * tM[c]);
+                double r = __builtin_rint((double)z * Mreg[j][k]);
                 r = fmin(fmax(r, -128.0), 127.0);
                 o[k] = (int)r;
             }
             const int pw = (o[0] & 0xff) | ((o[1] & 0xff) << 8) | ((o[2] & 0xff) << 16) | ((o[3] & 0xff) << 24);
-            if (a.out_blocks) *reinterpret_cast<int*>(a.out + block_off(brow, block_col(4 * d))) = pw;
-            else *reinterpret_cast<int*>(a.out + (int64_t)row * a.ldo + 4 * d) = pw;
+            if (d < nd) {
+                if (a.out_blocks) *reinterpret_cast<int*>(a.out + block_off(brow, block_col(4 * d))) = pw;
+                else *reinterpret_cast<int*>(a.out + (int64_t)row * a.ldo + 4 * d) = pw;
+            }
         }
     }
 }
@@ -601,9 +608,11 @@ IVIT_EXPORT int ivit_ibert_layernorm_i8(const int8_t* x, int64_t ldx, int rows, 
     // the fast form (sums decided without term-by-term float32 additions) needs dword rows and C <= 1024 (its error bound)
     const bool fast = C % 4 == 0 && C <= 1024 && ldx % 4 == 0 && ldo % 4 == 0 && ((uintptr_t)x % 4 == 0) && ((uintptr_t)out % 4 == 0);
     if (fast) {
-        const size_t lds = (size_t)C * 12 + 2048;
+        const size_t lds = 0;
         const int nj = (C / 4 + 63) / 64;
-        const dim3 grid(grid_for_rows(rows)), blk(NT);
+        // one resident set of workgroups (4 per CU at 121 VGPRs): the per-lane constants are set up once per wave
+        const int want = grid_for_rows(rows);
+        const dim3 grid(want < 1024 ? want : 1024), blk(NT);
         hipStream_t st = ivit_stream(stream);
         if (nj <= 1) hipLaunchKernelGGL(ibert_layernorm_i8_fast_kernel<1>, grid, blk, lds, st, a);
         else if (nj <= 2) hipLaunchKernelGGL(ibert_layernorm_i8_fast_kernel<2>, grid, blk, lds, st, a);

@@ -1,5 +1,5 @@
 """Throughput of the module-by-module path (what runs when the fused engine does not apply: I-BERT operators -- the fork's
-default --, non-8-bit widths) next to the fused engine, DeiT-B.  usage: bench_module_path.py [batch]"""
+default --, non-8-bit widths) next to the fused engine, DeiT-B.  usage: bench_module_path.py [batch] [--engine-only] [--family ibert]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -7,7 +7,10 @@ import ivit_amd as ivit
 from ivit_amd import synth
 from ivit_amd.quantization_utils import QuantAct
 DEV = "cuda:0"
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+ENGINE_ONLY = "--engine-only" in sys.argv
+FAMS = [sys.argv[sys.argv.index("--family") + 1]] if "--family" in sys.argv else ["ivit", "ibert"]
+_pos = [a for a in sys.argv[1:] if a.isdigit()]
+B = int(_pos[0]) if _pos else 64
 fs = synth.make_float_state("deit_base_patch16_224", 7)
 imgs = torch.from_numpy(synth.make_images(min(B, 16), 99)).to(DEV)
 imgs = imgs.repeat((B + imgs.shape[0] - 1) // imgs.shape[0], 1, 1, 1)[:B].contiguous()
@@ -24,16 +27,17 @@ def timed(model, n=5):
     return (time.perf_counter() - t0) / n * 1e3
 
 
-for fam in ("ivit", "ibert"):
+for fam in FAMS:
     model = ivit.deit_base_patch16_224(gelu_type=fam, softmax_type=fam, layernorm_type=fam)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in fs.items()}, strict=False)
     model.to(DEV).eval()
     with torch.no_grad():
         model(imgs[:8])               # calibration forward (running min / max)
     ivit.freeze_model(model)
-    model.use_engine = False
-    ms = timed(model)
-    print(f"{fam:5s} module path  batch {B}: {ms:8.2f} ms / forward  ({B / ms * 1e3:8.0f} img/s)", flush=True)
+    if not ENGINE_ONLY:
+        model.use_engine = False
+        ms = timed(model)
+        print(f"{fam:5s} module path  batch {B}: {ms:8.2f} ms / forward  ({B / ms * 1e3:8.0f} img/s)", flush=True)
     model.use_engine = True
     print(f"{fam:5s} engine       batch {B}: {timed(model, 10):8.2f} ms / forward  (reason if not taken: {model.engine_unsupported_reason()})", flush=True)
     if os.environ.get("IVIT_KERNEL_SPLIT"):   # per-kernel time of the engine forward (torch profiler)
