@@ -346,20 +346,32 @@ __global__ __launch_bounds__(NT) void ibert_layernorm_i8_kernel(IbLnI8Args a)
 // Undecided rows (and std = 0) take ib_ln_row_literal.  Element steps are the literal float32 operations on phi(q) from a
 // 256-entry table; the QuantAct's z = round(fl(fl(v * s) / s)) equals v for |v| < 2^21 (two roundings: error < 0.25).
 template <int NJ>
-__global__ __launch_bounds__(NT) void ibert_layernorm_i8_fast_kernel(IbLnI8Args a)
+__global__ __launch_bounds__(NT, 4) void ibert_layernorm_i8_fast_kernel(IbLnI8Args a)
 {
     __shared__ float tphi[256], tdphi[256];
     const int C = a.C, nd = C >> 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // a lane always works on the same channels (dwords lane + 64 j): their requantisers and biases stay in registers
-    double Mreg[NJ][4];
-    float breg[NJ][4];
+    // The QuantAct tail -- x = v * s, z = round(x / s), RNE(float64(z) * M) -- by the bracket certificate of the I-ViT LayerNorm
+    // (rowops.hip): z = v (1 + eps), |eps| <= 2^-22 (two float32 roundings; v is an integer up to ~2^31), so
+    // the number the reference rounds lies between v * lo and v * hi for float32 lo <= M (1 - 1.25 * 2^-22), hi >= M (1 + 1.25 * 2^-22);
+    // fma(v, lo, 1.5 * 2^23) == fma(v, hi, 1.5 * 2^23) certifies the result (|v * M| < 2^22: M <= 2^-9 is the loader's contract).
+    // A row with an uncertified element is redone literally.
+    float lo_r[NJ][4], hi_r[NJ][4], breg[NJ][4];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const int d = min(lane + 64 * j, nd - 1);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            Mreg[j][k] = dyadic_mult(a.m[4 * d + k], a.e[4 * d + k]);
+            const double M = dyadic_mult(a.m[4 * d + k], a.e[4 * d + k]);
+            const double lod = M * (1.0 - 1.25 / 4194304.0), hid = M * (1.0 + 1.25 / 4194304.0);
+            float lf = (float)lod, hf = (float)hid;
+            if ((double)lf > lod) lf = __int_as_float(__float_as_int(lf) - 1);   // largest float32 <= lod (lod > 0)
+            if ((double)hf < hid) hf = __int_as_float(__float_as_int(hf) + 1);   // smallest float32 >= hid
+            const float sl = a.s_out[4 * d + k];
+            const bool okc = fabsf(sl) >= 1e-30f && fabsf(sl) <= 1e30f && lod > 1e-35 && hid < 1e30;   // see layernorm_i8_kernel
+            lo_r[j][k] = okc ? lf : 0.0f;
+            hi_r[j][k] = okc ? hf : __builtin_inff();
             breg[j][k] = a.bias_int[4 * d + k];
         }
     }
@@ -426,23 +438,19 @@ __global__ __launch_bounds__(NT) void ibert_layernorm_i8_fast_kernel(IbLnI8Args 
         const float std_int = floorf(sqrtf((float)V)) * a.shift_pow2;             // :142
         const float factor = floorf(2147483648.0f / std_int);                    // :143
         const BlockRow brow = block_row(row, C);
+        unsigned unc = 0;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int d = lane + 64 * j;
             int o[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const int c = 4 * d + k;
                 float v = floorf((y0[j][k] * factor) / 2.0f);                     // :144
                 v = v + breg[j][k];                                               // :151
-                float z = v;
-                if (!(fabsf(v) < 2097152.0f) && d < nd) {                         // rare: the QuantAct's quotient literally
-                    const float so = a.s_out[c];
-                    z = rintf((v * so) / so);
-                }
-                double r = __builtin_rint((double)z * Mreg[j][k]);
-                r = fmin(fmax(r, -128.0), 127.0);
-                o[k] = (int)r;
+                const int tl = __float_as_int(__builtin_fmaf(v, lo_r[j][k], 12582912.0f));
+                const int th = __float_as_int(__builtin_fmaf(v, hi_r[j][k], 12582912.0f));
+                o[k] = clamp_i32(tl, 0x4B400000 - 128, 0x4B400000 + 127);         // low byte = the int8 result
+                unc |= (d < nd && tl != th) ? 1u : 0u;                            // uncertified: the row is redone literally
             }
             const int pw = (o[0] & 0xff) | ((o[1] & 0xff) << 8) | ((o[2] & 0xff) << 16) | ((o[3] & 0xff) << 24);
             if (d < nd) {
@@ -450,6 +458,7 @@ __global__ __launch_bounds__(NT) void ibert_layernorm_i8_fast_kernel(IbLnI8Args 
                 else *reinterpret_cast<int*>(a.out + (int64_t)row * a.ldo + 4 * d) = pw;
             }
         }
+        if (__builtin_amdgcn_ballot_w64(unc != 0) != 0) ib_ln_row_literal(a, row, lane);   // wave-uniform, rare
     }
 }
 
