@@ -239,22 +239,43 @@ __global__ __launch_bounds__(NT, 3) void attention_kernel(AttnArgs a)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) Pp[0][r] += e12[r];
             }
+            // all-gather over the four lanes of a query (lane = 16 g + l15) in VALU instructions: v_permlane32_swap of a value
+            // with itself leaves every lane with the values of rows {0,1} and {2,3} of 16 lanes, v_permlane16_swap of each of
+            // those with itself then separates row 0 / 1 and row 2 / 3: out[g'] = the value lane 16 g' + l15 held
+            typedef unsigned v2u __attribute__((ext_vector_type(2)));
+            auto gather4 = [&](float x, float (&out)[4]) {
+                const unsigned xb = (unsigned)__float_as_int(x);
+                const v2u h = __builtin_amdgcn_permlane32_swap(xb, xb, false, false);       // h.x: rows 0,1,0,1; h.y: rows 2,3,2,3
+                const v2u a01 = __builtin_amdgcn_permlane16_swap(h.x, h.x, false, false);   // .x: row 0 everywhere, .y: row 1
+                const v2u a23 = __builtin_amdgcn_permlane16_swap(h.y, h.y, false, false);   // .x: row 2, .y: row 3
+                out[0] = __int_as_float((int)a01.x);
+                out[1] = __int_as_float((int)a01.y);
+                out[2] = __int_as_float((int)a23.x);
+                out[3] = __int_as_float((int)a23.y);
+            };
             float fin = 0.0f;
+            {
+                float t12[4][4];                   // [r][g']
 #pragma unroll
-            for (int gp = 0; gp < 4; ++gp)         // scalar tail: keys 8 nv .. T - 1 in order
+                for (int r = 0; r < 4; ++r) gather4(e12[r], t12[r]);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int key = 192 + 4 * gp + r;
-                    const float val = __shfl(e12[r], (gp << 4) | l15);
-                    if (key >= 8 * nv && key < T) fin += val;
-                }
+                for (int gp = 0; gp < 4; ++gp)     // scalar tail: keys 8 nv .. T - 1 in order
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = 192 + 4 * gp + r;
+                        if (key >= 8 * nv && key < T) fin += t12[r][gp];
+                    }
+            }
             float A[4][2][4];
 #pragma unroll
-            for (int gp = 0; gp < 4; ++gp)
+            for (int hi = 0; hi < 2; ++hi)
 #pragma unroll
-                for (int hi = 0; hi < 2; ++hi)
+                for (int r = 0; r < 4; ++r) {
+                    float t[4];
+                    gather4(Pp[hi][r], t);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) A[gp][hi][r] = __shfl(Pp[hi][r], (gp << 4) | l15);
+                    for (int gp = 0; gp < 4; ++gp) A[gp][hi][r] = t[gp];
+                }
 #pragma unroll
             for (int l = 0; l < 8; ++l) {
                 const int gm = l >> 2, r = l & 3;
@@ -309,7 +330,11 @@ __global__ __launch_bounds__(NT, 3) void attention_kernel(AttnArgs a)
         // packed probabilities: dword t of key step ks = bytes r = 0..3 of key tile 4ks + t
         v4i pk[NKS];
         v4i pkh[MODE >= 3 ? NKS : 1];      // I-BERT: probabilities reach 128 (a one-hot row): 128 = 127 + 1, the 1 in a second operand
-        bool any_hi = false;
+        // I-BERT: p = floor(fl32(e * factor) / 2^25) in [0, 128] (ibert_modules.py:314, output_bit = 8).  factor / 2 is an exact
+        // scaling, so u = trunc(e * (factor / 2)) has p in its top byte like the Shiftmax product below -- except p = 128, which
+        // shows as the sign bit of u: the OR of all u of the tile is tested once and the tile repacked in that rare case.
+        const float factor_h = factor * 0.5f;
+        unsigned any_u = 0;
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
@@ -322,14 +347,8 @@ __global__ __launch_bounds__(NT, 3) void attention_kernel(AttnArgs a)
                     for (int r = 0; r < 4; ++r) {
                         const float ev = ef_is_float ? __int_as_float(s[4 * ks + t][r]) : (float)(unsigned)s[4 * ks + t][r];
                         if constexpr (MODE >= 3) {
-                            // floor(fl32(e * factor) / 2^25) in [0, 128] (ibert_modules.py:314, output_bit = 8), kept in the
-                            // top byte like the Shiftmax form below: min(., 127) << 24, the overflow bit separately
-                            const unsigned pi = (unsigned)((ev * factor) * 2.98023223876953125e-08f);
-                            p[r] = min(pi, 127u) << 24;
-                            if (pi > 127u) {
-                                any_hi = true;
-                                pkh[ks][t] |= 1 << (8 * r);
-                            }
+                            p[r] = (unsigned)(ev * factor_h);
+                            any_u |= p[r];
                         } else {
                             p[r] = (unsigned)(ev * factor);  // float32 product (:175), < 2^31
                         }
@@ -341,8 +360,22 @@ __global__ __launch_bounds__(NT, 3) void attention_kernel(AttnArgs a)
                 }
                 pk[ks][t] = (int)w;
             }
+        const bool any_hi = MODE >= 3 && __builtin_amdgcn_ballot_w64((any_u >> 31) != 0) != 0;   // wave-uniform, almost never
+        if constexpr (MODE >= 3) {
+            if (any_hi) {      // a byte 0x80 (p = 128) becomes 127 in pk and 1 in pkh
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const unsigned w = (unsigned)pk[ks][t];
+                        const unsigned h128 = (w >> 7) & 0x01010101u;          // 1 in every byte that is 0x80
+                        pk[ks][t] = (int)(w - h128);                          // 0x80 -> 0x7f (no borrow: the byte is >= 1)
+                        pkh[ks][t] = (int)h128;
+                    }
+            }
+        }
 
-        const bool hi_pass = MODE >= 3 && __builtin_amdgcn_ballot_w64(any_hi) != 0;   // wave-uniform, almost never
+        const bool hi_pass = any_hi;
         // ---- O^T = Vt . P^T, requantised (attn.qact2), 4 consecutive d per dword
         const int64_t orow_idx = (int64_t)b * T + qrow;
         const BlockRow obrow = block_row((int)orow_idx, a.heads * HD);

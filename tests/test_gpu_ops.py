@@ -484,6 +484,61 @@ def test_attention_fused(B, H, T, p_at):
     assert np.abs(exp).max() > 20
 
 
+@pytest.mark.parametrize("T,band", [(197, False), (197, True), (203, True), (193, False)])
+def test_attention_fused_ibert(T, band):
+    """ivit_attention_fused_i8_ibert against its specification evaluated in numpy: requantised scores, table lookup over
+    (row max, q), float32 row sum in torch's reduction order (oracle torch_rowsum), factor = floor(2^32 / S),
+    p = floor(fl32(e * factor) / 2^25), P.V.  The table is synthetic -- non-integer floats, so that the summation order
+    matters, and entry 16384 at distance 0 for some row maxima, so that a one-hot row gives p = 128 (the two-operand path)"""
+    from ivit_amd.prepare import shiftexp_band
+    rng = np.random.default_rng(T + band)
+    B, H, hd = 2, 2, 64
+    qkv = np.clip(np.rint(rng.normal(0, 30, size=(3, B, H, T, hd))), -128, 127).astype(np.int8)
+    qkv[0, 0, 0, 5] = 0
+    qkv[0, 0, 0, 5, :8] = 127                       # a query with one dominant key -> one-hot row
+    qkv[1, 0, 0] = np.clip(qkv[1, 0, 0], -20, 20)
+    qkv[1, 0, 0, 17, :8] = 127
+    ms, es = dyadic(np.float32(2.0 ** -11), np.float32(2.0 ** -2))
+    mo, eo = dyadic(np.float32(2.0 ** -11), np.float32(2.0 ** -3))
+    dist = np.arange(256)
+    prof = np.floor(16384.0 * np.exp(-dist / 9.0))                           # exp-like, 0 beyond ~90 steps
+    tab = np.zeros((256, 256), np.float32)
+    for qm in range(256):
+        for qq in range(qm + 1):
+            v = prof[qm - qq]
+            # fl(fl(k * s) / s)-like perturbation (relative 2^-22) except on the power-of-two entry that makes p = 128 reachable
+            tab[qm, qq] = np.float32(v) if (qm - qq == 0 and qm % 3 == 0) else np.float32(v * (1.0 + ((qm * 7 + qq) % 5 - 2) * 2.0 ** -22))
+    dtab = dev(tab.reshape(-1))
+    bandt, bw = (None, 0)
+    if band:
+        bt, bw = shiftexp_band(tab.view(np.uint32))
+        assert bw and bw <= 128
+        bandt = dev(bt.view(np.float32).reshape(-1))
+    exp = np.empty((B, T, H * hd), np.int32)
+    n128 = 0
+    for b in range(B):
+        for h in range(H):
+            S = orc.gemm_i8(qkv[0, b, h], qkv[1, b, h])
+            ka = orc.requant(S, ms.astype(np.float64), es, 8)
+            P = np.empty((T, T), np.int32)
+            for i in range(T):
+                e = tab[int(ka[i].max()) + 128, ka[i] + 128].astype(np.float32)
+                Ssum = orc.torch_rowsum(e)
+                factor = np.floor(np.float32(4294967296.0) / np.float32(Ssum)).astype(np.float32)
+                P[i] = np.floor((e * factor).astype(np.float32) / np.float32(2.0 ** 25)).astype(np.int32)
+            n128 += int((P == 128).sum())
+            assert P.max() <= 128 and P.min() >= 0
+            O = P.astype(np.int64) @ qkv[2, b, h].astype(np.int64)
+            exp[b, :, h * hd:(h + 1) * hd] = orc.requant(O.astype(np.int32), mo.astype(np.float64), eo, 8)
+    assert n128 > 0                                  # the p = 128 path is exercised
+    out = torch.full((B * T, H * hd), 99, dtype=torch.int8, device=DEV)
+    _lib.call("ivit_attention_fused_i8_ibert", _lib.ptr(dev(qkv)), _lib.ptr(out), B, H, T, hd, int(ms[0]), int(es[0]), int(mo[0]),
+              int(eo[0]), _lib.ptr(dtab), _lib.ptr(bandt), bw, 0, st())
+    got = out.cpu().numpy().astype(np.int32).reshape(B, T, H * hd)
+    assert np.array_equal(got, exp), f"{(got != exp).sum()} of {got.size} differ"
+    assert np.abs(exp).max() > 20
+
+
 def test_attention_unsupported_geometry():
     a = torch.zeros(1 << 16, dtype=torch.int8, device=DEV)
     with pytest.raises(_lib.IvitError, match="unsupported geometry"):
