@@ -9,6 +9,7 @@
 // the rows where it is not).  Scalar constants (b_int, c_int, x0_int, scales) are computed by the caller in float32
 // exactly as the reference computes them on the host side of every call.
 #include <limits.h>
+#include <type_traits>
 
 #include "common.h"
 #include "rowsum.h"
@@ -413,18 +414,22 @@ __global__ __launch_bounds__(NT, 4) void ibert_layernorm_i8_fast_kernel(IbLnI8Ar
         const float mean_int = (float)__builtin_rint(m0);
         float y0[NJ][4];
         int V = 0;
+        auto variance_terms = [&](auto shift1_tag) {      // two copies: the division by 2^shift (~10 instructions) only where shift > 0
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const unsigned u = (unsigned)w[j] ^ 0x80808080u;
+            for (int j = 0; j < NJ; ++j) {
+                const unsigned u = (unsigned)w[j] ^ 0x80808080u;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float y = tphi[(u >> (8 * k)) & 255] - mean_int;            // :128
-                y0[j][k] = y;
-                const float ys = shift1 ? floorf(y) : floorf(y / a.shift_pow2);   // :129
-                const int yi = (lane + 64 * j < nd) ? (int)ys : 0;
-                V += yi * yi;                                                     // :130-131, exact
+                for (int k = 0; k < 4; ++k) {
+                    const float y = tphi[(u >> (8 * k)) & 255] - mean_int;        // :128
+                    y0[j][k] = y;
+                    const float ys = decltype(shift1_tag)::value ? floorf(y) : floorf(y / a.shift_pow2);   // :129 (x / 1 == x)
+                    const int yi = (lane + 64 * j < nd) ? (int)ys : 0;
+                    V += yi * yi;                                                 // :130-131, exact
+                }
             }
-        }
+        };
+        if (shift1) variance_terms(std::true_type{});
+        else variance_terms(std::false_type{});
         V = wave_reduce_sum_i32(V);
         bool ok = V > 0;
         if (V >= (1 << 24)) {
