@@ -47,6 +47,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches in the timed region instead of HIP-graph replay")
     ap.add_argument("--probe-forwards", type=int, default=3, help="forwards of the instrumented pass (0 = skip)")
+    ap.add_argument("--operators", choices=("ivit", "ibert"), default="ivit",
+                    help="operator family of GELU / Softmax / LayerNorm: 'ivit' (the headline, BASELINE.json) or 'ibert' (the fork's "
+                         "default family; ranges calibrated on the spot, as calibrated; no cpu_baseline)")
     ap.add_argument("--natural-scales", action="store_true",
                     help="the same model with its activation ranges AS CALIBRATED (fixture deit_base_natural) instead of "
                          "power-of-two snapped: the regime of a real checkpoint, phi tables active (DESIGN.md section 2)")
@@ -176,8 +179,23 @@ def worker(args):
         dev = f"cuda:{local_rank}"
         if world > 1:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
-        fs, ranges, cfg, meta, _ = load_synthetic_model(MODEL_TAG + ("_natural" if args.natural_scales else ""))
-        eng = IntViTEngine(fs, ranges, cfg["embed_dim"], cfg["depth"], cfg["num_heads"], device=dev, max_batch=batch)
+        if args.operators == "ibert":
+            # no fixture for this family at DeiT-B: build the module tree, calibrate its ranges on one small batch, freeze, and take
+            # the fused engine the frozen model dispatches to (dispatch.py)
+            import ivit_amd as ivit
+            model = ivit.deit_base_patch16_224(gelu_type="ibert", softmax_type="ibert", layernorm_type="ibert")
+            model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_float_state("deit_base_patch16_224", 7).items()},
+                                  strict=False)
+            model.to(dev).eval()
+            with torch.no_grad():
+                model(torch.from_numpy(synth.make_images(8, 4242)).to(dev))
+            ivit.freeze_model(model)
+            eng = model.engine(batch)
+            assert eng.family == "ibert"
+            fs = ranges = cfg = None
+        else:
+            fs, ranges, cfg, meta, _ = load_synthetic_model(MODEL_TAG + ("_natural" if args.natural_scales else ""))
+            eng = IntViTEngine(fs, ranges, cfg["embed_dim"], cfg["depth"], cfg["num_heads"], device=dev, max_batch=batch)
         images = torch.from_numpy(synth.make_images(batch, 5000 + rank)).to(dev)  # resident in HBM
     dp = DataParallelTop1(eng, world, graph=not args.no_graph)
 
@@ -244,10 +262,13 @@ def worker(args):
                           else "launcher self-test (stub engine, CPU, gloo)",
                           "global_batch": world * batch, "parallelism": f"dp{world}",
                           "launch": "eager" if args.no_graph else "hip-graph replay",
-                          "activation_ranges": "as calibrated (natural scales)" if args.natural_scales else "power-of-two"},
+                          "activation_ranges": "as calibrated (natural scales)" if (args.natural_scales or args.operators == "ibert")
+                          else "power-of-two",
+                          "operators": "I-ViT (IVITIntLayerNorm, Shiftmax, ShiftGELU)" if args.operators == "ivit"
+                          else "I-BERT (IBERTIntLayerNorm, IBERTIntSoftmax, IBERTIntGELU)"},
                "mfma_util_end_to_end": round(value / world * MAC_PER_IMAGE / 2.5166e15, 4),
                "roofline": roof}
-        if world == 1 and not stub and not args.no_cpu_baseline:
+        if world == 1 and not stub and not args.no_cpu_baseline and args.operators == "ivit":
             out["cpu_baseline"] = cpu_baseline(fs, ranges, cfg)
         print(json.dumps(out, ensure_ascii=False), flush=True)
     if world > 1:

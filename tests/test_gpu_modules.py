@@ -430,6 +430,23 @@ def test_ibert_model_module_path_matches_reference_golden():
     assert np.array_equal(bits(ye), bits(y))
 
 
+def test_mixed_operator_families_take_the_module_path():
+    """the fused engine implements all-'ivit' and all-'ibert'; a mixture (the reference's registry allows any combination,
+    vit_quant.py:188-190) runs module by module and says why"""
+    fs = synth.make_float_state("deit_tiny_patch16_224", 5)
+    model = ivit.deit_tiny_patch16_224(gelu_type="ibert", softmax_type="ivit", layernorm_type="ivit")
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in fs.items()}, strict=False)
+    model.to(DEV).eval()
+    imgs = torch.from_numpy(synth.make_images(2, 3)).to(DEV)
+    with torch.no_grad():
+        model(imgs)
+    ivit.freeze_model(model)
+    assert "operator family" in model.engine_unsupported_reason() and not model.takes_engine(imgs)
+    with torch.no_grad():
+        y = model(imgs)
+    assert y.shape == (2, 1000) and torch.isfinite(y).all()
+
+
 @pytest.mark.parametrize("regime", ["pow2", "natural"])
 def test_ibert_engine_equals_module_path_deit_small_width(regime):
     """a wider I-BERT model than the reference fixtures cover (DeiT-S: C = 384, 6 heads; 12 fresh images; ranges calibrated
