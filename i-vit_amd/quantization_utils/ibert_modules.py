@@ -132,13 +132,7 @@ class IBERTIntGELU(nn.Module):
 
     def constants(self, s):
         """(b_int, c_int, shift_int, s_out) in float32, :205-206, 214-216, 229, 232."""
-        s = f32(s)
-        sf = f32(s / f32(self.k))
-        b_int = np.floor(f32(f32(self.coeff[1]) / sf))
-        c_int = np.floor(f32(f32(self.coeff[2]) / f32(sf * sf)))
-        sf2 = f32(f32(f32(sf * sf) * f32(self.coeff[0])) * f32(2 ** self.n))
-        shift_int = np.floor(f32(f32(1.0) / sf2))
-        return float(b_int), float(c_int), float(shift_int), f32(f32(s * sf2) / f32(2))
+        return gelu_constants(s)
 
     def forward(self, x, scaling_factor=None):
         s = float(scaling_factor.reshape(-1)[0])
@@ -173,10 +167,7 @@ class IBERTIntSoftmax(nn.Module):
     def forward(self, x, scaling_factor):
         s = f32(float(scaling_factor.reshape(-1)[0]))
         L = x.shape[-1]
-        x0_int = np.floor(f32(f32(self.x0) / s))                                   # :287
-        b_int = np.floor(f32(f32(self.coef[1]) / s))                               # :277
-        c_int = np.floor(f32(f32(self.coef[2]) / f32(s * s)))                      # :278
-        exp_sf = f32(f32(f32(self.coef[0]) * f32(s * s)) / f32(2 ** self.n))       # :282, 294
+        x0_int, b_int, c_int, exp_sf = softmax_constants(s, -1.0, 1.0)[:4]         # :277-294 (the range-dependent ones below)
         xin = x.contiguous().float()                                               # literal kernel: x / s itself (:303)
         rows = xin.numel() // L
         st = _st()
@@ -187,11 +178,10 @@ class IBERTIntSoftmax(nn.Module):
                       float(exp_sf), 1.0, 1 << 30, 30, self.output_bit, None, L, _lib.ptr(ex), st)
             self.act._observe(ex)
         lo, hi = float(self.act.x_min.reshape(-1)[0]), float(self.act.x_max.reshape(-1)[0])
-        act_sf = max(f32(f32(max(-f32(lo), f32(hi))) / f32(2 ** 15 - 1)), f32(EPS32))   # quant_utils.py:52-70, 16 bit
+        act_sf, m, e = softmax_constants(s, lo, hi)[4:]                                 # quant_utils.py:52-70, 16 bit
         self.act.act_scaling_factor = torch.full((1,), float(act_sf), dtype=torch.float32, device=x.device)
-        m, e = dyadic(exp_sf, act_sf)
         out = torch.empty(xin.shape, dtype=torch.float32, device=x.device)
         _lib.call("ivit_ibert_softmax_f32_f32", _lib.ptr(xin), L, rows, L, float(s), float(x0_int), float(b_int), float(c_int),
-                  float(exp_sf), float(act_sf), int(m[0]), int(e[0]), self.output_bit, _lib.ptr(out), L, None, st)
+                  float(exp_sf), float(act_sf), m, e, self.output_bit, _lib.ptr(out), L, None, st)
         so = torch.tensor([2 / 2 ** self.output_bit], dtype=torch.float32, device=x.device)   # :317
         return out, so
