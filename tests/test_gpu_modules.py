@@ -362,8 +362,9 @@ def test_ibert_layernorm_module_kat(ikat):
         assert np.array_equal(got[~nan].view(np.int32), want[~nan].view(np.int32))
 
 
-@pytest.mark.parametrize("C,s_in", [(192, 2.0 ** -4), (768, 0.0371), (384, 0.05), (1024, 0.0213), (100, 0.0371), (198, 0.0371)])
-def test_ibert_layernorm_i8_engine_kernel_equals_modules(C, s_in):
+@pytest.mark.parametrize("C,s_in,shift", [(192, 2.0 ** -4, 0), (768, 0.0371, 0), (384, 0.05, 0), (1024, 0.0213, 0), (100, 0.0371, 0),
+                                          (198, 0.0371, 0), (768, 0.0371, 2), (384, 2.0 ** -5, 1), (198, 0.05, 1)])
+def test_ibert_layernorm_i8_engine_kernel_equals_modules(C, s_in, shift):
     """ivit_ibert_layernorm_i8 (the fused engine's kernel: sums decided from exact integers, undecided rows literally) ==
     IBERTIntLayerNorm (literal float32 kernel) followed by a QuantAct, on random rows, rows whose mean is an exact tie
     (sum q = C * k + C / 2: the float32 reduction order decides), constant rows + one outlier, saturating rows"""
@@ -391,6 +392,7 @@ def test_ibert_layernorm_i8_engine_kernel_equals_modules(C, s_in):
     ln = q.IBERTIntLayerNorm(C).to(DEV)
     ln.weight.data = torch.from_numpy(gamma).to(DEV)
     ln.bias.data = torch.from_numpy(beta).to(DEV)
+    ln.shift.fill_(float(shift))          # the overflow buffer a calibration pass may have raised (ibert_modules.py:134-137)
     ln.fix()
     act = q.QuantAct().to(DEV)
     act.x_min.fill_(-2.9)
@@ -406,7 +408,7 @@ def test_ibert_layernorm_i8_engine_kernel_equals_modules(C, s_in):
     out = torch.zeros(rows, C, dtype=torch.int8, device=DEV)
     dq, db, dsl = torch.from_numpy(qv).to(DEV), torch.from_numpy(lp.bias_int).to(DEV), torch.from_numpy(lp.s_ln).to(DEV)
     dm, de = torch.from_numpy(lp.m.view(np.int32)).to(DEV), torch.from_numpy(lp.e).to(DEV)
-    _lib.call("ivit_ibert_layernorm_i8", _lib.ptr(dq), C, rows, C, float(s_in), _lib.ptr(db), _lib.ptr(dsl), 1.0, _lib.ptr(dm),
+    _lib.call("ivit_ibert_layernorm_i8", _lib.ptr(dq), C, rows, C, float(s_in), _lib.ptr(db), _lib.ptr(dsl), float(2.0 ** shift), _lib.ptr(dm),
               _lib.ptr(de), _lib.ptr(out), C, 0, _lib.stream_ptr())
     got = out.cpu().numpy().astype(np.int32)
     bad = np.argwhere(got != exp)
