@@ -171,6 +171,14 @@ def test_gemm_requant_residual_i16(M, N, K):
         _lib.call("ivit_residual_requant_i16", _lib.ptr(k8d), 8, None, None, m1, e1, _lib.ptr(dres), m2, e2, _lib.ptr(out2), M, N,
                   0, 0, 0, 0, st())
         assert torch.equal(out, out2)
+        # the weights-in-registers kernel (fragment-packed W): what the Swin engine uses where K % 192 == 0 and M >= 2048
+        if M >= 2048 and N >= 128 and N % 64 == 0 and K % 192 == 0:
+            Wf = torch.zeros((N + 63) // 64 * 64 * K, dtype=torch.int8, device=DEV)
+            _lib.call("ivit_pack_weight_frags_i8", _lib.ptr(dW), K, N, K, _lib.ptr(Wf), st())
+            out3 = torch.zeros(M, N, dtype=torch.int16, device=DEV)
+            _lib.call("ivit_gemm_i8_requant_residual_i16_ex", _lib.ptr(dA), K, _lib.ptr(Wf), K, _lib.ptr(db), _lib.ptr(dm), _lib.ptr(de),
+                      _lib.ptr(dres), N, m1, e1, m2, e2, _lib.ptr(out3), N, M, N, K, 8, st())
+            assert torch.equal(out, out3)
 
 
 @pytest.mark.parametrize("regime", ["tiny_gamma", "big_bias", "saturating", "vanishing"])
