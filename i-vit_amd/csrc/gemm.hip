@@ -481,7 +481,8 @@ constexpr int WR_STAGE = WR_TOK * BK;                       // 8 KiB
 constexpr int WR_RING = WR_STAGES * WR_STAGE;               // 24 KiB
 constexpr int WR_CS = WR_TOK * (WR_CH + 4);                 // 32.5 KiB epilogue staging
 constexpr int WR_TAB = WR_CH * 12;                          // float2 lohi[256]; int bias[256]
-constexpr int WR_SMEM = WR_RING + WR_CS + 2 * WR_TAB;       // 62.5 KiB: two workgroups per CU
+constexpr int WR_LUT = WR_RING + WR_CS + 2 * WR_TAB;        // 256-byte output map (GemmArgs::lut)
+constexpr int WR_SMEM = WR_LUT + 256;                       // 62.75 KiB: two workgroups per CU
 
 struct WrWork { int m0, n0, half; };   // m0 < 0: none
 
@@ -765,7 +766,8 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_wreg_kernel(GemmArgs g)
             int tid_o = tid;   // opaque: the epilogue's per-thread addresses are computed here, not carried through the main loop
             asm volatile("" : "+v"(tid_o));
             epilogue_i8<EPI, 2, TJ, 32 * TJ, BIG_NT, 0, WR_CH, Hook>(acc, g, cs, tab, cur.m0, cur.n0, 64 * wave, 0, tid_o, (tid_o >> 5) & 1,
-                                                                      tid_o & 31, hook);
+                                                                      tid_o & 31, hook,
+                                                                      g.lut ? reinterpret_cast<const unsigned char*>(smem + WR_LUT) : nullptr);
             if constexpr (ABL & 32) __builtin_amdgcn_s_setprio(0);   // lab: main loops back at priority 0 (the epilogue raises it to 2)
         }
     };
@@ -774,6 +776,7 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_wreg_kernel(GemmArgs g)
     WrWork cur = wr_work(g, 0, b, G);
     if (cur.m0 < 0) return;   // uniform
     table_write(table_issue(cur.n0), smem + WR_RING + WR_CS);
+    if (g.lut) smem[WR_LUT + tid] = (char)g.lut[tid];     // BIG_NT == 256; visible after the first tile's barriers
     prefetch(cur);
 
     for (int it = 0; cur.m0 >= 0; ++it) {
@@ -844,6 +847,7 @@ int launch_gemm(GemmArgs& g, const char* name, ivit_stream_t stream)
         IVIT_REQUIRE(!g.w_blocks || g.ldw == g.K, "%s: a block-layout W operand is dense (ldw == K)", name);
     }
     if (g.w_frags) IVIT_REQUIRE(!g.a_blocks || g.lda == g.K, "%s: a block-layout A operand is dense (lda == K)", name);
+    IVIT_REQUIRE(!g.lut || (g.w_frags && EPI == EPI_RQ), "%s: the output map needs the fragment-packed weight form (IVIT_W_FRAGS)", name);
     if (g.w_frags) {
         IVIT_REQUIRE(EPI != EPI_I32 && EPI != EPI_RQ16 && g.M >= 2048 && g.N >= 128 && g.N % 64 == 0 && (g.K / BK) % 3 == 0 && !g.w_blocks && !g_force_small,
                      "%s: the fragment-packed weight needs M >= 2048, N >= 128, N %% 64 == 0, K %% 192 == 0 and a requantising epilogue", name);
@@ -958,6 +962,20 @@ IVIT_EXPORT int ivit_gemm_i8_requant_ex(const int8_t* A, int64_t lda, const int8
     IVIT_REQUIRE(!g.out_blocks || (N % 64 == 0 && ldo == N && ((int64_t)M + 15) * N < 2147483648ll),
                  "ivit_gemm_i8_requant_ex: block-layout output needs N %% 64 == 0, ldo == N and a buffer below 2 GiB");
     return launch_gemm<EPI_RQ>(g, "ivit_gemm_i8_requant_ex", stream);
+}
+
+IVIT_EXPORT int ivit_gemm_i8_requant_lut_ex(const int8_t* A, int64_t lda, const int8_t* W, int64_t ldw, const int32_t* bias,
+                                            const uint32_t* m, const int32_t* e, const int8_t* lut, int8_t* out, int64_t ldo,
+                                            int M, int N, int K, int layouts, ivit_stream_t stream)
+{
+    GemmArgs g{};
+    g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.m = m; g.e = e;
+    g.out = out; g.ldo = ldo; g.M = M; g.N = N; g.K = K; g.lut = lut;
+    g.a_blocks = layouts & 1; g.w_blocks = (layouts >> 1) & 1; g.out_blocks = (layouts >> 2) & 1; g.w_frags = (layouts >> 3) & 1;
+    IVIT_REQUIRE(lut && (layouts & ~15) == 0 && g.w_frags, "ivit_gemm_i8_requant_lut_ex: needs a map and IVIT_W_FRAGS");
+    IVIT_REQUIRE(!g.out_blocks || (N % 64 == 0 && ldo == N && ((int64_t)M + 15) * N < 2147483648ll),
+                 "ivit_gemm_i8_requant_lut_ex: block-layout output needs N %% 64 == 0, ldo == N and a buffer below 2 GiB");
+    return launch_gemm<EPI_RQ>(g, "ivit_gemm_i8_requant_lut_ex", stream);
 }
 
 IVIT_EXPORT int ivit_gemm_i8_requant(const int8_t* A, int64_t lda, const int8_t* W, int64_t ldw, const int32_t* bias,

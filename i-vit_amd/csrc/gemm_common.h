@@ -64,6 +64,8 @@ struct GemmArgs {
     int a_blocks, w_blocks;   // operand in the block layout (common.h: ivit_block_offset); persistent kernel only
     int out_blocks;           // EPI_RQ: the int8 output in the block layout (row length N): it is the next GEMM's A operand
     int w_frags;              // W is the MFMA-fragment copy (ivit_pack_weight_frags_i8): the weights-in-registers kernel
+    const int8_t* lut;        // EPI_RQ, weights-in-registers kernel: out = lut[q + 128] applied to every requantised byte (an
+                              // elementwise int8 -> int8 operator behind the QuantAct, e.g. I-BERT GELU + mlp.qact1), or NULL
 };
 
 IVIT_DEV int nk_of(const GemmArgs& g) { return g.K / 64; }
@@ -123,7 +125,8 @@ struct NoHook {
 
 template <int EPI, int TI, int TJ, int TOK, int NTHREADS, int ABL = 0, int CH = 128, typename Hook = NoHook>
 IVIT_DEV void epilogue_i8(v16i (&acc)[TI][TJ], const GemmArgs& g, char* smem, const char* rq_lds, int m0, int n0,
-                          int wch, int wtok, int tid, int h, int l31, const Hook& hook = Hook())
+                          int wch, int wtok, int tid, int h, int l31, const Hook& hook = Hook(),
+                          const unsigned char* lut_lds = nullptr)
 {
     // The epilogue is a short VALU burst next to the co-resident workgroup's MFMA stream: give it issue priority
     // so its dependent chains do not wait behind queued MFMAs (which run in the matrix pipe once issued).
@@ -332,6 +335,16 @@ IVIT_DEV void epilogue_i8(v16i (&acc)[TI][TJ], const GemmArgs& g, char* smem, co
             op[0] = make_int4(ow[0], ow[1], ow[2], ow[3]);
             op[1] = make_int4(ow[4], ow[5], ow[6], ow[7]);
             continue;
+        }
+        if constexpr (EPI == EPI_RQ) {
+            if (lut_lds) {      // uniform: a 256-entry int8 -> int8 map (LDS) over the 16 bytes of the chunk
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const unsigned u = (unsigned)v[it][d] ^ 0x80808080u;      // q + 128 per byte
+                    v[it][d] = (int)((unsigned)lut_lds[u & 255] | ((unsigned)lut_lds[(u >> 8) & 255] << 8) |
+                                     ((unsigned)lut_lds[(u >> 16) & 255] << 16) | ((unsigned)lut_lds[u >> 24] << 24));
+                }
+            }
         }
         int64_t off;
         if constexpr (EPI == EPI_QKV) {

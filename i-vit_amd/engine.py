@@ -214,6 +214,7 @@ class IntViTEngine(GraphReplay):
         # (DESIGN.md section 5): the GEMM gains 4-6 % from a block-layout A, the producer pays for 64-byte row segments
         self.block_a = {"ln": True, "attn": True, "gelu": True}
         self.gelu_in_place = True     # GELU overwrites the fc1 output (same layout on both sides)
+        self.fuse_ibert_gelu = True   # family "ibert": GELU + mlp.qact1 as a byte map in the fc1 epilogue (False: A/B, tests)
         self.probe = None
         self._alloc(max_batch)
         self._compact(True)
@@ -356,11 +357,21 @@ class IntViTEngine(GraphReplay):
             tap(p + "qact3", ws["h"], (B, T, C), a_ln)
             # mlp.fc1 writes the block layout and GELU works IN PLACE on it: the 155 MB intermediate exists once, so the pair
             # (GELU output, fc2 operand) stays inside the 256 MB Infinity Cache (separate buffers: 310 MB; -0.18 ms / forward)
-            self._gemm(ws["h"], C, blk["fc1"], ws["f1"], 4 * C, M, st, a_blocks=a_ln, blocks=blk_l, out_blocks=a_ge)
-            tap(p + "mlp.qact_gelu", ws["f1"], (B, T, 4 * C), a_ge)
-            g_buf = ws["f1"] if self.gelu_in_place else ws["g"]
-            _lib.call("ivit_shiftgelu_lut_i8_ex", _lib.ptr(ws["f1"]), 4 * C, M, 4 * C, _lib.ptr(blk["gelu_lut"]),
-                      _lib.ptr(g_buf), 4 * C, 3 if a_ge else 0, st)
+            f1 = blk["fc1"]
+            if (self.family == "ibert" and self.fuse_ibert_gelu and taps is None and blk_l and self.weight_frags
+                    and f1.get("Wf") is not None):
+                # I-BERT GELU + mlp.qact1 is a map of the requantised byte alone (no row maximum): applied in the fc1 epilogue,
+                # the GELU kernel and its pass over the 4C-wide intermediate disappear
+                g_buf = ws["f1"]
+                _lib.call("ivit_gemm_i8_requant_lut_ex", _lib.ptr(ws["h"]), C, _lib.ptr(f1["Wf"]), f1["K"], _lib.ptr(f1["b"]),
+                          _lib.ptr(f1["m"]), _lib.ptr(f1["e"]), _lib.ptr(blk["gelu_lut"]), _lib.ptr(g_buf), 4 * C, M, f1["N"], f1["K"],
+                          8 | int(a_ln) | (4 if a_ge else 0), st)
+            else:
+                self._gemm(ws["h"], C, f1, ws["f1"], 4 * C, M, st, a_blocks=a_ln, blocks=blk_l, out_blocks=a_ge)
+                tap(p + "mlp.qact_gelu", ws["f1"], (B, T, 4 * C), a_ge)
+                g_buf = ws["f1"] if self.gelu_in_place else ws["g"]
+                _lib.call("ivit_shiftgelu_lut_i8_ex", _lib.ptr(ws["f1"]), 4 * C, M, 4 * C, _lib.ptr(blk["gelu_lut"]),
+                          _lib.ptr(g_buf), 4 * C, 3 if a_ge else 0, st)
             tap(p + "mlp.qact1", g_buf, (B, T, 4 * C), a_ge)
             self._gemm_res(g_buf, 4 * C, blk["fc2"], x2, blk["res2"], x, M, st, blocks=blk_l, a_blocks=a_ge)
             tap(p + "qact4", x, (B, T, C))

@@ -102,6 +102,13 @@ int ivit_gemm_i8_requant_ex(const int8_t* A, int64_t lda, const int8_t* W, int64
                             const uint32_t* m, const int32_t* e, int8_t* out, int64_t ldo,
                             int M, int N, int K, int layouts, ivit_stream_t stream);
 
+/* ivit_gemm_i8_requant_ex followed by an elementwise int8 -> int8 map on every output: out = lut[k + 128], lut int8[256] -- an
+ * operator behind the QuantAct that depends on the value alone (I-BERT GELU + mlp.qact1: ivit_ibert_gelu_build_lut row 0),
+ * applied in the epilogue instead of by a kernel of its own.  Needs IVIT_W_FRAGS (the weights-in-registers kernel). */
+int ivit_gemm_i8_requant_lut_ex(const int8_t* A, int64_t lda, const int8_t* W, int64_t ldw, const int32_t* bias,
+                                const uint32_t* m, const int32_t* e, const int8_t* lut, int8_t* out, int64_t ldo,
+                                int M, int N, int K, int layouts, ivit_stream_t stream);
+
 /* as above, then the two-operand QuantAct of the residual connection
  * (vit_quant.py:147,153; quant_utils.py:232-245):
  *   k = clamp8(RNE(acc * m[n] / 2^e[n]))

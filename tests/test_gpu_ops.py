@@ -377,6 +377,38 @@ def test_gemm_weight_fragment_layout(M, N, K):
                   _lib.ptr(out), N, M, N, 128, 8, st())
 
 
+@pytest.mark.parametrize("M,N,K", [(2600, 512, 384), (197 * 16, 3072, 768)])
+def test_gemm_requant_output_map(M, N, K):
+    """ivit_gemm_i8_requant_lut_ex: a 256-entry int8 -> int8 map applied to every requantised output in the epilogue of the
+    weights-in-registers kernel (row-major and block-layout output) == the oracle's requant followed by the map"""
+    rng = np.random.default_rng(M + N + 7)
+    A = rng.integers(-128, 128, size=(M, K)).astype(np.int8)
+    W = rng.integers(-128, 128, size=(N, K)).astype(np.int8)
+    b = rng.integers(-50000, 50000, size=N).astype(np.int32)
+    m, e = rand_me(rng, N, -16, -9)
+    md, ed = me_dev(m, e)
+    lut = rng.integers(-128, 128, size=256).astype(np.int8)
+    k8 = orc.requant(orc.gemm_i8(A, W, b), m.astype(np.float64), e, 8)
+    exp = lut[k8 + 128].astype(np.int32)
+    dA, dW, db, dl = dev(A), dev(W), dev(b), dev(lut)
+    R16 = (M + 15) // 16 * 16
+    At = torch.zeros(R16 * K, dtype=torch.int8, device=DEV)
+    _lib.call("ivit_tile_operand_i8", _lib.ptr(dA), K, M, K, _lib.ptr(At), st())
+    Wf = torch.zeros((N + 63) // 64 * 64 * K, dtype=torch.int8, device=DEV)
+    _lib.call("ivit_pack_weight_frags_i8", _lib.ptr(dW), K, N, K, _lib.ptr(Wf), st())
+    out = torch.zeros(M, N, dtype=torch.int8, device=DEV)
+    _lib.call("ivit_gemm_i8_requant_lut_ex", _lib.ptr(dA), K, _lib.ptr(Wf), K, _lib.ptr(db), _lib.ptr(md), _lib.ptr(ed), _lib.ptr(dl),
+              _lib.ptr(out), N, M, N, K, 8, st())
+    assert np.array_equal(out.cpu().numpy().astype(np.int32), exp)
+    outb = torch.zeros(R16 * N, dtype=torch.int8, device=DEV)
+    _lib.call("ivit_gemm_i8_requant_lut_ex", _lib.ptr(At), K, _lib.ptr(Wf), K, _lib.ptr(db), _lib.ptr(md), _lib.ptr(ed), _lib.ptr(dl),
+              _lib.ptr(outb), N, M, N, K, 13, st())
+    assert np.array_equal(outb.cpu().numpy(), _block_layout_host(exp.astype(np.int8)))
+    with pytest.raises(_lib.IvitError, match="IVIT_W_FRAGS"):
+        _lib.call("ivit_gemm_i8_requant_lut_ex", _lib.ptr(dA), K, _lib.ptr(dW), K, _lib.ptr(db), _lib.ptr(md), _lib.ptr(ed), _lib.ptr(dl),
+                  _lib.ptr(out), N, M, N, K, 0, st())
+
+
 def test_producers_write_block_layout():
     """LayerNorm, fused attention and the GELU table kernel with out_blocks = 1 == ivit_tile_operand_i8 of their
     row-major output (ragged row counts: the last 16-row block is partly padding)"""
