@@ -449,12 +449,13 @@ def test_mixed_operator_families_take_the_module_path():
     assert y.shape == (2, 1000) and torch.isfinite(y).all()
 
 
-@pytest.mark.parametrize("regime", ["pow2", "natural"])
-def test_ibert_engine_equals_module_path_deit_small_width(regime):
-    """a wider I-BERT model than the reference fixtures cover (DeiT-S: C = 384, 6 heads; 12 fresh images; ranges calibrated
-    here, snapped to powers of two or left as calibrated): fused engine == module-by-module path, float logits bitwise"""
-    fs = synth.make_float_state("deit_small_patch16_224", 23)
-    model = ivit.deit_small_patch16_224(gelu_type="ibert", softmax_type="ibert", layernorm_type="ibert")
+@pytest.mark.parametrize("regime,size", [("pow2", "small"), ("natural", "small"), ("natural", "base")])
+def test_ibert_engine_equals_module_path_deit_small_width(regime, size):
+    """wider I-BERT models than the reference fixtures cover (DeiT-S: C = 384, 6 heads; DeiT-B: C = 768, 12 heads; 12 fresh
+    images = 2364 token rows: the large-batch kernels incl. the GELU map in the fc1 epilogue; ranges calibrated here, snapped to
+    powers of two or left as calibrated): fused engine == module-by-module path, float logits bitwise"""
+    fs = synth.make_float_state(f"deit_{size}_patch16_224", 23)
+    model = getattr(ivit, f"deit_{size}_patch16_224")(gelu_type="ibert", softmax_type="ibert", layernorm_type="ibert")
     model.load_state_dict({k: torch.from_numpy(v) for k, v in fs.items()}, strict=False)
     model.to(DEV).eval()
     with torch.no_grad():
