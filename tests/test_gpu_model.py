@@ -110,6 +110,23 @@ def test_batch_invariance_and_oracle_on_fresh_images():
     assert np.array_equal(li3.cpu().numpy(), li[5:6])
 
 
+@pytest.mark.parametrize("tag,family", [("deit_base", "ivit"), ("deit_base_natural", "ivit")])
+def test_logits_do_not_depend_on_the_batch_size(tag, family):
+    """DeiT-B through every kernel-selection regime of the engine: batch 1 .. 10 (small-tile GEMMs, row-major operands), 11, 12
+    (first persistent / weights-in-registers launches, ragged 128-token tiles: 2167 and 2364 rows), 37, 130 (partial last
+    tiles, half-tile tail or not) -- an image's INT32 logits are the same in all of them"""
+    fs, ranges, cfg, meta, z = load_synthetic_model(tag)
+    eng = IntViTEngine(fs, ranges, cfg["embed_dim"], cfg["depth"], cfg["num_heads"], device=DEV, max_batch=130, family=family)
+    imgs = torch.from_numpy(synth.make_images(130, 777)).to(DEV)
+    ref = eng.forward(imgs)[0].cpu().numpy().copy()
+    assert len(set(ref.argmax(1).tolist())) > 10
+    for n in (1, 3, 10, 11, 12, 37):
+        got = eng.forward(imgs[:n].contiguous())[0].cpu().numpy()
+        assert np.array_equal(got, ref[:n]), n
+    got = eng.forward(imgs[93:130].contiguous())[0].cpu().numpy()
+    assert np.array_equal(got, ref[93:130])
+
+
 def test_block_layout_path_equals_row_major_path():
     """batch large enough for the persistent GEMM (M = 13 * 197 >= 2048, not a multiple of 16: the last 16-row block of
     every block-layout operand is partly padding): activations + weights in the block layout vs everything row-major --
