@@ -68,7 +68,7 @@ def build_model(model_config: Optional[dict] = None, num_classes: int = 1000, ge
     if factory.__name__.startswith("swin"):
         for k, v in ops.items():
             if not str(v).lower().startswith("ivit"):
-                raise KeyError(f"{k}={v!r}: only the 'ivit' operators are implemented by the MI355X integer path")
+                raise KeyError(f"{k}={v!r}: the Swin models of the MI355X integer path implement the 'ivit' operators only (DeiT / ViT: 'ivit' and 'ibert')")
         return factory(pretrained=False, num_classes=cfg.get("num_classes", num_classes),
                        drop_rate=cfg.get("drop_rate", 0.0), drop_path_rate=cfg.get("drop_path_rate", 0.1))
     bws = {k: (bitwidth if bitwidth is not None else cfg.get(k, 8)) for k in _BW_KEYS}
