@@ -765,7 +765,7 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_wreg_kernel(GemmArgs g)
         } else {
             int tid_o = tid;   // opaque: the epilogue's per-thread addresses are computed here, not carried through the main loop
             asm volatile("" : "+v"(tid_o));
-            epilogue_i8<EPI, 2, TJ, 32 * TJ, BIG_NT, 0, WR_CH, Hook>(acc, g, cs, tab, cur.m0, cur.n0, 64 * wave, 0, tid_o, (tid_o >> 5) & 1,
+            epilogue_i8<EPI, 2, TJ, 32 * TJ, BIG_NT, (ABL & 64), WR_CH, Hook>(acc, g, cs, tab, cur.m0, cur.n0, 64 * wave, 0, tid_o, (tid_o >> 5) & 1,
                                                                       tid_o & 31, hook,
                                                                       g.lut ? reinterpret_cast<const unsigned char*>(smem + WR_LUT) : nullptr);
             if constexpr (ABL & 32) __builtin_amdgcn_s_setprio(0);   // lab: main loops back at priority 0 (the epilogue raises it to 2)
@@ -865,10 +865,10 @@ int launch_gemm(GemmArgs& g, const char* name, ivit_stream_t stream)
             const dim3 grid(ntiles < 512 ? ntiles : 512);
 #if IVIT_LAB
             if constexpr (EPI == EPI_RQ) {   // ablations (scripts/gemm_ab.py --frags): what each stream of the kernel costs
-                switch (g_debug_flags & 63) {
+                switch (g_debug_flags & 127) {
 #define IVIT_WR_ABL(v) case v: hipLaunchKernelGGL((gemm_i8_wreg_kernel<EPI_RQ, v>), grid, dim3(BIG_NT), 0, ivit_stream(stream), g); IVIT_CHECK_LAUNCH(name)
                     case 16: g.res = (const int8_t*)g_stamp_buf; hipLaunchKernelGGL((gemm_i8_wreg_kernel<EPI_RQ, 16>), (g_debug_flags & 4096) ? dim3(256) : grid, dim3(BIG_NT), (g_debug_flags & 4096) ? 40960 : 0, ivit_stream(stream), g); IVIT_CHECK_LAUNCH(name);
-                    IVIT_WR_ABL(32); IVIT_WR_ABL(1); IVIT_WR_ABL(2); IVIT_WR_ABL(4); IVIT_WR_ABL(6); IVIT_WR_ABL(8); IVIT_WR_ABL(14); IVIT_WR_ABL(15); IVIT_WR_ABL(7);
+                    IVIT_WR_ABL(64); IVIT_WR_ABL(32); IVIT_WR_ABL(1); IVIT_WR_ABL(2); IVIT_WR_ABL(4); IVIT_WR_ABL(6); IVIT_WR_ABL(8); IVIT_WR_ABL(14); IVIT_WR_ABL(15); IVIT_WR_ABL(7);
 #undef IVIT_WR_ABL
                     default: break;
                 }

@@ -175,8 +175,16 @@ IVIT_DEV void epilogue_i8(v16i (&acc)[TI][TJ], const GemmArgs& g, char* smem, co
                         b[j][jj] = acc[i][j][4 * q + jj] + (int)lo[jj];
                     } else {
                         const float a = (float)acc[i][j][4 * q + jj];
-                        const int tl = __float_as_int(__builtin_fmaf(a, lo[jj], 12582912.0f));
-                        const int th = __float_as_int(__builtin_fmaf(a, hi[jj], 12582912.0f));
+                        int tl, th;
+                        if constexpr (ABL & 64) {   // A/B: both brackets in one packed fma (lo, hi are adjacent table entries)
+                            typedef float v2f_ __attribute__((ext_vector_type(2)));
+                            const v2f_ r = __builtin_elementwise_fma((v2f_){a, a}, (v2f_){lo[jj], hi[jj]}, (v2f_){12582912.0f, 12582912.0f});
+                            tl = __float_as_int(r.x);
+                            th = __float_as_int(r.y);
+                        } else {
+                            tl = __float_as_int(__builtin_fmaf(a, lo[jj], 12582912.0f));
+                            th = __float_as_int(__builtin_fmaf(a, hi[jj], 12582912.0f));
+                        }
                         // unc += |tl - th| in ONE instruction (v_sad_u32): zero iff every certificate of the batch holds.
                         // tl, th are bit patterns of floats next to 1.5 * 2^23, their differences are tiny: no wrap-around.
                         if constexpr (ABL & 32) {   // A/B: the former two-instruction form
