@@ -19,6 +19,12 @@
 // float32 (= the reference's float32 sum whenever that is exact).
 #include "common.h"
 
+#if IVIT_LAB
+extern int g_ln_ablate;     // rowops.hip (ivit_debug_ln_ablate); bits 20-24 ablate phases of attention_kernel<0> (scripts/attn_ablate.py)
+#else
+constexpr int g_ln_ablate = 0;
+#endif
+
 namespace {
 
 constexpr int NT = 256;
@@ -55,6 +61,7 @@ struct AttnArgs {
     // I-BERT softmax (MODE 3): exp_int after the internal QuantAct(16), as the float32 the reference sums and multiplies, for
     // every (row max, q): [256][256], built by ivit_ibert_softmax_build_table
     const float* ib_table;
+    int abl;   // lab build: 1 no score requant, 2 no table lookups, 4 no probability products, 8 no P.V + output, 16 one query tile per wave
 };
 
 constexpr int BAND_PAD = 4;   // dwords: keeps slice rows 16-byte aligned and rotates their banks
@@ -133,7 +140,7 @@ __global__ __launch_bounds__(NT, 3) void attention_kernel(AttnArgs a)
 
     // 13 query tiles over 4 waves: one wave gets four tiles, the others three.  Which wave that is rotates with the
     // workgroup index, so that the co-resident workgroups of a CU do not all put their extra tile on the same SIMD
-    for (int qt = (wave + bh) & 3; qt < nqt; qt += 4) {
+    for (int qt = (wave + bh) & 3; qt < ((IVIT_LAB && (a.abl & 16)) ? 4 : nqt); qt += 4) {
         const int qrow = qt * 16 + l15;  // this lane's query
         const int qld = min(qrow, T - 1);
         const v4i qf = *reinterpret_cast<const v4i*>(qg + (int64_t)qld * HD + 16 * g);
@@ -151,7 +158,7 @@ __global__ __launch_bounds__(NT, 3) void attention_kernel(AttnArgs a)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 // |S| <= 64*128*128 = 2^20, m < 2^32: the product is exact in float64
-                int nk = clamp_i32(requant_exact(acc[r], -a.Ms), -127, 128);
+                int nk = (IVIT_LAB && (a.abl & 1)) ? (acc[r] & 127) : clamp_i32(requant_exact(acc[r], -a.Ms), -127, 128);
                 if (kt == NKT - 1) nk = (16 * kt + 4 * g + r < T) ? nk : 1000;
                 s[kt][r] = nk;
                 nmin = min(nmin, nk);
@@ -308,6 +315,9 @@ __global__ __launch_bounds__(NT, 3) void attention_kernel(AttnArgs a)
                     const bool pad = s[kt][r] == 1000;
                     e = pad ? 0u : e;
                     ef = pad ? 0u : ef;
+                } else if (IVIT_LAB && (a.abl & 2)) {
+                    e = (unsigned)s[kt][r];
+                    ef = (unsigned)__float_as_int(1.0f);
                 } else {
                     e = lut[rmax + s[kt][r]];
                     ef = lut[256 + rmax + s[kt][r]];
@@ -349,6 +359,8 @@ __global__ __launch_bounds__(NT, 3) void attention_kernel(AttnArgs a)
                         if constexpr (MODE >= 3) {
                             p[r] = (unsigned)(ev * factor_h);
                             any_u |= p[r];
+                        } else if (IVIT_LAB && (a.abl & 4)) {
+                            p[r] = (unsigned)s[4 * ks + t][r];
                         } else {
                             p[r] = (unsigned)(ev * factor);  // float32 product (:175), < 2^31
                         }
@@ -379,7 +391,12 @@ __global__ __launch_bounds__(NT, 3) void attention_kernel(AttnArgs a)
         // ---- O^T = Vt . P^T, requantised (attn.qact2), 4 consecutive d per dword
         const int64_t orow_idx = (int64_t)b * T + qrow;
         const BlockRow obrow = block_row((int)orow_idx, a.heads * HD);
-        int8_t* orow = a.out + orow_idx * ((int64_t)a.heads * HD) + hh * HD + 4 * g;
+        int8_t* orow = a.out + orow_idx * ((int64_t)a.heads * HD) + hh * HD;
+        if (IVIT_LAB && (a.abl & 8)) {
+            if (pk[0][0] == 0x12345678) a.out[0] = 1;
+            continue;
+        }
+        unsigned wq[4];    // wq[dt]: bytes d = 16 dt + 4 g + 0..3 of this lane's query
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
             v4i acc = {0, 0, 0, 0};
@@ -391,18 +408,31 @@ __global__ __launch_bounds__(NT, 3) void attention_kernel(AttnArgs a)
                 if constexpr (MODE >= 3)
                     if (hi_pass) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(vf, pkh[ks], acc, 0, 0, 0);
             }
-            if (qrow < T) {
-                unsigned w = 0;
+            unsigned w = 0;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    // |O| <= 208*127*128 < 2^22: exact float64 product
-                    int o = clamp_i32(requant_exact(acc[r], a.Mo), -128, 127);
-                    w |= ((unsigned)o & 0xffu) << (8 * r);
-                }
-                if (a.out_blocks)   // column = 64 hh + 16 dt + 4 g: chunk index dt, column block hh
-                    *reinterpret_cast<unsigned*>(a.out + obrow.base + (unsigned)hh * 1024u + (((unsigned)dt ^ obrow.rs) << 4) + 4u * g) = w;
+            for (int r = 0; r < 4; ++r) {
+                // |O| <= 208*127*128 < 2^22: exact float64 product
+                int o = clamp_i32(requant_exact(acc[r], a.Mo), -128, 127);
+                w |= ((unsigned)o & 0xffu) << (8 * r);
+            }
+            wq[dt] = w;
+        }
+        // A query's 64 output bytes sit as 4 x 4 dwords in its four lanes (g = lane >> 4).  A 4 x 4 word transpose across those
+        // lanes -- two v_permlane32_swap, two v_permlane16_swap -- leaves lane g with the 16 CONTIGUOUS bytes d = 16 g .. 16 g + 15:
+        // one 16-byte store per lane instead of four 4-byte ones (a quarter of the store instructions and of the segments the
+        // memory pipeline has to merge).
+        {
+            typedef unsigned v2u __attribute__((ext_vector_type(2)));
+            const v2u ab = __builtin_amdgcn_permlane32_swap(wq[0], wq[2], false, false);    // g < 2: (w0[g], w0[g+2]); g >= 2: (w2[g-2], w2[g])
+            const v2u cd = __builtin_amdgcn_permlane32_swap(wq[1], wq[3], false, false);    // g < 2: (w1[g], w1[g+2]); g >= 2: (w3[g-2], w3[g])
+            const v2u ac = __builtin_amdgcn_permlane16_swap(ab.x, cd.x, false, false);      // (w_g[0], w_g[1]) of the lanes 0, 1
+            const v2u bd = __builtin_amdgcn_permlane16_swap(ab.y, cd.y, false, false);      // (w_g[2], w_g[3])
+            if (qrow < T) {
+                const v4i chunk = {(int)ac.x, (int)ac.y, (int)bd.x, (int)bd.y};
+                if (a.out_blocks)   // column = 64 hh + 16 g: chunk index g, column block hh
+                    *reinterpret_cast<v4i*>(a.out + obrow.base + (unsigned)hh * 1024u + (((unsigned)g ^ obrow.rs) << 4)) = chunk;
                 else
-                    *reinterpret_cast<unsigned*>(orow + 16 * dt) = w;
+                    *reinterpret_cast<v4i*>(orow + 16 * g) = chunk;
             }
         }
     }
@@ -438,8 +468,8 @@ IVIT_EXPORT int ivit_attention_fused_i8_compat_band(const int8_t* qkv, int8_t* o
                        head_dim, tokens);
         return IVIT_ERR_UNSUPPORTED;
     }
-    IVIT_REQUIRE(((uintptr_t)qkv % 16 == 0) && ((uintptr_t)out % 4 == 0) && ((heads * head_dim) % 4 == 0),
-                 "ivit_attention_fused_i8: misaligned operand");
+    IVIT_REQUIRE(((uintptr_t)qkv % 16 == 0) && ((uintptr_t)out % 16 == 0) && ((heads * head_dim) % 16 == 0),
+                 "ivit_attention_fused_i8: misaligned operand (16-byte rows)");
     IVIT_REQUIRE(s_attn > 0.0f, "ivit_attention_fused_i8: scale must be positive");
     IVIT_REQUIRE(out_blocks == 0 || (out_blocks == 1 && ((uintptr_t)out % 16 == 0) &&
                                      ((int64_t)batch * tokens + 15) * heads * head_dim < 2147483648ll),
@@ -448,6 +478,7 @@ IVIT_EXPORT int ivit_attention_fused_i8_compat_band(const int8_t* qkv, int8_t* o
     IVIT_REQUIRE(band_w == 0 || (band && band_w >= 16 && band_w <= 256 && band_w % 16 == 0 && (uintptr_t)band % 16 == 0),
                  "ivit_attention_fused_i8_compat_band: band table must be 16-byte aligned, width a multiple of 16 in [16, 256]");
     AttnArgs a{};
+    a.abl = (g_ln_ablate >> 20) & 31;
     a.exp2d = exp2d;
     a.band = band;
     a.band_w = band_w;
@@ -486,7 +517,7 @@ IVIT_EXPORT int ivit_attention_fused_i8_ibert(const int8_t* qkv, int8_t* out, in
         ivit_set_error("ivit_attention_fused_i8_ibert: unsupported geometry head_dim=%d tokens=%d (need 64, 193..207)", head_dim, tokens);
         return IVIT_ERR_UNSUPPORTED;
     }
-    IVIT_REQUIRE(((uintptr_t)qkv % 16 == 0) && ((uintptr_t)out % 4 == 0) && ((uintptr_t)table % 4 == 0),
+    IVIT_REQUIRE(((uintptr_t)qkv % 16 == 0) && ((uintptr_t)out % 16 == 0) && ((uintptr_t)table % 4 == 0),
                  "ivit_attention_fused_i8_ibert: misaligned operand");
     IVIT_REQUIRE(out_blocks == 0 || (out_blocks == 1 && ((uintptr_t)out % 16 == 0) &&
                                      ((int64_t)batch * tokens + 15) * heads * head_dim < 2147483648ll),
