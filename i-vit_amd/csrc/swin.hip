@@ -809,20 +809,27 @@ __global__ __launch_bounds__(NT) void window_attention_kernel(WinAttnArgs a)
                 }
                 pk[t] = (int)w;
             }
-            int8_t* orow = a.out + ((int64_t)win * T + qrow) * a.ldo + hh * WHD + 4 * g;
+            int8_t* orow = a.out + ((int64_t)win * T + qrow) * a.ldo + hh * WHD;
+            unsigned wq[2];      // wq[dt]: bytes d = 16 dt + 4 g + 0..3 of this lane's query
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) {
                 const int d = 16 * dt + l15;
                 const v4i vf = *reinterpret_cast<const v4i*>(vt + d * WVT_ROW + (((g + 2 * ((d >> 2) & 1)) & 3) << 4));
                 v4i acc = {0, 0, 0, 0};
                 acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(vf, pk, acc, 0, 0, 0);
-                if (qrow < T) {
-                    unsigned w = 0;
+                unsigned w = 0;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        w |= ((unsigned)clamp_i32(requant_exact(acc[r], a.Mo), -128, 127) & 0xffu) << (8 * r);
-                    *reinterpret_cast<unsigned*>(orow + 16 * dt) = w;
-                }
+                for (int r = 0; r < 4; ++r)
+                    w |= ((unsigned)clamp_i32(requant_exact(acc[r], a.Mo), -128, 127) & 0xffu) << (8 * r);
+                wq[dt] = w;
+            }
+            // the query's 32 bytes sit as 2 x 4 dwords in its four lanes: a word exchange (v_permlane32_swap, v_permlane16_swap)
+            // leaves lane g with the 8 contiguous bytes d = 8 g .. 8 g + 7 -> one 8-byte store instead of two 4-byte ones
+            {
+                typedef unsigned v2u __attribute__((ext_vector_type(2)));
+                const v2u ab = __builtin_amdgcn_permlane32_swap(wq[0], wq[1], false, false);   // g < 2: (w0[g], w0[g+2]); g >= 2: (w1[g-2], w1[g])
+                const v2u pr = __builtin_amdgcn_permlane16_swap(ab.x, ab.y, false, false);     // lane g: words 2 (g & 1), 2 (g & 1) + 1 of w_{g >> 1}
+                if (qrow < T) *reinterpret_cast<int2*>(orow + 8 * g) = make_int2((int)pr.x, (int)pr.y);
             }
         }
     }
@@ -1000,7 +1007,7 @@ IVIT_EXPORT int ivit_window_attention_i8_compat(const int8_t* qkv, int8_t* out, 
         ivit_set_error("ivit_window_attention_i8: unsupported geometry head_dim=%d tokens=%d (need 32, 2..64)", head_dim, tokens);
         return IVIT_ERR_UNSUPPORTED;
     }
-    IVIT_REQUIRE(((uintptr_t)qkv % 16 == 0) && ((uintptr_t)out % 4 == 0) && ldo % 4 == 0 && ldo >= (int64_t)heads * head_dim,
+    IVIT_REQUIRE(((uintptr_t)qkv % 16 == 0) && ((uintptr_t)out % 8 == 0) && ldo % 8 == 0 && ldo >= (int64_t)heads * head_dim,
                  "ivit_window_attention_i8: misaligned operand or ldo too small");
     IVIT_REQUIRE(((uintptr_t)bias_add % 8 == 0) && ((uintptr_t)mask_region % 4 == 0), "ivit_window_attention_i8: misaligned table");
     IVIT_REQUIRE(mask_value <= 0 && mask_value >= -32768, "ivit_window_attention_i8: mask_value=%d outside [-32768, 0]", mask_value);
