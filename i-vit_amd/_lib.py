@@ -59,6 +59,7 @@ SIGNATURES = {
     "ivit_requant_i32": [vp, i64, ci, vp, vp, ci, vp, vp, vp, ci, ci, vp, vp],
     "ivit_residual_requant_i8": [vp, u32, i32, vp, u32, i32, vp, i64, vp],
     "ivit_embed_assemble_i8": [vp, vp, vp, u32, i32, vp, ci, ci, ci, vp],
+    "ivit_embed_assemble_i16": [vp, vp, vp, u32, i32, vp, ci, ci, ci, vp],
     "ivit_head_argmax": [vp, vp, ci, ci, vp, vp, vp],
     "ivit_bgemm_qk_i8": [vp, vp, vp, ci, ci, ci, ci, vp],
     "ivit_bgemm_pv_i8": [vp, vp, vp, ci, ci, ci, ci, vp],

@@ -1145,6 +1145,36 @@ __global__ __launch_bounds__(NT) void embed_kernel(const int8_t* patch, const in
     }
 }
 
+// the same with a 16-bit patch embedding (patch_embed_bw = 16) and a 16-bit block input (block_input_bw = 16, vit_quant.py:180-187):
+// out16 = clamp16(RNE(patch16 * Mq) + pos_add[tok]), cls row precomputed
+__global__ __launch_bounds__(NT) void embed16_kernel(const int16_t* patch, const int32_t* pos_add, const int16_t* cls_row,
+                                                     double Mq, int16_t* out, int batch, int tokens, int C)
+{
+    const int cd = C >> 2;
+    const int64_t total = (int64_t)batch * tokens * cd;
+    for (int64_t q = (int64_t)blockIdx.x * NT + threadIdx.x; q < total; q += (int64_t)gridDim.x * NT) {
+        const int d = (int)(q % cd);
+        const int64_t r = q / cd;
+        const int tok = (int)(r % tokens);
+        const int b = (int)(r / tokens);
+        int2 res;
+        if (tok == 0) {
+            res = *reinterpret_cast<const int2*>(cls_row + 4 * d);
+        } else {
+            const int2 w = *reinterpret_cast<const int2*>(patch + ((int64_t)b * (tokens - 1) + tok - 1) * C + 4 * d);
+            const int4 pa = *reinterpret_cast<const int4*>(pos_add + (int64_t)tok * C + 4 * d);
+            const int k[4] = {(int)(int16_t)w.x, w.x >> 16, (int)(int16_t)w.y, w.y >> 16};
+            const int p4[4] = {pa.x, pa.y, pa.z, pa.w};
+            int o[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) o[c] = clamp_i32(requant_exact(k[c], Mq) + p4[c], -32768, 32767);
+            res.x = (o[0] & 0xffff) | (o[1] << 16);
+            res.y = (o[2] & 0xffff) | (o[3] << 16);
+        }
+        *reinterpret_cast<int2*>(out + ((int64_t)b * tokens + tok) * C + 4 * d) = res;
+    }
+}
+
 // classifier: logits_f32 = float(acc) * s_acc (quant_modules.py:225-226); arg-max, first index on ties
 __global__ __launch_bounds__(NT) void head_argmax_kernel(const int32_t* acc, const float* s_acc, int batch, int N,
                                                          float* logits, int32_t* top1)
@@ -1678,6 +1708,22 @@ IVIT_EXPORT int ivit_embed_assemble_i8(const int8_t* patch, const int16_t* pos_a
     hipLaunchKernelGGL(embed_kernel, dim3(ew_grid(total)), dim3(NT), 0, ivit_stream(stream), patch, pos_add, cls_row,
                        Mq, out, batch, tokens, C);
     IVIT_CHECK_LAUNCH("ivit_embed_assemble_i8");
+}
+
+IVIT_EXPORT int ivit_embed_assemble_i16(const int16_t* patch, const int32_t* pos_add, const int16_t* cls_row, uint32_t m,
+                                        int32_t e, int16_t* out, int batch, int tokens, int C, ivit_stream_t stream)
+{
+    IVIT_REQUIRE(patch && pos_add && cls_row && out, "ivit_embed_assemble_i16: NULL operand");
+    IVIT_REQUIRE(batch > 0 && tokens > 1 && C > 0 && C % 4 == 0, "ivit_embed_assemble_i16: bad shape");
+    IVIT_REQUIRE(((uintptr_t)patch % 8 == 0) && ((uintptr_t)out % 8 == 0) && ((uintptr_t)cls_row % 8 == 0) &&
+                     ((uintptr_t)pos_add % 16 == 0),
+                 "ivit_embed_assemble_i16: misaligned");
+    const double Mq = ivit_dyadic_to_double(m, e);
+    IVIT_REQUIRE(Mq < 32768.0, "ivit_embed_assemble_i16: requant multiplier too large");
+    const int64_t total = (int64_t)batch * tokens * (C / 4);
+    hipLaunchKernelGGL(embed16_kernel, dim3(ew_grid(total)), dim3(NT), 0, ivit_stream(stream), patch, pos_add, cls_row,
+                       Mq, out, batch, tokens, C);
+    IVIT_CHECK_LAUNCH("ivit_embed_assemble_i16");
 }
 
 IVIT_EXPORT int ivit_head_argmax(const int32_t* acc, const float* s_acc, int batch, int N, float* logits_f32,

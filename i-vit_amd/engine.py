@@ -22,7 +22,8 @@ import torch
 
 from . import _lib
 from .graph import GraphReplay
-from .prepare import dyadic, f32, pad_head, phi_tables, quant_sym, requant_host, shiftexp2d, shiftexp_band
+from .prepare import (LayerNormParams, dyadic, f32, markstein_division_ok, pad_head, phi_is_identity, phi_tables, quant_sym,
+                      requant_host, shiftexp2d, shiftexp_band)
 from .synth import IMG_SIZE, NUM_PATCHES, NUM_TOKENS, PATCH
 
 
@@ -34,7 +35,7 @@ def _np(v):
 
 class IntViTEngine(GraphReplay):
     def __init__(self, float_state=None, ranges=None, embed_dim: int = 768, depth: int = 12, num_heads: int = 12,
-                 device="cuda:0", max_batch: int = 256, source=None, family: str = "ivit"):
+                 device="cuda:0", max_batch: int = 256, source=None, family: str = "ivit", stream_bits: int = 8):
         """float_state: name -> float32 array (the reference's state_dict names, SURVEY Appendix D);
         ranges: QuantAct name -> (x_min, x_max) of the frozen model.  Alternatively `source`: any object with the
         FloatSource interface of export.py (e.g. export.ExportSource: integer parameters + scale table, no floats)."""
@@ -44,6 +45,12 @@ class IntViTEngine(GraphReplay):
         if family not in ("ivit", "ibert"):
             raise ValueError(f"operator family {family!r}: the fused engine implements 'ivit' and 'ibert'")
         self.family = family
+        # width of the residual stream and of the QuantActs that feed it (vit_quant.py:180-187): 8, or 16 = patch_embed_bw,
+        # block_input_bw, attention_out_bw, mlp_out_bw, norm2_in_bw, att_block_out_bw all 16 (softmax_bw, pos_encoding_bw 8): the
+        # GEMM operands stay int8, the stream and the projection / fc2 outputs are int16 (the kernels of the Swin engine)
+        if stream_bits not in (8, 16) or (stream_bits == 16 and family != "ivit"):
+            raise ValueError("stream_bits must be 8, or 16 with the 'ivit' operators")
+        self.stream_bits = sb = stream_bits
         self.hd = embed_dim // num_heads
         if self.hd != 64:
             raise ValueError("fused attention kernel supports head_dim 64 only")
@@ -78,6 +85,13 @@ class IntViTEngine(GraphReplay):
 
         def ln_dev(prefix, s_out, s_in):
             lp = source.layernorm(prefix, s_out)
+            if sb == 16:
+                # I-LayerNorm on the 16-bit stream (csrc/swin.hip); natural input scale: the literal / Markstein-quotient forms
+                d = dict(kind="i16", bias=dev(lp.bias_int), s=dev(lp.s_ln), m=dev(lp.m.view(np.int32)), e=dev(lp.e), s_in=None, fast_div=0)
+                if not phi_is_identity(s_in, 16):
+                    self.natural_sites += 1
+                    d.update(s_in=float(s_in), fast_div=int(markstein_division_ok(s_in, 16)))
+                return d
             if family == "ibert":
                 # IBERTIntLayerNorm has the same per-channel constants (bias_int, s_out = sqrt(C) / 2^30 * gamma,
                 # ibert_modules.py:145-153) and an overflow shift buffer (:134-137); the kernel works on fl(q * s_in) literally
@@ -104,18 +118,24 @@ class IntViTEngine(GraphReplay):
         s0 = s("qact_input")
         self.inv_s0 = float(f32(1.0) / s0)
         pe = source.linear("patch_embed.proj", s0)
-        s_pe = s("patch_embed.qact")
+        s_pe = s("patch_embed.qact", sb)
         self.patch = lin_dev(pe, s_pe)
-        s_pos, s_x = s("qact_pos"), s("qact1")
+        s_pos, s_x = s("qact_pos"), s("qact1", sb)
         m1, e1 = dyadic(s_pe, s_x)
         m2, e2 = dyadic(s_pos, s_x)
         kpos = quant_sym(source.tensor("pos_embed").reshape(T, C), s_pos, 8)
         pos_add = requant_host(kpos, m2[0], e2[0])                       # RNE(k_pos * m2 / 2^e2)
         z_cls = np.rint((source.tensor("cls_token").reshape(C) / s_pe).astype(f32))   # quant_utils.py:220 on the raw cls row
-        cls_row = np.clip(requant_host(z_cls, m1[0], e1[0]) + pos_add[0], -128, 127)
-        assert np.abs(pos_add).max() < 32768
-        self.pos_add = dev(pos_add.astype(np.int16))
-        self.cls_row = dev(cls_row.astype(np.int8))
+        qlim = 2 ** (sb - 1)
+        cls_row = np.clip(requant_host(z_cls, m1[0], e1[0]) + pos_add[0], -qlim, qlim - 1)
+        if sb == 16:
+            assert np.abs(pos_add).max() < 2 ** 31
+            self.pos_add = dev(pos_add.astype(np.int32))
+            self.cls_row = dev(cls_row.astype(np.int16))
+        else:
+            assert np.abs(pos_add).max() < 32768
+            self.pos_add = dev(pos_add.astype(np.int16))
+            self.cls_row = dev(cls_row.astype(np.int8))
         self.embed_me = (int(m1[0]), int(e1[0]))
 
         # ---- blocks
@@ -154,9 +174,9 @@ class IntViTEngine(GraphReplay):
                     blk["attn"].update(band=dev(band.view(np.int32)), band_w=bw)
                 else:                              # very fine input scale: full-table gather
                     blk["attn"]["exp2d"] = dev(tab.view(np.int32))
-            s_a3 = s(p + "attn.qact3")
+            s_a3 = s(p + "attn.qact3", sb)
             blk["proj"] = lin_dev(source.linear(p + "attn.proj", s_a2), s_a3)
-            s_b2 = s(p + "qact2")
+            s_b2 = s(p + "qact2", sb)
             blk["res1"] = scalar_me(s_a3, s_b2) + scalar_me(s_x, s_b2)
             s_b3 = s(p + "qact3")
             blk["ln2"] = ln_dev(p + "norm2", s_b3, s_b2)
@@ -177,9 +197,9 @@ class IntViTEngine(GraphReplay):
                 g_remap, _ = phi_dev(s_g)              # ShiftGELU sees trunc(phi(q)) (ivit_modules.py:106-107)
                 _lib.call("ivit_shiftgelu_build_lut_ex", float(s_g), mg, eg, _lib.ptr(g_remap), _lib.ptr(lut), self._stream())
             blk["gelu_lut"] = lut
-            s_m2 = s(p + "mlp.qact2")
+            s_m2 = s(p + "mlp.qact2", sb)
             blk["fc2"] = lin_dev(source.linear(p + "mlp.fc2", s_m1), s_m2)
-            s_b4 = s(p + "qact4")
+            s_b4 = s(p + "qact4", sb)
             blk["res2"] = scalar_me(s_m2, s_b4) + scalar_me(s_b2, s_b4)
             s_x = s_b4
             self.blocks.append(blk)
@@ -236,6 +256,11 @@ class IntViTEngine(GraphReplay):
             qkv=torch.empty(3 * M * C, **i8), ao=torch.empty(M16, C, **i8),
             f1=torch.empty(M16, 4 * C, **i8), g=torch.empty(M16, 4 * C, **i8), untile=torch.empty(M, 4 * C, **i8),
             cls=torch.empty(B, C, **i8),
+            **({} if self.stream_bits == 8 else dict(
+                pe16=torch.empty(B * NUM_PATCHES, C, dtype=torch.int16, device=self.dev),
+                x16=torch.empty(M, C, dtype=torch.int16, device=self.dev), y16=torch.empty(M, C, dtype=torch.int16, device=self.dev),
+                k16=torch.empty(M, C, dtype=torch.int16, device=self.dev),
+                cls16=torch.empty(B, C, dtype=torch.int16, device=self.dev))),
             logits=torch.empty(B, self.head["N"], dtype=torch.int32, device=self.dev),
             logits_f=torch.empty(B, self.head["N"], dtype=torch.float32, device=self.dev),
             top1=torch.empty(B, dtype=torch.int32, device=self.dev),
@@ -306,6 +331,10 @@ class IntViTEngine(GraphReplay):
         assert images.is_cuda and images.dtype == torch.float32 and images.is_contiguous()
         B = images.shape[0]
         assert images.shape[1:] == (3, IMG_SIZE, IMG_SIZE) and 0 < B <= self.max_batch
+        if self.stream_bits == 16:
+            if taps is not None:
+                raise NotImplementedError("taps are not recorded on the 16-bit-stream path")
+            return self._forward16(images)
         C, H, hd, T = self.C, self.H, self.hd, NUM_TOKENS
         M = B * T
         ws = self.ws
@@ -378,6 +407,67 @@ class IntViTEngine(GraphReplay):
         # final LayerNorm is row-wise and only the cls row is consumed (vit_quant.py:302-304)
         self._ln(x, T * C, B, self.ln_f, ws["cls"], st)
         tap("qact2", ws["cls"], (B, C))
+        hd_ = self.head
+        _lib.call("ivit_gemm_i8_i32", _lib.ptr(ws["cls"]), C, _lib.ptr(hd_["W"]), hd_["K"], _lib.ptr(hd_["b"]),
+                  _lib.ptr(ws["logits"]), hd_["N"], B, hd_["N"], C, st)
+        _lib.call("ivit_head_argmax", _lib.ptr(ws["logits"]), _lib.ptr(self.head_scale), B, hd_["N"],
+                  _lib.ptr(ws["logits_f"]), _lib.ptr(ws["top1"]), st)
+        nc = self.num_classes
+        return ws["logits"][:B, :nc], ws["logits_f"][:B, :nc], ws["top1"][:B]
+
+    # ------------------------------------------------------------------ 16-bit residual stream
+    def _ln16(self, x16, rows, ln, out, st):
+        C = self.C
+        if ln["s_in"] is not None:
+            _lib.call("ivit_layernorm_i16_i8_compat", _lib.ptr(x16), rows, C, ln["s_in"], ln["fast_div"], _lib.ptr(ln["bias"]),
+                      _lib.ptr(ln["s"]), _lib.ptr(ln["m"]), _lib.ptr(ln["e"]), _lib.ptr(out), C, 0, 0, 0, 0, st)
+        else:
+            _lib.call("ivit_layernorm_i16_i8", _lib.ptr(x16), rows, C, _lib.ptr(ln["bias"]), _lib.ptr(ln["s"]), _lib.ptr(ln["m"]),
+                      _lib.ptr(ln["e"]), _lib.ptr(out), C, 0, 0, 0, 0, st)
+
+    def _forward16(self, images: torch.Tensor):
+        """stream_bits = 16: the same dataflow with an int16 residual stream.  LayerNorm reads int16 rows (csrc/swin.hip), the
+        projection / fc2 GEMMs requantise their accumulators to 16 bits per channel (attn.qact3 / mlp.qact2 at 16 bits) and the
+        residual QuantActs are the 16-bit two-operand kernel; qkv / fc1 / attention / GELU are the int8 kernels unchanged."""
+        B = images.shape[0]
+        ws, C, H, hd, T = self.ws, self.C, self.H, self.hd, NUM_TOKENS
+        M = B * T
+        st = self._stream()
+        big = bool(self.block_operands) and M >= 2048 and C % 64 == 0
+        _lib.call("ivit_quantize_patchify_f32_i8", _lib.ptr(images), _lib.ptr(ws["a0"]), B, 3, IMG_SIZE, PATCH, self.inv_s0, st)
+        pt = self.patch
+        _lib.call("ivit_gemm_i8_requant_i16", _lib.ptr(ws["a0"]), 3 * PATCH * PATCH, _lib.ptr(pt["W"]), pt["K"], _lib.ptr(pt["b"]),
+                  _lib.ptr(pt["m"]), _lib.ptr(pt["e"]), _lib.ptr(ws["pe16"]), C, B * NUM_PATCHES, C, pt["K"], st)
+        _lib.call("ivit_embed_assemble_i16", _lib.ptr(ws["pe16"]), _lib.ptr(self.pos_add), _lib.ptr(self.cls_row),
+                  self.embed_me[0], self.embed_me[1], _lib.ptr(ws["x16"]), B, T, C, st)
+        x, y = ws["x16"], ws["y16"]
+        for blk in self.blocks:
+            self._ln16(x, M, blk["ln1"], ws["h"], st)
+            q = blk["qkv"]
+            qw, qlay = self._w(q, big)
+            _lib.call("ivit_gemm_i8_requant_qkv_ex", _lib.ptr(ws["h"]), C, qw, q["K"], _lib.ptr(q["b"]),
+                      _lib.ptr(q["m"]), _lib.ptr(q["e"]), _lib.ptr(ws["qkv"]), T, H, hd, M, 3 * C, C, qlay, st)
+            a = blk["attn"]
+            _lib.call("ivit_attention_fused_i8_compat_band", _lib.ptr(ws["qkv"]), _lib.ptr(ws["ao"]), B, H, T, hd,
+                      a["ms"][0], a["ms"][1], a["s_attn"], a["mo"][0], a["mo"][1], _lib.ptr(a["exp2d"]), _lib.ptr(a["band"]),
+                      a["band_w"], 0, st)
+            pj, r = blk["proj"], blk["res1"]
+            _lib.call("ivit_gemm_i8_requant_i16", _lib.ptr(ws["ao"]), C, _lib.ptr(pj["W"]), pj["K"], _lib.ptr(pj["b"]),
+                      _lib.ptr(pj["m"]), _lib.ptr(pj["e"]), _lib.ptr(ws["k16"]), C, M, C, pj["K"], st)
+            _lib.call("ivit_residual_requant_i16", _lib.ptr(ws["k16"]), 16, None, None, r[0], r[1], _lib.ptr(x), r[2], r[3],
+                      _lib.ptr(y), M, C, 0, 0, 0, 0, st)
+            self._ln16(y, M, blk["ln2"], ws["h"], st)
+            self._gemm(ws["h"], C, blk["fc1"], ws["f1"], 4 * C, M, st, a_blocks=False, blocks=big, out_blocks=False)
+            _lib.call("ivit_shiftgelu_lut_i8_ex", _lib.ptr(ws["f1"]), 4 * C, M, 4 * C, _lib.ptr(blk["gelu_lut"]),
+                      _lib.ptr(ws["f1"]), 4 * C, 0, st)
+            f2, r = blk["fc2"], blk["res2"]
+            _lib.call("ivit_gemm_i8_requant_i16", _lib.ptr(ws["f1"]), 4 * C, _lib.ptr(f2["W"]), f2["K"], _lib.ptr(f2["b"]),
+                      _lib.ptr(f2["m"]), _lib.ptr(f2["e"]), _lib.ptr(ws["k16"]), C, M, C, f2["K"], st)
+            _lib.call("ivit_residual_requant_i16", _lib.ptr(ws["k16"]), 16, None, None, r[0], r[1], _lib.ptr(y), r[2], r[3],
+                      _lib.ptr(x), M, C, 0, 0, 0, 0, st)
+        # final LayerNorm: only the cls rows are consumed (vit_quant.py:302-304); the int16 kernel wants dense rows
+        ws["cls16"][:B].copy_(x.view(-1, T, C)[:B, 0])
+        self._ln16(ws["cls16"], B, self.ln_f, ws["cls"], st)
         hd_ = self.head
         _lib.call("ivit_gemm_i8_i32", _lib.ptr(ws["cls"]), C, _lib.ptr(hd_["W"]), hd_["K"], _lib.ptr(hd_["b"]),
                   _lib.ptr(ws["logits"]), hd_["N"], B, hd_["N"], C, st)

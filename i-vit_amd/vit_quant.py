@@ -161,9 +161,18 @@ class VisionTransformer(EngineDispatch, nn.Module):
             return f"geometry {self.geometry} (fused engine: 224x224, patch 16, 3 channels, mlp_ratio 4, qkv bias)"
         if self.num_classes <= 0:
             return "no classification head"
-        # every QuantAct of the DeiT / ViT engine is 8 bit, except the 16-bit one inside IBERTIntSoftmax (ibert_modules.py:247)
+        # every QuantAct of the DeiT / ViT engine is 8 bit, except the 16-bit one inside IBERTIntSoftmax (ibert_modules.py:247) ...
         inner = {f"blocks.{i}.attn.int_softmax.act": 16 for i in range(self.depth)} if self.op_types[0] == "ibert" else {}
         bad = self._width_mismatch(inner)
+        self._stream_bits = 8
+        if bad and self.op_types[0] == "ivit":
+            # ... or the 16-bit residual stream: patch_embed_bw = block_input_bw = attention_out_bw = mlp_out_bw = norm2_in_bw =
+            # att_block_out_bw = 16 with softmax_bw = pos_encoding_bw = 8 (vit_quant.py:180-187), engine stream_bits = 16
+            w16 = {"patch_embed.qact": 16, "qact1": 16}
+            for i in range(self.depth):
+                w16.update({f"blocks.{i}.attn.qact3": 16, f"blocks.{i}.mlp.qact2": 16, f"blocks.{i}.qact2": 16, f"blocks.{i}.qact4": 16})
+            if self._width_mismatch(w16) is None:
+                bad, self._stream_bits = None, 16
         if bad:
             return bad
         a, m = self.blocks[0].attn.int_softmax, self.blocks[0].mlp.act
@@ -174,7 +183,8 @@ class VisionTransformer(EngineDispatch, nn.Module):
     def _build_engine(self, device, max_batch):
         from .engine import IntViTEngine
         return IntViTEngine(dict(self.state_dict()), self.ranges(), self.embed_dim, self.depth, self.num_heads,
-                            device=device, max_batch=max_batch, family=self.op_types[0])
+                            device=device, max_batch=max_batch, family=self.op_types[0],
+                            stream_bits=getattr(self, "_stream_bits", 8) if self.engine_unsupported_reason() is None else 8)
 
     def forward(self, x):
         if self.takes_engine(x):

@@ -297,6 +297,11 @@ int ivit_residual_requant_i8(const int8_t* a, uint32_t m_a, int32_t e_a, const i
 int ivit_embed_assemble_i8(const int8_t* patch, const int16_t* pos_add, const int8_t* cls_row, uint32_t m,
                            int32_t e, int8_t* out, int batch, int tokens, int C, ivit_stream_t stream);
 
+/* the same for a 16-bit patch embedding and block input (patch_embed_bw = block_input_bw = 16, vit_quant.py:180-187):
+ * out16 = clamp16(RNE(patch16 * m / 2^e) + pos_add[tok][c]) for tok >= 1, out16[b][0] = cls_row; pos_add int32 [tokens, C]. */
+int ivit_embed_assemble_i16(const int16_t* patch, const int32_t* pos_add, const int16_t* cls_row, uint32_t m,
+                            int32_t e, int16_t* out, int batch, int tokens, int C, ivit_stream_t stream);
+
 /* ---- classifier output (quant_modules.py:225-226; scripts/inference.py:249-250) ----------------
  * logits_f32[b][n] = fl(float(acc[b][n]) * s_acc[n]); top1[b] = argmax_n logits_f32 (first max).
  * logits_f32 may be NULL. */

@@ -482,7 +482,7 @@ def test_ibert_engine_equals_module_path_deit_small_width(regime, size):
 
 # ----------------------------------------------------------------------------------- engine dispatch (dispatch.py)
 @pytest.mark.parametrize("tag", ["deit_tiny_w16", "deit_tiny_w16all"])
-def test_non_8bit_widths_take_the_module_path_and_match_the_reference(tag):
+def test_non_8bit_widths_match_the_reference(tag):
     """the reference's width knobs (vit_quant.py:180-187): a DeiT-T with a 16-bit residual stream -- and, `w16all`, what
     `--bitwidth 16` sets (quant_train.py:299-306): every knob at 16 incl. the 16-bit Shiftmax output feeding P.V and the
     16-bit position embedding -- is NOT what the fused int8 engine computes: the mirror must say so and run it module by
@@ -496,17 +496,61 @@ def test_non_8bit_widths_take_the_module_path_and_match_the_reference(tag):
             mod.x_max.fill_(float(ranges[name][1]))
     model.to(DEV)
     ivit.freeze_model(model)
-    assert "16-bit" in model.engine_unsupported_reason()
     imgs = torch.from_numpy(synth.make_images(2, meta["image_seed"])).to(DEV)
-    assert not model.takes_engine(imgs)
+    if tag == "deit_tiny_w16":
+        # the 16-bit residual stream (softmax and position embedding at 8 bits) is a pattern the fused engine implements
+        # (IntViTEngine(stream_bits=16)): the default path, and it reproduces the reference's logits, too
+        assert model.engine_unsupported_reason() is None and model.takes_engine(imgs)
+        with torch.no_grad():
+            ye = model(imgs)
+        assert model.engine(2).stream_bits == 16
+        assert np.array_equal(bits(ye), z["logits_f32_bits"][:2])
+        model.use_engine = False
+    else:
+        assert "16-bit" in model.engine_unsupported_reason()
+        assert not model.takes_engine(imgs)
     with torch.no_grad():
         y = model(imgs)
-    assert model._engine is None
+    if tag != "deit_tiny_w16":
+        assert model._engine is None
     assert np.array_equal(bits(y), z["logits_f32_bits"][:2])
     assert np.array_equal(y.argmax(dim=1).cpu().numpy(), z["top1"][:2])
     # and it really is a different function from the all-8-bit model with the same weights
     z8 = load_synthetic_model("deit_tiny")[4]
     assert not np.array_equal(z["logits_f32_bits"][:2], z8["logits_f32_bits"][:2])
+
+
+@pytest.mark.parametrize("regime", ["pow2", "natural"])
+def test_16bit_stream_engine_equals_module_path_deit_small(regime):
+    """DeiT-S with the 16-bit residual stream (patch_embed / block_input / attention_out / mlp_out / norm2_in / att_block_out at
+    16 bits), 12 fresh images (2364 token rows: persistent GEMMs, int16 LayerNorm, 16-bit residual kernels): engine ==
+    module-by-module path, float logits bitwise, with power-of-two ranges and with ranges as calibrated"""
+    w = dict(patch_embed_bw=16, pos_encoding_bw=8, block_input_bw=16, attention_out_bw=16, softmax_bw=8, mlp_out_bw=16, norm2_in_bw=16,
+             att_block_out_bw=16)
+    fs = synth.make_float_state("deit_small_patch16_224", 31)
+    model = ivit.deit_small_patch16_224(**w)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in fs.items()}, strict=False)
+    model.to(DEV).eval()
+    with torch.no_grad():
+        model(torch.from_numpy(synth.make_images(4, 91)).to(DEV))
+    if regime == "pow2":
+        for mod in model.modules():
+            if isinstance(mod, q.QuantAct):
+                qmax = 2 ** (mod.activation_bit - 1) - 1
+                a = max(-float(mod.x_min), float(mod.x_max)) / qmax
+                p = 2.0 ** np.ceil(np.log2(a))
+                mod.x_max.fill_(qmax * p)
+                mod.x_min.fill_(-qmax * p)
+    ivit.freeze_model(model)
+    imgs = torch.from_numpy(synth.make_images(12, 92)).to(DEV)
+    assert model.takes_engine(imgs), model.engine_unsupported_reason()
+    with torch.no_grad():
+        ye = model(imgs)
+        assert model.engine(12).stream_bits == 16
+        model.use_engine = False
+        ym = model(imgs)
+    assert np.array_equal(bits(ye), bits(ym))
+    assert len(set(ym.argmax(dim=1).cpu().tolist())) > 1
 
 
 def test_engine_follows_load_state_dict_and_range_changes():
