@@ -29,6 +29,7 @@ SIGNATURES = {
     "ivit_layernorm_i8_compat": [vp, i64, ci, ci, vp, vp, vp, vp, vp, vp, vp, i64, ci, vp],
     "ivit_attention_fused_i8_compat": [vp, vp, ci, ci, ci, ci, u32, i32, f32, u32, i32, vp, ci, vp],
     "ivit_attention_fused_i8_compat_band": [vp, vp, ci, ci, ci, ci, u32, i32, f32, u32, i32, vp, vp, ci, ci, vp],
+    "ivit_attention_fused_i8_wide": [vp, vp, ci, ci, ci, ci, u32, i32, f32, u32, i32, vp, vp, ci, ci, ci, vp],
     "ivit_shiftgelu_build_lut_ex": [f32, u32, i32, vp, vp, vp],
     "ivit_shiftgelu_lut_i8_ex": [vp, i64, ci, ci, vp, vp, i64, ci, vp],
     "ivit_pack_weight_frags_i8": [vp, i64, ci, ci, vp, vp],
@@ -83,6 +84,7 @@ SIGNATURES = {
     "ivit_ibert_gelu_build_lut": [f32, f32, f32, f32, f32, u32, i32, vp, vp],
     "ivit_ibert_softmax_build_table": [f32, f32, f32, f32, f32, f32, u32, i32, vp, vp],
     "ivit_attention_fused_i8_ibert": [vp, vp, ci, ci, ci, ci, u32, i32, u32, i32, vp, vp, ci, ci, vp],
+    "ivit_attention_fused_i8_ibert_wide": [vp, vp, ci, ci, ci, ci, u32, i32, u32, i32, vp, vp, ci, ci, ci, vp],
     "ivit_ibert_layernorm_i8": [vp, i64, ci, ci, f32, vp, vp, f32, vp, vp, vp, i64, ci, vp],
     "ivit_ibert_gelu_f32_f32": [vp, i64, f32, f32, f32, f32, f32, vp, vp],
     "ivit_ibert_softmax_f32_f32": [vp, i64, ci, ci, f32, f32, f32, f32, f32, f32, u32, i32, ci, vp, i64, vp, vp],

@@ -74,7 +74,9 @@ IVIT_DEV int kswz(int r, int c) { return r * HD + (((c + 2 * ((r >> 2) & 1)) & 3
 // MODE 0: power-of-two input scale (256-entry table); 1: natural scale, band rows in LDS; 2: natural scale, full-table gather;
 // 3 / 4: the I-BERT softmax (ibert_modules.py:237-319) from its (row max, q) table (3: gathered from global memory, 4: band rows
 // staged in LDS like mode 1), row sum in torch's float32 reduction order
-template <int MODE>
+// PB: width of the softmax output (softmax_bw, vit_quant.py:184): 8, or 16 -- probabilities up to 2^15 as three 7-bit planes
+// (p = c + 128 b + 16384 a), one P.V MFMA set per plane (the a plane only when a wave has such a score)
+template <int MODE, int PB = 8>
 __global__ __launch_bounds__(NT, 3) void attention_kernel(AttnArgs a)
 {
     __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
@@ -339,7 +341,8 @@ __global__ __launch_bounds__(NT, 3) void attention_kernel(AttnArgs a)
 
         // packed probabilities: dword t of key step ks = bytes r = 0..3 of key tile 4ks + t
         v4i pk[NKS];
-        v4i pkh[MODE >= 3 ? NKS : 1];      // I-BERT: probabilities reach 128 (a one-hot row): 128 = 127 + 1, the 1 in a second operand
+        v4i pkb[PB == 16 ? NKS : 1];       // 16-bit probabilities: the second 7-bit plane
+        v4i pkh[(MODE >= 3 || PB == 16) ? NKS : 1];      // I-BERT: probabilities reach 128 (a one-hot row): 128 = 127 + 1, the 1 in a second operand
         // I-BERT: p = floor(fl32(e * factor) / 2^25) in [0, 128] (ibert_modules.py:314, output_bit = 8).  factor / 2 is an exact
         // scaling, so u = trunc(e * (factor / 2)) has p in its top byte like the Shiftmax product below -- except p = 128, which
         // shows as the sign bit of u: the OR of all u of the tile is tested once and the tile repacked in that rare case.
@@ -350,7 +353,8 @@ __global__ __launch_bounds__(NT, 3) void attention_kernel(AttnArgs a)
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 unsigned w = 0;
-                if constexpr (MODE >= 3) pkh[ks][t] = 0;
+                if constexpr (MODE >= 3 || PB == 16) pkh[ks][t] = 0;
+                if constexpr (PB == 16) pkb[ks][t] = 0;
                 if (4 * ks + t < NKT) {
                     unsigned p[4];
 #pragma unroll
@@ -365,15 +369,45 @@ __global__ __launch_bounds__(NT, 3) void attention_kernel(AttnArgs a)
                             p[r] = (unsigned)(ev * factor);  // float32 product (:175), < 2^31
                         }
                     }
+                    if constexpr (PB == 16) {
+                        // p16 = u >> 16 = floor(fl32(e * factor) / 2^16) (Shiftmax :175) resp. / 2^17 (I-BERT :314) with u as above:
+                        // plane c = bits 16..22 (byte 2 & 0x7f), plane b = bits 23..29 (byte 3 of u << 1, & 0x7f), plane a = bits 30, 31
+                        if constexpr (MODE < 3) any_u |= p[0] | p[1] | p[2] | p[3];
+                        const unsigned c4 = __builtin_amdgcn_perm(p[1], p[0], 0x0c0c0602u) | __builtin_amdgcn_perm(p[3], p[2], 0x06020c0cu);
+                        const unsigned b4 = __builtin_amdgcn_perm(p[1] << 1, p[0] << 1, 0x0c0c0703u) |
+                                            __builtin_amdgcn_perm(p[3] << 1, p[2] << 1, 0x07030c0cu);
+                        w = c4 & 0x7f7f7f7fu;
+                        pkb[ks][t] = (int)(b4 & 0x7f7f7f7fu);
+                    } else {
                     // floor(. / 2^24) = the top byte of each product: gather the four top bytes with two byte permutes
                     const unsigned lo = __builtin_amdgcn_perm(p[1], p[0], 0x0c0c0703u);  // [p0.b3, p1.b3, 0, 0]
                     const unsigned hi = __builtin_amdgcn_perm(p[3], p[2], 0x07030c0cu);  // [0, 0, p2.b3, p3.b3]
                     w = lo | hi;
+                    }
                 }
                 pk[ks][t] = (int)w;
             }
-        const bool any_hi = MODE >= 3 && __builtin_amdgcn_ballot_w64((any_u >> 31) != 0) != 0;   // wave-uniform, almost never
-        if constexpr (MODE >= 3) {
+        const bool any_hi = (MODE >= 3 || PB == 16) &&
+                            __builtin_amdgcn_ballot_w64((any_u >> (PB == 16 ? 30 : 31)) != 0) != 0;   // wave-uniform, almost never
+        if constexpr (PB == 16) {
+            if (any_hi) {      // plane a (bits 30, 31 of u: p16 >= 16384) from the products again
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        unsigned w = 0;
+                        if (4 * ks + t < NKT) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const float ev = ef_is_float ? __int_as_float(s[4 * ks + t][r]) : (float)(unsigned)s[4 * ks + t][r];
+                                const unsigned u = (unsigned)(ev * (MODE >= 3 ? factor_h : factor));
+                                w |= (u >> 30) << (8 * r);
+                            }
+                        }
+                        pkh[ks][t] = (int)w;
+                    }
+            }
+        } else if constexpr (MODE >= 3) {
             if (any_hi) {      // a byte 0x80 (p = 128) becomes 127 in pk and 1 in pkh
 #pragma unroll
                 for (int ks = 0; ks < NKS; ++ks)
@@ -400,19 +434,33 @@ __global__ __launch_bounds__(NT, 3) void attention_kernel(AttnArgs a)
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
             v4i acc = {0, 0, 0, 0};
+            v4i accb = {0, 0, 0, 0}, acca = {0, 0, 0, 0};
             const int d = 16 * dt + l15;
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {
                 const v4i vf = *reinterpret_cast<const v4i*>(smem + K_BYTES + d * VT_ROW + (((4 * ks + g) ^ (d & 15)) << 4));
                 acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(vf, pk[ks], acc, 0, 0, 0);
-                if constexpr (MODE >= 3)
+                if constexpr (PB == 16) {
+                    accb = __builtin_amdgcn_mfma_i32_16x16x64_i8(vf, pkb[ks], accb, 0, 0, 0);
+                    if (hi_pass) acca = __builtin_amdgcn_mfma_i32_16x16x64_i8(vf, pkh[ks], acca, 0, 0, 0);
+                } else if constexpr (MODE >= 3) {
                     if (hi_pass) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(vf, pkh[ks], acc, 0, 0, 0);
+                }
             }
             unsigned w = 0;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                // |O| <= 208*127*128 < 2^22: exact float64 product
-                int o = clamp_i32(requant_exact(acc[r], a.Mo), -128, 127);
+                int o;
+                if constexpr (PB == 16) {
+                    // O = sum p16 * v up to 208 * 32768 * 128 < 2^30: the reference's float64 product rounds at 53 bits first
+                    // (quant_utils.py:229-230), so product and rounding are two steps here
+                    const int O = acc[r] + (accb[r] << 7) + (acca[r] << 14);
+                    const double t = (double)O * a.Mo + IVIT_MAGIC;
+                    o = clamp_i32((int)(unsigned)__double_as_longlong(t), -128, 127);
+                } else {
+                    // |O| <= 208*127*128 < 2^22: exact float64 product
+                    o = clamp_i32(requant_exact(acc[r], a.Mo), -128, 127);
+                }
                 w |= ((unsigned)o & 0xffu) << (8 * r);
             }
             wq[dt] = w;
@@ -461,6 +509,16 @@ IVIT_EXPORT int ivit_attention_fused_i8_compat_band(const int8_t* qkv, int8_t* o
                                                     int32_t e_o, const uint32_t* exp2d, const uint32_t* band, int band_w,
                                                     int out_blocks, ivit_stream_t stream)
 {
+    return ivit_attention_fused_i8_wide(qkv, out, batch, heads, tokens, head_dim, m_s, e_s, s_attn, m_o, e_o, exp2d, band, band_w, 8,
+                                        out_blocks, stream);
+}
+
+IVIT_EXPORT int ivit_attention_fused_i8_wide(const int8_t* qkv, int8_t* out, int batch, int heads, int tokens, int head_dim,
+                                             uint32_t m_s, int32_t e_s, float s_attn, uint32_t m_o, int32_t e_o,
+                                             const uint32_t* exp2d, const uint32_t* band, int band_w, int softmax_bits,
+                                             int out_blocks, ivit_stream_t stream)
+{
+    IVIT_REQUIRE(softmax_bits == 8 || softmax_bits == 16, "ivit_attention_fused_i8_wide: softmax_bits must be 8 or 16");
     IVIT_REQUIRE(qkv && out, "ivit_attention_fused_i8: NULL operand");
     IVIT_REQUIRE(batch > 0 && heads > 0, "ivit_attention_fused_i8: empty batch");
     if (head_dim != HD || tokens <= 16 * (NKT - 1) || tokens > KP) {
@@ -500,9 +558,17 @@ IVIT_EXPORT int ivit_attention_fused_i8_compat_band(const int8_t* qkv, int8_t* o
         if (x <= 15 * a.x0) { a.ksat = i; break; }
     }
     const size_t band_lds_bytes = band_w ? (size_t)4 * 16 * (band_w + BAND_PAD) * sizeof(unsigned) : 0;
-    if (band_w) hipLaunchKernelGGL(attention_kernel<1>, dim3(batch * heads), dim3(NT), band_lds_bytes, ivit_stream(stream), a);
-    else if (exp2d) hipLaunchKernelGGL(attention_kernel<2>, dim3(batch * heads), dim3(NT), 0, ivit_stream(stream), a);
-    else hipLaunchKernelGGL(attention_kernel<0>, dim3(batch * heads), dim3(NT), 0, ivit_stream(stream), a);
+    const dim3 grid(batch * heads), blk(NT);
+    hipStream_t st = ivit_stream(stream);
+    if (softmax_bits == 16) {
+        if (band_w) hipLaunchKernelGGL((attention_kernel<1, 16>), grid, blk, band_lds_bytes, st, a);
+        else if (exp2d) hipLaunchKernelGGL((attention_kernel<2, 16>), grid, blk, 0, st, a);
+        else hipLaunchKernelGGL((attention_kernel<0, 16>), grid, blk, 0, st, a);
+    } else {
+        if (band_w) hipLaunchKernelGGL(attention_kernel<1>, grid, blk, band_lds_bytes, st, a);
+        else if (exp2d) hipLaunchKernelGGL(attention_kernel<2>, grid, blk, 0, st, a);
+        else hipLaunchKernelGGL(attention_kernel<0>, grid, blk, 0, st, a);
+    }
     IVIT_CHECK_LAUNCH("ivit_attention_fused_i8");
 }
 
@@ -510,6 +576,16 @@ IVIT_EXPORT int ivit_attention_fused_i8_ibert(const int8_t* qkv, int8_t* out, in
                                               uint32_t m_s, int32_t e_s, uint32_t m_o, int32_t e_o, const float* table,
                                               const float* band, int band_w, int out_blocks, ivit_stream_t stream)
 {
+    return ivit_attention_fused_i8_ibert_wide(qkv, out, batch, heads, tokens, head_dim, m_s, e_s, m_o, e_o, table, band, band_w, 8,
+                                              out_blocks, stream);
+}
+
+IVIT_EXPORT int ivit_attention_fused_i8_ibert_wide(const int8_t* qkv, int8_t* out, int batch, int heads, int tokens, int head_dim,
+                                                   uint32_t m_s, int32_t e_s, uint32_t m_o, int32_t e_o, const float* table,
+                                                   const float* band, int band_w, int softmax_bits, int out_blocks,
+                                                   ivit_stream_t stream)
+{
+    IVIT_REQUIRE(softmax_bits == 8 || softmax_bits == 16, "ivit_attention_fused_i8_ibert_wide: softmax_bits must be 8 or 16");
     IVIT_REQUIRE(qkv && out && table && batch > 0 && heads > 0, "ivit_attention_fused_i8_ibert: bad operand");
     IVIT_REQUIRE(band_w == 0 || (band && band_w >= 16 && band_w <= 256 && band_w % 16 == 0 && (uintptr_t)band % 16 == 0),
                  "ivit_attention_fused_i8_ibert: band table must be 16-byte aligned, width a multiple of 16 in [16, 256]");
@@ -532,8 +608,13 @@ IVIT_EXPORT int ivit_attention_fused_i8_ibert(const int8_t* qkv, int8_t* out, in
     a.band = reinterpret_cast<const unsigned*>(band);
     a.band_w = band_w;
     const size_t band_lds_bytes = band_w ? (size_t)4 * 16 * (band_w + BAND_PAD) * sizeof(unsigned) : 0;
-    if (band_w) hipLaunchKernelGGL(attention_kernel<4>, dim3(batch * heads), dim3(NT), band_lds_bytes, ivit_stream(stream), a);
-    else hipLaunchKernelGGL(attention_kernel<3>, dim3(batch * heads), dim3(NT), 0, ivit_stream(stream), a);
+    if (softmax_bits == 16) {
+        if (band_w) hipLaunchKernelGGL((attention_kernel<4, 16>), dim3(batch * heads), dim3(NT), band_lds_bytes, ivit_stream(stream), a);
+        else hipLaunchKernelGGL((attention_kernel<3, 16>), dim3(batch * heads), dim3(NT), 0, ivit_stream(stream), a);
+    } else {
+        if (band_w) hipLaunchKernelGGL(attention_kernel<4>, dim3(batch * heads), dim3(NT), band_lds_bytes, ivit_stream(stream), a);
+        else hipLaunchKernelGGL(attention_kernel<3>, dim3(batch * heads), dim3(NT), 0, ivit_stream(stream), a);
+    }
     IVIT_CHECK_LAUNCH("ivit_attention_fused_i8_ibert");
 }
 

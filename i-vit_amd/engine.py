@@ -35,7 +35,8 @@ def _np(v):
 
 class IntViTEngine(GraphReplay):
     def __init__(self, float_state=None, ranges=None, embed_dim: int = 768, depth: int = 12, num_heads: int = 12,
-                 device="cuda:0", max_batch: int = 256, source=None, family: str = "ivit", stream_bits: int = 8):
+                 device="cuda:0", max_batch: int = 256, source=None, family: str = "ivit", stream_bits: int = 8,
+                 softmax_bits: int = 8, pos_bits: int = 8):
         """float_state: name -> float32 array (the reference's state_dict names, SURVEY Appendix D);
         ranges: QuantAct name -> (x_min, x_max) of the frozen model.  Alternatively `source`: any object with the
         FloatSource interface of export.py (e.g. export.ExportSource: integer parameters + scale table, no floats)."""
@@ -51,6 +52,10 @@ class IntViTEngine(GraphReplay):
         if stream_bits not in (8, 16) or (stream_bits == 16 and family != "ivit"):
             raise ValueError("stream_bits must be 8, or 16 with the 'ivit' operators")
         self.stream_bits = sb = stream_bits
+        # softmax_bw / pos_encoding_bw (vit_quant.py:181, 184) may be 16 on the 16-bit-stream path ('--bitwidth 16' sets all eight)
+        if softmax_bits not in (8, 16) or pos_bits not in (8, 16) or (sb == 8 and (softmax_bits, pos_bits) != (8, 8)):
+            raise ValueError("softmax_bits / pos_bits: 8, or 16 together with stream_bits = 16")
+        self.softmax_bits, self.pos_bits = softmax_bits, pos_bits
         self.hd = embed_dim // num_heads
         if self.hd != 64:
             raise ValueError("fused attention kernel supports head_dim 64 only")
@@ -120,10 +125,10 @@ class IntViTEngine(GraphReplay):
         pe = source.linear("patch_embed.proj", s0)
         s_pe = s("patch_embed.qact", sb)
         self.patch = lin_dev(pe, s_pe)
-        s_pos, s_x = s("qact_pos"), s("qact1", sb)
+        s_pos, s_x = s("qact_pos", pos_bits), s("qact1", sb)
         m1, e1 = dyadic(s_pe, s_x)
         m2, e2 = dyadic(s_pos, s_x)
-        kpos = quant_sym(source.tensor("pos_embed").reshape(T, C), s_pos, 8)
+        kpos = quant_sym(source.tensor("pos_embed").reshape(T, C), s_pos, pos_bits)
         pos_add = requant_host(kpos, m2[0], e2[0])                       # RNE(k_pos * m2 / 2^e2)
         z_cls = np.rint((source.tensor("cls_token").reshape(C) / s_pe).astype(f32))   # quant_utils.py:220 on the raw cls row
         qlim = 2 ** (sb - 1)
@@ -149,7 +154,7 @@ class IntViTEngine(GraphReplay):
             blk["qkv"] = lin_dev(source.linear(p + "attn.qkv", s_q1), s_a1)
             s_S = f32(f32(s_a1 * s_a1) * f32(hd ** -0.5))                 # vit_quant.py:72-75
             s_at = s(p + "attn.qact_attn1")
-            s_pv = f32(f32(1.0 / 128.0) * s_a1)                           # Shiftmax scale 2^-7 x value scale
+            s_pv = f32(f32(1.0 / 2 ** (softmax_bits - 1)) * s_a1)         # Shiftmax scale 2^-(bits-1) (:176) x value scale
             s_a2 = s(p + "attn.qact2")
             blk["attn"] = dict(ms=scalar_me(s_S, s_at), s_attn=float(s_at), mo=scalar_me(s_pv, s_a2), exp2d=None, band=None, band_w=0)
             if family == "ibert":
@@ -448,9 +453,9 @@ class IntViTEngine(GraphReplay):
             _lib.call("ivit_gemm_i8_requant_qkv_ex", _lib.ptr(ws["h"]), C, qw, q["K"], _lib.ptr(q["b"]),
                       _lib.ptr(q["m"]), _lib.ptr(q["e"]), _lib.ptr(ws["qkv"]), T, H, hd, M, 3 * C, C, qlay, st)
             a = blk["attn"]
-            _lib.call("ivit_attention_fused_i8_compat_band", _lib.ptr(ws["qkv"]), _lib.ptr(ws["ao"]), B, H, T, hd,
+            _lib.call("ivit_attention_fused_i8_wide", _lib.ptr(ws["qkv"]), _lib.ptr(ws["ao"]), B, H, T, hd,
                       a["ms"][0], a["ms"][1], a["s_attn"], a["mo"][0], a["mo"][1], _lib.ptr(a["exp2d"]), _lib.ptr(a["band"]),
-                      a["band_w"], 0, st)
+                      a["band_w"], self.softmax_bits, 0, st)
             pj, r = blk["proj"], blk["res1"]
             _lib.call("ivit_gemm_i8_requant_i16", _lib.ptr(ws["ao"]), C, _lib.ptr(pj["W"]), pj["K"], _lib.ptr(pj["b"]),
                       _lib.ptr(pj["m"]), _lib.ptr(pj["e"]), _lib.ptr(ws["k16"]), C, M, C, pj["K"], st)

@@ -164,19 +164,21 @@ class VisionTransformer(EngineDispatch, nn.Module):
         # every QuantAct of the DeiT / ViT engine is 8 bit, except the 16-bit one inside IBERTIntSoftmax (ibert_modules.py:247) ...
         inner = {f"blocks.{i}.attn.int_softmax.act": 16 for i in range(self.depth)} if self.op_types[0] == "ibert" else {}
         bad = self._width_mismatch(inner)
-        self._stream_bits = 8
+        self._engine_widths = (8, 8, 8)        # (stream, softmax, position embedding)
+        a, m = self.blocks[0].attn.int_softmax, self.blocks[0].mlp.act
+        sm_bits = int(getattr(a, "output_bit", 8))
         if bad and self.op_types[0] == "ivit":
             # ... or the 16-bit residual stream: patch_embed_bw = block_input_bw = attention_out_bw = mlp_out_bw = norm2_in_bw =
-            # att_block_out_bw = 16 with softmax_bw = pos_encoding_bw = 8 (vit_quant.py:180-187), engine stream_bits = 16
+            # att_block_out_bw = 16 (vit_quant.py:180-187), softmax_bw and pos_encoding_bw 8 or 16: engine stream_bits = 16
             w16 = {"patch_embed.qact": 16, "qact1": 16}
             for i in range(self.depth):
                 w16.update({f"blocks.{i}.attn.qact3": 16, f"blocks.{i}.mlp.qact2": 16, f"blocks.{i}.qact2": 16, f"blocks.{i}.qact4": 16})
-            if self._width_mismatch(w16) is None:
-                bad, self._stream_bits = None, 16
+            for pos_bits in (8, 16):
+                if self._width_mismatch({**w16, "qact_pos": pos_bits}) is None and sm_bits in (8, 16):
+                    bad, self._engine_widths = None, (16, sm_bits, pos_bits)
         if bad:
             return bad
-        a, m = self.blocks[0].attn.int_softmax, self.blocks[0].mlp.act
-        if getattr(a, "output_bit", 8) != 8 or getattr(m, "output_bit", 8) != 8:
+        if (sm_bits != 8 and self._engine_widths[0] == 8) or getattr(m, "output_bit", 8) != 8:
             return "Shiftmax / ShiftGELU output width != 8"
         return None
 
@@ -184,7 +186,8 @@ class VisionTransformer(EngineDispatch, nn.Module):
         from .engine import IntViTEngine
         return IntViTEngine(dict(self.state_dict()), self.ranges(), self.embed_dim, self.depth, self.num_heads,
                             device=device, max_batch=max_batch, family=self.op_types[0],
-                            stream_bits=getattr(self, "_stream_bits", 8) if self.engine_unsupported_reason() is None else 8)
+                            **dict(zip(("stream_bits", "softmax_bits", "pos_bits"),
+                                       self._engine_widths if self.engine_unsupported_reason() is None else (8, 8, 8))))
 
     def forward(self, x):
         if self.takes_engine(x):

@@ -200,6 +200,12 @@ int ivit_attention_fused_i8_compat_band(const int8_t* qkv, int8_t* out, int batc
                                         uint32_t m_s, int32_t e_s, float s_attn, uint32_t m_o, int32_t e_o,
                                         const uint32_t* exp2d, const uint32_t* band, int band_w, int out_blocks,
                                         ivit_stream_t stream);
+/* the same with the softmax output width as a parameter (softmax_bw, vit_quant.py:184): softmax_bits = 8 or 16.  16:
+ * p = floor(fl32(e * factor) / 2^16) <= 2^15 at scale 2^-15 (ivit_modules.py:175-176), carried into P.V as three 7-bit planes;
+ * (m_o, e_o) then is the requantiser of 2^-15 * s_v. */
+int ivit_attention_fused_i8_wide(const int8_t* qkv, int8_t* out, int batch, int heads, int tokens, int head_dim, uint32_t m_s,
+                                 int32_t e_s, float s_attn, uint32_t m_o, int32_t e_o, const uint32_t* exp2d,
+                                 const uint32_t* band, int band_w, int softmax_bits, int out_blocks, ivit_stream_t stream);
 
 /* ---- I-LayerNorm + the QuantAct behind it ---------------------------------------------------
  * IVITIntLayerNorm.forward (ivit_modules.py:30-65) then QuantAct (fixedpoint_mul).
@@ -469,6 +475,10 @@ int ivit_ibert_softmax_build_table(float s, float x0_int, float b_int, float c_i
 int ivit_attention_fused_i8_ibert(const int8_t* qkv, int8_t* out, int batch, int heads, int tokens, int head_dim, uint32_t m_s,
                                   int32_t e_s, uint32_t m_o, int32_t e_o, const float* table, const float* band, int band_w,
                                   int out_blocks, ivit_stream_t stream);
+/* softmax_bits = 16: p = floor(fl32(e * factor) / 2^17) <= 2^15 at scale 2 / 2^16 (ibert_modules.py:314-317) */
+int ivit_attention_fused_i8_ibert_wide(const int8_t* qkv, int8_t* out, int batch, int heads, int tokens, int head_dim, uint32_t m_s,
+                                       int32_t e_s, uint32_t m_o, int32_t e_o, const float* table, const float* band, int band_w,
+                                       int softmax_bits, int out_blocks, ivit_stream_t stream);
 int ivit_ibert_layernorm_i8(const int8_t* x, int64_t ldx, int rows, int C, float s_in, const float* bias_int, const float* s_out,
                             float shift_pow2, const uint32_t* m, const int32_t* e, int8_t* out, int64_t ldo, int out_blocks,
                             ivit_stream_t stream);

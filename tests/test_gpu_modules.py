@@ -497,27 +497,39 @@ def test_non_8bit_widths_match_the_reference(tag):
     model.to(DEV)
     ivit.freeze_model(model)
     imgs = torch.from_numpy(synth.make_images(2, meta["image_seed"])).to(DEV)
-    if tag == "deit_tiny_w16":
-        # the 16-bit residual stream (softmax and position embedding at 8 bits) is a pattern the fused engine implements
-        # (IntViTEngine(stream_bits=16)): the default path, and it reproduces the reference's logits, too
-        assert model.engine_unsupported_reason() is None and model.takes_engine(imgs)
-        with torch.no_grad():
-            ye = model(imgs)
-        assert model.engine(2).stream_bits == 16
-        assert np.array_equal(bits(ye), z["logits_f32_bits"][:2])
-        model.use_engine = False
-    else:
-        assert "16-bit" in model.engine_unsupported_reason()
-        assert not model.takes_engine(imgs)
+    # the 16-bit residual stream -- with the softmax output and the position embedding at 8 bits (w16) or at 16 (w16all) -- is a
+    # pattern the fused engine implements (IntViTEngine(stream_bits=16, ...)): the default path, and it reproduces the reference's
+    # logits, too
+    assert model.engine_unsupported_reason() is None and model.takes_engine(imgs)
+    with torch.no_grad():
+        ye = model(imgs)
+    eng = model.engine(2)
+    assert (eng.stream_bits, eng.softmax_bits, eng.pos_bits) == ((16, 8, 8) if tag == "deit_tiny_w16" else (16, 16, 16))
+    assert np.array_equal(bits(ye), z["logits_f32_bits"][:2])
+    model.use_engine = False
     with torch.no_grad():
         y = model(imgs)
-    if tag != "deit_tiny_w16":
-        assert model._engine is None
     assert np.array_equal(bits(y), z["logits_f32_bits"][:2])
     assert np.array_equal(y.argmax(dim=1).cpu().numpy(), z["top1"][:2])
     # and it really is a different function from the all-8-bit model with the same weights
     z8 = load_synthetic_model("deit_tiny")[4]
     assert not np.array_equal(z["logits_f32_bits"][:2], z8["logits_f32_bits"][:2])
+
+
+def test_unsupported_width_pattern_takes_the_module_path():
+    """only att_block_out_bw = 16 (one of the reference's sweep points): not a pattern of the fused engine -> module path"""
+    fs = synth.make_float_state("deit_tiny_patch16_224", 5)
+    model = ivit.deit_tiny_patch16_224(att_block_out_bw=16)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in fs.items()}, strict=False)
+    model.to(DEV).eval()
+    imgs = torch.from_numpy(synth.make_images(2, 3)).to(DEV)
+    with torch.no_grad():
+        model(imgs)
+    ivit.freeze_model(model)
+    assert "16-bit" in model.engine_unsupported_reason() and not model.takes_engine(imgs)
+    with torch.no_grad():
+        y = model(imgs)
+    assert model._engine is None and torch.isfinite(y).all()
 
 
 @pytest.mark.parametrize("regime", ["pow2", "natural"])
@@ -527,6 +539,8 @@ def test_16bit_stream_engine_equals_module_path_deit_small(regime):
     module-by-module path, float logits bitwise, with power-of-two ranges and with ranges as calibrated"""
     w = dict(patch_embed_bw=16, pos_encoding_bw=8, block_input_bw=16, attention_out_bw=16, softmax_bw=8, mlp_out_bw=16, norm2_in_bw=16,
              att_block_out_bw=16)
+    if regime == "natural":     # ... and here every knob at 16 ('--bitwidth 16'): 16-bit Shiftmax output into P.V, 16-bit pos_embed
+        w.update(pos_encoding_bw=16, softmax_bw=16)
     fs = synth.make_float_state("deit_small_patch16_224", 31)
     model = ivit.deit_small_patch16_224(**w)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in fs.items()}, strict=False)
