@@ -51,6 +51,7 @@ SIGNATURES = {
     "ivit_shiftmax_f32_i8": [vp, i64, ci, ci, f32, vp, i64, vp],
     "ivit_shiftmax_f32_i16": [vp, i64, ci, ci, f32, ci, vp, i64, vp],
     "ivit_bgemm_pv_i16_i8": [vp, vp, vp, ci, ci, ci, ci, vp],
+    "ivit_bgemm_pv_i32_i8": [vp, vp, vp, ci, ci, ci, ci, i64, vp],
     "ivit_quantize_input_f32_i32": [vp, vp, i64, f32, ci, vp],
     "ivit_shiftgelu_i8": [vp, i64, ci, ci, f32, u32, i32, vp, i64, vp],
     "ivit_shiftgelu_i8_i32": [vp, i64, ci, ci, f32, vp, i64, vp],
@@ -86,6 +87,7 @@ SIGNATURES = {
     "ivit_attention_fused_i8_ibert": [vp, vp, ci, ci, ci, ci, u32, i32, u32, i32, vp, vp, ci, ci, vp],
     "ivit_attention_fused_i8_ibert_wide": [vp, vp, ci, ci, ci, ci, u32, i32, u32, i32, vp, vp, ci, ci, ci, vp],
     "ivit_ibert_layernorm_i8": [vp, i64, ci, ci, f32, vp, vp, f32, vp, vp, vp, i64, ci, vp],
+    "ivit_ibert_layernorm_i16_i8": [vp, i64, ci, ci, f32, vp, vp, f32, vp, vp, vp, i64, vp],
     "ivit_ibert_gelu_f32_f32": [vp, i64, f32, f32, f32, f32, f32, vp, vp],
     "ivit_ibert_softmax_f32_f32": [vp, i64, ci, ci, f32, f32, f32, f32, f32, f32, u32, i32, ci, vp, i64, vp, vp],
     "ivit_ibert_layernorm_f32_f32": [vp, i64, ci, ci, vp, ci, vp, vp, f32, vp, i64, vp],

@@ -300,11 +300,12 @@ struct IbLnI8Args {
 };
 
 // one row, literally (whole wave)
+template <typename TX = int8_t>
 IVIT_DEV void ib_ln_row_literal(const IbLnI8Args& a, int row, int lane)
 {
     const int C = a.C;
     {
-        const int8_t* xr = a.x + (int64_t)row * a.ldx;
+        const TX* xr = reinterpret_cast<const TX*>(a.x) + (int64_t)row * a.ldx;
         auto xint = [&](int c) { return ((float)xr[c] * a.s_in) / a.s_in; };                  // :126 on fl(q * s)
         const float mean_int = rintf(torch_rowsum(xint, C, lane) / (float)C);                 // :127
         auto sq = [&](int c) {
@@ -331,10 +332,11 @@ IVIT_DEV void ib_ln_row_literal(const IbLnI8Args& a, int row, int lane)
     }
 }
 
+template <typename TX>
 __global__ __launch_bounds__(NT) void ibert_layernorm_i8_kernel(IbLnI8Args a)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int row = blockIdx.x * WPB + wave; row < a.rows; row += gridDim.x * WPB) ib_ln_row_literal(a, row, lane);
+    for (int row = blockIdx.x * WPB + wave; row < a.rows; row += gridDim.x * WPB) ib_ln_row_literal<TX>(a, row, lane);
 }
 
 // The same result without evaluating the two float32 row sums term by term.  Both sums only feed a rounding:
@@ -634,6 +636,18 @@ IVIT_EXPORT int ivit_ibert_layernorm_i8(const int8_t* x, int64_t ldx, int rows, 
         else hipLaunchKernelGGL(ibert_layernorm_i8_fast_kernel<4>, grid, blk, lds, st, a);
         IVIT_CHECK_LAUNCH("ivit_ibert_layernorm_i8");
     }
-    hipLaunchKernelGGL(ibert_layernorm_i8_kernel, dim3(grid_for_rows(rows)), dim3(NT), 0, ivit_stream(stream), a);
+    hipLaunchKernelGGL(ibert_layernorm_i8_kernel<int8_t>, dim3(grid_for_rows(rows)), dim3(NT), 0, ivit_stream(stream), a);
     IVIT_CHECK_LAUNCH("ivit_ibert_layernorm_i8");
+}
+
+IVIT_EXPORT int ivit_ibert_layernorm_i16_i8(const int16_t* x, int64_t ldx, int rows, int C, float s_in, const float* bias_int,
+                                            const float* s_out, float shift_pow2, const uint32_t* m, const int32_t* e, int8_t* out,
+                                            int64_t ldo, ivit_stream_t stream)
+{
+    IVIT_REQUIRE(x && out && bias_int && s_out && m && e && rows > 0 && C > 0 && ldx >= C && ldo >= C && s_in > 0.0f,
+                 "ivit_ibert_layernorm_i16_i8: bad operand");
+    IVIT_REQUIRE(shift_pow2 >= 1.0f, "ivit_ibert_layernorm_i16_i8: shift_pow2 = 2^shift must be >= 1");
+    IbLnI8Args a{reinterpret_cast<const int8_t*>(x), ldx, rows, C, s_in, bias_int, s_out, shift_pow2, m, e, out, ldo, 0};
+    hipLaunchKernelGGL(ibert_layernorm_i8_kernel<int16_t>, dim3(grid_for_rows(rows)), dim3(NT), 0, ivit_stream(stream), a);
+    IVIT_CHECK_LAUNCH("ivit_ibert_layernorm_i16_i8");
 }

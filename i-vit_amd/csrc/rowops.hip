@@ -601,7 +601,7 @@ __global__ __launch_bounds__(NT, (G == 4 && NJ <= 3 ? 5 : G == 8 && NJ <= 3 ? 4 
             }
         }
     };
-    int step = ((wave_id & 1) && (abl & 64)) ? G / 2 : G;     // lab bit 6: the de-phasing experiment (no gain)
+    int step = ((wave_id & 1) != 0 && (abl & 64) != 0) ? G / 2 : G;     // lab bit 6: the de-phasing experiment (no gain)
     for (int row0 = r_begin; row0 < r_end; row0 += step, step = G) {
         const int nrow = min(step, r_end - row0);
         int w[G][NJ];
@@ -1785,6 +1785,17 @@ IVIT_EXPORT int ivit_bgemm_pv_i16_i8(const int16_t* P, const int8_t* V, int32_t*
     hipLaunchKernelGGL((bgemm_kernel<true, int16_t>), dim3(ew_grid((int64_t)batch * Tq * D)), dim3(NT), 0, ivit_stream(stream),
                        P, V, O, batch, Tq, Tk, D);
     IVIT_CHECK_LAUNCH("ivit_bgemm_pv_i16_i8");
+}
+
+IVIT_EXPORT int ivit_bgemm_pv_i32_i8(const int32_t* P, const int8_t* V, int32_t* O, int batch, int Tq, int Tk, int D, int64_t p_absmax,
+                                     ivit_stream_t stream)
+{
+    IVIT_REQUIRE(P && V && O && batch > 0 && Tq > 0 && Tk > 0 && D > 0, "ivit_bgemm_pv_i32_i8: bad operand");
+    IVIT_REQUIRE(p_absmax >= 0 && p_absmax * 128 * Tk < 2147483648ll, "ivit_bgemm_pv_i32_i8: |P| <= %lld over Tk=%d keys overflows int32",
+                 (long long)p_absmax, Tk);
+    hipLaunchKernelGGL((bgemm_kernel<true, int32_t>), dim3(ew_grid((int64_t)batch * Tq * D)), dim3(NT), 0, ivit_stream(stream),
+                       P, V, O, batch, Tq, Tk, D);
+    IVIT_CHECK_LAUNCH("ivit_bgemm_pv_i32_i8");
 }
 
 IVIT_EXPORT int ivit_f32_to_i32(const float* x, int64_t rows, int C, const float* s, int n_s, int mode, int32_t* z,

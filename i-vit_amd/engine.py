@@ -49,8 +49,8 @@ class IntViTEngine(GraphReplay):
         # width of the residual stream and of the QuantActs that feed it (vit_quant.py:180-187): 8, or 16 = patch_embed_bw,
         # block_input_bw, attention_out_bw, mlp_out_bw, norm2_in_bw, att_block_out_bw all 16 (softmax_bw, pos_encoding_bw 8): the
         # GEMM operands stay int8, the stream and the projection / fc2 outputs are int16 (the kernels of the Swin engine)
-        if stream_bits not in (8, 16) or (stream_bits == 16 and family != "ivit"):
-            raise ValueError("stream_bits must be 8, or 16 with the 'ivit' operators")
+        if stream_bits not in (8, 16):
+            raise ValueError("stream_bits must be 8 or 16")
         self.stream_bits = sb = stream_bits
         # softmax_bw / pos_encoding_bw (vit_quant.py:181, 184) may be 16 on the 16-bit-stream path ('--bitwidth 16' sets all eight)
         if softmax_bits not in (8, 16) or pos_bits not in (8, 16) or (sb == 8 and (softmax_bits, pos_bits) != (8, 8)):
@@ -90,6 +90,13 @@ class IntViTEngine(GraphReplay):
 
         def ln_dev(prefix, s_out, s_in):
             lp = source.layernorm(prefix, s_out)
+            if sb == 16 and family == "ibert":
+                try:
+                    shift = float(np.asarray(source.tensor(prefix + ".shift")).reshape(-1)[0])
+                except KeyError:
+                    shift = 0.0
+                return dict(kind="ib16", bias=dev(lp.bias_int), s=dev(lp.s_ln), m=dev(lp.m.view(np.int32)), e=dev(lp.e),
+                            s_in=float(s_in), shift_pow2=float(2.0 ** shift))
             if sb == 16:
                 # I-LayerNorm on the 16-bit stream (csrc/swin.hip); natural input scale: the literal / Markstein-quotient forms
                 d = dict(kind="i16", bias=dev(lp.bias_int), s=dev(lp.s_ln), m=dev(lp.m.view(np.int32)), e=dev(lp.e), s_in=None, fast_div=0)
@@ -423,6 +430,10 @@ class IntViTEngine(GraphReplay):
     # ------------------------------------------------------------------ 16-bit residual stream
     def _ln16(self, x16, rows, ln, out, st):
         C = self.C
+        if ln["kind"] == "ib16":
+            _lib.call("ivit_ibert_layernorm_i16_i8", _lib.ptr(x16), C, rows, C, ln["s_in"], _lib.ptr(ln["bias"]), _lib.ptr(ln["s"]),
+                      ln["shift_pow2"], _lib.ptr(ln["m"]), _lib.ptr(ln["e"]), _lib.ptr(out), C, st)
+            return
         if ln["s_in"] is not None:
             _lib.call("ivit_layernorm_i16_i8_compat", _lib.ptr(x16), rows, C, ln["s_in"], ln["fast_div"], _lib.ptr(ln["bias"]),
                       _lib.ptr(ln["s"]), _lib.ptr(ln["m"]), _lib.ptr(ln["e"]), _lib.ptr(out), C, 0, 0, 0, 0, st)
@@ -453,9 +464,14 @@ class IntViTEngine(GraphReplay):
             _lib.call("ivit_gemm_i8_requant_qkv_ex", _lib.ptr(ws["h"]), C, qw, q["K"], _lib.ptr(q["b"]),
                       _lib.ptr(q["m"]), _lib.ptr(q["e"]), _lib.ptr(ws["qkv"]), T, H, hd, M, 3 * C, C, qlay, st)
             a = blk["attn"]
-            _lib.call("ivit_attention_fused_i8_wide", _lib.ptr(ws["qkv"]), _lib.ptr(ws["ao"]), B, H, T, hd,
-                      a["ms"][0], a["ms"][1], a["s_attn"], a["mo"][0], a["mo"][1], _lib.ptr(a["exp2d"]), _lib.ptr(a["band"]),
-                      a["band_w"], self.softmax_bits, 0, st)
+            if self.family == "ibert":
+                _lib.call("ivit_attention_fused_i8_ibert_wide", _lib.ptr(ws["qkv"]), _lib.ptr(ws["ao"]), B, H, T, hd,
+                          a["ms"][0], a["ms"][1], a["mo"][0], a["mo"][1], _lib.ptr(a["ib_table"]), _lib.ptr(a["band"]), a["band_w"],
+                          self.softmax_bits, 0, st)
+            else:
+                _lib.call("ivit_attention_fused_i8_wide", _lib.ptr(ws["qkv"]), _lib.ptr(ws["ao"]), B, H, T, hd,
+                          a["ms"][0], a["ms"][1], a["s_attn"], a["mo"][0], a["mo"][1], _lib.ptr(a["exp2d"]), _lib.ptr(a["band"]),
+                          a["band_w"], self.softmax_bits, 0, st)
             pj, r = blk["proj"], blk["res1"]
             _lib.call("ivit_gemm_i8_requant_i16", _lib.ptr(ws["ao"]), C, _lib.ptr(pj["W"]), pj["K"], _lib.ptr(pj["b"]),
                       _lib.ptr(pj["m"]), _lib.ptr(pj["e"]), _lib.ptr(ws["k16"]), C, M, C, pj["K"], st)

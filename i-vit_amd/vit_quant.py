@@ -167,10 +167,10 @@ class VisionTransformer(EngineDispatch, nn.Module):
         self._engine_widths = (8, 8, 8)        # (stream, softmax, position embedding)
         a, m = self.blocks[0].attn.int_softmax, self.blocks[0].mlp.act
         sm_bits = int(getattr(a, "output_bit", 8))
-        if bad and self.op_types[0] == "ivit":
+        if bad:
             # ... or the 16-bit residual stream: patch_embed_bw = block_input_bw = attention_out_bw = mlp_out_bw = norm2_in_bw =
             # att_block_out_bw = 16 (vit_quant.py:180-187), softmax_bw and pos_encoding_bw 8 or 16: engine stream_bits = 16
-            w16 = {"patch_embed.qact": 16, "qact1": 16}
+            w16 = {"patch_embed.qact": 16, "qact1": 16, **inner}
             for i in range(self.depth):
                 w16.update({f"blocks.{i}.attn.qact3": 16, f"blocks.{i}.mlp.qact2": 16, f"blocks.{i}.qact2": 16, f"blocks.{i}.qact4": 16})
             for pos_bits in (8, 16):

@@ -324,6 +324,10 @@ int ivit_bgemm_pv_i8(const int8_t* P, const int8_t* V, int32_t* O, int batch, in
 /* P of more than 8 bits (Shiftmax with output_bit up to 16: values <= 32767, a row sums to ~2^15 so |acc| < 2^23) */
 int ivit_bgemm_pv_i16_i8(const int16_t* P, const int8_t* V, int32_t* O, int batch, int Tq, int Tk, int D,
                          ivit_stream_t stream);
+/* P as int32 with |P| <= p_absmax (I-BERT's softmax with output_bit = 16 reaches 2^15 on a one-hot row, ibert_modules.py:314);
+ * refused when p_absmax * 128 * Tk does not fit int32 */
+int ivit_bgemm_pv_i32_i8(const int32_t* P, const int8_t* V, int32_t* O, int batch, int Tq, int Tk, int D, int64_t p_absmax,
+                         ivit_stream_t stream);
 
 /* ---- float <-> integer views at module edges (quant_utils.py:220; quant_modules.py:223,385-387) --
  * z = round(x / s[c]) (mode 0) or trunc(x / s[c]) (mode 1, the `.to(int32)` of ivit_modules.py:38,107);
@@ -482,6 +486,10 @@ int ivit_attention_fused_i8_ibert_wide(const int8_t* qkv, int8_t* out, int batch
 int ivit_ibert_layernorm_i8(const int8_t* x, int64_t ldx, int rows, int C, float s_in, const float* bias_int, const float* s_out,
                             float shift_pow2, const uint32_t* m, const int32_t* e, int8_t* out, int64_t ldo, int out_blocks,
                             ivit_stream_t stream);
+/* the same on an int16 row (norm2_in_bw / att_block_out_bw = 16: the 16-bit residual stream); literal form, row-major output */
+int ivit_ibert_layernorm_i16_i8(const int16_t* x, int64_t ldx, int rows, int C, float s_in, const float* bias_int,
+                                const float* s_out, float shift_pow2, const uint32_t* m, const int32_t* e, int8_t* out, int64_t ldo,
+                                ivit_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -416,6 +416,47 @@ def test_ibert_layernorm_i8_engine_kernel_equals_modules(C, s_in, shift):
     assert np.abs(exp).max() > 50
 
 
+@pytest.mark.parametrize("C,s_in,shift", [(384, 2.0 ** -9, 0), (768, 1.37e-4, 1), (198, 3.1e-4, 0)])
+def test_ibert_layernorm_i16_kernel_equals_modules(C, s_in, shift):
+    """ivit_ibert_layernorm_i16_i8 (the 16-bit residual stream's LayerNorm under the I-BERT operators) == IBERTIntLayerNorm + QuantAct
+    on int16 rows: random, tiny-variance, full-range"""
+    rng = np.random.default_rng(C + 1)
+    rows = 131
+    qv = np.clip(np.rint(rng.normal(0, 6000, size=(rows, C))), -32768, 32767).astype(np.int16)
+    qv[0] = 7
+    qv[0, 3] = 9000
+    qv[1] = 32767
+    qv[1, ::2] = -32768
+    qv[2] = rng.integers(-40, 40, size=C)
+    gamma = rng.uniform(0.5, 1.5, size=C).astype(np.float32)
+    beta = rng.uniform(-1, 1, size=C).astype(np.float32)
+    ln = q.IBERTIntLayerNorm(C).to(DEV)
+    ln.weight.data = torch.from_numpy(gamma).to(DEV)
+    ln.bias.data = torch.from_numpy(beta).to(DEV)
+    ln.shift.fill_(float(shift))
+    ln.fix()
+    act = q.QuantAct().to(DEV)
+    act.x_min.fill_(-2.9)
+    act.x_max.fill_(3.1)
+    act.fix()
+    s_t = torch.tensor([s_in], dtype=torch.float32, device=DEV)
+    x = (torch.from_numpy(qv.astype(np.float32)).to(DEV) * s_t)
+    with torch.no_grad():
+        y, s_ln = ln(x, s_t)
+        z, s_z = act(y, s_ln)
+    exp = torch.round(z / s_z).to(torch.int32).cpu().numpy()
+    lp = LayerNormParams(gamma, beta, float(s_z))
+    out = torch.zeros(rows, C, dtype=torch.int8, device=DEV)
+    dq, db, dsl = torch.from_numpy(qv).to(DEV), torch.from_numpy(lp.bias_int).to(DEV), torch.from_numpy(lp.s_ln).to(DEV)
+    dm, de = torch.from_numpy(lp.m.view(np.int32)).to(DEV), torch.from_numpy(lp.e).to(DEV)
+    _lib.call("ivit_ibert_layernorm_i16_i8", _lib.ptr(dq), C, rows, C, float(s_in), _lib.ptr(db), _lib.ptr(dsl), float(2.0 ** shift),
+              _lib.ptr(dm), _lib.ptr(de), _lib.ptr(out), C, _lib.stream_ptr())
+    got = out.cpu().numpy().astype(np.int32)
+    bad = np.argwhere(got != exp)
+    assert bad.size == 0, (len(bad), bad[:5], got[tuple(bad[0])], exp[tuple(bad[0])])
+    assert np.abs(exp).max() > 50
+
+
 def test_ibert_model_module_path_matches_reference_golden():
     """DeiT-T with gelu / softmax / layernorm = 'ibert' (the fork's default operator family) through the module path:
     float logits bitwise equal to the reference's."""
@@ -530,6 +571,31 @@ def test_unsupported_width_pattern_takes_the_module_path():
     with torch.no_grad():
         y = model(imgs)
     assert model._engine is None and torch.isfinite(y).all()
+
+
+def test_ibert_int16_engine_equals_module_path():
+    """the authors' 'I-BERT INT16' configuration (.vscode/launch.json: --bitwidth 16 with the I-BERT operators): DeiT-S, every
+    width knob at 16, ranges as calibrated, 12 fresh images: fused engine (stream_bits = softmax_bits = pos_bits = 16,
+    family 'ibert') == module-by-module path, float logits bitwise"""
+    w = {k: 16 for k in ("patch_embed_bw", "pos_encoding_bw", "block_input_bw", "attention_out_bw", "softmax_bw", "mlp_out_bw",
+                         "norm2_in_bw", "att_block_out_bw")}
+    fs = synth.make_float_state("deit_small_patch16_224", 41)
+    model = ivit.deit_small_patch16_224(gelu_type="ibert", softmax_type="ibert", layernorm_type="ibert", **w)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in fs.items()}, strict=False)
+    model.to(DEV).eval()
+    with torch.no_grad():
+        model(torch.from_numpy(synth.make_images(4, 93)).to(DEV))
+    ivit.freeze_model(model)
+    imgs = torch.from_numpy(synth.make_images(12, 94)).to(DEV)
+    assert model.takes_engine(imgs), model.engine_unsupported_reason()
+    with torch.no_grad():
+        ye = model(imgs)
+        eng = model.engine(12)
+        assert (eng.family, eng.stream_bits, eng.softmax_bits, eng.pos_bits) == ("ibert", 16, 16, 16)
+        model.use_engine = False
+        ym = model(imgs)
+    assert np.array_equal(bits(ye), bits(ym))
+    assert len(set(ym.argmax(dim=1).cpu().tolist())) > 1
 
 
 @pytest.mark.parametrize("regime", ["pow2", "natural"])

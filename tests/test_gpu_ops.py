@@ -516,11 +516,11 @@ def test_attention_fused(B, H, T, p_at):
     assert np.abs(exp).max() > 20
 
 
-@pytest.mark.parametrize("T,band", [(197, False), (197, True), (203, True), (193, False)])
-def test_attention_fused_ibert(T, band):
+@pytest.mark.parametrize("T,band,pbits", [(197, False, 8), (197, True, 8), (203, True, 8), (193, False, 8), (197, True, 16), (193, False, 16)])
+def test_attention_fused_ibert(T, band, pbits):
     """ivit_attention_fused_i8_ibert against its specification evaluated in numpy: requantised scores, table lookup over
     (row max, q), float32 row sum in torch's reduction order (oracle torch_rowsum), factor = floor(2^32 / S),
-    p = floor(fl32(e * factor) / 2^25), P.V.  The table is synthetic -- non-integer floats, so that the summation order
+    p = floor(fl32(e * factor) / 2^(33 - pbits)), P.V (pbits = 16: ivit_attention_fused_i8_ibert_wide, p up to 2^15).  The table is synthetic -- non-integer floats, so that the summation order
     matters, and entry 16384 at distance 0 for some row maxima, so that a one-hot row gives p = 128 (the two-operand path)"""
     from ivit_amd.prepare import shiftexp_band
     rng = np.random.default_rng(T + band)
@@ -531,7 +531,7 @@ def test_attention_fused_ibert(T, band):
     qkv[1, 0, 0] = np.clip(qkv[1, 0, 0], -20, 20)
     qkv[1, 0, 0, 17, :8] = 127
     ms, es = dyadic(np.float32(2.0 ** -11), np.float32(2.0 ** -2))
-    mo, eo = dyadic(np.float32(2.0 ** -11), np.float32(2.0 ** -3))
+    mo, eo = dyadic(np.float32(2.0 ** (-3 - pbits)), np.float32(2.0 ** -3))
     dist = np.arange(256)
     prof = np.floor(16384.0 * np.exp(-dist / 9.0))                           # exp-like, 0 beyond ~90 steps
     tab = np.zeros((256, 256), np.float32)
@@ -557,15 +557,19 @@ def test_attention_fused_ibert(T, band):
                 e = tab[int(ka[i].max()) + 128, ka[i] + 128].astype(np.float32)
                 Ssum = orc.torch_rowsum(e)
                 factor = np.floor(np.float32(4294967296.0) / np.float32(Ssum)).astype(np.float32)
-                P[i] = np.floor((e * factor).astype(np.float32) / np.float32(2.0 ** 25)).astype(np.int32)
-            n128 += int((P == 128).sum())
-            assert P.max() <= 128 and P.min() >= 0
+                P[i] = np.floor((e * factor).astype(np.float32) / np.float32(2.0 ** (33 - pbits))).astype(np.int32)
+            n128 += int((P == 1 << (pbits - 1)).sum())
+            assert P.max() <= 1 << (pbits - 1) and P.min() >= 0
             O = P.astype(np.int64) @ qkv[2, b, h].astype(np.int64)
             exp[b, :, h * hd:(h + 1) * hd] = orc.requant(O.astype(np.int32), mo.astype(np.float64), eo, 8)
     assert n128 > 0                                  # the p = 128 path is exercised
     out = torch.full((B * T, H * hd), 99, dtype=torch.int8, device=DEV)
-    _lib.call("ivit_attention_fused_i8_ibert", _lib.ptr(dev(qkv)), _lib.ptr(out), B, H, T, hd, int(ms[0]), int(es[0]), int(mo[0]),
-              int(eo[0]), _lib.ptr(dtab), _lib.ptr(bandt), bw, 0, st())
+    if pbits == 8:
+        _lib.call("ivit_attention_fused_i8_ibert", _lib.ptr(dev(qkv)), _lib.ptr(out), B, H, T, hd, int(ms[0]), int(es[0]), int(mo[0]),
+                  int(eo[0]), _lib.ptr(dtab), _lib.ptr(bandt), bw, 0, st())
+    else:
+        _lib.call("ivit_attention_fused_i8_ibert_wide", _lib.ptr(dev(qkv)), _lib.ptr(out), B, H, T, hd, int(ms[0]), int(es[0]),
+                  int(mo[0]), int(eo[0]), _lib.ptr(dtab), _lib.ptr(bandt), bw, pbits, 0, st())
     got = out.cpu().numpy().astype(np.int32).reshape(B, T, H * hd)
     assert np.array_equal(got, exp), f"{(got != exp).sum()} of {got.size} differ"
     assert np.abs(exp).max() > 20
