@@ -42,6 +42,7 @@ SIGNATURES = {
     "ivit_gemm_i8_requant_lut_ex": [vp, i64, vp, i64, vp, vp, vp, vp, vp, i64, ci, ci, ci, ci, vp],
     "ivit_gemm_i8_requant_i16": [vp, i64, vp, i64, vp, vp, vp, vp, i64, ci, ci, ci, vp],
     "ivit_gemm_i8_requant_residual_i16_ex": [vp, i64, vp, i64, vp, vp, vp, vp, i64, u32, i32, u32, i32, vp, i64, ci, ci, ci, ci, vp],
+    "ivit_gemm_i8_requant_i16_residual_i16_ex": [vp, i64, vp, i64, vp, vp, vp, vp, i64, u32, i32, u32, i32, vp, i64, ci, ci, ci, ci, vp],
     "ivit_gemm_i8_requant_qkv": [vp, i64, vp, i64, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp],
     "ivit_gemm_i8_i32": [vp, i64, vp, i64, vp, vp, i64, ci, ci, ci, vp],
     "ivit_attention_fused_i8": [vp, vp, ci, ci, ci, ci, u32, i32, f32, u32, i32, vp],

@@ -765,6 +765,9 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_wreg_kernel(GemmArgs g)
         } else {
             int tid_o = tid;   // opaque: the epilogue's per-thread addresses are computed here, not carried through the main loop
             asm volatile("" : "+v"(tid_o));
+            if constexpr (EPI == EPI_RQ16_RES16)
+                epilogue_rq16_res16<TJ, BIG_NT, Hook>(acc, g, cs, cur.m0, cur.n0, 64 * wave, tid_o, (tid_o >> 5) & 1, tid_o & 31, hook);
+            else
             epilogue_i8<EPI, 2, TJ, 32 * TJ, BIG_NT, (ABL & 64), WR_CH, Hook>(acc, g, cs, tab, cur.m0, cur.n0, 64 * wave, 0, tid_o, (tid_o >> 5) & 1,
                                                                       tid_o & 31, hook,
                                                                       g.lut ? reinterpret_cast<const unsigned char*>(smem + WR_LUT) : nullptr);
@@ -827,7 +830,7 @@ int launch_gemm(GemmArgs& g, const char* name, ivit_stream_t stream)
     if (EPI == EPI_RESID)
         IVIT_REQUIRE(g.res && g.ldr >= g.N && g.ldr % 16 == 0 && ((uintptr_t)g.res % 16 == 0),
                      "%s: residual operand missing or misaligned", name);
-    if (EPI == EPI_RESID16)
+    if (EPI == EPI_RESID16 || EPI == EPI_RQ16_RES16)
         IVIT_REQUIRE(g.res && g.ldr >= g.N && g.ldr % 8 == 0 && ((uintptr_t)g.res % 16 == 0) && g.ldo >= g.N && g.ldo % 8 == 0,
                      "%s: 16-bit residual / output rows must be 16-byte aligned (ld multiples of 8 elements)", name);
     if (EPI == EPI_QKV) {
@@ -878,6 +881,9 @@ int launch_gemm(GemmArgs& g, const char* name, ivit_stream_t stream)
             IVIT_CHECK_LAUNCH(name);
         }
     }
+    if constexpr (EPI == EPI_RQ16_RES16) {
+        IVIT_REQUIRE(false, "%s: needs the fragment-packed weight form (IVIT_W_FRAGS: M >= 2048, N >= 128, N %% 64 == 0, K %% 192 == 0)", name);
+    } else
     if constexpr (EPI != EPI_I32 && EPI != EPI_RQ16) {
 #if IVIT_LAB
         if (EPI <= EPI_QKV && !blocks && (g_debug_flags & (31 | 32 | 128 | 256 | 512 | 1024 | 8192 | 4194304 | 8388608))) {   // a lab form was asked for (tests, scripts)
@@ -1069,6 +1075,26 @@ IVIT_EXPORT int ivit_gemm_i8_requant_i16(const int8_t* A, int64_t lda, const int
     g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.m = m; g.e = e;
     g.out = out; g.ldo = ldo; g.M = M; g.N = N; g.K = K;
     return launch_gemm<EPI_RQ16>(g, "ivit_gemm_i8_requant_i16", stream);
+}
+
+IVIT_EXPORT int ivit_gemm_i8_requant_i16_residual_i16_ex(const int8_t* A, int64_t lda, const int8_t* W, int64_t ldw,
+                                                         const int32_t* bias, const uint32_t* m, const int32_t* e,
+                                                         const int16_t* res, int64_t ldr, uint32_t m_main, int32_t e_main,
+                                                         uint32_t m_res, int32_t e_res, int16_t* out, int64_t ldo, int M, int N,
+                                                         int K, int layouts, ivit_stream_t stream)
+{
+    GemmArgs g{};
+    g.a_blocks = layouts & 1; g.w_frags = (layouts >> 3) & 1;
+    IVIT_REQUIRE((layouts & ~9) == 0 && g.w_frags, "ivit_gemm_i8_requant_i16_residual_i16_ex: layouts must be IVIT_W_FRAGS (| IVIT_A_BLOCKS)");
+    g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.m = m; g.e = e;
+    g.res = reinterpret_cast<const int8_t*>(res); g.ldr = ldr;
+    g.out = out; g.ldo = ldo; g.M = M; g.N = N; g.K = K;
+    g.M_main = ivit_dyadic_to_double(m_main, e_main);
+    g.M_res = ivit_dyadic_to_double(m_res, e_res);
+    IVIT_REQUIRE(g.M_main < 32768.0 && g.M_res < 32768.0, "ivit_gemm_i8_requant_i16_residual_i16_ex: residual multiplier too large");
+    IVIT_REQUIRE(ldo % 8 == 0 && ldr % 8 == 0 && ((uintptr_t)res % 16 == 0) && ((uintptr_t)out % 16 == 0) && N % 8 == 0,
+                 "ivit_gemm_i8_requant_i16_residual_i16_ex: 16-bit rows must be 16-byte aligned");
+    return launch_gemm<EPI_RQ16_RES16>(g, "ivit_gemm_i8_requant_i16_residual_i16_ex", stream);
 }
 
 IVIT_EXPORT int ivit_gemm_i8_i32(const int8_t* A, int64_t lda, const int8_t* W, int64_t ldw, const int32_t* bias,

@@ -37,7 +37,10 @@ constexpr int SMEM_BYTES = 2 * STAGE_BYTES;  // 32 KiB >= 128 * 132
 //   out16 = clamp16(RNE(k8 * M_main) + RNE(res16 * M_res)) with res / out int16 (res, out of GemmArgs reinterpreted)
 // EPI_RQ16 (Swin attn.proj + attn.qact4): out16 = clamp16(RNE(acc * M[n])), int16 rows, straight from the accumulator registers
 // (small-tile kernel only)
-enum { EPI_RQ = 0, EPI_RESID = 1, EPI_QKV = 2, EPI_I32 = 3, EPI_RESID16 = 4, EPI_RQ16 = 5 };
+// EPI_RQ16_RES16 (ViT attn.proj / mlp.fc2 on a 16-bit residual stream: attn.qact3 / mlp.qact2 at 16 bits + the block's residual
+//   QuantAct): k16 = clamp16(RNE(acc * M[n])), out16 = clamp16(RNE(k16 * M_main) + RNE(res16 * M_res)), straight from the
+//   accumulator registers (weights-in-registers kernel only)
+enum { EPI_RQ = 0, EPI_RESID = 1, EPI_QKV = 2, EPI_I32 = 3, EPI_RESID16 = 4, EPI_RQ16 = 5, EPI_RQ16_RES16 = 6 };
 
 
 struct GemmArgs {
@@ -368,6 +371,102 @@ IVIT_DEV void epilogue_i8(v16i (&acc)[TI][TJ], const GemmArgs& g, char* smem, co
             off = (EPI == EPI_RQ && g.out_blocks) ? (int64_t)block_off(block_row(t, g.N), block_col(cn)) : (int64_t)t * g.ldo + cn;
         }
         *reinterpret_cast<int4*>(out + off) = make_int4(v[it][0], v[it][1], v[it][2], v[it][3]);
+    }
+}
+
+// ---- 16-bit epilogue of the weights-in-registers kernel (EPI_RQ16_RES16).  A wave owns 64 of the tile's 256 channels x 32 TJ
+// tokens; a lane holds, per accumulator quad, 4 consecutive channels of one token.  Straight from the registers that is one
+// 8-byte access per lane into 32 different rows per instruction -- measured ~75 us per launch over the int8 epilogue, the
+// texture path serialising on the rows.  So, like the int8 epilogue, the tile is transposed through LDS -- 64 tokens at a time:
+// 64 rows x 256 int16 is exactly the staging region of the int8 tile (128 rows x 256 bytes) -- and phase B moves 16-byte chunks,
+// 32 consecutive threads per 512-byte row, for the residual load and the store alike.
+// A 16-bit result is too wide for the float32 bracket certificate of the int8 epilogue (an undecided bracket every ~100
+// outputs), so the arithmetic is the reference's float64 (quant_utils.py:229-230: product rounded to 53 bits, then RNE; the two
+// 16-bit operands of the residual QuantAct have exact products: one fused multiply-add each).
+template <int TJ, int NTHREADS, typename Hook>
+IVIT_DEV void epilogue_rq16_res16(v16i (&acc)[2][TJ], const GemmArgs& g, char* cs, int m0, int n0, int wch, int tid, int h, int l31,
+                                  const Hook& hook)
+{
+    constexpr int CH = 256;
+    constexpr int RS = CH * 2 + 8;            // LDS row stride: 130 dwords, consecutive rows two banks apart
+    constexpr int CPR = CH / 8;               // 16-byte chunks (8 channels) per row
+    constexpr int NIT = 64 * CPR / NTHREADS;  // chunks per thread and round
+    static_assert(TJ % 2 == 0 && 64 * CPR % NTHREADS == 0, "rounds of 64 tokens");
+    __builtin_amdgcn_s_setprio(2);
+    hook.issue();
+    const int16_t* res = reinterpret_cast<const int16_t*>(g.res);
+    int16_t* out = reinterpret_cast<int16_t*>(g.out);
+#pragma unroll
+    for (int rd = 0; rd < TJ / 2; ++rd) {
+        // ---- phase A: k16 = clamp16(RNE(acc * M[n])) of token sub-tiles 2 rd, 2 rd + 1 -> cs[token][channel]
+#pragma unroll
+        for (int grp = 0; grp < 8; ++grp) {
+            const int i = grp >> 2, q = grp & 3;
+            const int cl = wch + 32 * i + 8 * q + 4 * h;
+            const int c0 = min(n0 + cl, g.N - 4);
+            const uint4 m4 = *reinterpret_cast<const uint4*>(g.m + c0);
+            const int4 e4 = *reinterpret_cast<const int4*>(g.e + c0);
+            const double Mc[4] = {dyadic_mult(m4.x, e4.x), dyadic_mult(m4.y, e4.y), dyadic_mult(m4.z, e4.z), dyadic_mult(m4.w, e4.w)};
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                int o[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double p = (double)acc[i][2 * rd + jj][4 * q + r] * Mc[r];
+                    o[r] = clamp_i32((int)(unsigned)__double_as_longlong(p + IVIT_MAGIC), -32768, 32767);
+                }
+                v2i ow;
+                ow.x = (o[0] & 0xffff) | (o[1] << 16);
+                ow.y = (o[2] & 0xffff) | (o[3] << 16);
+                *reinterpret_cast<v2i*>(cs + (32 * jj + l31) * RS + 2 * cl) = ow;
+            }
+        }
+        // ---- phase B work items: the residual loads go out before the barrier
+        v4i rr[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int qd = tid + NTHREADS * it;
+            const int tl = qd / CPR, cc = qd % CPR;
+            const int t = min(m0 + 64 * rd + tl, g.M - 1), cn = min(n0 + 8 * cc, g.N - 8);
+            rr[it] = *reinterpret_cast<const v4i*>(res + (int64_t)t * g.ldr + cn);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        // two batches of NIT / 2 chunks: 16 registers of staged values live instead of 32 (the accumulators of the next round are)
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {
+            constexpr int NH = NIT / 2;
+            v4i kk[NH];
+#pragma unroll
+            for (int u = 0; u < NH; ++u) {
+                const int qd = tid + NTHREADS * (NH * hb + u);
+                lds_read16_async(kk[u], lds_addr(cs) + (unsigned)((qd / CPR) * RS + 16 * (qd % CPR)));
+            }
+#pragma unroll
+            for (int u = 0; u < NH; ++u) lds_wait(kk[u]);
+            if (hb == 1 && rd + 1 < TJ / 2) {      // the next round's phase A overwrites the staging rows
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+            }
+            if (rd == 0 && hb == 0) hook.consume();   // vmcnt(0) while no store of this epilogue is in flight
+#pragma unroll
+            for (int u = 0; u < NH; ++u) {
+                const int it = NH * hb + u;
+                const int qd = tid + NTHREADS * it;
+                const int tl = qd / CPR, cc = qd % CPR;
+                const int t = m0 + 64 * rd + tl, cn = n0 + 8 * cc;
+                v4i ov;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const int kw = kk[u][d], rw = rr[it][d];
+                    const int lo = clamp_i32(requant_exact((int)(int16_t)kw, g.M_main) + requant_exact((int)(int16_t)rw, g.M_res), -32768, 32767);
+                    const int hi = clamp_i32(requant_exact(kw >> 16, g.M_main) + requant_exact(rw >> 16, g.M_res), -32768, 32767);
+                    ov[d] = (lo & 0xffff) | (hi << 16);
+                }
+                if (t < g.M && cn < g.N) *reinterpret_cast<v4i*>(out + (int64_t)t * g.ldo + cn) = ov;
+            }
+        }
     }
 }
 

@@ -246,6 +246,7 @@ class IntViTEngine(GraphReplay):
         # (DESIGN.md section 5): the GEMM gains 4-6 % from a block-layout A, the producer pays for 64-byte row segments
         self.block_a = {"ln": True, "attn": True, "gelu": True}
         self.gelu_in_place = True     # GELU overwrites the fc1 output (same layout on both sides)
+        self.fuse_res16 = True        # 16-bit stream: projection / fc2 + both QuantActs in one kernel (False: A/B, tests)
         self.fuse_ibert_gelu = True   # family "ibert": GELU + mlp.qact1 as a byte map in the fc1 epilogue (False: A/B, tests)
         self.probe = None
         self._alloc(max_batch)
@@ -456,7 +457,21 @@ class IntViTEngine(GraphReplay):
                   _lib.ptr(pt["m"]), _lib.ptr(pt["e"]), _lib.ptr(ws["pe16"]), C, B * NUM_PATCHES, C, pt["K"], st)
         _lib.call("ivit_embed_assemble_i16", _lib.ptr(ws["pe16"]), _lib.ptr(self.pos_add), _lib.ptr(self.cls_row),
                   self.embed_me[0], self.embed_me[1], _lib.ptr(ws["x16"]), B, T, C, st)
-        x, y = ws["x16"], ws["y16"]
+        x = ws["x16"]
+        inplace = big and self.weight_frags and self.fuse_res16 and all(b[k].get("Wf") is not None for b in self.blocks for k in ("proj", "fc2"))
+
+        def gemm_res16(A, lda, lin, r, res, out):
+            # projection / fc2 + its 16-bit QuantAct + the block's residual QuantAct: one kernel in the weights-in-registers form
+            if big and self.weight_frags and self.fuse_res16 and lin.get("Wf") is not None:
+                _lib.call("ivit_gemm_i8_requant_i16_residual_i16_ex", _lib.ptr(A), lda, _lib.ptr(lin["Wf"]), lin["K"], _lib.ptr(lin["b"]),
+                          _lib.ptr(lin["m"]), _lib.ptr(lin["e"]), _lib.ptr(res), C, r[0], r[1], r[2], r[3], _lib.ptr(out), C, M, C,
+                          lin["K"], 8, st)
+                return
+            _lib.call("ivit_gemm_i8_requant_i16", _lib.ptr(A), lda, _lib.ptr(lin["W"]), lin["K"], _lib.ptr(lin["b"]),
+                      _lib.ptr(lin["m"]), _lib.ptr(lin["e"]), _lib.ptr(ws["k16"]), C, M, C, lin["K"], st)
+            _lib.call("ivit_residual_requant_i16", _lib.ptr(ws["k16"]), 16, None, None, r[0], r[1], _lib.ptr(res), r[2], r[3],
+                      _lib.ptr(out), M, C, 0, 0, 0, 0, st)
+
         for blk in self.blocks:
             self._ln16(x, M, blk["ln1"], ws["h"], st)
             q = blk["qkv"]
@@ -472,20 +487,20 @@ class IntViTEngine(GraphReplay):
                 _lib.call("ivit_attention_fused_i8_wide", _lib.ptr(ws["qkv"]), _lib.ptr(ws["ao"]), B, H, T, hd,
                           a["ms"][0], a["ms"][1], a["s_attn"], a["mo"][0], a["mo"][1], _lib.ptr(a["exp2d"]), _lib.ptr(a["band"]),
                           a["band_w"], self.softmax_bits, 0, st)
-            pj, r = blk["proj"], blk["res1"]
-            _lib.call("ivit_gemm_i8_requant_i16", _lib.ptr(ws["ao"]), C, _lib.ptr(pj["W"]), pj["K"], _lib.ptr(pj["b"]),
-                      _lib.ptr(pj["m"]), _lib.ptr(pj["e"]), _lib.ptr(ws["k16"]), C, M, C, pj["K"], st)
-            _lib.call("ivit_residual_requant_i16", _lib.ptr(ws["k16"]), 16, None, None, r[0], r[1], _lib.ptr(x), r[2], r[3],
-                      _lib.ptr(y), M, C, 0, 0, 0, 0, st)
+            y = x if inplace else ws["y16"]     # the fused epilogue's thread reads a residual chunk and writes the same chunk
+            gemm_res16(ws["ao"], C, blk["proj"], blk["res1"], x, y)
             self._ln16(y, M, blk["ln2"], ws["h"], st)
-            self._gemm(ws["h"], C, blk["fc1"], ws["f1"], 4 * C, M, st, a_blocks=False, blocks=big, out_blocks=False)
-            _lib.call("ivit_shiftgelu_lut_i8_ex", _lib.ptr(ws["f1"]), 4 * C, M, 4 * C, _lib.ptr(blk["gelu_lut"]),
-                      _lib.ptr(ws["f1"]), 4 * C, 0, st)
-            f2, r = blk["fc2"], blk["res2"]
-            _lib.call("ivit_gemm_i8_requant_i16", _lib.ptr(ws["f1"]), 4 * C, _lib.ptr(f2["W"]), f2["K"], _lib.ptr(f2["b"]),
-                      _lib.ptr(f2["m"]), _lib.ptr(f2["e"]), _lib.ptr(ws["k16"]), C, M, C, f2["K"], st)
-            _lib.call("ivit_residual_requant_i16", _lib.ptr(ws["k16"]), 16, None, None, r[0], r[1], _lib.ptr(y), r[2], r[3],
-                      _lib.ptr(x), M, C, 0, 0, 0, 0, st)
+            f1 = blk["fc1"]
+            if self.family == "ibert" and self.fuse_ibert_gelu and big and self.weight_frags and f1.get("Wf") is not None:
+                # I-BERT GELU + mlp.qact1 as a byte map in the fc1 epilogue (see forward)
+                _lib.call("ivit_gemm_i8_requant_lut_ex", _lib.ptr(ws["h"]), C, _lib.ptr(f1["Wf"]), f1["K"], _lib.ptr(f1["b"]),
+                          _lib.ptr(f1["m"]), _lib.ptr(f1["e"]), _lib.ptr(blk["gelu_lut"]), _lib.ptr(ws["f1"]), 4 * C, M, f1["N"], f1["K"],
+                          8, st)
+            else:
+                self._gemm(ws["h"], C, f1, ws["f1"], 4 * C, M, st, a_blocks=False, blocks=big, out_blocks=False)
+                _lib.call("ivit_shiftgelu_lut_i8_ex", _lib.ptr(ws["f1"]), 4 * C, M, 4 * C, _lib.ptr(blk["gelu_lut"]),
+                          _lib.ptr(ws["f1"]), 4 * C, 0, st)
+            gemm_res16(ws["f1"], 4 * C, blk["fc2"], blk["res2"], y, x)
         # final LayerNorm: only the cls rows are consumed (vit_quant.py:302-304); the int16 kernel wants dense rows
         ws["cls16"][:B].copy_(x.view(-1, T, C)[:B, 0])
         self._ln16(ws["cls16"], B, self.ln_f, ws["cls"], st)

@@ -161,6 +161,16 @@ int ivit_gemm_i8_requant_i16(const int8_t* A, int64_t lda, const int8_t* W, int6
                              const uint32_t* m, const int32_t* e, int16_t* out, int64_t ldo, int M, int N, int K,
                              ivit_stream_t stream);
 
+/* the two calls above in one (ViT attn.proj + attn.qact3 at 16 bits + qact2, mlp.fc2 + mlp.qact2 at 16 bits + qact4,
+ * vit_quant.py:131-150 with attention_out_bw = mlp_out_bw = norm2_in_bw = att_block_out_bw = 16):
+ *   k16 = clamp16(RNE(acc * m[n] / 2^e[n])),  out = clamp16(RNE(k16 * M_main) + RNE(res * M_res)),  res / out int16 rows.
+ * Weights-in-registers kernel only: `layouts` carries IVIT_W_FRAGS (optionally IVIT_A_BLOCKS) and the shape limits of that
+ * form apply; other shapes use the two calls. */
+int ivit_gemm_i8_requant_i16_residual_i16_ex(const int8_t* A, int64_t lda, const int8_t* W, int64_t ldw, const int32_t* bias,
+                                             const uint32_t* m, const int32_t* e, const int16_t* res, int64_t ldr,
+                                             uint32_t m_main, int32_t e_main, uint32_t m_res, int32_t e_res, int16_t* out,
+                                             int64_t ldo, int M, int N, int K, int layouts, ivit_stream_t stream);
+
 /* raw accumulators (classifier head; module-level QuantLinear): out int32 [M, N], N % 4 == 0 */
 int ivit_gemm_i8_i32(const int8_t* A, int64_t lda, const int8_t* W, int64_t ldw, const int32_t* bias,
                      int32_t* out, int64_t ldo, int M, int N, int K, ivit_stream_t stream);

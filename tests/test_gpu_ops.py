@@ -144,6 +144,42 @@ def test_gemm_requant_i16(M, N, K):
     assert (np.abs(exp) < 30000).any()
 
 
+@pytest.mark.parametrize("M,N,K", [(2050, 768, 192), (4099, 384, 384), (128 * 37 + 64, 192, 768)])
+def test_gemm_requant_i16_residual_i16(M, N, K):
+    """ivit_gemm_i8_requant_i16_residual_i16_ex (projection / fc2 on a 16-bit residual stream: per-channel 16-bit QuantAct of the
+    accumulators, then the two-operand 16-bit residual QuantAct) == oracle; ragged M (half tiles, partial last tile), saturation
+    in both steps, scale pairs with exact ties, in place over the residual"""
+    rng = np.random.default_rng(M + N)
+    A = rng.integers(-128, 128, size=(M, K)).astype(np.int8)
+    W = rng.integers(-128, 128, size=(N, K)).astype(np.int8)
+    b = rng.integers(-50000, 50000, size=N).astype(np.int32)
+    res = np.clip(np.rint(rng.normal(0, 9000, size=(M, N))), -32768, 32767).astype(np.int16)
+    m, e = rand_me(rng, N, -8, 1)           # the 16-bit intermediate spans and exceeds the int16 range
+    md, ed = me_dev(m, e)
+    k16 = orc.requant(orc.gemm_i8(A, W, b), m.astype(np.float64), e, 16)
+    assert (np.abs(k16) >= 32767).any() and (np.abs(k16) < 30000).any()
+    dA, dW, db, dres = dev(A), dev(W), dev(b), dev(res)
+    Wf = torch.empty((N + 63) // 64 * 64 * K, dtype=torch.int8, device=DEV)
+    _lib.call("ivit_pack_weight_frags_i8", _lib.ptr(dW), K, N, K, _lib.ptr(Wf), st())
+    for s_main, s_res, s_out in [(0.7 * 2 ** -4, 2 ** -5, 2 ** -4), (2 ** -5, 2 ** -5, 2 ** -4), (1.0, 1.0, 1.0), (0.3337, 0.0421, 0.0517),
+                                 (1.0, 1.0, 0.4)]:
+        m1, e1 = dyadic(np.float32(s_main), np.float32(s_out))
+        m2, e2 = dyadic(np.float32(s_res), np.float32(s_out))
+        exp = orc.requant(k16, m1.astype(np.float64), e1, 16, z2=res.astype(np.int32), m2=m2.astype(np.float64), e2=e2)
+        out = torch.full((M, N), 77, dtype=torch.int16, device=DEV)
+        _lib.call("ivit_gemm_i8_requant_i16_residual_i16_ex", _lib.ptr(dA), K, _lib.ptr(Wf), K, _lib.ptr(db), _lib.ptr(md), _lib.ptr(ed),
+                  _lib.ptr(dres), N, int(m1[0]), int(e1[0]), int(m2[0]), int(e2[0]), _lib.ptr(out), N, M, N, K, 8, st())
+        got = out.cpu().numpy().astype(np.int32)
+        assert np.array_equal(got, exp), (s_main, s_res, s_out, int((got != exp).sum()))
+        inpl = dres.clone()
+        _lib.call("ivit_gemm_i8_requant_i16_residual_i16_ex", _lib.ptr(dA), K, _lib.ptr(Wf), K, _lib.ptr(db), _lib.ptr(md), _lib.ptr(ed),
+                  _lib.ptr(inpl), N, int(m1[0]), int(e1[0]), int(m2[0]), int(e2[0]), _lib.ptr(inpl), N, M, N, K, 8, st())
+        assert torch.equal(inpl, out)
+    with pytest.raises(_lib.IvitError, match="IVIT_W_FRAGS"):
+        _lib.call("ivit_gemm_i8_requant_i16_residual_i16_ex", _lib.ptr(dA), K, _lib.ptr(dW), K, _lib.ptr(db), _lib.ptr(md), _lib.ptr(ed),
+                  _lib.ptr(dres), N, 1 << 30, 30, 1 << 30, 30, _lib.ptr(out), N, M, N, K, 0, st())
+
+
 def test_gemm_mfma_layout_identity():
     """A = I-like selector with an asymmetric W catches any row/column swap of the MFMA maps."""
     K = 128
