@@ -469,6 +469,114 @@ __global__ __launch_bounds__(NT, 4) void ibert_layernorm_i8_fast_kernel(IbLnI8Ar
     }
 }
 
+// ---- int16 rows (the 16-bit residual stream).  No table of phi(q) = fl(fl(q s) / s) fits 65536 inputs, and with terms up to 2^15
+// the float32 row sums cannot be decided from the exact integers (the reduction's rounding error reaches the spacing of the
+// means): the row sums ARE evaluated in torch's order, but from registers.  A lane holds the elements c = lane + 64 k.  Torch's
+// kernel (rowsum.h) keeps 32 accumulator lanes, lane l adding the elements l + 32 i in sequence: i = 2 k of this layout sit in
+// wave lane l, i = 2 k + 1 in wave lane l + 32 -- one v_permlane32_swap per register brings them together, then the cascade of
+// rowsum.h runs unrolled on registers (C % 64 == 0: no leftover vectors, no scalar tail).  Element steps are the literal float32
+// operations; the QuantAct tail takes the bracket certificate of ibert_layernorm_i8_fast_kernel, an uncertified row (and
+// std = 0) is redone by ib_ln_row_literal.
+template <int NK>
+IVIT_DEV float torch_rowsum_regs(const float (&own)[NK], int lane)
+{
+    float oth[NK];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        typedef unsigned v2u __attribute__((ext_vector_type(2)));
+        const unsigned u = (unsigned)__float_as_int(own[k]);
+        const v2u r = __builtin_amdgcn_permlane32_swap(u, u, false, false);   // lanes < 32: (own, lane + 32's)
+        oth[k] = __int_as_float((int)r.y);
+    }
+    constexpr int size_ilp = 2 * NK;
+    constexpr int lg = size_ilp <= 1 ? 0 : size_ilp <= 2 ? 1 : size_ilp <= 4 ? 2 : size_ilp <= 8 ? 3 : size_ilp <= 16 ? 4 : size_ilp <= 32 ? 5 : 6;
+    static_assert(size_ilp <= 64, "C <= 2048");
+    constexpr int lp = lg / 4 > 4 ? lg / 4 : 4, step = 1 << lp, mask = step - 1;
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+#pragma unroll
+    for (int gq = 0; gq < size_ilp / step; ++gq) {
+#pragma unroll
+        for (int j = 0; j < step; ++j) {
+            const int i = gq * step + j;
+            acc0 += (i & 1) ? oth[i >> 1] : own[i >> 1];
+        }
+        const int i = (gq + 1) * step;
+        acc1 += acc0; acc0 = 0.f;
+        if ((i & (mask << lp)) == 0) {
+            acc2 += acc1; acc1 = 0.f;
+            if ((i & (mask << (2 * lp))) == 0) { acc3 += acc2; acc2 = 0.f; }
+        }
+    }
+#pragma unroll
+    for (int i = size_ilp / step * step; i < size_ilp; ++i) acc0 += (i & 1) ? oth[i >> 1] : own[i >> 1];
+    acc0 += acc1; acc0 += acc2; acc0 += acc3;
+    const float p1 = __shfl(acc0, (lane + 8) & 63), p2 = __shfl(acc0, (lane + 16) & 63), p3 = __shfl(acc0, (lane + 24) & 63);
+    const float v = ((acc0 + p1) + p2) + p3;
+    float fin = 0.f;
+#pragma unroll
+    for (int l = 0; l < 8; ++l) fin += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+    return fin;
+}
+
+template <int NK>
+__global__ __launch_bounds__(NT) void ibert_layernorm_i16_fast_kernel(IbLnI8Args a)
+{
+    const int C = a.C;     // == 64 NK
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float lo_r[NK], hi_r[NK], breg[NK];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        const int c = lane + 64 * k;
+        const double M = dyadic_mult(a.m[c], a.e[c]);
+        const double lod = M * (1.0 - 1.25 / 4194304.0), hid = M * (1.0 + 1.25 / 4194304.0);
+        float lf = (float)lod, hf = (float)hid;
+        if ((double)lf > lod) lf = __int_as_float(__float_as_int(lf) - 1);
+        if ((double)hf < hid) hf = __int_as_float(__float_as_int(hf) + 1);
+        const float sl = a.s_out[c];
+        const bool okc = fabsf(sl) >= 1e-30f && fabsf(sl) <= 1e30f && lod > 1e-35 && hid < 1e30;
+        lo_r[k] = okc ? lf : 0.0f;
+        hi_r[k] = okc ? hf : __builtin_inff();
+        breg[k] = a.bias_int[c];
+    }
+    const float inv_shift = 1.0f / a.shift_pow2;      // a power of two: y / 2^shift == y * 2^-shift exactly
+    for (int row = blockIdx.x * WPB + wave; row < a.rows; row += gridDim.x * WPB) {
+        const int16_t* xr = reinterpret_cast<const int16_t*>(a.x) + (int64_t)row * a.ldx;
+        int xq[NK];
+#pragma unroll
+        for (int k = 0; k < NK; ++k) xq[k] = xr[lane + 64 * k];
+        float ph[NK];
+#pragma unroll
+        for (int k = 0; k < NK; ++k) ph[k] = ((float)xq[k] * a.s_in) / a.s_in;                 // :126 on fl(q * s)
+        const float mean_int = rintf(torch_rowsum_regs<NK>(ph, lane) / (float)C);            // :127
+        float sq[NK];
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            ph[k] = ph[k] - mean_int;                                                          // :128
+            const float ys = floorf(ph[k] * inv_shift);                                        // :129
+            sq[k] = ys * ys;                                                                   // :130
+        }
+        const float var_int = torch_rowsum_regs<NK>(sq, lane);                                // :131
+        const float std_int = floorf(sqrtf(var_int)) * a.shift_pow2;                           // :142
+        if (!(std_int > 0.0f)) {                           // wave-uniform
+            ib_ln_row_literal<int16_t>(a, row, lane);
+            continue;
+        }
+        const float factor = floorf(2147483648.0f / std_int);                                 // :143
+        unsigned unc = 0;
+        int8_t* orow = a.out + (int64_t)row * a.ldo;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            float v = floorf((ph[k] * factor) / 2.0f);                                         // :144
+            v = v + breg[k];                                                                   // :151
+            const int tl = __float_as_int(__builtin_fmaf(v, lo_r[k], 12582912.0f));
+            const int th = __float_as_int(__builtin_fmaf(v, hi_r[k], 12582912.0f));
+            unc |= (tl != th) ? 1u : 0u;                                                     // uncertified: the row is redone literally
+            orow[lane + 64 * k] = (int8_t)clamp_i32(tl, 0x4B400000 - 128, 0x4B400000 + 127);
+        }
+        if (__builtin_amdgcn_ballot_w64(unc != 0) != 0) ib_ln_row_literal<int16_t>(a, row, lane);   // wave-uniform, rare
+    }
+}
+
 struct IbLnLitArgs {
     const float* x;
     int64_t ldx;
@@ -648,6 +756,12 @@ IVIT_EXPORT int ivit_ibert_layernorm_i16_i8(const int16_t* x, int64_t ldx, int r
                  "ivit_ibert_layernorm_i16_i8: bad operand");
     IVIT_REQUIRE(shift_pow2 >= 1.0f, "ivit_ibert_layernorm_i16_i8: shift_pow2 = 2^shift must be >= 1");
     IbLnI8Args a{reinterpret_cast<const int8_t*>(x), ldx, rows, C, s_in, bias_int, s_out, shift_pow2, m, e, out, ldo, 0};
-    hipLaunchKernelGGL(ibert_layernorm_i8_kernel<int16_t>, dim3(grid_for_rows(rows)), dim3(NT), 0, ivit_stream(stream), a);
+    const dim3 grid(grid_for_rows(rows)), blk(NT);
+    hipStream_t st = ivit_stream(stream);
+    if (C == 192) hipLaunchKernelGGL(ibert_layernorm_i16_fast_kernel<3>, grid, blk, 0, st, a);
+    else if (C == 384) hipLaunchKernelGGL(ibert_layernorm_i16_fast_kernel<6>, grid, blk, 0, st, a);
+    else if (C == 768) hipLaunchKernelGGL(ibert_layernorm_i16_fast_kernel<12>, grid, blk, 0, st, a);
+    else if (C == 1024) hipLaunchKernelGGL(ibert_layernorm_i16_fast_kernel<16>, grid, blk, 0, st, a);
+    else hipLaunchKernelGGL(ibert_layernorm_i8_kernel<int16_t>, grid, blk, 0, st, a);
     IVIT_CHECK_LAUNCH("ivit_ibert_layernorm_i16_i8");
 }
