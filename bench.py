@@ -50,6 +50,9 @@ def parse_args(argv=None):
     ap.add_argument("--operators", choices=("ivit", "ibert"), default="ivit",
                     help="operator family of GELU / Softmax / LayerNorm: 'ivit' (the headline, BASELINE.json) or 'ibert' (the fork's "
                          "default family; ranges calibrated on the spot, as calibrated; no cpu_baseline)")
+    ap.add_argument("--bitwidth", type=int, choices=(8, 16), default=8,
+                    help="the reference's quant_train.py --bitwidth: 16 sets all eight width knobs of vit_quant.py:180-187 to 16 "
+                         "(16-bit residual stream, softmax output, position embedding; GEMM operands stay int8).  Not the headline.")
     ap.add_argument("--natural-scales", action="store_true",
                     help="the same model with its activation ranges AS CALIBRATED (fixture deit_base_natural) instead of "
                          "power-of-two snapped: the regime of a real checkpoint, phi tables active (DESIGN.md section 2)")
@@ -179,11 +182,14 @@ def worker(args):
         dev = f"cuda:{local_rank}"
         if world > 1:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
-        if args.operators == "ibert":
-            # no fixture for this family at DeiT-B: build the module tree, calibrate its ranges on one small batch, freeze, and take
+        if args.operators == "ibert" or args.bitwidth != 8:
+            # no fixture for these at DeiT-B: build the module tree, calibrate its ranges on one small batch, freeze, and take
             # the fused engine the frozen model dispatches to (dispatch.py)
             import ivit_amd as ivit
-            model = ivit.deit_base_patch16_224(gelu_type="ibert", softmax_type="ibert", layernorm_type="ibert")
+            knobs = ("patch_embed_bw", "pos_encoding_bw", "block_input_bw", "attention_out_bw", "softmax_bw", "mlp_out_bw",
+                     "norm2_in_bw", "att_block_out_bw")
+            op = args.operators
+            model = ivit.deit_base_patch16_224(gelu_type=op, softmax_type=op, layernorm_type=op, **{k: args.bitwidth for k in knobs})
             model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_float_state("deit_base_patch16_224", 7).items()},
                                   strict=False)
             model.to(dev).eval()
@@ -191,7 +197,7 @@ def worker(args):
                 model(torch.from_numpy(synth.make_images(8, 4242)).to(dev))
             ivit.freeze_model(model)
             eng = model.engine(batch)
-            assert eng.family == "ibert"
+            assert eng.family == args.operators and eng.stream_bits == args.bitwidth, model.engine_unsupported_reason()
             fs = ranges = cfg = None
         else:
             fs, ranges, cfg, meta, _ = load_synthetic_model(MODEL_TAG + ("_natural" if args.natural_scales else ""))
@@ -240,8 +246,9 @@ def worker(args):
         macs = [float(M) * N * K for _, _, (M, N, K), _ in rows]
         avg_ms = sum(ms) / len(ms)
         achieved = 2.0 * sum(macs) / (sum(ms) * 1e-3) / 1e12
-        traffic, traffic_src = pmc_traffic(("gemm_i8_wreg_kernel<1, 0>", "gemm_i8_wreg_kernel<1>", "gemm_i8_pers_kernel<1, 0>", "gemm_i8_pers_kernel<1>"))   # names as profiled
-        roof = {"bound": "mfma", "kernel": "gemm_i8_wreg_kernel<EPI_RESID> (attn.proj + mlp.fc2, residual QuantAct fused)",
+        traffic, traffic_src = (None, None) if args.bitwidth != 8 else pmc_traffic(("gemm_i8_wreg_kernel<1, 0>", "gemm_i8_wreg_kernel<1>", "gemm_i8_pers_kernel<1, 0>", "gemm_i8_pers_kernel<1>"))   # names as profiled
+        roof = {"bound": "mfma", "kernel": "gemm_i8_wreg_kernel<EPI_RESID> (attn.proj + mlp.fc2, residual QuantAct fused)" if args.bitwidth == 8
+                else "gemm_i8_wreg_kernel<EPI_RQ16_RES16> (attn.proj + mlp.fc2, 16-bit QuantAct + 16-bit residual QuantAct fused)",
                 "achieved": round(achieved, 1), "peak": INT8_PEAK_TOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / INT8_PEAK_TOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "launches": len(ms), "avg_launch_ms": round(avg_ms, 4),
@@ -262,13 +269,14 @@ def worker(args):
                           else "launcher self-test (stub engine, CPU, gloo)",
                           "global_batch": world * batch, "parallelism": f"dp{world}",
                           "launch": "eager" if args.no_graph else "hip-graph replay",
-                          "activation_ranges": "as calibrated (natural scales)" if (args.natural_scales or args.operators == "ibert")
+                          "bitwidth": args.bitwidth,
+                          "activation_ranges": "as calibrated (natural scales)" if (args.natural_scales or args.operators == "ibert" or args.bitwidth != 8)
                           else "power-of-two",
                           "operators": "I-ViT (IVITIntLayerNorm, Shiftmax, ShiftGELU)" if args.operators == "ivit"
                           else "I-BERT (IBERTIntLayerNorm, IBERTIntSoftmax, IBERTIntGELU)"},
                "mfma_util_end_to_end": round(value / world * MAC_PER_IMAGE / 2.5166e15, 4),
                "roofline": roof}
-        if world == 1 and not stub and not args.no_cpu_baseline and args.operators == "ivit":
+        if world == 1 and not stub and not args.no_cpu_baseline and args.operators == "ivit" and args.bitwidth == 8:
             out["cpu_baseline"] = cpu_baseline(fs, ranges, cfg)
         print(json.dumps(out, ensure_ascii=False), flush=True)
     if world > 1:

@@ -463,9 +463,14 @@ class IntViTEngine(GraphReplay):
         def gemm_res16(A, lda, lin, r, res, out):
             # projection / fc2 + its 16-bit QuantAct + the block's residual QuantAct: one kernel in the weights-in-registers form
             if big and self.weight_frags and self.fuse_res16 and lin.get("Wf") is not None:
+                probe = self.probe
+                if probe is not None:     # bench.py's instrumented pass, as in _gemm_res
+                    probe.begin("gemm_resid", st)
                 _lib.call("ivit_gemm_i8_requant_i16_residual_i16_ex", _lib.ptr(A), lda, _lib.ptr(lin["Wf"]), lin["K"], _lib.ptr(lin["b"]),
                           _lib.ptr(lin["m"]), _lib.ptr(lin["e"]), _lib.ptr(res), C, r[0], r[1], r[2], r[3], _lib.ptr(out), C, M, C,
                           lin["K"], 8, st)
+                if probe is not None:
+                    probe.end("gemm_resid", st, (M, C, lin["K"]))
                 return
             _lib.call("ivit_gemm_i8_requant_i16", _lib.ptr(A), lda, _lib.ptr(lin["W"]), lin["K"], _lib.ptr(lin["b"]),
                       _lib.ptr(lin["m"]), _lib.ptr(lin["e"]), _lib.ptr(ws["k16"]), C, M, C, lin["K"], st)
