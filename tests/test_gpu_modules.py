@@ -600,6 +600,38 @@ def test_ibert_int16_engine_equals_module_path():
     assert len(set(ym.argmax(dim=1).cpu().tolist())) > 1
 
 
+@pytest.mark.parametrize("family,pattern", [("ivit", "w16"), ("ivit", "all16"), ("ibert", "all16")])
+def test_16bit_engine_fused_kernels_at_deit_base_width(family, pattern):
+    """DeiT-B width (C = 768: the weights-in-registers GEMMs, i.e. projection / fc2 + 16-bit QuantAct + residual QuantAct in one
+    kernel, in place on the int16 stream), 3 blocks, 13 images (2561 token rows: 20 full tiles + a ragged one): engine == its
+    unfused form == the module-by-module path, float logits bitwise"""
+    from ivit_amd.vit_quant import VisionTransformer
+    a16 = 16 if pattern == "all16" else 8
+    w = dict(patch_embed_bw=16, pos_encoding_bw=a16, block_input_bw=16, attention_out_bw=16, softmax_bw=a16, mlp_out_bw=16,
+             norm2_in_bw=16, att_block_out_bw=16)
+    fs = synth.make_float_state("deit_base_patch16_224", 51, depth=3)
+    model = VisionTransformer(patch_size=16, embed_dim=768, depth=3, num_heads=12, mlp_ratio=4, qkv_bias=True, gelu_type=family,
+                              softmax_type=family, layernorm_type=family, **w)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in fs.items()}, strict=False)
+    model.to(DEV).eval()
+    with torch.no_grad():
+        model(torch.from_numpy(synth.make_images(4, 95)).to(DEV))
+    ivit.freeze_model(model)
+    imgs = torch.from_numpy(synth.make_images(13, 96)).to(DEV)
+    assert model.takes_engine(imgs), model.engine_unsupported_reason()
+    with torch.no_grad():
+        ye = model(imgs).clone()
+        eng = model.engine(13)
+        assert eng.stream_bits == 16 and eng.family == family
+        assert all(b[k].get("Wf") is not None for b in eng.blocks for k in ("proj", "fc2", "fc1"))      # the fused kernels ran
+        eng.fuse_res16 = eng.fuse_ibert_gelu = False
+        yu = model(imgs).clone()
+        model.use_engine = False
+        ym = model(imgs)
+    assert np.array_equal(bits(ye), bits(ym)) and np.array_equal(bits(yu), bits(ym))
+    assert len(set(ym.argmax(dim=1).cpu().tolist())) > 1
+
+
 @pytest.mark.parametrize("regime", ["pow2", "natural"])
 def test_16bit_stream_engine_equals_module_path_deit_small(regime):
     """DeiT-S with the 16-bit residual stream (patch_embed / block_input / attention_out / mlp_out / norm2_in / att_block_out at
