@@ -161,12 +161,15 @@ def worker(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    # a rendezvous in the environment (torch.distributed.run, or this script's own launcher) means the distributed path, also
+    # for ONE rank: `python -m torch.distributed.run --nproc-per-node 1 bench.py` runs the same RCCL calls as N ranks do
+    grouped = world > 1 or "WORLD_SIZE" in os.environ
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
 
     if stub:
         dev, batch = "cpu", 8
-        if world > 1:
+        if grouped:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         eng = _StubEngine()
         if os.environ.get("IVIT_BENCH_STUB_FAIL_RANK") == str(rank):   # launcher test: a rank that dies after rendezvous
@@ -180,7 +183,7 @@ def worker(args):
         batch = BATCH
         torch.cuda.set_device(local_rank)
         dev = f"cuda:{local_rank}"
-        if world > 1:
+        if grouped:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
         if args.operators == "ibert" or args.bitwidth != 8:
             # no fixture for these at DeiT-B: build the module tree, calibrate its ranges on one small batch, freeze, and take
@@ -206,7 +209,7 @@ def worker(args):
     dp = DataParallelTop1(eng, world, graph=not args.no_graph)
 
     def sync():
-        if world > 1:
+        if grouped:
             dist.barrier()
         if not stub:
             torch.cuda.synchronize()
@@ -220,7 +223,7 @@ def worker(args):
         dp.step(images)
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if grouped:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -256,7 +259,7 @@ def worker(args):
                 "algorithmic_ops_per_launch": 2.0 * sum(macs) / len(macs),
                 "how": f"device-scope HIP events around each of the {len(ms)} launches in {args.probe_forwards} eager "
                        "forwards run after the timed region, minus the duration of an empty event pair"}
-    if world > 1:
+    if grouped:
         dist.barrier()
 
     if rank == 0:
@@ -279,7 +282,7 @@ def worker(args):
         if world == 1 and not stub and not args.no_cpu_baseline and args.operators == "ivit" and args.bitwidth == 8:
             out["cpu_baseline"] = cpu_baseline(fs, ranges, cfg)
         print(json.dumps(out, ensure_ascii=False), flush=True)
-    if world > 1:
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
     return 0

@@ -18,8 +18,8 @@ def shard_bounds(n: int, world: int, rank: int):
 
 def gather_top1(local_top1: torch.Tensor, world: int) -> torch.Tensor:
     """all-gather of equal-sized per-rank top-1 vectors -> [world * B_local] in rank order."""
-    if world == 1:
-        return local_top1
+    if world == 1 and not (dist.is_available() and dist.is_initialized()):
+        return local_top1      # no process group: a plain single-GPU run (a one-rank group still runs the collective)
     out = torch.empty(world * local_top1.numel(), dtype=local_top1.dtype, device=local_top1.device)
     dist.all_gather_into_tensor(out, local_top1.contiguous())
     return out
