@@ -22,7 +22,7 @@ GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 TAGS = {"deit_tiny": "deit_tiny_patch16_224", "deit_small": "deit_small_patch16_224",
         "deit_base": "deit_base_patch16_224", "vit_base": "vit_base_patch16_224",
         "swin_tiny": "swin_tiny_patch4_window7_224", "deit_tiny_ibert": "deit_tiny_patch16_224",
-        "deit_tiny_natural": "deit_tiny_patch16_224", "deit_tiny_w16": "deit_tiny_patch16_224", "deit_tiny_w16all": "deit_tiny_patch16_224", "swin_tiny_natural": "swin_tiny_patch4_window7_224", "deit_small_natural": "deit_small_patch16_224",
+        "deit_tiny_natural": "deit_tiny_patch16_224", "deit_tiny_w16": "deit_tiny_patch16_224", "deit_tiny_w16all": "deit_tiny_patch16_224", "deit_tiny_ibert_w16all": "deit_tiny_patch16_224", "swin_tiny_natural": "swin_tiny_patch4_window7_224", "deit_small_natural": "deit_small_patch16_224",
         "deit_base_natural": "deit_base_patch16_224", "deit_tiny_ibert_natural": "deit_tiny_patch16_224"}
 
 

@@ -834,9 +834,12 @@ def gen_w16(tag="deit_tiny_w16"):
 def gen_ibert_natural(tag="deit_tiny_ibert_natural"):
     """DeiT-T with the fork's DEFAULT operator family (I-BERT, vit_quant.py:188-190) and its ranges AS CALIBRATED: the
     reference's logits / top-1 / tap digests.  No CPU oracle restates I-BERT at natural scales; the fixture pins the mirror's
-    module path (literal float kernels of csrc/ibert.hip) on the GPU."""
+    module path (literal float kernels of csrc/ibert.hip) on the GPU.
+    tag deit_tiny_ibert_w16all: the same with every width knob at 16 (the authors' INT16 runs, .vscode/launch.json:104-200,
+    quant_train.py:299-306): 16-bit residual stream, 16-bit IBERTIntSoftmax output (p reaches 2^15) into P.V, 16-bit pos_embed."""
     factory, wseed, cseeds, cb, iseed, nimg = "deit_tiny_patch16_224", 11, (101, 111), 4, 1001, 2
-    model = getattr(ref_models, factory)(pretrained=False, gelu_type="ibert", softmax_type="ibert", layernorm_type="ibert")
+    widths = W16_ALL if tag.endswith("_w16all") else {}
+    model = getattr(ref_models, factory)(pretrained=False, gelu_type="ibert", softmax_type="ibert", layernorm_type="ibert", **widths)
     fs = synth.make_float_state(factory, wseed)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in fs.items()}, strict=False)
     model.eval()
@@ -864,8 +867,9 @@ def gen_ibert_natural(tag="deit_tiny_ibert_natural"):
     out = {
         "meta": np.array(json.dumps(dict(tag=tag, factory=factory, family="ibert", weight_seed=wseed, calib_seeds=list(cseeds),
                                          calib_batch=cb, image_seed=iseed, n_images=nimg, qkv_gain=synth.QKV_GAIN,
-                                         regime="natural", ln_shifts=shifts, torch=torch.__version__))),
+                                         regime="natural", ln_shifts=shifts, widths=widths, torch=torch.__version__))),
         "range_names": np.array(list(ranges)),
+        "range_bits": np.array([int(dict(model.named_modules())[n].activation_bit) for n in ranges], np.int32),
         "x_min": np.array([v[0] for v in ranges.values()], np.float32),
         "x_max": np.array([v[1] for v in ranges.values()], np.float32),
         "logits_int32": torch.round(y / s_head).to(torch.int64).numpy().astype(np.int32),
@@ -901,7 +905,7 @@ if __name__ == "__main__":
     for w in what:
         if w == "ops":
             gen_ops()
-        elif w.endswith("_w16") or w.endswith("_w16all"):
+        elif (w.endswith("_w16") or w.endswith("_w16all")) and "ibert" not in w:
             gen_w16(w)
         elif w == "compat_ops":
             gen_compat_ops()
@@ -909,7 +913,7 @@ if __name__ == "__main__":
             gen_ibert_ops()
         elif w == "schema":
             gen_schema()
-        elif w == "deit_tiny_ibert_natural":
+        elif w in ("deit_tiny_ibert_natural", "deit_tiny_ibert_w16all"):
             gen_ibert_natural(w)
         elif w.endswith("_natural") and not w.startswith("swin"):
             gen_natural(w)

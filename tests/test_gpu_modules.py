@@ -557,6 +557,58 @@ def test_non_8bit_widths_match_the_reference(tag):
     assert not np.array_equal(z["logits_f32_bits"][:2], z8["logits_f32_bits"][:2])
 
 
+def test_ibert_int16_matches_the_reference():
+    """the authors' INT16 configuration with the fork's default operators (I-BERT; every width knob at 16, ranges as calibrated,
+    LayerNorm overflow shifts 1 and 2 from the calibration pass): fixture deit_tiny_ibert_w16all.npz from the reference.  The
+    module path reproduces every QuantAct tap, the INT32 logits and top-1 -- incl. the 16-bit IBERTIntSoftmax output (p up to
+    2^15) through QuantMatMul -- and the fused engine (stream / softmax / pos_embed at 16 bits) gives the module path's float
+    logits bitwise"""
+    import zlib
+    fs, ranges, cfg, meta, z = load_synthetic_model("deit_tiny_ibert_w16all")
+    assert meta["family"] == "ibert" and set(meta["widths"].values()) == {16}
+    model = ivit.deit_tiny_patch16_224(gelu_type="ibert", softmax_type="ibert", layernorm_type="ibert", **meta["widths"])
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in fs.items()}, strict=False)
+    mods = dict(model.named_modules())
+    for name, bw in zip([str(n) for n in z["range_names"]], z["range_bits"]):
+        assert int(mods[name].activation_bit) == int(bw), name
+        mods[name].x_min.fill_(float(ranges[name][0]))
+        mods[name].x_max.fill_(float(ranges[name][1]))
+    assert sorted(set(meta["ln_shifts"].values())) == [1.0, 2.0]
+    for name, sh in meta["ln_shifts"].items():
+        mods[name].shift.fill_(float(sh))
+    model.to(DEV)
+    ivit.freeze_model(model)
+    imgs = torch.from_numpy(synth.make_images(meta["n_images"], meta["image_seed"])).to(DEV)
+    assert model.takes_engine(imgs), model.engine_unsupported_reason()
+    with torch.no_grad():
+        ye = model(imgs).clone()
+    eng = model.engine(2)
+    assert (eng.family, eng.stream_bits, eng.softmax_bits, eng.pos_bits) == ("ibert", 16, 16, 16)
+    model.use_engine = False
+    got = {}
+
+    def hook(name):
+        def fn(mod, inp, outp):
+            y, sc = outp
+            got[name] = zlib.crc32(np.ascontiguousarray(torch.round(y / sc).to(torch.int64).cpu().numpy().astype(np.int32)).tobytes())
+        return fn
+
+    for name, mod in model.named_modules():
+        if isinstance(mod, q.QuantAct) and not name.endswith("int_softmax.act"):
+            mod.register_forward_hook(hook(name))
+    with torch.no_grad():
+        y = model(imgs)
+    gold = dict(zip([str(x) for x in z["tap_names"]], z["tap_crc32"]))
+    bad = [n for n in got if n in gold and got[n] != int(gold[n])]
+    assert len(got) >= 100 and not bad, bad[:6]
+    li = np.rint(y.cpu().numpy().astype(np.float64) / z["head_scale"].astype(np.float64)).astype(np.int32)
+    assert np.array_equal(li, z["logits_int32"])
+    # (natural scales: the reference's head multiplies fl(fl(q s) / s) in a float32 GEMM -- its float logits carry that noise in
+    # the last bits; the contract is the INT32 logits, DESIGN.md section 2)
+    assert np.array_equal(y.argmax(dim=1).cpu().numpy(), z["top1"])
+    assert np.array_equal(bits(ye), bits(y))
+
+
 def test_unsupported_width_pattern_takes_the_module_path():
     """only att_block_out_bw = 16 (one of the reference's sweep points): not a pattern of the fused engine -> module path"""
     fs = synth.make_float_state("deit_tiny_patch16_224", 5)
