@@ -18,6 +18,7 @@ from __future__ import annotations
 import torch
 
 from .quantization_utils import QuantAct
+from .quantization_utils import quant_modules as _qm
 
 
 class EngineDispatch:
@@ -96,6 +97,8 @@ class EngineDispatch:
         return eng
 
     def takes_engine(self, x: torch.Tensor) -> bool:
+        if getattr(self, "_io_stat_hooks", False) and _qm.io_stats_enabled():
+            return False      # attach_io_stat_hooks: the collector's hooks sit on the sub-modules, which the fused engine never calls
         return (self.use_engine and not self.training and x.is_cuda and self.is_frozen()
                 and self.engine_unsupported_reason() is None)
 

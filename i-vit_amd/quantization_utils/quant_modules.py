@@ -28,6 +28,109 @@ def _st():
     return _lib.stream_ptr()
 
 
+# ----------------------------------------------------------------------------- I/O-statistics collector
+# quant_modules.py:17-125 of the reference: forward hooks on every sub-module record the extrema of each layer's input and
+# output, as floats and in integer units (x / scale), and the shapes; scripts/inference.py:367-400 attaches them by default and
+# writes io_stats_*.pkl / .csv (summarised by scripts/analyze_io_stats.py).  Same names, same record keys, same quirks (a layer
+# with a per-channel scale raises inside the hook and is silently dropped, :79-81).  The extrema come from the HIP reduction
+# (ivit_minmax_f32); min / max of x / s for a positive scalar s are the correctly rounded quotients of min / max of x
+# (monotone), so the integer-unit columns equal the reference's without a pass over x / s.
+# Hooks sit on the sub-modules: a model carrying them runs module by module (dispatch.takes_engine), never the fused engine.
+_LAYER_IO_STATS = []        # global buffer
+_IO_STATS_ENABLED = True    # global enable / disable flag
+
+
+def _minmax(t: torch.Tensor):
+    ta = t.detach().contiguous().float()
+    mm = torch.empty(2, dtype=torch.float32, device=ta.device)
+    _lib.call("ivit_minmax_f32", _lib.ptr(ta), ta.numel(), _lib.ptr(mm), _st())
+    return mm[0], mm[1]
+
+
+def _collect_io_stats(module, inputs, output, module_name):
+    if not _IO_STATS_ENABLED:
+        return
+    try:
+        x_scaled = inputs[0]
+        scale_x = inputs[1] if len(inputs) > 1 and torch.is_tensor(inputs[1]) else None
+        y_scaled = output[0] if isinstance(output, (tuple, list)) else output
+        scale_y = output[1] if isinstance(output, (tuple, list)) and torch.is_tensor(output[1]) else None
+        x_lo, x_hi = _minmax(x_scaled)
+        y_lo, y_hi = _minmax(y_scaled)
+        sx = scale_x.item() if scale_x is not None else None          # a per-channel scale raises here, as in the reference
+        sy = scale_y.item() if scale_y is not None else None
+
+        def ints(lo, hi, sc):      # (x / s).min(), (x / s).max() for s > 0; a negative s swaps the ends
+            if sc is None:
+                return None, None
+            a, b = (lo / sc).item(), (hi / sc).item()
+            return (a, b) if a <= b else (b, a)
+
+        xi, yi = ints(x_lo, x_hi, scale_x), ints(y_lo, y_hi, scale_y)
+        rec = {"layer": module_name, "type": module.__class__.__name__,
+               "min_in": x_lo.item(), "max_in": x_hi.item(), "min_out": y_lo.item(), "max_out": y_hi.item(),
+               "scale_in": sx, "scale_out": sy,
+               "min_in_int": xi[0], "max_in_int": xi[1], "min_out_int": yi[0], "max_out_int": yi[1],
+               "shape_in": tuple(x_scaled.shape), "shape_out": tuple(y_scaled.shape)}
+        if isinstance(module, QuantMatMul):
+            A, sA, B, sB = inputs[0], inputs[1], inputs[2], inputs[3]
+            ai, bi = ints(*_minmax(A), sA), ints(*_minmax(B), sB)
+            rec.update({"min_A_int": ai[0], "max_A_int": ai[1], "shape_A": tuple(A.shape),
+                        "min_B_int": bi[0], "max_B_int": bi[1], "shape_B": tuple(B.shape)})
+        _LAYER_IO_STATS.append(rec)
+    except Exception:
+        pass    # swallow any hook error so that evaluation never breaks (quant_modules.py:79-81)
+
+
+def attach_io_stat_hooks(model: nn.Module):
+    """Recursively attach `_collect_io_stats` as a forward hook to every sub-module (quant_modules.py:83-89)."""
+    from functools import partial
+    for name, module in model.named_modules():
+        if module is model:      # skip the top-level container to avoid double-logging
+            continue
+        module.register_forward_hook(partial(_collect_io_stats, module_name=name))
+    model._io_stat_hooks = True
+
+
+def io_stats_enabled() -> bool:
+    return _IO_STATS_ENABLED
+
+
+def enable_io_stats():
+    global _IO_STATS_ENABLED
+    _IO_STATS_ENABLED = True
+
+
+def disable_io_stats():
+    global _IO_STATS_ENABLED
+    _IO_STATS_ENABLED = False
+
+
+def clear_io_stats():
+    _LAYER_IO_STATS.clear()
+
+
+def get_io_stats_df():
+    """a new DataFrame of all gathered statistics (quant_modules.py:110-112)"""
+    import pandas as pd
+    return pd.DataFrame(_LAYER_IO_STATS)
+
+
+def save_io_stats_df(path: str = "io_stats.pkl", to_csv: bool = False):
+    """Export the collected statistics to `path` (pickle) plus an optional CSV next to it; returns the DataFrame (:115-125)."""
+    df = get_io_stats_df()
+    df.to_pickle(path)
+    if to_csv:
+        df.to_csv(path.rsplit(".", 1)[0] + ".csv", index=False)
+    return df
+
+
+def softmax(x, dim: int, onnx_trace: bool = False):
+    """float helper the reference re-exports (quant_utils.py:263-267); not on the integer path"""
+    import torch.nn.functional as F
+    return F.softmax(x.float(), dim=dim) if onnx_trace else F.softmax(x, dim=dim, dtype=torch.float32)
+
+
 def _dev_table(a, device):
     return torch.from_numpy(np.ascontiguousarray(a)).to(device)
 

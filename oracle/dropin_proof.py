@@ -77,7 +77,8 @@ def reference_signatures():
             cls = getattr(mod, n)
             out[n] = {"init": sig(cls.__init__), "forward": sig(cls.forward),
                       "methods": sorted(m for m in ("fix", "unfix") if callable(getattr(cls, m, None)))}
-    for n in ("get_gelu", "get_softmax", "get_layernorm"):
+    for n in ("get_gelu", "get_softmax", "get_layernorm", "attach_io_stat_hooks", "save_io_stats_df", "enable_io_stats",
+              "disable_io_stats", "clear_io_stats", "softmax"):      # the last six: the I/O-statistics collector + a float helper
         out[n] = {"call": sig(getattr(rq, n))}
     for n in ("freeze_model", "unfreeze_model"):
         out[n] = {"call": sig(getattr(rm, n))}

@@ -609,6 +609,47 @@ def test_ibert_int16_matches_the_reference():
     assert np.array_equal(bits(ye), bits(y))
 
 
+def test_io_stats_collector(tmp_path):
+    """attach_io_stat_hooks / save_io_stats_df (quant_modules.py:17-125; what scripts/inference.py:367-400 does by default): one
+    record per sub-module call with the extrema in float and integer units; the model runs module by module while the collector is
+    on (its hooks sit on the sub-modules) and goes back to the fused engine when it is disabled"""
+    model, meta, z = load_model("deit_tiny")
+    imgs = torch.from_numpy(synth.make_images(2, meta["image_seed"])).to(DEV)
+    ivit.clear_io_stats()
+    ivit.enable_io_stats()
+    ivit.attach_io_stat_hooks(model)
+    assert not model.takes_engine(imgs)
+    cap = {}
+    model.blocks[3].qact2.register_forward_hook(lambda m, i, o: cap.update(y=o[0].detach().clone(), s=o[1].detach().clone()))
+    with torch.no_grad():
+        y = model(imgs)
+    assert np.array_equal(bits(y), z["logits_f32_bits"][:2])
+    df = ivit.save_io_stats_df(str(tmp_path / "io_stats_val.pkl"), to_csv=True)
+    assert (tmp_path / "io_stats_val.pkl").exists() and (tmp_path / "io_stats_val.csv").exists()
+    assert {"layer", "type", "min_in", "max_in", "min_out", "max_out", "scale_in", "scale_out", "min_in_int", "max_in_int",
+            "min_out_int", "max_out_int", "shape_in", "shape_out", "min_A_int", "max_B_int", "shape_A"} <= set(df.columns)
+    row = df[df.layer == "blocks.3.qact2"].iloc[0]
+    yi = cap["y"] / cap["s"]
+    assert row["type"] == "QuantAct" and row["min_out_int"] == yi.min().item() and row["max_out_int"] == yi.max().item()
+    assert row["min_out"] == cap["y"].min().item() and row["scale_out"] == cap["s"].item() and tuple(row["shape_out"]) == (2, 197, 192)
+    assert -128 <= row["min_out_int"] < 0 < row["max_out_int"] <= 127
+    mm = df[df.type == "QuantMatMul"]
+    assert len(mm) == 24 and (mm["max_B_int"] <= 127).all() and (mm["min_A_int"] >= -128).all()
+    # the reference's quirk (quant_modules.py:79-81, SURVEY section 4): a layer whose scale is per channel raises inside the hook and
+    # is silently dropped -- every QuantLinear, every LayerNorm and the QuantAct behind them
+    layers = set(df.layer)
+    assert (df.type == "QuantAct").sum() >= 60 and "blocks.11.qact4" in layers and "blocks.0.attn.qkv" not in layers and "blocks.11.norm2" not in layers
+    n = len(df)
+    ivit.disable_io_stats()
+    assert model.takes_engine(imgs)
+    with torch.no_grad():
+        y2 = model(imgs)
+    assert np.array_equal(bits(y2), z["logits_f32_bits"][:2]) and len(ivit.get_io_stats_df()) == n
+    ivit.clear_io_stats()
+    ivit.enable_io_stats()
+    assert len(ivit.get_io_stats_df()) == 0
+
+
 def test_unsupported_width_pattern_takes_the_module_path():
     """only att_block_out_bw = 16 (one of the reference's sweep points): not a pattern of the fused engine -> module path"""
     fs = synth.make_float_state("deit_tiny_patch16_224", 5)
