@@ -125,10 +125,7 @@ def save_io_stats_df(path: str = "io_stats.pkl", to_csv: bool = False):
     return df
 
 
-def softmax(x, dim: int, onnx_trace: bool = False):
-    """float helper the reference re-exports (quant_utils.py:263-267); not on the integer path"""
-    import torch.nn.functional as F
-    return F.softmax(x.float(), dim=dim) if onnx_trace else F.softmax(x, dim=dim, dtype=torch.float32)
+from .quant_utils import *  # noqa: E402,F401,F403  (the reference's quant_modules does the same, quant_modules.py:15)
 
 
 def _dev_table(a, device):

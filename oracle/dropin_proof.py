@@ -82,6 +82,11 @@ def reference_signatures():
         out[n] = {"call": sig(getattr(rq, n))}
     for n in ("freeze_model", "unfreeze_model"):
         out[n] = {"call": sig(getattr(rm, n))}
+    ru = importlib.import_module("models.quantization_utils.quant_utils")     # the functional layer under the modules
+    for n in ("linear_quantize", "symmetric_linear_quantization_params", "batch_frexp"):
+        out[n] = {"call": sig(getattr(ru, n))}
+    for n in ("SymmetricQuantFunction", "floor_ste", "round_ste", "fixedpoint_mul"):
+        out[n] = {"autograd_forward": sig(getattr(ru, n).forward)}
     return out
 
 

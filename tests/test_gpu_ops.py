@@ -799,6 +799,36 @@ def test_requant_generic_kat(kat):
         assert np.array_equal(out.cpu().numpy(), kat[c + "out"]), ci
 
 
+def test_fixedpoint_mul_and_symmetric_quant_functions_kat(kat):
+    """the reference's functional names (quant_utils.py:73-119, 178-261) in quantization_utils.quant_utils: fixedpoint_mul.apply on the
+    float views the reference's own call received (ops_kat.npz: one- and two-operand cases, 8 / 16 / 32 bits) and
+    SymmetricQuantFunction.apply on an activation, against the reference's outputs"""
+    from ivit_amd.quantization_utils import quant_utils as qu
+    done = 0
+    for ci in kat["rq_cases"]:
+        c = f"rq{ci}_"
+        z = kat[c + "z"]
+        if np.abs(z).max() >= 2 ** 22:          # x = z * s must round back to z
+            continue
+        pre = torch.from_numpy(np.atleast_1d(kat[c + "pre"]).astype(np.float32)).to(DEV)
+        x = torch.from_numpy(z.astype(np.float32)).to(DEV).view(1, *z.shape) * pre
+        zsf = torch.tensor([float(kat[c + "zsf"])], device=DEV)
+        ident = isf = None
+        if c + "z2" in kat:
+            isf = torch.tensor([float(kat[c + "pre2"])], device=DEV)
+            ident = torch.from_numpy(kat[c + "z2"].astype(np.float32)).to(DEV).view(1, *z.shape) * isf
+        y = qu.fixedpoint_mul.apply(x, pre, int(kat[c + "bits"]), "symmetric", zsf, ident, isf)
+        assert y.dtype == torch.float32 and y.shape == x.shape
+        assert np.array_equal(y.cpu().numpy().reshape(z.shape).astype(np.int32), kat[c + "out"]), ci
+        done += 1
+    assert done >= 4
+    x, s = kat["qs_x"], kat["qs_s"]
+    q = qu.SymmetricQuantFunction.apply(torch.from_numpy(x).to(DEV), 8, torch.tensor([float(s)], device=DEV), False)
+    assert q.dtype == torch.float32 and np.array_equal(q.cpu().numpy().astype(np.int32).reshape(-1), kat["qs_out"].astype(np.int32).reshape(-1))
+    with pytest.raises(_lib.IvitError, match="GPU"):
+        qu.fixedpoint_mul.apply(torch.zeros(1, 2, 4), torch.ones(1), 8, "symmetric", torch.ones(1), None, None)
+
+
 def test_quantize_and_patchify(kat):
     x = kat["qs_x"]
     s = kat["qs_s"]

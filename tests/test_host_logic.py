@@ -30,6 +30,23 @@ def test_dyadic_matches_reference_batch_frexp(kat):
         assert np.array_equal(e, kat[c + "e"])
 
 
+def test_batch_frexp_function_matches_reference(kat):
+    """quantization_utils.quant_utils.batch_frexp (the reference's functional name, quant_utils.py:151-175) on the ratio tensor the
+    reference forms: mantissas / exponents of the reference's own batch_frexp (ops_kat.npz)"""
+    import torch
+    from ivit_amd.quantization_utils import quant_utils as qu
+    for ci in kat["rq_cases"]:
+        c = f"rq{ci}_"
+        ratio = torch.from_numpy(np.atleast_1d(kat[c + "pre"])).double() / torch.tensor([float(kat[c + "zsf"])]).float().double()
+        m, e = qu.batch_frexp(ratio.view(1, 1, -1))
+        assert m.shape == (1, 1, ratio.numel()) and m.dtype == torch.int64
+        assert np.array_equal(m.numpy().reshape(-1).astype(np.float64), kat[c + "m"])
+        assert np.array_equal(e.numpy().reshape(-1).astype(np.int32), kat[c + "e"])
+    s = qu.symmetric_linear_quantization_params(8, torch.tensor([-0.3]), torch.tensor([1.27]))
+    assert s.dtype == torch.float32 and float(s) == float(np.float32(1.27) / np.float32(127.0))
+    assert float(qu.symmetric_linear_quantization_params(8, torch.tensor([0.0]), torch.tensor([0.0]))) == float(np.finfo(np.float32).eps)
+
+
 def test_linear_params_match_reference_quantlinear(kat):
     lp = prepare.LinearParams(kat["lin_W"], kat["lin_b"], kat["lin_sin"])
     assert np.array_equal(lp.sw, kat["lin_sw"])
@@ -250,10 +267,14 @@ def test_operator_signatures_match_reference_dropin_fixture(golden_dir):
             assert d1 == d0 or (d0 is not None and d1 is not None and d0.split(".")[-1] == d1.split(".")[-1]), (what, n1, d1, d0)
 
     for name, spec in fx["signatures"].items():
-        obj = getattr(qu, name, None) or getattr(lq, name, None) or getattr(mu, name, None)
+        obj = getattr(qu, name, None) or getattr(qu.quant_utils, name, None) or getattr(lq, name, None) or getattr(mu, name, None)
         assert obj is not None, name
         if "call" in spec:
             compatible(sig(obj), spec["call"], name)
+            continue
+        if "autograd_forward" in spec:     # torch.autograd.Function of quant_utils.py: forward(ctx, ...)
+            compatible(sig(obj.forward), spec["autograd_forward"], name + ".forward")
+            assert callable(obj.apply)
             continue
         compatible(sig(obj.__init__), spec["init"], name + ".__init__")
         compatible(sig(obj.forward), spec["forward"], name + ".forward")
