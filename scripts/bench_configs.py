@@ -23,8 +23,9 @@ GMAC = {"deit_tiny": 1.2537, "deit_small": 4.5989, "deit_base": 17.5638, "vit_ba
         "deit_base_natural": 17.5638, "swin_tiny_natural": 4.4906}
 
 
-def run(cid, steps=20, warmup=5, graph=False):
+def run(cid, steps=20, warmup=5, graph=False, batch=None):
     tag, B = CONFIGS[cid]
+    B = batch or B
     fs, ranges, cfg, meta, z = load_synthetic_model(tag)
     if tag.startswith("swin"):
         eng = IntSwinEngine(fs, ranges, cfg["embed_dim"], cfg["depths"], cfg["num_heads"], cfg["window"], device=DEV,
@@ -60,8 +61,16 @@ def run(cid, steps=20, warmup=5, graph=False):
 
 
 if __name__ == "__main__":
-    args = [a for a in sys.argv[1:] if a != "--graph"]
+    # `--batches 1,8,64` : the given configs at other batch sizes (latency / throughput against the batch, e.g. for serving)
+    batches = [None]
+    argv = sys.argv[1:]
+    if "--batches" in argv:
+        i = argv.index("--batches")
+        batches = [int(b) for b in argv[i + 1].split(",")]
+        argv = argv[:i] + argv[i + 2:]
+    args = [a for a in argv if a != "--graph"]
     for c in ([int(a) for a in args] or [k for k in sorted(CONFIGS) if k < 10]):
-        run(c)
-        if "--graph" in sys.argv:
-            run(c, graph=True)
+        for b in batches:
+            run(c, batch=b)
+            if "--graph" in sys.argv:
+                run(c, graph=True, batch=b)
