@@ -61,6 +61,7 @@ struct AttnArgs {
     // I-BERT softmax (MODE 3): exp_int after the internal QuantAct(16), as the float32 the reference sums and multiplies, for
     // every (row max, q): [256][256], built by ivit_ibert_softmax_build_table
     const float* ib_table;
+    int parts;  // workgroups per (image, head): the query tiles are dealt out among them (small batches: batch * heads << CUs)
     int abl;   // lab build: 1 no score requant, 2 no table lookups, 4 no probability products, 8 no P.V + output, 16 one query tile per wave
 };
 
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(NT, 3) void attention_kernel(AttnArgs a)
     __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
     extern __shared__ __attribute__((aligned(16))) unsigned band_lds[];   // [4 waves][16 queries][band_w + BAND_PAD], compat only
     const int T = a.tokens;
-    const int bh = blockIdx.x;
+    const int bh = blockIdx.x / a.parts, part = blockIdx.x - bh * a.parts;
     const int b = bh / a.heads, hh = bh - b * a.heads;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, l15 = lane & 15;
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(NT, 3) void attention_kernel(AttnArgs a)
 
     // 13 query tiles over 4 waves: one wave gets four tiles, the others three.  Which wave that is rotates with the
     // workgroup index, so that the co-resident workgroups of a CU do not all put their extra tile on the same SIMD
-    for (int qt = (wave + bh) & 3; qt < ((IVIT_LAB && (a.abl & 16)) ? 4 : nqt); qt += 4) {
+    for (int qt = ((wave + bh) & 3) + 4 * part; qt < ((IVIT_LAB && (a.abl & 16)) ? 4 : nqt); qt += 4 * a.parts) {
         const int qrow = qt * 16 + l15;  // this lane's query
         const int qld = min(qrow, T - 1);
         const v4i qf = *reinterpret_cast<const v4i*>(qg + (int64_t)qld * HD + 16 * g);
@@ -486,6 +487,17 @@ __global__ __launch_bounds__(NT, 3) void attention_kernel(AttnArgs a)
     }
 }
 
+// Workgroups per (image, head).  One is right once batch * heads fills the chip (every workgroup stages K and V^T of its head in
+// LDS once and walks all query tiles); a small batch leaves most CUs idle and is bound by that walk -- then the 13 query tiles
+// are dealt out among up to 4 workgroups per head (each stages K / V^T itself: L2 hits).
+int attention_parts(int batch_heads, int tokens)
+{
+    const int nqt = (tokens + 15) >> 4;
+    int parts = 1;
+    while (parts < 4 && batch_heads * parts * 2 <= 256 && 4 * parts < nqt) parts *= 2;
+    return parts;
+}
+
 }  // namespace
 
 IVIT_EXPORT int ivit_attention_fused_i8_ex(const int8_t* qkv, int8_t* out, int batch, int heads, int tokens,
@@ -558,7 +570,8 @@ IVIT_EXPORT int ivit_attention_fused_i8_wide(const int8_t* qkv, int8_t* out, int
         if (x <= 15 * a.x0) { a.ksat = i; break; }
     }
     const size_t band_lds_bytes = band_w ? (size_t)4 * 16 * (band_w + BAND_PAD) * sizeof(unsigned) : 0;
-    const dim3 grid(batch * heads), blk(NT);
+    a.parts = attention_parts(batch * heads, tokens);
+    const dim3 grid(batch * heads * a.parts), blk(NT);
     hipStream_t st = ivit_stream(stream);
     if (softmax_bits == 16) {
         if (band_w) hipLaunchKernelGGL((attention_kernel<1, 16>), grid, blk, band_lds_bytes, st, a);
@@ -608,12 +621,13 @@ IVIT_EXPORT int ivit_attention_fused_i8_ibert_wide(const int8_t* qkv, int8_t* ou
     a.band = reinterpret_cast<const unsigned*>(band);
     a.band_w = band_w;
     const size_t band_lds_bytes = band_w ? (size_t)4 * 16 * (band_w + BAND_PAD) * sizeof(unsigned) : 0;
+    a.parts = attention_parts(batch * heads, tokens);
     if (softmax_bits == 16) {
-        if (band_w) hipLaunchKernelGGL((attention_kernel<4, 16>), dim3(batch * heads), dim3(NT), band_lds_bytes, ivit_stream(stream), a);
-        else hipLaunchKernelGGL((attention_kernel<3, 16>), dim3(batch * heads), dim3(NT), 0, ivit_stream(stream), a);
+        if (band_w) hipLaunchKernelGGL((attention_kernel<4, 16>), dim3(batch * heads * a.parts), dim3(NT), band_lds_bytes, ivit_stream(stream), a);
+        else hipLaunchKernelGGL((attention_kernel<3, 16>), dim3(batch * heads * a.parts), dim3(NT), 0, ivit_stream(stream), a);
     } else {
-        if (band_w) hipLaunchKernelGGL(attention_kernel<4>, dim3(batch * heads), dim3(NT), band_lds_bytes, ivit_stream(stream), a);
-        else hipLaunchKernelGGL(attention_kernel<3>, dim3(batch * heads), dim3(NT), 0, ivit_stream(stream), a);
+        if (band_w) hipLaunchKernelGGL(attention_kernel<4>, dim3(batch * heads * a.parts), dim3(NT), band_lds_bytes, ivit_stream(stream), a);
+        else hipLaunchKernelGGL(attention_kernel<3>, dim3(batch * heads * a.parts), dim3(NT), 0, ivit_stream(stream), a);
     }
     IVIT_CHECK_LAUNCH("ivit_attention_fused_i8_ibert");
 }
