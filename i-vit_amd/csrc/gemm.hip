@@ -41,7 +41,7 @@ __global__ __launch_bounds__(NT) void gemm_i8_kernel(GemmArgs g)
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int h = lane >> 5, l31 = lane & 31;
-    if constexpr (EPI != EPI_I32 && EPI != EPI_RQ16) fill_rq_table(g, smem + SMEM_BYTES, n0, BN, tid);
+    if constexpr (EPI != EPI_I32 && EPI != EPI_RQ16 && EPI != EPI_RQ16_RES16) fill_rq_table(g, smem + SMEM_BYTES, n0, BN, tid);
 
     // ---- staging: thread moves chunks (row = tid/4 + 64 i, c = tid%4) of both tiles
     const int srow = tid >> 2, sc = tid & 3;
@@ -139,10 +139,13 @@ __global__ __launch_bounds__(NT) void gemm_i8_kernel(GemmArgs g)
                 }
             }
         return;
-    } else if constexpr (EPI == EPI_RQ16) {
+    } else if constexpr (EPI == EPI_RQ16 || EPI == EPI_RQ16_RES16) {
         // 16-bit per-channel QuantAct from the registers: a lane holds 4 consecutive channels of one token per register quad,
         // i.e. one 8-byte store.  quant_utils.py:229-230 literally: float64 product (53-bit rounding), then RNE.
+        // EPI_RQ16_RES16: + the two-operand 16-bit residual QuantAct on top (shapes the weights-in-registers kernel does not
+        // take: Swin attn.proj at C = 96 .. 384): one 8-byte residual load per store.
         int16_t* out = reinterpret_cast<int16_t*>(g.out);
+        const int16_t* res = reinterpret_cast<const int16_t*>(g.res);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -162,6 +165,13 @@ __global__ __launch_bounds__(NT) void gemm_i8_kernel(GemmArgs g)
                         const double p = (double)acc[i][j][4 * q + r] * Mc[r];
                         const double tt = p + IVIT_MAGIC;
                         o[r] = clamp_i32((int)(unsigned)__double_as_longlong(tt), -32768, 32767);
+                    }
+                    if constexpr (EPI == EPI_RQ16_RES16) {
+                        const int2 rw = *reinterpret_cast<const int2*>(res + (int64_t)t * g.ldr + c0);
+                        const int rv[4] = {(int)(int16_t)rw.x, rw.x >> 16, (int)(int16_t)rw.y, rw.y >> 16};
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            o[r] = clamp_i32(requant_exact(o[r], g.M_main) + requant_exact(rv[r], g.M_res), -32768, 32767);
                     }
                     int2 ow;
                     ow.x = (o[0] & 0xffff) | (o[1] << 16);
@@ -811,10 +821,10 @@ int launch_gemm(GemmArgs& g, const char* name, ivit_stream_t stream)
                  "%s: lda=%lld ldw=%lld must be >= K and multiples of 16", name, (long long)g.lda, (long long)g.ldw);
     IVIT_REQUIRE(((uintptr_t)g.A % 16 == 0) && ((uintptr_t)g.W % 16 == 0) && ((uintptr_t)g.out % 16 == 0),
                  "%s: operands must be 16-byte aligned", name);
-    if (EPI == EPI_I32 || EPI == EPI_RQ16) {
+    if (EPI == EPI_I32 || EPI == EPI_RQ16 || EPI == EPI_RQ16_RES16) {
         IVIT_REQUIRE(g.N % 4 == 0 && g.ldo % 4 == 0 && g.ldo >= g.N, "%s: N=%d ldo=%lld must be multiples of 4", name,
                      g.N, (long long)g.ldo);
-        if (EPI == EPI_RQ16)
+        if (EPI == EPI_RQ16 || EPI == EPI_RQ16_RES16)
             IVIT_REQUIRE(g.m && g.e && ((uintptr_t)g.m % 16 == 0) && ((uintptr_t)g.e % 16 == 0) && ((uintptr_t)g.out % 8 == 0),
                          "%s: requantiser tables missing or misaligned", name);
     } else {
@@ -881,10 +891,7 @@ int launch_gemm(GemmArgs& g, const char* name, ivit_stream_t stream)
             IVIT_CHECK_LAUNCH(name);
         }
     }
-    if constexpr (EPI == EPI_RQ16_RES16) {
-        IVIT_REQUIRE(false, "%s: needs the fragment-packed weight form (IVIT_W_FRAGS: M >= 2048, N >= 128, N %% 64 == 0, K %% 192 == 0)", name);
-    } else
-    if constexpr (EPI != EPI_I32 && EPI != EPI_RQ16) {
+    if constexpr (EPI != EPI_I32 && EPI != EPI_RQ16 && EPI != EPI_RQ16_RES16) {
 #if IVIT_LAB
         if (EPI <= EPI_QKV && !blocks && (g_debug_flags & (31 | 32 | 128 | 256 | 512 | 1024 | 8192 | 4194304 | 8388608))) {   // a lab form was asked for (tests, scripts)
             int rc = IVIT_OK;
@@ -1085,7 +1092,7 @@ IVIT_EXPORT int ivit_gemm_i8_requant_i16_residual_i16_ex(const int8_t* A, int64_
 {
     GemmArgs g{};
     g.a_blocks = layouts & 1; g.w_frags = (layouts >> 3) & 1;
-    IVIT_REQUIRE((layouts & ~9) == 0 && g.w_frags, "ivit_gemm_i8_requant_i16_residual_i16_ex: layouts must be IVIT_W_FRAGS (| IVIT_A_BLOCKS)");
+    IVIT_REQUIRE((layouts & ~9) == 0 && (g.w_frags || !g.a_blocks), "ivit_gemm_i8_requant_i16_residual_i16_ex: layouts is 0 or IVIT_W_FRAGS (| IVIT_A_BLOCKS)");
     g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.m = m; g.e = e;
     g.res = reinterpret_cast<const int8_t*>(res); g.ldr = ldr;
     g.out = out; g.ldo = ldo; g.M = M; g.N = N; g.K = K;

@@ -59,6 +59,22 @@ IVIT_DEV int64_t win_row(const WinMap& m, int64_t r)
     return ((int64_t)b * (m.H / m.ws) * nwx + (int64_t)wy * nwx + wx) * (m.ws * m.ws) + iy * m.ws + ix;
 }
 
+// the inverse: row R of the window-ordered tensor (window index, position in the window) -> row of the image-ordered one
+// (window_reverse + the roll back, swin_quant.py:278-287)
+IVIT_DEV int64_t win_row_inv(const WinMap& m, int64_t R)
+{
+    if (m.ws == 0) return R;
+    const int T = m.ws * m.ws, nwx = m.W / m.ws, nwy = m.H / m.ws;
+    const int64_t widx = R / T;
+    const int pos = (int)(R - widx * T);
+    const int iy = pos / m.ws, ix = pos - iy * m.ws;
+    const int b = (int)(widx / (nwy * nwx)), wrem = (int)(widx - (int64_t)b * (nwy * nwx));
+    const int wy = wrem / nwx, wx = wrem - wy * nwx;
+    int y = wy * m.ws + iy + m.shift; if (y >= m.H) y -= m.H;
+    int x = wx * m.ws + ix + m.shift; if (x >= m.W) x -= m.W;
+    return (int64_t)b * m.H * m.W + (int64_t)y * m.W + x;
+}
+
 // ------------------------------------------------------------------------------------------------
 // 8 -> 16 bit QuantAct (SwinTransformer.qact1, swin_quant.py:546; also used as an exact int8 -> int16 widening)
 // ------------------------------------------------------------------------------------------------
@@ -656,6 +672,10 @@ struct WinAttnArgs {
     // divides by s), both float32 [256] on the device; NULL: power-of-two scale
     const float* phi;
     const float* phim;
+    // ws != 0: the output rows go to their IMAGE positions (window reverse + roll back applied here): the projection is
+    // row-wise, so attn.proj and the residual QuantAct behind it then need no row map (and fuse into one GEMM)
+    WinMap omap;
+    int omap_inv;           // 65536 / ws + 1: (q * omap_inv) >> 16 == q / ws for q < 64
 };
 
 constexpr int WHD = 32;
@@ -684,6 +704,17 @@ __global__ __launch_bounds__(NT) void window_attention_kernel(WinAttnArgs a)
 
     for (int pair = blockIdx.x * WPB + wave; pair < npairs; pair += gridDim.x * WPB) {
         const int win = pair / a.heads, hh = pair - win * a.heads;
+        // image position of the window (wave-uniform): its image, its window row / column
+        int64_t img_base = 0;
+        int wy0 = 0, wx0 = 0;
+        if (a.omap.ws) {
+            const int nwx = a.omap.W / a.omap.ws;
+            const int bimg = win / a.nW, wrem = win - bimg * a.nW;
+            const int wy = wrem / nwx;
+            wy0 = wy * a.omap.ws + a.omap.shift;
+            wx0 = (wrem - wy * nwx) * a.omap.ws + a.omap.shift;
+            img_base = (int64_t)bimg * a.omap.H * a.omap.W;
+        }
         const int8_t* qg = a.qkv + (int64_t)pair * T * WHD;
         const int8_t* kg = qg + plane;
         const int8_t* vg = qg + 2 * plane;
@@ -809,7 +840,16 @@ __global__ __launch_bounds__(NT) void window_attention_kernel(WinAttnArgs a)
                 }
                 pk[t] = (int)w;
             }
-            int8_t* orow = a.out + ((int64_t)win * T + qrow) * a.ldo + hh * WHD;
+            int64_t orow_idx = (int64_t)win * T + qrow;
+            if (a.omap.ws) {      // window reverse + roll back: (iy, ix) of the query in its window -> (y, x) of the image
+                const int qr = min(qrow, T - 1);
+                const int iy = (qr * a.omap_inv) >> 16, ix = qr - iy * a.omap.ws;      // qr / ws for qr < 64 (checked by the launcher)
+                int y = wy0 + iy, x = wx0 + ix;
+                y = y >= a.omap.H ? y - a.omap.H : y;
+                x = x >= a.omap.W ? x - a.omap.W : x;
+                orow_idx = img_base + y * a.omap.W + x;
+            }
+            int8_t* orow = a.out + orow_idx * a.ldo + hh * WHD;
             unsigned wq[2];      // wq[dt]: bytes d = 16 dt + 4 g + 0..3 of this lane's query
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) {
@@ -994,11 +1034,11 @@ IVIT_EXPORT int ivit_window_attention_i8(const int8_t* qkv, int8_t* out, int64_t
                                            tokens, head_dim, m_s, e_s, m_b, e_b, s_attn, m_o, e_o, nullptr, nullptr, stream);
 }
 
-IVIT_EXPORT int ivit_window_attention_i8_compat(const int8_t* qkv, int8_t* out, int64_t ldo, const int16_t* bias_add,
-                                                const uint8_t* mask_region, int mask_value, int windows, int windows_per_image,
-                                                int heads, int tokens, int head_dim, uint32_t m_s, int32_t e_s, uint32_t m_b,
-                                                int32_t e_b, float s_attn, uint32_t m_o, int32_t e_o, const float* phi,
-                                                const float* phi_masked, ivit_stream_t stream)
+static int window_attention_launch(const int8_t* qkv, int8_t* out, int64_t ldo, const int16_t* bias_add,
+                                   const uint8_t* mask_region, int mask_value, int windows, int windows_per_image,
+                                   int heads, int tokens, int head_dim, uint32_t m_s, int32_t e_s, uint32_t m_b,
+                                   int32_t e_b, float s_attn, uint32_t m_o, int32_t e_o, const float* phi,
+                                   const float* phi_masked, WinMap omap, ivit_stream_t stream)
 {
     IVIT_REQUIRE(qkv && out && bias_add, "ivit_window_attention_i8: NULL operand");
     IVIT_REQUIRE(windows > 0 && heads > 0 && windows_per_image > 0 && windows % windows_per_image == 0,
@@ -1014,6 +1054,10 @@ IVIT_EXPORT int ivit_window_attention_i8_compat(const int8_t* qkv, int8_t* out, 
     IVIT_REQUIRE(s_attn > 0.0f, "ivit_window_attention_i8: scale must be positive");
     IVIT_REQUIRE((phi == nullptr) == (phi_masked == nullptr), "ivit_window_attention_i8_compat: phi and phi_masked go together");
     WinAttnArgs a;
+    a.omap = omap;
+    a.omap_inv = omap.ws ? 65536 / omap.ws + 1 : 0;
+    for (int qv = 0; qv < 64 && omap.ws; ++qv)
+        IVIT_REQUIRE(((qv * a.omap_inv) >> 16) == qv / omap.ws, "ivit_window_attention_i8_unwindow: window size %d unsupported", omap.ws);
     a.phi = phi; a.phim = phi_masked;
     a.qkv = qkv; a.out = out; a.ldo = ldo; a.bias = bias_add; a.region = mask_region; a.mask_value = mask_value;
     a.nwin = windows; a.heads = heads; a.T = tokens; a.nW = windows_per_image;
@@ -1036,4 +1080,28 @@ IVIT_EXPORT int ivit_window_attention_i8_compat(const int8_t* qkv, int8_t* out, 
     const int grid = (npairs + WPB - 1) / WPB;
     hipLaunchKernelGGL(window_attention_kernel, dim3(grid < 8192 ? grid : 8192), dim3(NT), 0, ivit_stream(stream), a);
     IVIT_CHECK_LAUNCH("ivit_window_attention_i8");
+}
+
+IVIT_EXPORT int ivit_window_attention_i8_compat(const int8_t* qkv, int8_t* out, int64_t ldo, const int16_t* bias_add,
+                                                const uint8_t* mask_region, int mask_value, int windows, int windows_per_image,
+                                                int heads, int tokens, int head_dim, uint32_t m_s, int32_t e_s, uint32_t m_b,
+                                                int32_t e_b, float s_attn, uint32_t m_o, int32_t e_o, const float* phi,
+                                                const float* phi_masked, ivit_stream_t stream)
+{
+    return window_attention_launch(qkv, out, ldo, bias_add, mask_region, mask_value, windows, windows_per_image, heads, tokens,
+                                   head_dim, m_s, e_s, m_b, e_b, s_attn, m_o, e_o, phi, phi_masked, WinMap{0, 0, 0, 0}, stream);
+}
+
+IVIT_EXPORT int ivit_window_attention_i8_unwindow(const int8_t* qkv, int8_t* out, int64_t ldo, const int16_t* bias_add,
+                                                  const uint8_t* mask_region, int mask_value, int windows, int windows_per_image,
+                                                  int heads, int tokens, int head_dim, uint32_t m_s, int32_t e_s, uint32_t m_b,
+                                                  int32_t e_b, float s_attn, uint32_t m_o, int32_t e_o, const float* phi,
+                                                  const float* phi_masked, int H, int W, int ws, int shift, ivit_stream_t stream)
+{
+    IVIT_REQUIRE(ws > 0 && ws * ws == tokens && H > 0 && W > 0 && H % ws == 0 && W % ws == 0 && shift >= 0 && shift < ws &&
+                 windows_per_image == (H / ws) * (W / ws),
+                 "ivit_window_attention_i8_unwindow: H=%d W=%d ws=%d shift=%d do not describe %d windows of %d tokens per image", H, W, ws,
+                 shift, windows_per_image, tokens);
+    return window_attention_launch(qkv, out, ldo, bias_add, mask_region, mask_value, windows, windows_per_image, heads, tokens,
+                                   head_dim, m_s, e_s, m_b, e_b, s_attn, m_o, e_o, phi, phi_masked, WinMap{H, W, ws, shift}, stream);
 }

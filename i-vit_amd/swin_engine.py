@@ -113,6 +113,7 @@ class IntSwinEngine(GraphReplay):
             d.update(m=dev(m.view(np.int32)), e=dev(e))
             return d
 
+        self.proj_fused = True     # attention output in image order + attn.proj / attn.qact4 / qact2 in one GEMM (False: A/B, tests)
         self.proj_i16 = True       # attn.proj writes the 16-bit attn.qact4 output instead of raw accumulators
         self.natural_sites = 0     # operators whose input scale is not a power of two: literal / table-driven kernels
 
@@ -378,13 +379,27 @@ class IntSwinEngine(GraphReplay):
                     hm = ws["qkv"][: 3 * M * C].view(3, nwin, nH, N, HEAD_DIM)
                     taps[p + "attn.qact1"] = hm.permute(1, 3, 0, 2, 4).reshape(nwin, N, 3 * C).clone()
                 a = blk["attn"]
-                _lib.call("ivit_window_attention_i8_compat", _lib.ptr(ws["qkv"]), _lib.ptr(ws["ao"]), ld, _lib.ptr(a["bias"]),
-                          _lib.ptr(a["region"]), a["mask_value"], nwin, a["nW"], nH, N, HEAD_DIM, a["ms"][0], a["ms"][1], a["mb"][0],
-                          a["mb"][1], a["s_attn"], a["mo"][0], a["mo"][1], _lib.ptr(a["phi"]), _lib.ptr(a["phim"]), st)
+                fuse_proj = self.proj_fused and taps is None
+                if fuse_proj:
+                    # the attention output goes straight to its image rows (window reverse + roll back in the store address):
+                    # attn.proj + attn.qact4 + the residual QuantAct qact2 are then ONE GEMM, in place on the residual stream
+                    _lib.call("ivit_window_attention_i8_unwindow", _lib.ptr(ws["qkv"]), _lib.ptr(ws["ao"]), ld, _lib.ptr(a["bias"]),
+                              _lib.ptr(a["region"]), a["mask_value"], nwin, a["nW"], nH, N, HEAD_DIM, a["ms"][0], a["ms"][1],
+                              a["mb"][0], a["mb"][1], a["s_attn"], a["mo"][0], a["mo"][1], _lib.ptr(a["phi"]), _lib.ptr(a["phim"]),
+                              H, W, win, shift, st)
+                else:
+                    _lib.call("ivit_window_attention_i8_compat", _lib.ptr(ws["qkv"]), _lib.ptr(ws["ao"]), ld, _lib.ptr(a["bias"]),
+                              _lib.ptr(a["region"]), a["mask_value"], nwin, a["nW"], nH, N, HEAD_DIM, a["ms"][0], a["ms"][1], a["mb"][0],
+                              a["mb"][1], a["s_attn"], a["mo"][0], a["mo"][1], _lib.ptr(a["phi"]), _lib.ptr(a["phim"]), st)
                 tap(p + "attn.qact3", ws["ao"], M, C, ld)
                 pj = blk["proj"]
                 r = blk["res1"]
-                if self.proj_i16:
+                if fuse_proj:
+                    w_, lay = (_lib.ptr(pj["Wf"]), 8) if (M >= 2048 and pj.get("Wf") is not None) else (_lib.ptr(pj["W"]), 0)
+                    _lib.call("ivit_gemm_i8_requant_i16_residual_i16_ex", _lib.ptr(ws["ao"]), ld, w_, pj["K"], _lib.ptr(pj["b"]),
+                              _lib.ptr(pj["m"]), _lib.ptr(pj["e"]), _lib.ptr(x), C, r[0], r[1], r[2], r[3], _lib.ptr(x2), C, M, C,
+                              pj["K"], lay, st)
+                elif self.proj_i16:
                     # attn.proj + the 16-bit attn.qact4 in the GEMM epilogue (int16 [M, C] in window order, half the bytes of
                     # raw accumulators), then window reverse / un-shift + the residual QuantAct
                     _lib.call("ivit_gemm_i8_requant_i16", _lib.ptr(ws["ao"]), ld, _lib.ptr(pj["W"]), pj["K"], _lib.ptr(pj["b"]),

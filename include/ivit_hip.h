@@ -164,8 +164,9 @@ int ivit_gemm_i8_requant_i16(const int8_t* A, int64_t lda, const int8_t* W, int6
 /* the two calls above in one (ViT attn.proj + attn.qact3 at 16 bits + qact2, mlp.fc2 + mlp.qact2 at 16 bits + qact4,
  * vit_quant.py:131-150 with attention_out_bw = mlp_out_bw = norm2_in_bw = att_block_out_bw = 16):
  *   k16 = clamp16(RNE(acc * m[n] / 2^e[n])),  out = clamp16(RNE(k16 * M_main) + RNE(res * M_res)),  res / out int16 rows.
- * Weights-in-registers kernel only: `layouts` carries IVIT_W_FRAGS (optionally IVIT_A_BLOCKS) and the shape limits of that
- * form apply; other shapes use the two calls. */
+ * `layouts`: IVIT_W_FRAGS (optionally | IVIT_A_BLOCKS) where that form applies -- the epilogue is then transposed through LDS --
+ * or 0: any shape, the 128 x 128-tile kernel with the epilogue straight from its registers (Swin attn.proj at C = 96 .. 384).
+ * N % 8 == 0, ldr / ldo multiples of 8, res / out 16-byte aligned; out may alias res. */
 int ivit_gemm_i8_requant_i16_residual_i16_ex(const int8_t* A, int64_t lda, const int8_t* W, int64_t ldw, const int32_t* bias,
                                              const uint32_t* m, const int32_t* e, const int16_t* res, int64_t ldr,
                                              uint32_t m_main, int32_t e_main, uint32_t m_res, int32_t e_res, int16_t* out,
@@ -426,6 +427,15 @@ int ivit_window_attention_i8_compat(const int8_t* qkv, int8_t* out, int64_t ldo,
                                     int tokens, int head_dim, uint32_t m_s, int32_t e_s, uint32_t m_b, int32_t e_b,
                                     float s_attn, uint32_t m_o, int32_t e_o, const float* phi, const float* phi_masked,
                                     ivit_stream_t stream);
+/* The same with the output rows at their IMAGE positions: window_reverse and the roll back (swin_quant.py:278-287) applied to
+ * the row index here, `out` [batch * H * W, heads * head_dim].  attn.proj is row-wise, so it and the residual QuantAct behind it
+ * then work on image-ordered rows without a map (ivit_gemm_i8_requant_i16_residual_i16_ex).  tokens == ws * ws, windows_per_image
+ * == (H / ws) * (W / ws), 0 <= shift < ws. */
+int ivit_window_attention_i8_unwindow(const int8_t* qkv, int8_t* out, int64_t ldo, const int16_t* bias_add,
+                                      const uint8_t* mask_region, int mask_value, int windows, int windows_per_image, int heads,
+                                      int tokens, int head_dim, uint32_t m_s, int32_t e_s, uint32_t m_b, int32_t e_b,
+                                      float s_attn, uint32_t m_o, int32_t e_o, const float* phi, const float* phi_masked,
+                                      int H, int W, int ws, int shift, ivit_stream_t stream);
 
 /* =================================================================================================
  * I-BERT operator family (models/quantization_utils/ibert_modules.py; registry key 'ibert', the fork's default,

@@ -38,6 +38,8 @@ def run(cid, steps=20, warmup=5, graph=False, batch=None):
         eng.weight_frags = os.environ["IVIT_WEIGHT_FRAGS"] != "0"
     if os.environ.get("IVIT_PROJ_I16") and hasattr(eng, "proj_i16"):   # A/B (Swin): 0 = raw int32 accumulators out of attn.proj
         eng.proj_i16 = os.environ["IVIT_PROJ_I16"] != "0"
+    if os.environ.get("IVIT_PROJ_FUSED") and hasattr(eng, "proj_fused"):   # A/B (Swin): 0 = attention in window order, proj GEMM + residual kernel
+        eng.proj_fused = os.environ["IVIT_PROJ_FUSED"] != "0"
     if os.environ.get("IVIT_COMPACT_WS") and hasattr(eng, "_compact"):   # A/B: 0 = every intermediate in its own buffer
         eng._compact(os.environ["IVIT_COMPACT_WS"] != "0")
     if os.environ.get("IVIT_GELU_INPLACE") and hasattr(eng, "gelu_in_place"):   # A/B: 0 = GELU into its own buffer

@@ -144,6 +144,26 @@ def test_gemm_requant_i16(M, N, K):
     assert (np.abs(exp) < 30000).any()
 
 
+@pytest.mark.parametrize("M,N,K", [(333, 96, 128), (1000, 200, 64)])
+def test_gemm_requant_i16_residual_i16_small_shapes(M, N, K):
+    """the same entry point on shapes only the 128 x 128-tile kernel takes (Swin attn.proj at C = 96; N not a multiple of 64)"""
+    rng = np.random.default_rng(M + N)
+    A = rng.integers(-128, 128, size=(M, K)).astype(np.int8)
+    W = rng.integers(-128, 128, size=(N, K)).astype(np.int8)
+    b = rng.integers(-50000, 50000, size=N).astype(np.int32)
+    res = np.clip(np.rint(rng.normal(0, 9000, size=(M, N))), -32768, 32767).astype(np.int16)
+    m, e = rand_me(rng, N, -8, 1)
+    md, ed = me_dev(m, e)
+    k16 = orc.requant(orc.gemm_i8(A, W, b), m.astype(np.float64), e, 16)
+    m1, e1 = dyadic(np.float32(0.3337), np.float32(0.0517))
+    m2, e2 = dyadic(np.float32(0.0421), np.float32(0.0517))
+    exp = orc.requant(k16, m1.astype(np.float64), e1, 16, z2=res.astype(np.int32), m2=m2.astype(np.float64), e2=e2)
+    buf = dev(res).clone()
+    _lib.call("ivit_gemm_i8_requant_i16_residual_i16_ex", _lib.ptr(dev(A)), K, _lib.ptr(dev(W)), K, _lib.ptr(dev(b)), _lib.ptr(md), _lib.ptr(ed),
+              _lib.ptr(buf), N, int(m1[0]), int(e1[0]), int(m2[0]), int(e2[0]), _lib.ptr(buf), N, M, N, K, 0, st())
+    assert np.array_equal(buf.cpu().numpy().astype(np.int32), exp)
+
+
 @pytest.mark.parametrize("M,N,K", [(2050, 768, 192), (4099, 384, 384), (128 * 37 + 64, 192, 768)])
 def test_gemm_requant_i16_residual_i16(M, N, K):
     """ivit_gemm_i8_requant_i16_residual_i16_ex (projection / fc2 on a 16-bit residual stream: per-channel 16-bit QuantAct of the
@@ -175,9 +195,11 @@ def test_gemm_requant_i16_residual_i16(M, N, K):
         _lib.call("ivit_gemm_i8_requant_i16_residual_i16_ex", _lib.ptr(dA), K, _lib.ptr(Wf), K, _lib.ptr(db), _lib.ptr(md), _lib.ptr(ed),
                   _lib.ptr(inpl), N, int(m1[0]), int(e1[0]), int(m2[0]), int(e2[0]), _lib.ptr(inpl), N, M, N, K, 8, st())
         assert torch.equal(inpl, out)
-    with pytest.raises(_lib.IvitError, match="IVIT_W_FRAGS"):
+        # layouts = 0: row-major weights, the 128 x 128-tile kernel with the epilogue from its registers (any shape)
+        out0 = torch.full((M, N), 55, dtype=torch.int16, device=DEV)
         _lib.call("ivit_gemm_i8_requant_i16_residual_i16_ex", _lib.ptr(dA), K, _lib.ptr(dW), K, _lib.ptr(db), _lib.ptr(md), _lib.ptr(ed),
-                  _lib.ptr(dres), N, 1 << 30, 30, 1 << 30, 30, _lib.ptr(out), N, M, N, K, 0, st())
+                  _lib.ptr(dres), N, int(m1[0]), int(e1[0]), int(m2[0]), int(e2[0]), _lib.ptr(out0), N, M, N, K, 0, st())
+        assert torch.equal(out0, out)
 
 
 def test_gemm_mfma_layout_identity():

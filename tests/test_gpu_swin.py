@@ -332,6 +332,22 @@ def test_window_attention(B_, nW, nH, N, s_attn, masked):
     assert np.array_equal(got[:, : nH * hd].astype(np.int32).reshape(B_, N, nH * hd), ref)
     assert not got[:, nH * hd:].any()
     assert Pm.max() > 0
+    # the same rows at their image positions (window reverse + roll back in the store address)
+    ws_ = int(round(np.sqrt(N)))
+    if ws_ * ws_ == N and B_ % nW == 0:
+        from ivit_amd.swin_engine import window_row_map
+        gh, gw = {1: (1, 1), 2: (1, 2), 4: (2, 2)}[nW]
+        H, W = gh * ws_, gw * ws_
+        for shift in sorted({0, ws_ // 2}):
+            out2 = torch.zeros(B_ * N, ld, dtype=torch.int8, device=DEV)
+            _lib.call("ivit_window_attention_i8_unwindow", _lib.ptr(dev(qkv)), _lib.ptr(out2), ld, _lib.ptr(dev(bias_pad)),
+                      _lib.ptr(None if region is None else dev(region)), mval, B_, nW, nH, N, hd, ms[0], ms[1], mb[0], mb[1],
+                      float(s_at), mo[0], mo[1], None, None, H, W, ws_, shift, st())
+            dst = window_row_map(B_ // nW, H, W, ws_, shift)        # image row r -> its row in window order
+            assert np.array_equal(out2.cpu().numpy(), got[dst]), shift
+        with pytest.raises(_lib.IvitError, match="do not describe"):
+            _lib.call("ivit_window_attention_i8_unwindow", _lib.ptr(dev(qkv)), _lib.ptr(out), ld, _lib.ptr(dev(bias_pad)), None, 0, B_, nW,
+                      nH, N, hd, ms[0], ms[1], mb[0], mb[1], float(s_at), mo[0], mo[1], None, None, H + 1, W, ws_, 0, st())
 
 
 def test_window_attention_rejects_unsupported_geometry():
