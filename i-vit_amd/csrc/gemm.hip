@@ -139,13 +139,14 @@ __global__ __launch_bounds__(NT) void gemm_i8_kernel(GemmArgs g)
                 }
             }
         return;
-    } else if constexpr (EPI == EPI_RQ16 || EPI == EPI_RQ16_RES16) {
+    } else if constexpr (EPI == EPI_RQ16_RES16) {
+        static_assert(SMEM_BYTES + BN * 8 >= 128 * RQ16S_RS, "staging tile");
+        epilogue_rq16_res16_small(acc, g, smem, m0, n0, wm, wn, tid, h, l31);
+        return;
+    } else if constexpr (EPI == EPI_RQ16) {
         // 16-bit per-channel QuantAct from the registers: a lane holds 4 consecutive channels of one token per register quad,
         // i.e. one 8-byte store.  quant_utils.py:229-230 literally: float64 product (53-bit rounding), then RNE.
-        // EPI_RQ16_RES16: + the two-operand 16-bit residual QuantAct on top (shapes the weights-in-registers kernel does not
-        // take: Swin attn.proj at C = 96 .. 384): one 8-byte residual load per store.
         int16_t* out = reinterpret_cast<int16_t*>(g.out);
-        const int16_t* res = reinterpret_cast<const int16_t*>(g.res);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -165,13 +166,6 @@ __global__ __launch_bounds__(NT) void gemm_i8_kernel(GemmArgs g)
                         const double p = (double)acc[i][j][4 * q + r] * Mc[r];
                         const double tt = p + IVIT_MAGIC;
                         o[r] = clamp_i32((int)(unsigned)__double_as_longlong(tt), -32768, 32767);
-                    }
-                    if constexpr (EPI == EPI_RQ16_RES16) {
-                        const int2 rw = *reinterpret_cast<const int2*>(res + (int64_t)t * g.ldr + c0);
-                        const int rv[4] = {(int)(int16_t)rw.x, rw.x >> 16, (int)(int16_t)rw.y, rw.y >> 16};
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            o[r] = clamp_i32(requant_exact(o[r], g.M_main) + requant_exact(rv[r], g.M_res), -32768, 32767);
                     }
                     int2 ow;
                     ow.x = (o[0] & 0xffff) | (o[1] << 16);

@@ -470,6 +470,65 @@ IVIT_DEV void epilogue_rq16_res16(v16i (&acc)[2][TJ], const GemmArgs& g, char* c
     }
 }
 
+// The same for the 128 x 128-tile kernel (wave (wm, wn): tokens 64 wm + 32 j + l31, channels 64 wn + 32 i + 8 q + 4 h): the whole
+// tile of 16-bit intermediates is staged at once -- 128 rows x (256 + 8) bytes is exactly the kernel's LDS (two main-loop stages
+// + the requantiser table, all dead here) -- then 16-byte chunks, 16 consecutive threads per 256-byte row.
+constexpr int RQ16S_RS = 128 * 2 + 8;
+IVIT_DEV void epilogue_rq16_res16_small(v16i (&acc)[2][2], const GemmArgs& g, char* cs, int m0, int n0, int wm, int wn, int tid,
+                                        int h, int l31)
+{
+    constexpr int RS = RQ16S_RS, CPR = 16, NTH = 256, NIT = 128 * CPR / NTH;
+    const int16_t* res = reinterpret_cast<const int16_t*>(g.res);
+    int16_t* out = reinterpret_cast<int16_t*>(g.out);
+#pragma unroll
+    for (int grp = 0; grp < 8; ++grp) {
+        const int i = grp >> 2, q = grp & 3;
+        const int cl = 64 * wn + 32 * i + 8 * q + 4 * h;
+        const int c0 = min(n0 + cl, g.N - 4);
+        const uint4 m4 = *reinterpret_cast<const uint4*>(g.m + c0);
+        const int4 e4 = *reinterpret_cast<const int4*>(g.e + c0);
+        const double Mc[4] = {dyadic_mult(m4.x, e4.x), dyadic_mult(m4.y, e4.y), dyadic_mult(m4.z, e4.z), dyadic_mult(m4.w, e4.w)};
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            int o[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double p = (double)acc[i][j][4 * q + r] * Mc[r];
+                o[r] = clamp_i32((int)(unsigned)__double_as_longlong(p + IVIT_MAGIC), -32768, 32767);
+            }
+            v2i ow;
+            ow.x = (o[0] & 0xffff) | (o[1] << 16);
+            ow.y = (o[2] & 0xffff) | (o[3] << 16);
+            *reinterpret_cast<v2i*>(cs + (64 * wm + 32 * j + l31) * RS + 2 * cl) = ow;
+        }
+    }
+    v4i rr[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int qd = tid + NTH * it;
+        const int tl = qd / CPR, cc = qd % CPR;
+        const int t = min(m0 + tl, g.M - 1), cn = min(n0 + 8 * cc, g.N - 8);
+        rr[it] = *reinterpret_cast<const v4i*>(res + (int64_t)t * g.ldr + cn);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int qd = tid + NTH * it;
+        const int tl = qd / CPR, cc = qd % CPR;
+        const int t = m0 + tl, cn = n0 + 8 * cc;
+        const v4i kk = *reinterpret_cast<const v4i*>(cs + tl * RS + 16 * cc);
+        v4i ov;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const int kw = kk[d], rw = rr[it][d];
+            const int lo = clamp_i32(requant_exact((int)(int16_t)kw, g.M_main) + requant_exact((int)(int16_t)rw, g.M_res), -32768, 32767);
+            const int hi = clamp_i32(requant_exact(kw >> 16, g.M_main) + requant_exact(rw >> 16, g.M_res), -32768, 32767);
+            ov[d] = (lo & 0xffff) | (hi << 16);
+        }
+        if (t < g.M && cn < g.N) *reinterpret_cast<v4i*>(out + (int64_t)t * g.ldo + cn) = ov;
+    }
+}
+
 // ---- 256 x 128 LDS-DMA tiles (persistent kernel, relaunch form, deep-ring form)
 constexpr int BTOK = 256, BCH = 128, BIG_NT = 256, BIG_STAGES = 3;
 constexpr int BIG_A_BYTES = BTOK * BK;                 // 16 KiB

@@ -458,17 +458,18 @@ class IntViTEngine(GraphReplay):
         _lib.call("ivit_embed_assemble_i16", _lib.ptr(ws["pe16"]), _lib.ptr(self.pos_add), _lib.ptr(self.cls_row),
                   self.embed_me[0], self.embed_me[1], _lib.ptr(ws["x16"]), B, T, C, st)
         x = ws["x16"]
-        inplace = big and self.weight_frags and self.fuse_res16 and all(b[k].get("Wf") is not None for b in self.blocks for k in ("proj", "fc2"))
+        inplace = bool(self.fuse_res16)
 
         def gemm_res16(A, lda, lin, r, res, out):
             # projection / fc2 + its 16-bit QuantAct + the block's residual QuantAct: one kernel in the weights-in-registers form
-            if big and self.weight_frags and self.fuse_res16 and lin.get("Wf") is not None:
+            if self.fuse_res16:
+                frags = big and self.weight_frags and lin.get("Wf") is not None      # else: the 128 x 128-tile kernel, any shape
                 probe = self.probe
                 if probe is not None:     # bench.py's instrumented pass, as in _gemm_res
                     probe.begin("gemm_resid", st)
-                _lib.call("ivit_gemm_i8_requant_i16_residual_i16_ex", _lib.ptr(A), lda, _lib.ptr(lin["Wf"]), lin["K"], _lib.ptr(lin["b"]),
-                          _lib.ptr(lin["m"]), _lib.ptr(lin["e"]), _lib.ptr(res), C, r[0], r[1], r[2], r[3], _lib.ptr(out), C, M, C,
-                          lin["K"], 8, st)
+                _lib.call("ivit_gemm_i8_requant_i16_residual_i16_ex", _lib.ptr(A), lda, _lib.ptr(lin["Wf"] if frags else lin["W"]), lin["K"],
+                          _lib.ptr(lin["b"]), _lib.ptr(lin["m"]), _lib.ptr(lin["e"]), _lib.ptr(res), C, r[0], r[1], r[2], r[3], _lib.ptr(out),
+                          C, M, C, lin["K"], 8 if frags else 0, st)
                 if probe is not None:
                     probe.end("gemm_resid", st, (M, C, lin["K"]))
                 return
