@@ -487,15 +487,26 @@ __global__ __launch_bounds__(NT, 3) void attention_kernel(AttnArgs a)
     }
 }
 
-// Workgroups per (image, head).  One is right once batch * heads fills the chip (every workgroup stages K and V^T of its head in
-// LDS once and walks all query tiles); a small batch leaves most CUs idle and is bound by that walk -- then the 13 query tiles
-// are dealt out among up to 4 workgroups per head (each stages K / V^T itself: L2 hits).
-int attention_parts(int batch_heads, int tokens)
+// Workgroups per (image, head).  Every workgroup stages K and V^T of its head in LDS (~3 us) and walks query tiles (13 at
+// T = 197: 4 per wave, ~3.5 us each); `slots` workgroups are resident at once.  With batch * heads a multiple of the slots one
+// workgroup per head is right (DeiT-B b256: 3072 = 4 rounds of 768); a launch that fills only part of a round is bound by that
+// walk -- DeiT-S b64 (384 heads) took a whole round's 17 us -- so the tiles are dealt out among 2 or 4 workgroups per head when
+// the model below says the launch gets shorter (each stages K / V^T itself: L2 hits).
+int attention_parts(int batch_heads, int tokens, int slots)
 {
     const int nqt = (tokens + 15) >> 4;
-    int parts = 1;
-    while (parts < 4 && batch_heads * parts * 2 <= 256 && 4 * parts < nqt) parts *= 2;
-    return parts;
+#if IVIT_LAB
+    if ((g_ln_ablate >> 28) & 7) return (g_ln_ablate >> 28) & 7;      // lab: forced (scripts/attn_parts.py)
+#endif
+    int best = 1;
+    double best_t = 0.0;
+    for (int p = 1; p <= 4; p *= 2) {
+        if (p > 1 && 4 * (p / 2) >= nqt) break;     // no wave would lose a tile
+        const int rounds = (batch_heads * p + slots - 1) / slots, tiles = (nqt + 4 * p - 1) / (4 * p);
+        const double t = rounds * (3.0 + 3.45 * tiles);
+        if (p == 1 || t < 0.95 * best_t) { best = p; best_t = t; }
+    }
+    return best;
 }
 
 }  // namespace
@@ -570,7 +581,7 @@ IVIT_EXPORT int ivit_attention_fused_i8_wide(const int8_t* qkv, int8_t* out, int
         if (x <= 15 * a.x0) { a.ksat = i; break; }
     }
     const size_t band_lds_bytes = band_w ? (size_t)4 * 16 * (band_w + BAND_PAD) * sizeof(unsigned) : 0;
-    a.parts = attention_parts(batch * heads, tokens);
+    a.parts = attention_parts(batch * heads, tokens, band_w ? 512 : 768);
     const dim3 grid(batch * heads * a.parts), blk(NT);
     hipStream_t st = ivit_stream(stream);
     if (softmax_bits == 16) {
@@ -621,7 +632,7 @@ IVIT_EXPORT int ivit_attention_fused_i8_ibert_wide(const int8_t* qkv, int8_t* ou
     a.band = reinterpret_cast<const unsigned*>(band);
     a.band_w = band_w;
     const size_t band_lds_bytes = band_w ? (size_t)4 * 16 * (band_w + BAND_PAD) * sizeof(unsigned) : 0;
-    a.parts = attention_parts(batch * heads, tokens);
+    a.parts = attention_parts(batch * heads, tokens, band_w ? 512 : 768);
     if (softmax_bits == 16) {
         if (band_w) hipLaunchKernelGGL((attention_kernel<4, 16>), dim3(batch * heads * a.parts), dim3(NT), band_lds_bytes, ivit_stream(stream), a);
         else hipLaunchKernelGGL((attention_kernel<3, 16>), dim3(batch * heads * a.parts), dim3(NT), 0, ivit_stream(stream), a);
