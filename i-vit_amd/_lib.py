@@ -89,6 +89,7 @@ SIGNATURES = {
     "ivit_attention_fused_i8_ibert_wide": [vp, vp, ci, ci, ci, ci, u32, i32, u32, i32, vp, vp, ci, ci, ci, vp],
     "ivit_ibert_layernorm_i8": [vp, i64, ci, ci, f32, vp, vp, f32, vp, vp, vp, i64, ci, vp],
     "ivit_ibert_layernorm_i16_i8": [vp, i64, ci, ci, f32, vp, vp, f32, vp, vp, vp, i64, vp],
+    "ivit_ibert_layernorm_i16_i8_ex": [vp, i64, ci, ci, f32, vp, vp, f32, vp, vp, vp, i64, ci, vp],
     "ivit_ibert_gelu_f32_f32": [vp, i64, f32, f32, f32, f32, f32, vp, vp],
     "ivit_ibert_softmax_f32_f32": [vp, i64, ci, ci, f32, f32, f32, f32, f32, f32, u32, i32, ci, vp, i64, vp, vp],
     "ivit_ibert_layernorm_f32_f32": [vp, i64, ci, ci, vp, ci, vp, vp, f32, vp, i64, vp],

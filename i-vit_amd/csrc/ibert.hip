@@ -512,8 +512,10 @@ IVIT_DEV float torch_rowsum_regs(const float (&own)[NK], int lane)
     return fin;
 }
 
-template <int NK>
-__global__ __launch_bounds__(NT) void ibert_layernorm_i16_fast_kernel(IbLnI8Args a)
+// FASTDIV: x / s_in by the 3-instruction quotient q0 = x * r, e = fma(-s, q0, x), fma(e, r, q0) with r = RN(1 / s_in) -- correctly
+// rounded for every 16-bit q at this s_in, which the host checked exhaustively (prepare.markstein_division_ok) before asking for it.
+template <int NK, bool FASTDIV>
+__global__ __launch_bounds__(NT) void ibert_layernorm_i16_fast_kernel(IbLnI8Args a, float r_in)
 {
     const int C = a.C;     // == 64 NK
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -540,7 +542,16 @@ __global__ __launch_bounds__(NT) void ibert_layernorm_i16_fast_kernel(IbLnI8Args
         for (int k = 0; k < NK; ++k) xq[k] = xr[lane + 64 * k];
         float ph[NK];
 #pragma unroll
-        for (int k = 0; k < NK; ++k) ph[k] = ((float)xq[k] * a.s_in) / a.s_in;                 // :126 on fl(q * s)
+        for (int k = 0; k < NK; ++k) {
+            const float x = (float)xq[k] * a.s_in;                                             // fl(q * s)
+            if constexpr (FASTDIV) {
+                const float q0 = x * r_in;
+                const float e = __builtin_fmaf(-a.s_in, q0, x);
+                ph[k] = __builtin_fmaf(e, r_in, q0);                                           // :126
+            } else {
+                ph[k] = x / a.s_in;                                                            // :126
+            }
+        }
         const float mean_int = rintf(torch_rowsum_regs<NK>(ph, lane) / (float)C);            // :127
         float sq[NK];
 #pragma unroll
@@ -746,16 +757,30 @@ IVIT_EXPORT int ivit_ibert_layernorm_i16_i8(const int16_t* x, int64_t ldx, int r
                                             const float* s_out, float shift_pow2, const uint32_t* m, const int32_t* e, int8_t* out,
                                             int64_t ldo, ivit_stream_t stream)
 {
+    return ivit_ibert_layernorm_i16_i8_ex(x, ldx, rows, C, s_in, bias_int, s_out, shift_pow2, m, e, out, ldo, 0, stream);
+}
+
+IVIT_EXPORT int ivit_ibert_layernorm_i16_i8_ex(const int16_t* x, int64_t ldx, int rows, int C, float s_in, const float* bias_int,
+                                               const float* s_out, float shift_pow2, const uint32_t* m, const int32_t* e, int8_t* out,
+                                               int64_t ldo, int fast_division, ivit_stream_t stream)
+{
     IVIT_REQUIRE(x && out && bias_int && s_out && m && e && rows > 0 && C > 0 && ldx >= C && ldo >= C && s_in > 0.0f,
                  "ivit_ibert_layernorm_i16_i8: bad operand");
     IVIT_REQUIRE(shift_pow2 >= 1.0f, "ivit_ibert_layernorm_i16_i8: shift_pow2 = 2^shift must be >= 1");
     IbLnI8Args a{reinterpret_cast<const int8_t*>(x), ldx, rows, C, s_in, bias_int, s_out, shift_pow2, m, e, out, ldo, 0};
     const dim3 grid(grid_for_rows(rows)), blk(NT);
     hipStream_t st = ivit_stream(stream);
-    if (C == 192) hipLaunchKernelGGL(ibert_layernorm_i16_fast_kernel<3>, grid, blk, 0, st, a);
-    else if (C == 384) hipLaunchKernelGGL(ibert_layernorm_i16_fast_kernel<6>, grid, blk, 0, st, a);
-    else if (C == 768) hipLaunchKernelGGL(ibert_layernorm_i16_fast_kernel<12>, grid, blk, 0, st, a);
-    else if (C == 1024) hipLaunchKernelGGL(ibert_layernorm_i16_fast_kernel<16>, grid, blk, 0, st, a);
+    const float r_in = 1.0f / s_in;
+#define IB_LN16(NKv)                                                                                                   \
+    do {                                                                                                               \
+        if (fast_division) hipLaunchKernelGGL((ibert_layernorm_i16_fast_kernel<NKv, true>), grid, blk, 0, st, a, r_in); \
+        else hipLaunchKernelGGL((ibert_layernorm_i16_fast_kernel<NKv, false>), grid, blk, 0, st, a, r_in);              \
+    } while (0)
+    if (C == 192) IB_LN16(3);
+    else if (C == 384) IB_LN16(6);
+    else if (C == 768) IB_LN16(12);
+    else if (C == 1024) IB_LN16(16);
     else hipLaunchKernelGGL(ibert_layernorm_i8_kernel<int16_t>, grid, blk, 0, st, a);
+#undef IB_LN16
     IVIT_CHECK_LAUNCH("ivit_ibert_layernorm_i16_i8");
 }

@@ -96,7 +96,7 @@ class IntViTEngine(GraphReplay):
                 except KeyError:
                     shift = 0.0
                 return dict(kind="ib16", bias=dev(lp.bias_int), s=dev(lp.s_ln), m=dev(lp.m.view(np.int32)), e=dev(lp.e),
-                            s_in=float(s_in), shift_pow2=float(2.0 ** shift))
+                            s_in=float(s_in), shift_pow2=float(2.0 ** shift), fast_div=int(markstein_division_ok(s_in, 16)))
             if sb == 16:
                 # I-LayerNorm on the 16-bit stream (csrc/swin.hip); natural input scale: the literal / Markstein-quotient forms
                 d = dict(kind="i16", bias=dev(lp.bias_int), s=dev(lp.s_ln), m=dev(lp.m.view(np.int32)), e=dev(lp.e), s_in=None, fast_div=0)
@@ -432,8 +432,8 @@ class IntViTEngine(GraphReplay):
     def _ln16(self, x16, rows, ln, out, st):
         C = self.C
         if ln["kind"] == "ib16":
-            _lib.call("ivit_ibert_layernorm_i16_i8", _lib.ptr(x16), C, rows, C, ln["s_in"], _lib.ptr(ln["bias"]), _lib.ptr(ln["s"]),
-                      ln["shift_pow2"], _lib.ptr(ln["m"]), _lib.ptr(ln["e"]), _lib.ptr(out), C, st)
+            _lib.call("ivit_ibert_layernorm_i16_i8_ex", _lib.ptr(x16), C, rows, C, ln["s_in"], _lib.ptr(ln["bias"]), _lib.ptr(ln["s"]),
+                      ln["shift_pow2"], _lib.ptr(ln["m"]), _lib.ptr(ln["e"]), _lib.ptr(out), C, ln["fast_div"], st)
             return
         if ln["s_in"] is not None:
             _lib.call("ivit_layernorm_i16_i8_compat", _lib.ptr(x16), rows, C, ln["s_in"], ln["fast_div"], _lib.ptr(ln["bias"]),

@@ -510,6 +510,11 @@ int ivit_ibert_layernorm_i8(const int8_t* x, int64_t ldx, int rows, int C, float
 int ivit_ibert_layernorm_i16_i8(const int16_t* x, int64_t ldx, int rows, int C, float s_in, const float* bias_int,
                                 const float* s_out, float shift_pow2, const uint32_t* m, const int32_t* e, int8_t* out, int64_t ldo,
                                 ivit_stream_t stream);
+/* fast_division = 1: the caller has checked (for all 65536 inputs at this s_in) that the three-instruction quotient by the
+ * invariant s_in -- q0 = x * r, e = fma(-s, q0, x), fma(e, r, q0), r = RN(1 / s_in) -- is the correctly rounded x / s_in */
+int ivit_ibert_layernorm_i16_i8_ex(const int16_t* x, int64_t ldx, int rows, int C, float s_in, const float* bias_int,
+                                   const float* s_out, float shift_pow2, const uint32_t* m, const int32_t* e, int8_t* out, int64_t ldo,
+                                   int fast_division, ivit_stream_t stream);
 
 #ifdef __cplusplus
 }

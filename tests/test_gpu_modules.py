@@ -454,6 +454,12 @@ def test_ibert_layernorm_i16_kernel_equals_modules(C, s_in, shift):
     got = out.cpu().numpy().astype(np.int32)
     bad = np.argwhere(got != exp)
     assert bad.size == 0, (len(bad), bad[:5], got[tuple(bad[0])], exp[tuple(bad[0])])
+    from ivit_amd.prepare import markstein_division_ok
+    if markstein_division_ok(s_in, 16):       # the three-instruction quotient, where the host check allows it
+        out2 = torch.zeros(rows, C, dtype=torch.int8, device=DEV)
+        _lib.call("ivit_ibert_layernorm_i16_i8_ex", _lib.ptr(dq), C, rows, C, float(s_in), _lib.ptr(db), _lib.ptr(dsl), float(2.0 ** shift),
+                  _lib.ptr(dm), _lib.ptr(de), _lib.ptr(out2), C, 1, _lib.stream_ptr())
+        assert torch.equal(out2, out)
     assert np.abs(exp).max() > 50
 
 
