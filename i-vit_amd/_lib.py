@@ -71,6 +71,7 @@ SIGNATURES = {
     "ivit_narrow_i32_i8": [vp, vp, i64, vp, vp],
     # Swin (include/ivit_hip.h, second half)
     "ivit_quantize_patchify_ld_f32_i8": [vp, vp, i64, ci, ci, ci, ci, f32, vp],
+    "ivit_quantize_patchify_u8_i8": [vp, vp, i64, ci, ci, ci, ci, vp, vp],
     "ivit_minmax_f32": [vp, i64, vp, vp],
     "ivit_shiftmax_i32_i8": [vp, i64, ci, ci, f32, vp, i64, vp],
     "ivit_requant_i8_i16": [vp, u32, i32, vp, i64, vp],

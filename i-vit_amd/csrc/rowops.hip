@@ -1119,6 +1119,35 @@ __global__ __launch_bounds__(NT) void patchify_kernel(const float* img, int8_t* 
     }
 }
 
+// The same from uint8 pixels: the float pipeline in front of the model (ToTensor: v / 255; Normalize: (x - mean[c]) / std[c]) and
+// the input QuantAct depend on (channel, pixel value) alone -- 3 x 256 results, tabulated by the caller with the float32 sequence
+// itself; a quarter of the input bytes.  One thread: 4 consecutive pixels of a row.
+__global__ __launch_bounds__(NT) void patchify_u8_kernel(const uint8_t* img, int8_t* A, int64_t lda, int batch, int chans, int hw,
+                                                         int patch, const int8_t* lut)
+{
+    __shared__ int8_t s_lut[4 * 256];
+    for (int i = threadIdx.x; i < chans * 256; i += NT) s_lut[i] = lut[i];
+    __syncthreads();
+    const int g = hw / patch;
+    const int pw4 = patch >> 2;
+    const int64_t total = (int64_t)batch * chans * hw * (hw >> 2);
+    for (int64_t q = (int64_t)blockIdx.x * NT + threadIdx.x; q < total; q += (int64_t)gridDim.x * NT) {
+        int x4 = (int)(q % (hw >> 2));
+        int64_t r = q / (hw >> 2);
+        int y = (int)(r % hw);
+        r /= hw;
+        int c = (int)(r % chans);
+        int b = (int)(r / chans);
+        const unsigned v = *reinterpret_cast<const unsigned*>(img + (((int64_t)b * chans + c) * hw + y) * hw + 4 * x4);
+        const int8_t* t = s_lut + 256 * c;
+        int px = x4 / pw4, kw = (x4 - px * pw4) * 4;
+        int py = y / patch, kh = y - py * patch;
+        int64_t row = ((int64_t)b * g + py) * g + px;
+        int col = (c * patch + kh) * patch + kw;
+        *reinterpret_cast<int*>(A + row * lda + col) = pack4(t[v & 255], t[(v >> 8) & 255], t[(v >> 16) & 255], t[v >> 24]);
+    }
+}
+
 // cls row + position embedding, vit_quant.py:290-296 (see ivit_hip.h)
 __global__ __launch_bounds__(NT) void embed_kernel(const int8_t* patch, const int16_t* pos_add, const int8_t* cls_row,
                                                    double Mq, int8_t* out, int batch, int tokens, int C)
@@ -1686,6 +1715,19 @@ IVIT_EXPORT int ivit_quantize_patchify_f32_i8(const float* img, int8_t* A, int b
 {
     return launch_patchify("ivit_quantize_patchify_f32_i8", img, A, (int64_t)chans * patch * patch, batch, chans, hw, patch,
                            inv_scale, stream);
+}
+
+IVIT_EXPORT int ivit_quantize_patchify_u8_i8(const uint8_t* img, int8_t* A, int64_t lda, int batch, int chans, int hw, int patch,
+                                             const int8_t* lut, ivit_stream_t stream)
+{
+    IVIT_REQUIRE(img && A && lut && batch > 0 && chans > 0 && chans <= 4 && hw > 0 && patch > 0 && hw % patch == 0 && patch % 4 == 0,
+                 "ivit_quantize_patchify_u8_i8: bad shape (up to 4 channels, hw %% patch == 0, patch %% 4 == 0)");
+    IVIT_REQUIRE(lda >= (int64_t)chans * patch * patch && lda % 4 == 0 && ((uintptr_t)img % 4 == 0) && ((uintptr_t)A % 4 == 0),
+                 "ivit_quantize_patchify_u8_i8: lda too small or misaligned operand");
+    const int64_t total = (int64_t)batch * chans * hw * (hw / 4);
+    hipLaunchKernelGGL(patchify_u8_kernel, dim3(ew_grid(total)), dim3(NT), 0, ivit_stream(stream), img, A, lda, batch, chans, hw,
+                       patch, lut);
+    IVIT_CHECK_LAUNCH("ivit_quantize_patchify_u8_i8");
 }
 
 IVIT_EXPORT int ivit_quantize_patchify_ld_f32_i8(const float* img, int8_t* A, int64_t lda, int batch, int chans, int hw,

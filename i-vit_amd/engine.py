@@ -22,7 +22,7 @@ import torch
 
 from . import _lib
 from .graph import GraphReplay
-from .prepare import (LayerNormParams, dyadic, f32, markstein_division_ok, pad_head, phi_is_identity, phi_tables, quant_sym,
+from .prepare import (IMAGENET_MEAN, IMAGENET_STD, LayerNormParams, dyadic, f32, input_lut_u8, markstein_division_ok, pad_head, phi_is_identity, phi_tables, quant_sym,
                       requant_host, shiftexp2d, shiftexp_band)
 from .synth import IMG_SIZE, NUM_PATCHES, NUM_TOKENS, PATCH
 
@@ -129,6 +129,8 @@ class IntViTEngine(GraphReplay):
         # ---- stem
         s0 = s("qact_input")
         self.inv_s0 = float(f32(1.0) / s0)
+        self.s0 = float(s0)
+        self.input_lut = None
         pe = source.linear("patch_embed.proj", s0)
         s_pe = s("patch_embed.qact", sb)
         self.patch = lin_dev(pe, s_pe)
@@ -336,12 +338,28 @@ class IntViTEngine(GraphReplay):
         _lib.call("ivit_layernorm_i8_ex", _lib.ptr(x), ldx, rows, C, _lib.ptr(ln["bias"]), _lib.ptr(ln["s"]),
                   _lib.ptr(ln["m"]), _lib.ptr(ln["e"]), _lib.ptr(out), C, int(blocks), st)
 
+    def set_input_normalisation(self, mean=IMAGENET_MEAN, std=IMAGENET_STD):
+        """uint8 input: the (mean, std) of the Normalize transform in front of the model (default: ImageNet's).  forward() then
+        accepts uint8 [B,3,224,224] pixel tensors -- a quarter of the bytes of the float32 input -- and quantises them through a
+        3 x 256 table that holds the float pipeline's result per (channel, pixel value): same integers as the float path."""
+        self.input_lut = torch.from_numpy(input_lut_u8(self.s0, mean, std)).to(self.dev)
+
+    def _patchify(self, images, B, st):
+        ws = self.ws
+        if images.dtype == torch.uint8:
+            if self.input_lut is None:
+                self.set_input_normalisation()
+            _lib.call("ivit_quantize_patchify_u8_i8", _lib.ptr(images), _lib.ptr(ws["a0"]), 3 * PATCH * PATCH, B, 3, IMG_SIZE, PATCH,
+                      _lib.ptr(self.input_lut), st)
+        else:
+            _lib.call("ivit_quantize_patchify_f32_i8", _lib.ptr(images), _lib.ptr(ws["a0"]), B, 3, IMG_SIZE, PATCH, self.inv_s0, st)
+
     # ------------------------------------------------------------------ forward
     def forward(self, images: torch.Tensor, taps: dict | None = None):
         """images: float32 [B,3,224,224] on the engine's device.  Returns (logits_int32 [B,classes],
         logits_f32 [B,classes], top1 int32 [B]) -- views of the engine's workspace, valid until the
         next call.  `taps` (debug/tests) receives clones of intermediate int8 tensors."""
-        assert images.is_cuda and images.dtype == torch.float32 and images.is_contiguous()
+        assert images.is_cuda and images.dtype in (torch.float32, torch.uint8) and images.is_contiguous()
         B = images.shape[0]
         assert images.shape[1:] == (3, IMG_SIZE, IMG_SIZE) and 0 < B <= self.max_batch
         if self.stream_bits == 16:
@@ -365,8 +383,7 @@ class IntViTEngine(GraphReplay):
                     t = ws["untile"]
                 taps[name] = t.reshape(-1)[: int(np.prod(shape))].view(shape).clone()
 
-        _lib.call("ivit_quantize_patchify_f32_i8", _lib.ptr(images), _lib.ptr(ws["a0"]), B, 3, IMG_SIZE, PATCH,
-                  self.inv_s0, st)
+        self._patchify(images, B, st)
         self._gemm(ws["a0"], 3 * PATCH * PATCH, self.patch, ws["pe"], C, B * NUM_PATCHES, st,
                    blocks=bool(self.block_operands) and B * NUM_PATCHES >= 2048 and C >= 128)
         tap("patch_embed.qact", ws["pe"], (B, NUM_PATCHES, C))
@@ -451,7 +468,7 @@ class IntViTEngine(GraphReplay):
         M = B * T
         st = self._stream()
         big = bool(self.block_operands) and M >= 2048 and C % 64 == 0
-        _lib.call("ivit_quantize_patchify_f32_i8", _lib.ptr(images), _lib.ptr(ws["a0"]), B, 3, IMG_SIZE, PATCH, self.inv_s0, st)
+        self._patchify(images, B, st)
         pt = self.patch
         _lib.call("ivit_gemm_i8_requant_i16", _lib.ptr(ws["a0"]), 3 * PATCH * PATCH, _lib.ptr(pt["W"]), pt["K"], _lib.ptr(pt["b"]),
                   _lib.ptr(pt["m"]), _lib.ptr(pt["e"]), _lib.ptr(ws["pe16"]), C, B * NUM_PATCHES, C, pt["K"], st)

@@ -17,7 +17,7 @@ class GraphReplay:
         e.g. a loader's device-side staging buffer) -- no copy per step."""
         B = images.shape[0]
         cache = self.__dict__.setdefault("_graphs", {})
-        key = (B, images.data_ptr()) if resident else B
+        key = (B, images.dtype, images.data_ptr()) if resident else (B, images.dtype)
         if key not in cache:
             if resident:
                 static_in = images

@@ -197,3 +197,20 @@ def markstein_division_ok(s, bits: int = 16) -> bool:
     near_mid = np.abs(got - (got32.astype(np.float64) + np.spacing(got32).astype(np.float64) * np.where(got > got32, 0.5, -0.5))) \
         < np.abs(got) * 2.0 ** -50
     return bool(np.array_equal(got32, ref) and not near_mid.any())
+
+
+IMAGENET_MEAN, IMAGENET_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+
+
+def input_lut_u8(s_in, mean=IMAGENET_MEAN, std=IMAGENET_STD, bits: int = 8) -> np.ndarray:
+    """int8 [len(mean), 256]: what the float pipeline in front of the model makes of pixel value v of channel c -- torchvision's
+    ToTensor (v / 255 in float32), Normalize ((x - mean) / std in float32) and the input QuantAct
+    (SymmetricQuantFunction, quant_utils.py:79-97: clamp(round(1 / s * x))) -- each step in float32, in that order."""
+    v = np.arange(256, dtype=f32) / f32(255.0)
+    n = 2 ** (bits - 1) - 1
+    inv = f32(1.0) / f32(s_in)
+    rows = []
+    for m, sd in zip(mean, std):
+        x = ((v - f32(m)).astype(f32) / f32(sd)).astype(f32)
+        rows.append(np.clip(np.rint((inv * x).astype(f32)), -n - 1, n).astype(np.int8))
+    return np.stack(rows)

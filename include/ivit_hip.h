@@ -62,6 +62,12 @@ int ivit_quantize_patchify_f32_i8(const float* img, int8_t* A, int batch, int ch
  * K granularity of 64); columns [K, lda) are not written: the caller zero-fills them once. */
 int ivit_quantize_patchify_ld_f32_i8(const float* img, int8_t* A, int64_t lda, int batch, int chans, int hw, int patch,
                                      float inv_scale, ivit_stream_t stream);
+/* The same from uint8 pixels [batch, chans, hw, hw]: lut[c * 256 + v] is the int8 the float pipeline in front of the model gives
+ * pixel value v of channel c -- ToTensor (v / 255), Normalize ((x - mean[c]) / std[c]) and the input QuantAct
+ * (clamp(round(x / s)), quant_utils.py:79-97), evaluated by the caller in float32 in that order (ivit_amd.prepare.input_lut_u8):
+ * the results are identical to the float path on the same pixels and the input is a quarter of the bytes. */
+int ivit_quantize_patchify_u8_i8(const uint8_t* img, int8_t* A, int64_t lda, int batch, int chans, int hw, int patch,
+                                 const int8_t* lut, ivit_stream_t stream);
 
 /* ---- INT8 GEMM on v_mfma_i32_32x32x32_i8 with fused epilogues -------------------------------
  * QuantLinear.forward / QuantConv2d.forward (quant_modules.py:186-226, 478-511) followed by

@@ -46,6 +46,8 @@ def run(cid, steps=20, warmup=5, graph=False, batch=None):
         eng.gelu_in_place = os.environ["IVIT_GELU_INPLACE"] != "0"
     imgs = torch.from_numpy(synth.make_images(min(B, 16), 1000 + cid)).to(DEV)
     imgs = imgs.repeat((B + imgs.shape[0] - 1) // imgs.shape[0], 1, 1, 1)[:B].contiguous()
+    if os.environ.get("IVIT_INPUT_U8") == "1" and not tag.startswith("swin"):   # uint8 pixels instead of float32 images (a quarter of the input bytes)
+        imgs = torch.randint(0, 256, imgs.shape, dtype=torch.uint8, device=DEV)
     fwd = eng.forward_graph if graph else eng.forward
     for _ in range(warmup):
         fwd(imgs)

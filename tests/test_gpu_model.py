@@ -250,3 +250,32 @@ def test_graph_replay_matches_eager():
     assert np.array_equal(g2.cpu().numpy(), want[::-1])
     g3, _, _ = eng.forward_graph(imgs[:1].contiguous())
     assert np.array_equal(g3.cpu().numpy(), want[:1])
+
+
+def test_uint8_input_equals_the_float_pipeline():
+    """uint8 pixels through ivit_quantize_patchify_u8_i8 (a 3 x 256 table of what ToTensor + Normalize + the input QuantAct make
+    of every (channel, pixel value)) == the float32 images the reference's data pipeline would hand over (v / 255, (x - mean) / std
+    in float32, then the float path): the int8 patch operand and the logits, eager and HIP-graph replay"""
+    from ivit_amd.prepare import IMAGENET_MEAN, IMAGENET_STD, input_lut_u8
+    eng = build("deit_tiny", 5)[0]
+    rng = np.random.default_rng(77)
+    u8 = torch.from_numpy(rng.integers(0, 256, size=(5, 3, 224, 224), dtype=np.uint8)).to(DEV)
+    u8[0, 0, :16, :16] = 0
+    u8[0, 1, :16, :16] = 255
+    mean = torch.tensor(IMAGENET_MEAN, device=DEV).view(1, 3, 1, 1)
+    std = torch.tensor(IMAGENET_STD, device=DEV).view(1, 3, 1, 1)
+    xf = ((u8.float().div(255) - mean) / std).contiguous()          # torchvision ToTensor + Normalize
+    li_f, lf_f, t_f = [t.clone() for t in eng.forward(xf)]
+    a0_f = eng.ws["a0"][: 5 * 196].clone()
+    li_u, lf_u, t_u = [t.clone() for t in eng.forward(u8)]
+    assert torch.equal(eng.ws["a0"][: 5 * 196], a0_f) and a0_f.abs().max() > 40
+    assert torch.equal(li_u, li_f) and torch.equal(t_u, t_f)
+    li_g, _, t_g = [t.clone() for t in eng.forward_graph(u8)]
+    li_g2, _, _ = [t.clone() for t in eng.forward_graph(xf)]        # same batch, other dtype: its own graph
+    assert torch.equal(li_g, li_f) and torch.equal(li_g2, li_f)
+    lut = input_lut_u8(eng.s0)
+    assert lut.shape == (3, 256) and lut.dtype == np.int8 and (np.diff(lut.astype(np.int32), axis=1) >= 0).all()
+    eng.set_input_normalisation(mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5))
+    li_o, _, _ = eng.forward(u8)
+    xo = ((u8.float().div(255) - 0.5) / 0.5).contiguous()
+    assert torch.equal(li_o.clone(), eng.forward(xo)[0])
