@@ -22,7 +22,7 @@ import torch
 
 from . import _lib
 from .graph import GraphReplay
-from .prepare import (LayerNormParams, LinearParams, dyadic, f32, markstein_division_ok, pad_head, phi_is_identity, phi_table,
+from .prepare import (IMAGENET_MEAN, IMAGENET_STD, LayerNormParams, LinearParams, dyadic, f32, input_lut_u8, markstein_division_ok, pad_head, phi_is_identity, phi_table,
                       phi_tables, quant_sym,
                       requant_host, sym_scale)
 from .synth import IMG_SIZE
@@ -140,6 +140,8 @@ class IntSwinEngine(GraphReplay):
         # ---- stem (layers_quant.py:191-203 with norm_layer; swin_quant.py:541-546)
         s0 = s("qact_input")
         self.inv_s0 = float(f32(1.0) / s0)
+        self.s0 = float(s0)
+        self.input_lut = None
         s_bn = s("patch_embed.qact_before_norm")
         self.patch = lin_dev("patch_embed.proj", s0, s_bn)
         s_pq = s("patch_embed.qact")
@@ -318,11 +320,15 @@ class IntSwinEngine(GraphReplay):
                   _lib.ptr(ln["m"]), _lib.ptr(ln["e"]), _lib.ptr(out), ldo, H, W, ws, shift, st)
 
     # ------------------------------------------------------------------ forward
+    def set_input_normalisation(self, mean=IMAGENET_MEAN, std=IMAGENET_STD):
+        """uint8 input (see IntViTEngine.set_input_normalisation): the Normalize transform folded into the input table"""
+        self.input_lut = torch.from_numpy(input_lut_u8(self.s0, mean, std)).to(self.dev)
+
     def forward(self, images: torch.Tensor, taps: dict | None = None):
         """images: float32 [B,3,224,224] on the engine's device.  Returns (logits_int32 [B,1000], logits_f32, top1)
         -- views of the engine's workspace, valid until the next call.  `taps` (tests) receives clones of the
         intermediate integer tensors in the reference's layouts."""
-        assert images.is_cuda and images.dtype == torch.float32 and images.is_contiguous()
+        assert images.is_cuda and images.dtype in (torch.float32, torch.uint8) and images.is_contiguous()
         B = images.shape[0]
         assert images.shape[1:] == (3, IMG_SIZE, IMG_SIZE) and 0 < B <= self.max_batch
         ws = self.ws
@@ -340,8 +346,14 @@ class IntSwinEngine(GraphReplay):
                 v = v[perm]
             taps[name] = v.clone()
 
-        _lib.call("ivit_quantize_patchify_ld_f32_i8", _lib.ptr(images), _lib.ptr(ws["a0"]), 64, B, 3, IMG_SIZE, PATCH,
-                  self.inv_s0, st)
+        if images.dtype == torch.uint8:      # uint8 pixels: ToTensor + Normalize + the input QuantAct as a 3 x 256 table (engine.py)
+            if self.input_lut is None:
+                self.set_input_normalisation()
+            _lib.call("ivit_quantize_patchify_u8_i8", _lib.ptr(images), _lib.ptr(ws["a0"]), 64, B, 3, IMG_SIZE, PATCH,
+                      _lib.ptr(self.input_lut), st)
+        else:
+            _lib.call("ivit_quantize_patchify_ld_f32_i8", _lib.ptr(images), _lib.ptr(ws["a0"]), 64, B, 3, IMG_SIZE, PATCH,
+                      self.inv_s0, st)
         self._gemm(ws["a0"], 64, self.patch, ws["pe"], C0, M, st)
         tap("patch_embed.qact_before_norm", ws["pe"], M, C0)
         ln = self.patch_ln

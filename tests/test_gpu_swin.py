@@ -665,3 +665,18 @@ def test_layernorm_i16_natural_scale_random_vs_oracle(rows, Cn, s):
               _lib.ptr(dev(lp.s_ln)), _lib.ptr(dev(lp.m.view(np.int32))), _lib.ptr(dev(lp.e)), _lib.ptr(out), Cn, 0, 0, 0, 0, st())
     got = out.cpu().numpy().astype(np.int32)
     assert np.array_equal(got, exp), f"{(got != exp).sum()} of {got.size} differ"
+
+
+def test_swin_uint8_input_equals_the_float_pipeline():
+    """uint8 pixels (3 x 256 table of ToTensor + Normalize + the input QuantAct, 4 x 4 patches with the K padding) == the float32
+    images the data pipeline would hand over: INT32 logits"""
+    eng = build_swin(3)[0]
+    rng = np.random.default_rng(78)
+    u8 = torch.from_numpy(rng.integers(0, 256, size=(3, 3, 224, 224), dtype=np.uint8)).to(DEV)
+    from ivit_amd.prepare import IMAGENET_MEAN, IMAGENET_STD
+    mean = torch.tensor(IMAGENET_MEAN, device=DEV).view(1, 3, 1, 1)
+    std = torch.tensor(IMAGENET_STD, device=DEV).view(1, 3, 1, 1)
+    xf = ((u8.float().div(255) - mean) / std).contiguous()
+    li_f = eng.forward(xf)[0].clone()
+    li_u = eng.forward(u8)[0].clone()
+    assert torch.equal(li_u, li_f) and li_f.abs().max() > 0
