@@ -167,6 +167,12 @@ def worker(args):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
 
+    # stdout carries ONE JSON line.  RCCL prints a version banner to file descriptor 1 when its communicator comes up (at
+    # init_process_group with a device_id, or at the first collective): until the warm-up is over, fd 1 points at stderr.
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     if stub:
         dev, batch = "cpu", 8
         if grouped:
@@ -217,7 +223,12 @@ def worker(args):
     # ---- phase 1: the timed region
     for _ in range(args.warmup):
         dp.step(images)
+    if grouped:
+        dp.step(images)          # at least one collective before fd 1 comes back, also with --warmup 0
     sync()
+    sys.stdout.flush()
+    os.dup2(saved_stdout, 1)
+    os.close(saved_stdout)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         dp.step(images)
