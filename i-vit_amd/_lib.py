@@ -117,14 +117,10 @@ class IvitError(RuntimeError):
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile csrc/*.hip -> libivit_hip.so (hipcc --offload-arch=gfx950)."""
-    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
-    srcs.append(os.path.join(_HERE, "..", "include", "ivit_hip.h"))
-    stale = force or any(not os.path.exists(p) or any(os.path.getmtime(s) > os.path.getmtime(p) for s in srcs)
-                         for p in (LIB_PATH, LAB_PATH))
-    if stale:
-        cmd = ["make", "-C", CSRC, "-j4"] + ([] if verbose else ["-s"])
-        subprocess.check_call(cmd)
+    """Compile csrc/*.hip -> libivit_hip.so + libivit_hip_lab.so (hipcc --offload-arch=gfx950).  Always runs `make`: it is
+    incremental, and it also runs the register / scratch check of the GEMM kernels (csrc/Makefile, target `check`)."""
+    cmd = ["make", "-C", CSRC, "-j4"] + (["-B"] if force else []) + ([] if verbose else ["-s"])
+    subprocess.check_call(cmd)
     return LIB_PATH
 
 
