@@ -33,6 +33,7 @@ SIGNATURES = {
     "ivit_shiftgelu_build_lut_ex": [f32, u32, i32, vp, vp, vp],
     "ivit_shiftgelu_lut_i8_ex": [vp, i64, ci, ci, vp, vp, i64, ci, vp],
     "ivit_pack_weight_frags_i8": [vp, i64, ci, ci, vp, vp],
+    "ivit_pack_weight_frags16_i8": [vp, i64, ci, ci, vp, vp],
     "ivit_tile_operand_i8": [vp, i64, i64, ci, vp, vp],
     "ivit_untile_operand_i8": [vp, i64, ci, vp, i64, vp],
     "ivit_gemm_i8_requant_ex": [vp, i64, vp, i64, vp, vp, vp, vp, i64, ci, ci, ci, ci, vp],
@@ -105,6 +106,7 @@ SIGNATURES = {
 LAB_SIGNATURES = {
     "ivit_debug_force_small_gemm": [ci],
     "ivit_debug_set_gemm_flags": [ci],
+    "ivit_debug_set_gemm_flags2": [ci],
     "ivit_debug_ln_wave_per_row": [ci],
     "ivit_debug_ln_ablate": [ci],
     "ivit_debug_set_stamp_buffer": [vp],
@@ -173,6 +175,7 @@ class lab_session:
         L = lab()
         L.ivit_debug_force_small_gemm(0)
         L.ivit_debug_set_gemm_flags(0)
+        L.ivit_debug_set_gemm_flags2(0)
         L.ivit_debug_ln_wave_per_row(0)
         L.ivit_debug_ln_ablate(0)
         _use_lab = self.prev

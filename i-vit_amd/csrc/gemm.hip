@@ -518,7 +518,16 @@ IVIT_DEV WrWork wr_work(const GemmArgs& g, int i, int b, int G)
 }
 
 // ABL (lab build only): 1 no epilogue, 2 no weight loads in the loop, 4 no DMA in the loop, 8 no MFMA, 16 time stamps
-template <int EPI, int ABL = 0>
+//
+// S16: the same tile on v_mfma_i32_16x16x64_i8 (IVIT_W_FRAGS16) instead of v_mfma_i32_32x32x32_i8.  Same cycles per K step (32
+// instructions of 16 cycles against 16 of 32), same registers (32 accumulator tiles of 4), same bytes -- but under the power
+// limit the chip holds a higher clock on the 16x16 shape: bare loops on random int8 at this wave tile 4 000 against 3 353 TOPS
+// (2 029 against 1 687 MHz; with the token fragments re-read from LDS 3 572 against 3 099; equal on zeros --
+// scripts/probes/mfma_shape_probe.hip, profiles/r03a_mfma_shape_*.txt).  A fragment is 16 rows x 64 K bytes with lane
+// l = 16 c + r holding chunk c of row r, i.e. simply 1 KB in lane order: the LDS-DMA lays a token piece into its stage in
+// exactly that order (per-lane source addresses pick chunk (r, c) out of the row-major or block-layout operand), so the
+// fragment read is ds_read_b128 at lane * 16 -- conflict-free by construction, no swizzle on either side.
+template <int EPI, int ABL = 0, bool S16 = false>
 __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_wreg_kernel(GemmArgs g)
 {
     __shared__ __attribute__((aligned(16))) char smem[WR_SMEM];
@@ -539,15 +548,19 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_wreg_kernel(GemmArgs g)
         // loop they would occupy registers through the main loop (and were spilled)
         int lane_o = lane;
         asm volatile("" : "+v"(lane_o));
-        const int lrow_o = lane_o >> 2, lslot_o = lane_o & 3;
+        const int lrow_o = S16 ? (lane_o & 15) : (lane_o >> 2), lslot_o = S16 ? (lane_o >> 4) : (lane_o & 3);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int piece = wave + 4 * i;
             const int row = 16 * piece + lrow_o;
-            const int c = lslot_o ^ ((row >> 2) & 3);
+            // 32x32 form: LDS slot 4r + s holds chunk s ^ ((r >> 2) & 3) of row r (= the block layout: identity copy);
+            // S16: LDS slot 16 c + r holds chunk c of row r (fragment order)
+            const int c = S16 ? lslot_o : (lslot_o ^ ((row >> 2) & 3));
             asrc[i] = g.A + (int64_t)min(w.m0 + row, g.M - 1) * g.lda + 16 * c;
-            if (g.a_blocks)   // uniform block origin + lane * 16
-                asrc[i] = g.A + (int64_t)min((w.m0 >> 4) + piece, ((g.M + 15) >> 4) - 1) * (g.K >> 6) * 1024 + (unsigned)lane_o * 16u;
+            if (g.a_blocks) {  // uniform block origin + the chunk's position inside the 1 KB block
+                const unsigned pos = S16 ? (unsigned)(4 * lrow_o + (lslot_o ^ ((lrow_o >> 2) & 3))) : (unsigned)lane_o;
+                asrc[i] = g.A + (int64_t)min((w.m0 >> 4) + piece, ((g.M + 15) >> 4) - 1) * (g.K >> 6) * 1024 + pos * 16u;
+            }
         }
         const int cg = min((w.n0 >> 6) + wave, ((g.N + 63) >> 6) - 1);
         wsrc = g.W + (int64_t)cg * nk * 4096 + (unsigned)lane_o * 16u;
@@ -580,7 +593,8 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_wreg_kernel(GemmArgs g)
     };
 
     const unsigned smem_base = (unsigned)(__UINTPTR_TYPE__)(lptr_t)smem;
-    const unsigned abase[2] = {smem_base + (unsigned)swz(l31, h), smem_base + (unsigned)swz(l31, 2 + h)};
+    const unsigned abase[2] = {smem_base + (S16 ? (unsigned)lane * 16u : (unsigned)swz(l31, h)),
+                               smem_base + (S16 ? (unsigned)lane * 16u : (unsigned)swz(l31, 2 + h))};
     unsigned long long* stamp = nullptr;   // ABL & 16: [block][tile < 4][32]: tile start, loop start, loop end, epilogue end, step starts
 
     auto table_issue = [&](int n0) {
@@ -603,8 +617,10 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_wreg_kernel(GemmArgs g)
             lh.x = ((double)mf > M) ? __int_as_float(bits - 1) : mf;
             lh.y = ((double)mf < M) ? __int_as_float(bits + 1) : mf;
         }
-        reinterpret_cast<float2*>(tab)[tid] = lh;
-        reinterpret_cast<int*>(tab + WR_CH * 8)[tid] = r.bias;
+        int tid_w = tid;       // opaque: no loop-invariant address part is carried (and spilled) across the main loop
+        asm volatile("" : "+v"(tid_w));
+        reinterpret_cast<float2*>(tab)[tid_w] = lh;
+        reinterpret_cast<int*>(tab + WR_CH * 8)[tid_w] = r.bias;
     };
 
     // One work item: a full tile (128 tokens: 4 token sub-tiles per wave) or a half tile (64 tokens: 2).
@@ -613,13 +629,26 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_wreg_kernel(GemmArgs g)
         constexpr int TJ = HALF ? 2 : 4;
         constexpr int NP = HALF ? 1 : 2;          // DMA pieces per wave and K step
         v4i af0[TJ], af1[TJ];
-        auto load_frags = [&](unsigned stage_off, int ks, v4i (&af)[TJ]) {
-            const unsigned aa = abase[ks] + stage_off;
-            asm volatile("ds_read_b128 %0, %1" : "=v"(af[0]) : "v"(aa));
-            asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(af[1]) : "v"(aa));
-            if constexpr (TJ == 4) {
-                asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(af[2]) : "v"(aa));
-                asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(af[3]) : "v"(aa));
+        // 32x32 form: K half ks of the TJ token sub-tiles of 32;  S16: token sub-tiles TJ ks .. TJ ks + TJ - 1 of 16, all 64 K bytes
+        auto load_frags = [&](auto stage_tag, auto ks_tag, v4i (&af)[TJ]) {
+            constexpr int ST = decltype(stage_tag)::value, ks = decltype(ks_tag)::value;
+            constexpr unsigned stage_off = (unsigned)(ST * WR_STAGE);
+            if constexpr (S16) {   // one base register (lane * 16), everything else in the offset field
+                constexpr int O = ST * WR_STAGE + ks * TJ * 1024;
+                lds_read16_async_off<O>(af[0], abase[0]);
+                lds_read16_async_off<O + 1024>(af[1], abase[0]);
+                if constexpr (TJ == 4) {
+                    lds_read16_async_off<O + 2048>(af[2], abase[0]);
+                    lds_read16_async_off<O + 3072>(af[3], abase[0]);
+                }
+            } else {
+                const unsigned aa = abase[ks] + stage_off;
+                asm volatile("ds_read_b128 %0, %1" : "=v"(af[0]) : "v"(aa));
+                asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(af[1]) : "v"(aa));
+                if constexpr (TJ == 4) {
+                    asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(af[2]) : "v"(aa));
+                    asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(af[3]) : "v"(aa));
+                }
             }
         };
         auto wait_frags = [&](v4i (&af)[TJ]) {   // at most the newest group of reads outstanding
@@ -644,16 +673,39 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_wreg_kernel(GemmArgs g)
                     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(af[0]), "+v"(af[1]), "+v"(wn[0]), "+v"(wn[1]), "+v"(wn[2]), "+v"(wn[3])::"memory");
             }
         };
-        v16i acc[2][TJ];
+        v16i acc[S16 ? 1 : 2][S16 ? 1 : TJ];      // 32x32 form: channel sub-tile i (32) x token sub-tile j (32)
+        v4i acc16[S16 ? 4 : 1][S16 ? 2 * TJ : 1];  // S16: channel sub-tile i (16) x token sub-tile j (16)
         // K step kt on weight buffer wc (current), wn (next: waited for here), wf (the one after: loaded here)
-        auto step = [&](int kt, v4i (&wc)[4], v4i (&wn)[4], v4i (&wf)[4], auto issue_tag, auto last_tag) {
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>;
+        // stage_tag: kt % WR_STAGES as a compile-time constant (nk % 3 == 0: the unrolled steps know their stage)
+        auto step = [&](int kt, v4i (&wc)[4], v4i (&wn)[4], v4i (&wf)[4], auto issue_tag, auto last_tag, auto stage_tag) {
             constexpr bool ISSUE = decltype(issue_tag)::value;
             constexpr bool LAST = decltype(last_tag)::value;
+            constexpr int ST = decltype(stage_tag)::value;
             if constexpr (ABL & 16)
                 if (stamp && kt < 12) stamp[4 + kt] = __builtin_amdgcn_s_memtime();
-            load_frags((unsigned)((kt % WR_STAGES) * WR_STAGE), 1, af1);
+            load_frags(stage_tag, I1{}, af1);
             wait_frags(af0);
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (S16) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j) {
+                        if constexpr (!(ABL & 8)) acc16[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wc[i], af0[j], acc16[i][j], 0, 0, 0);
+                        else asm volatile("" : "+v"(acc16[i][j]) : "v"(wc[i]), "v"(af0[j]));
+                        if constexpr (ISSUE) {   // NP + 4 loads of K step kt + 2: one behind every other MFMA (full tile: 16 MFMAs,
+                            const int n = TJ * i + j;   // six loads), behind each of the first five (half tile: 8 MFMAs, five loads)
+                            const int u = HALF ? n : (n >> 1);
+                            if (HALF || (n & 1) == 0) {
+                                if (u < NP) { if constexpr (!(ABL & 4)) issue_dma(kt + 2, u); }
+                                else if (u < NP + 4) { if constexpr (!(ABL & 2)) issue_w(wf, kt + 2, u - NP); }
+                            }
+                        }
+                    }
+            } else {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -671,12 +723,22 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_wreg_kernel(GemmArgs g)
                         }
                     }
                 }
+            }
             __builtin_amdgcn_sched_barrier(0);
             wait_next(issue_tag, af1, wn);
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if constexpr (!LAST) load_frags((unsigned)(((kt + 1) % WR_STAGES) * WR_STAGE), 0, af0);
+            if constexpr (!LAST) load_frags(std::integral_constant<int, (ST + 1) % WR_STAGES>{}, I0{}, af0);
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (S16) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j) {
+                        if constexpr (!(ABL & 8)) acc16[i][TJ + j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wc[i], af1[j], acc16[i][TJ + j], 0, 0, 0);
+                        else asm volatile("" : "+v"(acc16[i][TJ + j]) : "v"(wc[i]), "v"(af1[j]));
+                    }
+            } else {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -684,6 +746,7 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_wreg_kernel(GemmArgs g)
                     if constexpr (!(ABL & 8)) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wc[2 * i + 1], af1[j], acc[i][j], 0, 0, 0);
                     else asm volatile("" : "+v"(acc[i][j]) : "v"(wc[2 * i + 1]), "v"(af1[j]));
                 }
+            }
             __builtin_amdgcn_sched_barrier(0);
         };
 
@@ -699,6 +762,22 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_wreg_kernel(GemmArgs g)
         asm volatile("" : "+v"(wr0[0]), "+v"(wr0[1]), "+v"(wr0[2]), "+v"(wr0[3])::"memory");
         __builtin_amdgcn_s_barrier();     // everyone's stage 0; table visible
         asm volatile("" ::: "memory");
+        if constexpr (S16) {   // lane (g4, l15): channels 64 wave + 16 i + 4 g4 + r of register r
+            int lane_b = lane;     // opaque: the address is derived here, not carried through the tile loop (it was spilled)
+            asm volatile("" : "+v"(lane_b));
+            const unsigned ba = lds_addr(tab) + (unsigned)(WR_CH * 8 + 4 * (64 * wave + 4 * (lane_b >> 4)));
+            v4i bq[4];
+            lds_read16_async_off<0>(bq[0], ba);
+            lds_read16_async_off<64>(bq[1], ba);
+            lds_read16_async_off<128>(bq[2], ba);
+            lds_read16_async_off<192>(bq[3], ba);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                lds_wait(bq[i]);
+#pragma unroll
+                for (int j = 0; j < 2 * TJ; ++j) acc16[i][j] = bq[i];
+            }
+        } else {
         v4i bq[2][4];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -719,18 +798,19 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_wreg_kernel(GemmArgs g)
                     acc[i][j][4 * q + 3] = b4.w;
                 }
             }
-        load_frags(0u, 0, af0);
+        }
+        load_frags(I0{}, I0{}, af0);
         if constexpr (ABL & 16)
             if (stamp) stamp[1] = __builtin_amdgcn_s_memtime();
         int kt = 0;
         for (; kt + 3 < nk; kt += 3) {
-            step(kt, wr0, wr1, wr2, T{}, F{});
-            step(kt + 1, wr1, wr2, wr0, T{}, F{});
-            step(kt + 2, wr2, wr0, wr1, T{}, F{});
+            step(kt, wr0, wr1, wr2, T{}, F{}, I0{});
+            step(kt + 1, wr1, wr2, wr0, T{}, F{}, I1{});
+            step(kt + 2, wr2, wr0, wr1, T{}, F{}, I2{});
         }
-        step(kt, wr0, wr1, wr2, T{}, F{});
-        step(kt + 1, wr1, wr2, wr0, F{}, F{});
-        step(kt + 2, wr2, wr0, wr1, F{}, T{});
+        step(kt, wr0, wr1, wr2, T{}, F{}, I0{});
+        step(kt + 1, wr1, wr2, wr0, F{}, F{}, I1{});
+        step(kt + 2, wr2, wr0, wr1, F{}, T{}, I2{});
         if constexpr (ABL & 16)
             if (stamp) stamp[2] = __builtin_amdgcn_s_memtime();
         // every wave's reads of every stage returned before the barrier of the last step: the ring is free
@@ -757,19 +837,31 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_wreg_kernel(GemmArgs g)
         Hook hook{table_issue, table_write, nxt.n0, tab_next, more, PersTableLoad{0u, 0, 0, false}};
         if constexpr (ABL & 1) {
             int sum = 0;
+            if constexpr (S16) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2 * TJ; ++j) sum ^= acc16[i][j][0] ^ acc16[i][j][1] ^ acc16[i][j][2] ^ acc16[i][j][3];
+            } else {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < TJ; ++j)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) sum ^= acc[i][j][r];
+            }
             if (sum == 0x12345679) reinterpret_cast<int*>(g.out)[tid] = sum;
             hook.issue();
             hook.consume();
         } else {
             int tid_o = tid;   // opaque: the epilogue's per-thread addresses are computed here, not carried through the main loop
             asm volatile("" : "+v"(tid_o));
-            if constexpr (EPI == EPI_RQ16_RES16)
+            if constexpr (S16) {
+                static_assert(!S16 || EPI != EPI_RQ16_RES16, "the 16-bit epilogue exists for the 32x32 form only");
+                epilogue_i8_16<EPI, 2 * TJ, BIG_NT, (ABL & 64), WR_CH, Hook>(acc16, g, cs, tab, cur.m0, cur.n0, 64 * wave, tid_o, (tid_o >> 4) & 3,
+                                                                          tid_o & 15, hook,
+                                                                          g.lut ? reinterpret_cast<const unsigned char*>(smem + WR_LUT) : nullptr);
+            } else if constexpr (EPI == EPI_RQ16_RES16)
                 epilogue_rq16_res16<TJ, BIG_NT, Hook>(acc, g, cs, cur.m0, cur.n0, 64 * wave, tid_o, (tid_o >> 5) & 1, tid_o & 31, hook);
             else
             epilogue_i8<EPI, 2, TJ, 32 * TJ, BIG_NT, (ABL & 64), WR_CH, Hook>(acc, g, cs, tab, cur.m0, cur.n0, 64 * wave, 0, tid_o, (tid_o >> 5) & 1,
@@ -846,6 +938,7 @@ int launch_gemm(GemmArgs& g, const char* name, ivit_stream_t stream)
                      "%s: N=%d != 3*heads*head_dim or M=%d %% tokens=%d != 0", name, g.N, g.M, g.tokens);
     }
     g.flags = g_debug_flags & (31 | 128 | 256 | 512);
+    g.flags2 = g_debug_flags2;
     const bool blocks = g.a_blocks || g.w_blocks;
     if (blocks && !g.w_frags) {
         IVIT_REQUIRE(EPI != EPI_I32 && EPI != EPI_RQ16 && g.M >= 2048 && g.N >= BCH && !g_force_small,
@@ -881,6 +974,14 @@ int launch_gemm(GemmArgs& g, const char* name, ivit_stream_t stream)
                 }
             }
 #endif
+            if (g.w_frags == 2) {     // IVIT_W_FRAGS16: the v_mfma_i32_16x16x64_i8 form
+                if constexpr (EPI != EPI_RQ16_RES16) {
+                    hipLaunchKernelGGL((gemm_i8_wreg_kernel<EPI, 0, true>), grid, dim3(BIG_NT), 0, ivit_stream(stream), g);
+                    IVIT_CHECK_LAUNCH(name);
+                } else {
+                    IVIT_REQUIRE(false, "%s: IVIT_W_FRAGS16 has no 16-bit epilogue; pack the weights with ivit_pack_weight_frags_i8", name);
+                }
+            }
             hipLaunchKernelGGL((gemm_i8_wreg_kernel<EPI>), grid, dim3(BIG_NT), 0, ivit_stream(stream), g);
             IVIT_CHECK_LAUNCH(name);
         }
@@ -945,7 +1046,32 @@ __global__ __launch_bounds__(256) void pack_weight_frags_kernel(const int8_t* W,
     }
 }
 
+// the same for v_mfma_i32_16x16x64_i8 (IVIT_W_FRAGS16): per 64 channels and K step four 1 KB pieces, piece i = channels 16 i ..
+// 16 i + 15, lane l = 16 c + r holds K bytes 16 c .. 16 c + 15 of channel 16 i + r
+__global__ __launch_bounds__(256) void pack_weight_frags16_kernel(const int8_t* W, int64_t ldw, int N, int K, int8_t* dst)
+{
+    const int c16 = K >> 4, n64 = (N + 63) & ~63;
+    const int64_t total = (int64_t)n64 * c16;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (int64_t)gridDim.x * 256) {
+        const int n = (int)(q / c16), k = (int)(q - (int64_t)n * c16) << 4;
+        int4 v = make_int4(0, 0, 0, 0);
+        if (n < N) v = *reinterpret_cast<const int4*>(W + (int64_t)n * ldw + k);
+        const int64_t off = ((int64_t)(n >> 6) * (K >> 6) + (k >> 6)) * 4096 + ((n >> 4) & 3) * 1024 + ((k >> 4) & 3) * 256 + (n & 15) * 16;
+        *reinterpret_cast<int4*>(dst + off) = v;
+    }
+}
+
 }  // namespace
+
+IVIT_EXPORT int ivit_pack_weight_frags16_i8(const int8_t* W, int64_t ldw, int N, int K, int8_t* dst, ivit_stream_t stream)
+{
+    IVIT_REQUIRE(W && dst && N > 0 && K > 0 && K % 64 == 0 && ldw >= K && ldw % 16 == 0 && ((uintptr_t)W % 16 == 0) && ((uintptr_t)dst % 16 == 0),
+                 "ivit_pack_weight_frags16_i8: bad operand (K must be a multiple of 64, rows 16-byte aligned)");
+    const int64_t total = (int64_t)((N + 63) & ~63) * (K >> 4);
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(pack_weight_frags16_kernel, dim3(grid), dim3(256), 0, ivit_stream(stream), W, ldw, N, K, dst);
+    IVIT_CHECK_LAUNCH("ivit_pack_weight_frags16_i8");
+}
 
 IVIT_EXPORT int ivit_pack_weight_frags_i8(const int8_t* W, int64_t ldw, int N, int K, int8_t* dst, ivit_stream_t stream)
 {
@@ -964,8 +1090,8 @@ IVIT_EXPORT int ivit_gemm_i8_requant_ex(const int8_t* A, int64_t lda, const int8
     GemmArgs g{};
     g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.m = m; g.e = e;
     g.out = out; g.ldo = ldo; g.M = M; g.N = N; g.K = K;
-    g.a_blocks = layouts & 1; g.w_blocks = (layouts >> 1) & 1; g.out_blocks = (layouts >> 2) & 1; g.w_frags = (layouts >> 3) & 1;
-    IVIT_REQUIRE((layouts & ~15) == 0, "ivit_gemm_i8_requant_ex: unknown layout bits");
+    g.a_blocks = layouts & 1; g.w_blocks = (layouts >> 1) & 1; g.out_blocks = (layouts >> 2) & 1; g.w_frags = (layouts & 16) ? 2 : ((layouts >> 3) & 1);
+    IVIT_REQUIRE((layouts & ~31) == 0 && (layouts & 24) != 24, "ivit_gemm_i8_requant_ex: unknown layout bits");
     IVIT_REQUIRE(!g.out_blocks || (N % 64 == 0 && ldo == N && ((int64_t)M + 15) * N < 2147483648ll),
                  "ivit_gemm_i8_requant_ex: block-layout output needs N %% 64 == 0, ldo == N and a buffer below 2 GiB");
     return launch_gemm<EPI_RQ>(g, "ivit_gemm_i8_requant_ex", stream);
@@ -978,8 +1104,8 @@ IVIT_EXPORT int ivit_gemm_i8_requant_lut_ex(const int8_t* A, int64_t lda, const 
     GemmArgs g{};
     g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.m = m; g.e = e;
     g.out = out; g.ldo = ldo; g.M = M; g.N = N; g.K = K; g.lut = lut;
-    g.a_blocks = layouts & 1; g.w_blocks = (layouts >> 1) & 1; g.out_blocks = (layouts >> 2) & 1; g.w_frags = (layouts >> 3) & 1;
-    IVIT_REQUIRE(lut && (layouts & ~15) == 0 && g.w_frags, "ivit_gemm_i8_requant_lut_ex: needs a map and IVIT_W_FRAGS");
+    g.a_blocks = layouts & 1; g.w_blocks = (layouts >> 1) & 1; g.out_blocks = (layouts >> 2) & 1; g.w_frags = (layouts & 16) ? 2 : ((layouts >> 3) & 1);
+    IVIT_REQUIRE(lut && (layouts & ~31) == 0 && (layouts & 24) != 24 && g.w_frags, "ivit_gemm_i8_requant_lut_ex: needs a map and IVIT_W_FRAGS");
     IVIT_REQUIRE(!g.out_blocks || (N % 64 == 0 && ldo == N && ((int64_t)M + 15) * N < 2147483648ll),
                  "ivit_gemm_i8_requant_lut_ex: block-layout output needs N %% 64 == 0, ldo == N and a buffer below 2 GiB");
     return launch_gemm<EPI_RQ>(g, "ivit_gemm_i8_requant_lut_ex", stream);
@@ -1005,8 +1131,8 @@ IVIT_EXPORT int ivit_gemm_i8_requant_residual_ex(const int8_t* A, int64_t lda, c
     g.M_res = ivit_dyadic_to_double(m_res, e_res);
     IVIT_REQUIRE(g.M_main < 1048576.0 && g.M_res < 1048576.0,
                  "ivit_gemm_i8_requant_residual_ex: residual multiplier >= 2^20 is outside the int8 fast path");
-    g.a_blocks = layouts & 1; g.w_blocks = (layouts >> 1) & 1; g.w_frags = (layouts >> 3) & 1;
-    IVIT_REQUIRE((layouts & ~11) == 0, "ivit_gemm_i8_requant_residual_ex: unknown layout bits");
+    g.a_blocks = layouts & 1; g.w_blocks = (layouts >> 1) & 1; g.w_frags = (layouts & 16) ? 2 : ((layouts >> 3) & 1);
+    IVIT_REQUIRE((layouts & ~27) == 0 && (layouts & 24) != 24, "ivit_gemm_i8_requant_residual_ex: unknown layout bits");
     return launch_gemm<EPI_RESID>(g, "ivit_gemm_i8_requant_residual_ex", stream);
 }
 
@@ -1026,8 +1152,8 @@ IVIT_EXPORT int ivit_gemm_i8_requant_residual_i16_ex(const int8_t* A, int64_t ld
                                                   int K, int layouts, ivit_stream_t stream)
 {
     GemmArgs g{};
-    g.a_blocks = layouts & 1; g.w_blocks = (layouts >> 1) & 1; g.w_frags = (layouts >> 3) & 1;
-    IVIT_REQUIRE((layouts & ~11) == 0, "ivit_gemm_i8_requant_residual_i16_ex: unknown layout bits");
+    g.a_blocks = layouts & 1; g.w_blocks = (layouts >> 1) & 1; g.w_frags = (layouts & 16) ? 2 : ((layouts >> 3) & 1);
+    IVIT_REQUIRE((layouts & ~27) == 0 && (layouts & 24) != 24, "ivit_gemm_i8_requant_residual_i16_ex: unknown layout bits");
     g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.m = m; g.e = e;
     g.res = reinterpret_cast<const int8_t*>(res); g.ldr = ldr;
     g.out = out; g.ldo = ldo; g.M = M; g.N = N; g.K = K;
@@ -1055,8 +1181,8 @@ IVIT_EXPORT int ivit_gemm_i8_requant_qkv_ex(const int8_t* A, int64_t lda, const 
     g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.m = m; g.e = e;
     g.out = qkv; g.ldo = 0; g.M = M; g.N = N; g.K = K;
     g.tokens = tokens; g.heads = heads; g.head_dim = head_dim;
-    g.a_blocks = layouts & 1; g.w_blocks = (layouts >> 1) & 1; g.w_frags = (layouts >> 3) & 1;
-    IVIT_REQUIRE((layouts & ~11) == 0, "ivit_gemm_i8_requant_qkv_ex: unknown layout bits");
+    g.a_blocks = layouts & 1; g.w_blocks = (layouts >> 1) & 1; g.w_frags = (layouts & 16) ? 2 : ((layouts >> 3) & 1);
+    IVIT_REQUIRE((layouts & ~27) == 0 && (layouts & 24) != 24, "ivit_gemm_i8_requant_qkv_ex: unknown layout bits");
     return launch_gemm<EPI_QKV>(g, "ivit_gemm_i8_requant_qkv_ex", stream);
 }
 
@@ -1085,7 +1211,7 @@ IVIT_EXPORT int ivit_gemm_i8_requant_i16_residual_i16_ex(const int8_t* A, int64_
                                                          int K, int layouts, ivit_stream_t stream)
 {
     GemmArgs g{};
-    g.a_blocks = layouts & 1; g.w_frags = (layouts >> 3) & 1;
+    g.a_blocks = layouts & 1; g.w_frags = (layouts & 16) ? 2 : ((layouts >> 3) & 1);
     IVIT_REQUIRE((layouts & ~9) == 0 && (g.w_frags || !g.a_blocks), "ivit_gemm_i8_requant_i16_residual_i16_ex: layouts is 0 or IVIT_W_FRAGS (| IVIT_A_BLOCKS)");
     g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.m = m; g.e = e;
     g.res = reinterpret_cast<const int8_t*>(res); g.ldr = ldr;

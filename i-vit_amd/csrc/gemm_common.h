@@ -17,10 +17,15 @@ extern int g_kernel_choice;   // 0 = automatic, 1 = never the 256x256 kernel
 extern bool g_force_small;    // route every problem through the small-tile kernel
 extern void* g_stamp_buf;     // timeline buffer of the stamped builds
 extern int g_debug_flags;     // see ivit_debug_set_gemm_flags
+extern int g_debug_flags2;    // see ivit_debug_set_gemm_flags2 (cache-policy A/B of the weights-in-registers kernel)
 #else
 constexpr int g_kernel_choice = 0;
 constexpr bool g_force_small = false;
 constexpr int g_debug_flags = 0;
+constexpr int g_debug_flags2 = 0;
+#endif
+#ifndef IVIT_STORE_POLICY
+#define IVIT_STORE_POLICY 0    // product default of store16_sel (see there)
 #endif
 
 namespace {
@@ -67,6 +72,7 @@ struct GemmArgs {
     int a_blocks, w_blocks;   // operand in the block layout (common.h: ivit_block_offset); persistent kernel only
     int out_blocks;           // EPI_RQ: the int8 output in the block layout (row length N): it is the next GEMM's A operand
     int w_frags;              // W is the MFMA-fragment copy (ivit_pack_weight_frags_i8): the weights-in-registers kernel
+    int flags2;               // lab build only (ivit_debug_set_gemm_flags2): cache policies of the epilogue's stores / residual loads
     const int8_t* lut;        // EPI_RQ, weights-in-registers kernel: out = lut[q + 128] applied to every requantised byte (an
                               // elementwise int8 -> int8 operator behind the QuantAct, e.g. I-BERT GELU + mlp.qact1), or NULL
 };
@@ -86,6 +92,8 @@ typedef int v2i __attribute__((ext_vector_type(2)));
 IVIT_DEV unsigned lds_addr(const void* p) { return (unsigned)(__UINTPTR_TYPE__)(lds_ptr_t)p; }
 IVIT_DEV void lds_read16_async(v4f& d, unsigned a) { asm volatile("ds_read_b128 %0, %1" : "=v"(d) : "v"(a)); }
 IVIT_DEV void lds_read16_async(v4i& d, unsigned a) { asm volatile("ds_read_b128 %0, %1" : "=v"(d) : "v"(a)); }
+template <int OFF> IVIT_DEV void lds_read16_async_off(v4i& d, unsigned a) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(a), "n"(OFF)); }
+template <int OFF> IVIT_DEV void lds_read16_async_off(v4f& d, unsigned a) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(a), "n"(OFF)); }
 IVIT_DEV void lds_read8x2_async(v2i& d, unsigned a) { asm volatile("ds_read2_b32 %0, %1 offset1:1" : "=v"(d) : "v"(a)); }
 IVIT_DEV void lds_wait(v4f& a, v4f& b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b)); }
 IVIT_DEV void lds_wait(v4i& a) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a)); }
@@ -96,6 +104,46 @@ IVIT_DEV int pack4_i8(int a, int b, int c, int d)
     return (a & 0xff) | ((b & 0xff) << 8) | ((c & 0xff) << 16) | ((d & 0xff) << 24);
 }
 
+
+// Cache policy of the epilogue's 16-byte output stores (MI355X_MICROARCH.md, "stores of each flavour": plain / nt keep the line in
+// the XCD's L2, sc1 / sc0 sc1 write through and drop it).  The output of a GEMM is consumed by the NEXT kernel, never by this one:
+// keeping it in L2 only displaces the weight and token panels the other workgroups of the XCD are re-reading.
+// POL: 0 plain, 1 nt, 2 sc1, 3 sc0 sc1.  The asm stores are invisible to the compiler's vmcnt bookkeeping, which can only make its
+// own counted waits wait for more (loads and stores retire in issue order).
+template <int POL>
+IVIT_DEV void store16_pol(void* p, int4 v)
+{
+    typedef int v4i_ __attribute__((ext_vector_type(4)));
+    const v4i_ d = {v.x, v.y, v.z, v.w};
+    if constexpr (POL == 0) *reinterpret_cast<int4*>(p) = v;
+    else if constexpr (POL == 1) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(d) : "memory");
+    else if constexpr (POL == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(d) : "memory");
+    else asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(d) : "memory");
+}
+IVIT_DEV void store16_sel(void* p, int4 v, int pol)
+{
+#if IVIT_LAB
+    switch (pol & 3) {     // uniform
+        case 1: store16_pol<1>(p, v); return;
+        case 2: store16_pol<2>(p, v); return;
+        case 3: store16_pol<3>(p, v); return;
+        default: break;
+    }
+#endif
+    store16_pol<IVIT_STORE_POLICY>(p, v);
+}
+// the residual operand is read exactly once: nt keeps it from displacing L2 lines that are re-read
+IVIT_DEV int4 load16_sel(const void* p, int pol)
+{
+#if IVIT_LAB
+    if (pol & 4) {
+        typedef int v4i_ __attribute__((ext_vector_type(4)));
+        const v4i_ d = __builtin_nontemporal_load(reinterpret_cast<const v4i_*>(p));
+        return make_int4(d.x, d.y, d.z, d.w);
+    }
+#endif
+    return *reinterpret_cast<const int4*>(p);
+}
 
 // ---- shared int8 epilogue --------------------------------------------------------------------
 // acc[TI][TJ]: TI channel sub-tiles x TJ token sub-tiles of 32x32 owned by this wave, channel origin
@@ -126,109 +174,13 @@ struct NoHook {
     IVIT_DEV void consume() const {}
 };
 
-template <int EPI, int TI, int TJ, int TOK, int NTHREADS, int ABL = 0, int CH = 128, typename Hook = NoHook>
-IVIT_DEV void epilogue_i8(v16i (&acc)[TI][TJ], const GemmArgs& g, char* smem, const char* rq_lds, int m0, int n0,
-                          int wch, int wtok, int tid, int h, int l31, const Hook& hook = Hook(),
-                          const unsigned char* lut_lds = nullptr)
+// Phase 2 of the int8 epilogues: the staged tile Cs[token][channel] (row stride CH + 4) -> 16-byte row-contiguous chunks: optional
+// residual QuantAct, optional head-major remap or byte map, store.  Called by every thread right after its phase-1 LDS writes.
+template <int EPI, int TOK, int NTHREADS, int ABL, int CH, typename Hook>
+IVIT_DEV void epilogue_phase2(const GemmArgs& g, char* smem, int m0, int n0, int tid, const Hook& hook, const unsigned char* lut_lds)
 {
-    // The epilogue is a short VALU burst next to the co-resident workgroup's MFMA stream: give it issue priority
-    // so its dependent chains do not wait behind queued MFMAs (which run in the matrix pipe once issued).
-    __builtin_amdgcn_s_setprio(2);
-    hook.issue();    // persistent kernels: the next tile's table loads have all of phase 1 to land
-    constexpr int CSS = CH + 4;       // LDS row stride: (CH/4 + 1) dwords, odd -> conflict-free dword writes
-    constexpr int CPR = CH / 16;      // 16-byte chunks per row
-    // Phase 1.  out = clamp8(RNE(acc * M)), M = m * 2^-e, must equal the reference's float64
-    // evaluation (quant_utils.py:229-230) bit for bit.  Fast path on the ordinary float32 VALU (the
-    // float64 ops contend with the MFMA pipe): with lo <= M <= hi the two float32 neighbours of M,
-    //   t_lo = fma(acc, lo, 1.5*2^23), t_hi = fma(acc, hi, 1.5*2^23)
-    // are RNE(acc*lo) and RNE(acc*hi) exactly (one rounding, ulp 1), and RNE is monotone, so
-    // t_lo == t_hi certifies RNE(acc*M) -- including exact ties, which straddle and fail the test.
-    // Valid while acc is exact in float32 and |acc*hi| < 2^22 (M <= 1 is part of the contract), i.e.
-    // |acc| < 2^22; anything else, and any failed certificate, takes the float64 path for that quad.
-    // (lo, hi) of the quad's four channels: read one batch ahead (double-buffered), invisible to the compiler (see lds_read16_async)
-    const unsigned rq_a = lds_addr(rq_lds) + 8u * (unsigned)(wch + 4 * h);
-    v4f lhbuf[2][2];
-    lds_read16_async(lhbuf[0][0], rq_a);
-    lds_read16_async(lhbuf[0][1], rq_a + 16u);
-#pragma unroll
-    for (int i = 0; i < TI; ++i) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int cl = wch + 32 * i + 8 * q + 4 * h;  // local channel of the quad
-            v4f& lh01 = lhbuf[(4 * i + q) & 1][0];      // lo0 hi0 lo1 hi1
-            v4f& lh23 = lhbuf[(4 * i + q) & 1][1];      // lo2 hi2 lo3 hi3
-            lds_wait(lh01, lh23);
-            if (4 * i + q + 1 < 4 * TI) {
-                const int nb = 4 * i + q + 1;
-                lds_read16_async(lhbuf[nb & 1][0], rq_a + 8u * (unsigned)(32 * (nb >> 2) + 8 * (nb & 3)));
-                lds_read16_async(lhbuf[nb & 1][1], rq_a + 8u * (unsigned)(32 * (nb >> 2) + 8 * (nb & 3)) + 16u);
-            }
-            const float lo[4] = {lh01.x, lh01.z, lh23.x, lh23.z};
-            const float hi[4] = {lh01.y, lh01.w, lh23.y, lh23.w};
-            // one branch-free batch of TJ*4 independent chains (instruction-level parallelism: the wave that
-            // runs this shares its SIMD with a main-loop wave, so there is no second VALU wave to hide latency)
-            int b[TJ][4];
-            unsigned unc = 0;      // OR of (t_lo ^ t_hi): non-zero <=> some certificate failed
-            float amax = 0.0f;
-#pragma unroll
-            for (int j = 0; j < TJ; ++j)
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
-                    if constexpr (ABL & 8) {
-                        b[j][jj] = acc[i][j][4 * q + jj] + (int)lo[jj];
-                    } else {
-                        const float a = (float)acc[i][j][4 * q + jj];
-                        int tl, th;
-                        if constexpr (ABL & 64) {   // A/B: both brackets in one packed fma (lo, hi are adjacent table entries)
-                            typedef float v2f_ __attribute__((ext_vector_type(2)));
-                            const v2f_ r = __builtin_elementwise_fma((v2f_){a, a}, (v2f_){lo[jj], hi[jj]}, (v2f_){12582912.0f, 12582912.0f});
-                            tl = __float_as_int(r.x);
-                            th = __float_as_int(r.y);
-                        } else {
-                            tl = __float_as_int(__builtin_fmaf(a, lo[jj], 12582912.0f));
-                            th = __float_as_int(__builtin_fmaf(a, hi[jj], 12582912.0f));
-                        }
-                        // unc += |tl - th| in ONE instruction (v_sad_u32): zero iff every certificate of the batch holds.
-                        // tl, th are bit patterns of floats next to 1.5 * 2^23, their differences are tiny: no wrap-around.
-                        if constexpr (ABL & 32) {   // A/B: the former two-instruction form
-                            unc |= (unsigned)(tl ^ th);
-                            asm volatile("" : "+v"(unc));
-                        } else {
-                            asm("v_sad_u32 %0, %1, %2, %3" : "=v"(unc) : "v"(tl), "v"(th), "v"(unc));
-                        }
-                        amax = fmaxf(amax, fabsf(a));
-                        b[j][jj] = clamp_i32(tl, 0x4B400000 - 128, 0x4B400000 + 127);  // low byte = int8 result
-                    }
-                }
-            if constexpr (!(ABL & 8)) {
-                const bool bad = (unc != 0) | (amax >= 4194304.0f);
-                if (__builtin_amdgcn_ballot_w64(bad) != 0) {  // rare: exact float64 evaluation of the batch
-                    const int c0 = min(n0 + cl, g.N - 4);
-                    const uint4 m4 = *reinterpret_cast<const uint4*>(g.m + c0);
-                    const int4 e4 = *reinterpret_cast<const int4*>(g.e + c0);
-                    const double Mc[4] = {dyadic_mult(m4.x, e4.x), dyadic_mult(m4.y, e4.y), dyadic_mult(m4.z, e4.z),
-                                          dyadic_mult(m4.w, e4.w)};
-#pragma unroll
-                    for (int j = 0; j < TJ; ++j)
-#pragma unroll
-                        for (int jj = 0; jj < 4; ++jj) {
-                            // quant_utils.py:229-230: float64 product (53-bit rounding), /2^e, round-half-even
-                            double p = (double)acc[i][j][4 * q + jj] * Mc[jj];
-                            double t = p + IVIT_MAGIC;
-                            b[j][jj] = clamp_i32((int)(unsigned)__double_as_longlong(t), -128, 127);
-                        }
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < TJ; ++j) {
-                const int tl_ = wtok + 32 * j + l31;
-                const unsigned w01 = __builtin_amdgcn_perm((unsigned)b[j][1], (unsigned)b[j][0], 0x0c0c0400u);
-                const unsigned w23 = __builtin_amdgcn_perm((unsigned)b[j][3], (unsigned)b[j][2], 0x04000c0cu);
-                *reinterpret_cast<unsigned*>(smem + tl_ * CSS + cl) = w01 | w23;
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
+    constexpr int CSS = CH + 4;
+    constexpr int CPR = CH / 16;
     unsigned long long t_p1 = 0, t_sync = 0;
     if constexpr (ABL & 512) t_p1 = __builtin_amdgcn_s_memtime();
     // Phase 2 work items of this thread: NIT chunks (token row tl, 16-byte column chunk cc).  The residual loads go out BEFORE the
@@ -244,7 +196,7 @@ IVIT_DEV void epilogue_i8(v16i (&acc)[TI][TJ], const GemmArgs& g, char* smem, co
                 const int tl = q / CPR, cc = q % CPR;
                 const int t = min(m0 + tl, g.M - 1), cn = min(n0 + 16 * cc, g.N - 16);
                 if constexpr (EPI == EPI_RESID) {
-                    rv[it] = *reinterpret_cast<const int4*>(g.res + (int64_t)t * g.ldr + cn);
+                    rv[it] = load16_sel(g.res + (int64_t)t * g.ldr + cn, g.flags2);
                 } else {
                     const int4* rp = reinterpret_cast<const int4*>(reinterpret_cast<const int16_t*>(g.res) + (int64_t)t * g.ldr + cn);
                     rw[it][0] = rp[0];
@@ -370,8 +322,186 @@ IVIT_DEV void epilogue_i8(v16i (&acc)[TI][TJ], const GemmArgs& g, char* smem, co
         } else {
             off = (EPI == EPI_RQ && g.out_blocks) ? (int64_t)block_off(block_row(t, g.N), block_col(cn)) : (int64_t)t * g.ldo + cn;
         }
-        *reinterpret_cast<int4*>(out + off) = make_int4(v[it][0], v[it][1], v[it][2], v[it][3]);
+        store16_sel(out + off, make_int4(v[it][0], v[it][1], v[it][2], v[it][3]), g.flags2);
     }
+}
+
+template <int EPI, int TI, int TJ, int TOK, int NTHREADS, int ABL = 0, int CH = 128, typename Hook = NoHook>
+IVIT_DEV void epilogue_i8(v16i (&acc)[TI][TJ], const GemmArgs& g, char* smem, const char* rq_lds, int m0, int n0,
+                          int wch, int wtok, int tid, int h, int l31, const Hook& hook = Hook(),
+                          const unsigned char* lut_lds = nullptr)
+{
+    // The epilogue is a short VALU burst next to the co-resident workgroup's MFMA stream: give it issue priority
+    // so its dependent chains do not wait behind queued MFMAs (which run in the matrix pipe once issued).
+    __builtin_amdgcn_s_setprio(2);
+    hook.issue();    // persistent kernels: the next tile's table loads have all of phase 1 to land
+    constexpr int CSS = CH + 4;       // LDS row stride: (CH/4 + 1) dwords, odd -> conflict-free dword writes
+    constexpr int CPR = CH / 16;      // 16-byte chunks per row
+    // Phase 1.  out = clamp8(RNE(acc * M)), M = m * 2^-e, must equal the reference's float64
+    // evaluation (quant_utils.py:229-230) bit for bit.  Fast path on the ordinary float32 VALU (the
+    // float64 ops contend with the MFMA pipe): with lo <= M <= hi the two float32 neighbours of M,
+    //   t_lo = fma(acc, lo, 1.5*2^23), t_hi = fma(acc, hi, 1.5*2^23)
+    // are RNE(acc*lo) and RNE(acc*hi) exactly (one rounding, ulp 1), and RNE is monotone, so
+    // t_lo == t_hi certifies RNE(acc*M) -- including exact ties, which straddle and fail the test.
+    // Valid while acc is exact in float32 and |acc*hi| < 2^22 (M <= 1 is part of the contract), i.e.
+    // |acc| < 2^22; anything else, and any failed certificate, takes the float64 path for that quad.
+    // (lo, hi) of the quad's four channels: read one batch ahead (double-buffered), invisible to the compiler (see lds_read16_async)
+    const unsigned rq_a = lds_addr(rq_lds) + 8u * (unsigned)(wch + 4 * h);
+    v4f lhbuf[2][2];
+    lds_read16_async(lhbuf[0][0], rq_a);
+    lds_read16_async(lhbuf[0][1], rq_a + 16u);
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int cl = wch + 32 * i + 8 * q + 4 * h;  // local channel of the quad
+            v4f& lh01 = lhbuf[(4 * i + q) & 1][0];      // lo0 hi0 lo1 hi1
+            v4f& lh23 = lhbuf[(4 * i + q) & 1][1];      // lo2 hi2 lo3 hi3
+            lds_wait(lh01, lh23);
+            if (4 * i + q + 1 < 4 * TI) {
+                const int nb = 4 * i + q + 1;
+                lds_read16_async(lhbuf[nb & 1][0], rq_a + 8u * (unsigned)(32 * (nb >> 2) + 8 * (nb & 3)));
+                lds_read16_async(lhbuf[nb & 1][1], rq_a + 8u * (unsigned)(32 * (nb >> 2) + 8 * (nb & 3)) + 16u);
+            }
+            const float lo[4] = {lh01.x, lh01.z, lh23.x, lh23.z};
+            const float hi[4] = {lh01.y, lh01.w, lh23.y, lh23.w};
+            // one branch-free batch of TJ*4 independent chains (instruction-level parallelism: the wave that
+            // runs this shares its SIMD with a main-loop wave, so there is no second VALU wave to hide latency)
+            int b[TJ][4];
+            unsigned unc = 0;      // OR of (t_lo ^ t_hi): non-zero <=> some certificate failed
+            float amax = 0.0f;
+#pragma unroll
+            for (int j = 0; j < TJ; ++j)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    if constexpr (ABL & 8) {
+                        b[j][jj] = acc[i][j][4 * q + jj] + (int)lo[jj];
+                    } else {
+                        const float a = (float)acc[i][j][4 * q + jj];
+                        int tl, th;
+                        if constexpr (ABL & 64) {   // A/B: both brackets in one packed fma (lo, hi are adjacent table entries)
+                            typedef float v2f_ __attribute__((ext_vector_type(2)));
+                            const v2f_ r = __builtin_elementwise_fma((v2f_){a, a}, (v2f_){lo[jj], hi[jj]}, (v2f_){12582912.0f, 12582912.0f});
+                            tl = __float_as_int(r.x);
+                            th = __float_as_int(r.y);
+                        } else {
+                            tl = __float_as_int(__builtin_fmaf(a, lo[jj], 12582912.0f));
+                            th = __float_as_int(__builtin_fmaf(a, hi[jj], 12582912.0f));
+                        }
+                        // unc += |tl - th| in ONE instruction (v_sad_u32): zero iff every certificate of the batch holds.
+                        // tl, th are bit patterns of floats next to 1.5 * 2^23, their differences are tiny: no wrap-around.
+                        if constexpr (ABL & 32) {   // A/B: the former two-instruction form
+                            unc |= (unsigned)(tl ^ th);
+                            asm volatile("" : "+v"(unc));
+                        } else {
+                            asm("v_sad_u32 %0, %1, %2, %3" : "=v"(unc) : "v"(tl), "v"(th), "v"(unc));
+                        }
+                        amax = fmaxf(amax, fabsf(a));
+                        b[j][jj] = clamp_i32(tl, 0x4B400000 - 128, 0x4B400000 + 127);  // low byte = int8 result
+                    }
+                }
+            if constexpr (!(ABL & 8)) {
+                const bool bad = (unc != 0) | (amax >= 4194304.0f);
+                if (__builtin_amdgcn_ballot_w64(bad) != 0) {  // rare: exact float64 evaluation of the batch
+                    const int c0 = min(n0 + cl, g.N - 4);
+                    const uint4 m4 = *reinterpret_cast<const uint4*>(g.m + c0);
+                    const int4 e4 = *reinterpret_cast<const int4*>(g.e + c0);
+                    const double Mc[4] = {dyadic_mult(m4.x, e4.x), dyadic_mult(m4.y, e4.y), dyadic_mult(m4.z, e4.z),
+                                          dyadic_mult(m4.w, e4.w)};
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j)
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) {
+                            // quant_utils.py:229-230: float64 product (53-bit rounding), /2^e, round-half-even
+                            double p = (double)acc[i][j][4 * q + jj] * Mc[jj];
+                            double t = p + IVIT_MAGIC;
+                            b[j][jj] = clamp_i32((int)(unsigned)__double_as_longlong(t), -128, 127);
+                        }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                const int tl_ = wtok + 32 * j + l31;
+                const unsigned w01 = __builtin_amdgcn_perm((unsigned)b[j][1], (unsigned)b[j][0], 0x0c0c0400u);
+                const unsigned w23 = __builtin_amdgcn_perm((unsigned)b[j][3], (unsigned)b[j][2], 0x04000c0cu);
+                *reinterpret_cast<unsigned*>(smem + tl_ * CSS + cl) = w01 | w23;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    epilogue_phase2<EPI, TOK, NTHREADS, ABL, CH, Hook>(g, smem, m0, n0, tid, hook, lut_lds);
+}
+
+// ---- the int8 epilogue for accumulators of v_mfma_i32_16x16x64_i8 (the weights-in-registers kernel's S16 form).
+// acc[i][j]: channel sub-tile i (16 channels) x token sub-tile j (16 tokens); lane (g4 = lane >> 4, l15 = lane & 15) holds token
+// 16 j + l15 and the four consecutive channels wch + 16 i + 4 g4 + r of register r -- again one dword of four channels per
+// token, so phase 1 is the arithmetic of epilogue_i8 with other loop bounds (batches of 16 outputs per certificate ballot) and
+// phase 2 is shared.
+template <int EPI, int NJ, int NTHREADS, int ABL, int CH, typename Hook>
+IVIT_DEV void epilogue_i8_16(v4i (&acc)[4][NJ], const GemmArgs& g, char* smem, const char* rq_lds, int m0, int n0, int wch, int tid,
+                             int g4, int l15, const Hook& hook, const unsigned char* lut_lds)
+{
+    static_assert(NJ % 4 == 0, "batches of four token sub-tiles");
+    __builtin_amdgcn_s_setprio(2);
+    hook.issue();
+    constexpr int CSS = CH + 4;
+    const unsigned rq_a = lds_addr(rq_lds) + 8u * (unsigned)(wch + 4 * g4);
+    v4f lhbuf[2][2];
+    lds_read16_async(lhbuf[0][0], rq_a);
+    lds_read16_async(lhbuf[0][1], rq_a + 16u);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int cl = wch + 16 * i + 4 * g4;   // local channel of the quad
+        v4f& lh01 = lhbuf[i & 1][0];            // lo0 hi0 lo1 hi1
+        v4f& lh23 = lhbuf[i & 1][1];            // lo2 hi2 lo3 hi3
+        lds_wait(lh01, lh23);
+        if (i + 1 < 4) {
+            lds_read16_async(lhbuf[(i + 1) & 1][0], rq_a + 8u * (unsigned)(16 * (i + 1)));
+            lds_read16_async(lhbuf[(i + 1) & 1][1], rq_a + 8u * (unsigned)(16 * (i + 1)) + 16u);
+        }
+        const float lo[4] = {lh01.x, lh01.z, lh23.x, lh23.z};
+        const float hi[4] = {lh01.y, lh01.w, lh23.y, lh23.w};
+#pragma unroll
+        for (int jb = 0; jb < NJ; jb += 4) {
+            int b[4][4];
+            unsigned unc = 0;
+            float amax = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float a = (float)acc[i][jb + j][r];
+                    const int tl = __float_as_int(__builtin_fmaf(a, lo[r], 12582912.0f));
+                    const int th = __float_as_int(__builtin_fmaf(a, hi[r], 12582912.0f));
+                    asm("v_sad_u32 %0, %1, %2, %3" : "=v"(unc) : "v"(tl), "v"(th), "v"(unc));
+                    amax = fmaxf(amax, fabsf(a));
+                    b[j][r] = clamp_i32(tl, 0x4B400000 - 128, 0x4B400000 + 127);  // low byte = int8 result
+                }
+            const bool bad = (unc != 0) | (amax >= 4194304.0f);
+            if (__builtin_amdgcn_ballot_w64(bad) != 0) {  // rare: exact float64 evaluation of the batch (quant_utils.py:229-230)
+                const int c0 = min(n0 + cl, g.N - 4);
+                const uint4 m4 = *reinterpret_cast<const uint4*>(g.m + c0);
+                const int4 e4 = *reinterpret_cast<const int4*>(g.e + c0);
+                const double Mc[4] = {dyadic_mult(m4.x, e4.x), dyadic_mult(m4.y, e4.y), dyadic_mult(m4.z, e4.z), dyadic_mult(m4.w, e4.w)};
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const double t = (double)acc[i][jb + j][r] * Mc[r] + IVIT_MAGIC;
+                        b[j][r] = clamp_i32((int)(unsigned)__double_as_longlong(t), -128, 127);
+                    }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int tl_ = 16 * (jb + j) + l15;
+                const unsigned w01 = __builtin_amdgcn_perm((unsigned)b[j][1], (unsigned)b[j][0], 0x0c0c0400u);
+                const unsigned w23 = __builtin_amdgcn_perm((unsigned)b[j][3], (unsigned)b[j][2], 0x04000c0cu);
+                *reinterpret_cast<unsigned*>(smem + tl_ * CSS + cl) = w01 | w23;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    epilogue_phase2<EPI, 16 * NJ, NTHREADS, ABL, CH, Hook>(g, smem, m0, n0, tid, hook, lut_lds);
 }
 
 // ---- 16-bit epilogue of the weights-in-registers kernel (EPI_RQ16_RES16).  A wave owns 64 of the tile's 256 channels x 32 TJ

@@ -7,6 +7,7 @@ int g_kernel_choice = 0;
 bool g_force_small = false;
 void* g_stamp_buf = nullptr;
 int g_debug_flags = 0;   // bits: see include/ivit_hip_debug.h
+int g_debug_flags2 = 0;
 
 namespace {
 
@@ -1306,6 +1307,12 @@ IVIT_EXPORT int ivit_debug_force_small_gemm(int on)
 IVIT_EXPORT int ivit_debug_set_gemm_flags(int flags)
 {
     g_debug_flags = flags;
+    return IVIT_OK;
+}
+
+IVIT_EXPORT int ivit_debug_set_gemm_flags2(int flags)
+{
+    g_debug_flags2 = flags;
     return IVIT_OK;
 }
 

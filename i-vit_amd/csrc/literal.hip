@@ -28,6 +28,7 @@ struct LnLitArgs {
     const float* s_ln;
     float* out;
     int64_t ldo;
+    int outer;     // the mean is taken over a strided (transposed) view: torch's outer-reduction order (rowsum.h)
 };
 
 // IVITIntLayerNorm.forward, ivit_modules.py:36-63, line by line
@@ -38,7 +39,7 @@ __global__ __launch_bounds__(NT) void layernorm_f32_f32_kernel(LnLitArgs a)
     for (int row = blockIdx.x * WPB + wave; row < a.rows; row += gridDim.x * WPB) {
         const float* xr = a.x + (int64_t)row * a.ldx;
         auto xint = [&](int c) { return xr[c] / a.s_in[a.n_s == 1 ? 0 : c]; };   // :36  x / scaling_factor
-        const float S = torch_rowsum(xint, C, lane);
+        const float S = a.outer ? torch_outer_rowsum(xint, C) : torch_rowsum(xint, C, lane);
         const float mean = S / (float)C;                                          // :37  mean = sum / C
         const int mean_int = (int)rintf(mean);                                    //      round_ste
         long long var = 0;

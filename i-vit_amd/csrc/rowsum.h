@@ -52,4 +52,33 @@ IVIT_DEV float torch_rowsum(F elem, int n, int lane)
     return fin;
 }
 
+// The same sum when the reduced dimension is NOT the contiguous one of the tensor (a transposed view, e.g. the Swin patch embedding:
+// layers_quant.py:198 hands `x.flatten(2).transpose(1, 2)` through an elementwise QuantAct, which keeps the strides, to the
+// LayerNorm's x_int.mean(axis=2)).  ATen then takes vectorized_outer_sum -> multi_row_sum: every output column is one accumulator
+// lane of its own, and the reduced index alone runs through the 4-level cascade -- level_step = 2^max(4, ceil_log2(n) / 4)
+// elements added in sequence, each finished group folded into the next level.  This is the order of every column whenever the
+// contiguous extent is a multiple of 32 columns (4 vectors of 8 floats; Swin: 3136 tokens) and the iteration is not split
+// inside it -- TensorIterator runs serially below 32768 outputs (up to 10 images) and with thread counts whose chunks are
+// multiples of 32 columns (1, 2, 4, 8, 16 threads at batch 128).  Serial; every lane that calls it gets the same value.
+template <class F>
+IVIT_DEV float torch_outer_rowsum(F elem, int n)
+{
+    int lg = 0;
+    while ((1 << lg) < n) ++lg;
+    const int lp = max(4, lg / 4), step = 1 << lp, mask = step - 1;
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+    int i = 0;
+    while (i + step <= n) {
+        for (int j = 0; j < step; ++j, ++i) acc0 += elem(i);
+        acc1 += acc0; acc0 = 0.f;
+        if ((i & (mask << lp)) == 0) {
+            acc2 += acc1; acc1 = 0.f;
+            if ((i & (mask << (2 * lp))) == 0) { acc3 += acc2; acc2 = 0.f; }
+        }
+    }
+    for (; i < n; ++i) acc0 += elem(i);
+    acc0 += acc1; acc0 += acc2; acc0 += acc3;
+    return acc0;
+}
+
 }  // namespace

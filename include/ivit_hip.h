@@ -96,6 +96,12 @@ int ivit_quantize_patchify_u8_i8(const uint8_t* img, int8_t* A, int64_t lda, int
  * ignored.  Results are identical to every other form. */
 #define IVIT_W_FRAGS 8
 int ivit_pack_weight_frags_i8(const int8_t* W, int64_t ldw, int N, int K, int8_t* dst, ivit_stream_t stream);
+/* IVIT_W_FRAGS16: the same idea for v_mfma_i32_16x16x64_i8 (the chip holds a higher clock on that shape under the power limit:
+ * DESIGN.md section 5): channel n, byte k at ((n / 64) * (K / 64) + k / 64) * 4096 + ((n / 16) % 4) * 1024 + ((k / 16) % 4) * 256
+ * + (n % 16) * 16 + k % 16 (copy made by ivit_pack_weight_frags16_i8; same size, same constraints as IVIT_W_FRAGS; the two bits
+ * exclude each other).  Accepted by the int8-output `_ex` forms (requant, requant_lut, residual, residual_i16, qkv). */
+#define IVIT_W_FRAGS16 16
+int ivit_pack_weight_frags16_i8(const int8_t* W, int64_t ldw, int N, int K, int8_t* dst, ivit_stream_t stream);
 int ivit_tile_operand_i8(const int8_t* src, int64_t ld, int64_t rows, int K, int8_t* dst, ivit_stream_t stream);
 int ivit_untile_operand_i8(const int8_t* src, int64_t rows, int K, int8_t* dst, int64_t ld, ivit_stream_t stream);
 

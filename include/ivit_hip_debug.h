@@ -23,6 +23,9 @@ int ivit_debug_force_small_gemm(int on);
  * four units per K step; bit 25 writes time stamps into the stamp buffer), bit 26 a 256-workgroup grid of the
  * persistent kernel without the LDS blocker (two-stream probe). */
 int ivit_debug_set_gemm_flags(int flags);
+/* Second flag word: A/B of cache policies in the GEMM epilogue (results stay correct).  Bits 0-1: policy of the int8 output
+ * stores (0 plain, 1 nt, 2 sc1, 3 sc0 sc1); bit 2: the residual operand is read with nt loads. */
+int ivit_debug_set_gemm_flags2(int flags);
 /* Diagnostic timeline buffer (8 x uint64 per workgroup) for the stamped build (flags = 512); scripts/gemm_timeline.py */
 int ivit_debug_set_stamp_buffer(void* buf);
 

@@ -1,6 +1,7 @@
 """Interleaved A/B timing of GEMM kernel variants (debug flags): every round runs each variant once, in turn, so that clock /
 thermal drift hits all variants alike; reports median and min per variant.
-usage: gemm_ab.py [--resid] [--blocks] [shape ...] -- flag flag ..."""
+usage: gemm_ab.py [--resid] [--blocks] [shape ...] -- flag flag ...
+A flag written a:b sets ivit_debug_set_gemm_flags(a) and ivit_debug_set_gemm_flags2(b) (cache-policy bits)."""
 import os; os.environ.setdefault("IVIT_USE_LAB_LIBRARY", "1")  # kernel-form knobs live in libivit_hip_lab.so
 import os
 import sys
@@ -20,10 +21,16 @@ QKV = "--qkv" in sys.argv         # head-major q/k/v epilogue (qkv shape only)
 BLOCKS = "--blocks" in sys.argv   # both operands in the block layout (persistent kernel only)
 FRAGS = "--frags" in sys.argv     # A in the block layout, W fragment-packed: the weights-in-registers kernel
 BOTH = "--both" in sys.argv       # blocks and frags, interleaved
-args = [a for a in sys.argv[1:] if a not in ("--resid", "--blocks", "--qkv", "--frags", "--both")]
+F16 = "--frags16" in sys.argv     # the 32x32x32 and the 16x16x64 form of the weights-in-registers kernel, interleaved
+args = [a for a in sys.argv[1:] if a not in ("--resid", "--blocks", "--qkv", "--frags", "--both", "--frags16")]
 split = args.index("--") if "--" in args else 0
 names = args[:split] or list(SHAPES)
-flags = [int(x) for x in args[split + 1:]] if "--" in args else [0]
+def _flag(x):
+    a, _, b = x.partition(":")
+    return (int(a), int(b or 0))
+
+
+flags = [_flag(x) for x in args[split + 1:]] if "--" in args else [(0, 0)]
 ROUNDS, ITERS = 7, 10
 rng = np.random.default_rng(0)
 for name in names:
@@ -41,7 +48,9 @@ for name in names:
     _lib.call("ivit_tile_operand_i8", _lib.ptr(A), K, M, K, _lib.ptr(At), _lib.stream_ptr())
     _lib.call("ivit_tile_operand_i8", _lib.ptr(W), K, N, K, _lib.ptr(Wt), _lib.stream_ptr())
     _lib.call("ivit_pack_weight_frags_i8", _lib.ptr(W), K, N, K, _lib.ptr(Wf), _lib.stream_ptr())
-    OPS = {"rows": (A, W, 0), "blocks": (At, Wt, 3), "frags": (At, Wf, 9)}
+    Wf16 = torch.empty_like(W)
+    _lib.call("ivit_pack_weight_frags16_i8", _lib.ptr(W), K, N, K, _lib.ptr(Wf16), _lib.stream_ptr())
+    OPS = {"rows": (A, W, 0), "blocks": (At, Wt, 3), "frags": (At, Wf, 9), "frags16": (At, Wf16, 17)}
     resid_t = torch.from_numpy(rng.integers(-128, 128, size=(M, N)).astype(np.int8)).to(DEV)
 
     def run(kind):
@@ -55,7 +64,14 @@ for name in names:
         else:
             _lib.call("ivit_gemm_i8_requant_ex", _lib.ptr(a_), K, _lib.ptr(w_), K, _lib.ptr(b), _lib.ptr(m), _lib.ptr(e), _lib.ptr(out),
                       N, M, N, K, LAY, _lib.stream_ptr())
-    kinds = ["blocks", "frags"] if BOTH else ["frags"] if FRAGS else ["blocks"] if BLOCKS else ["rows"]
+    kinds = ["frags", "frags16"] if F16 else ["blocks", "frags"] if BOTH else ["frags"] if FRAGS else ["blocks"] if BLOCKS else ["rows"]
+    if F16:      # the two forms must agree bit for bit before they are timed
+        run("frags")
+        ref_out = out.clone()
+        out.zero_()
+        run("frags16")
+        torch.cuda.synchronize()
+        assert torch.equal(ref_out, out), f"{name}: the 16x16x64 form differs from the 32x32x32 form"
     variants = [(k, f) for k in kinds for f in flags]
     for k in kinds:
         for _ in range(5):
@@ -63,7 +79,8 @@ for name in names:
     res = {v: [] for v in variants}
     for r in range(ROUNDS):
         for v in (variants if r % 2 == 0 else variants[::-1]):
-            _lib.call("ivit_debug_set_gemm_flags", v[1])
+            _lib.call("ivit_debug_set_gemm_flags", v[1][0])
+            _lib.call("ivit_debug_set_gemm_flags2", v[1][1])
             run(v[0])
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -74,7 +91,8 @@ for name in names:
             torch.cuda.synchronize()
             res[v].append(e0.elapsed_time(e1) / ITERS * 1e3)
     _lib.call("ivit_debug_set_gemm_flags", 0)
+    _lib.call("ivit_debug_set_gemm_flags2", 0)
     for v in variants:
         t = sorted(res[v])
         med, mn = t[len(t) // 2], t[0]
-        print(f"{name:5s} {v[0]:6s} flags={v[1]:8d}  median {med:7.1f} us ({2 * M * N * K / med / 1e6:7.1f} TOPS)   min {mn:7.1f} us", flush=True)
+        print(f"{name:5s} {v[0]:6s} flags={v[1][0]:8d}:{v[1][1]:<3d}  median {med:7.1f} us ({2 * M * N * K / med / 1e6:7.1f} TOPS)   min {mn:7.1f} us", flush=True)

@@ -382,10 +382,23 @@ def _frag_layout_host(W):
     return out
 
 
+def _frag16_layout_host(W):
+    """include/ivit_hip.h IVIT_W_FRAGS16 (the v_mfma_i32_16x16x64_i8 fragment order), restated independently"""
+    N, K = W.shape
+    n64 = (N + 63) // 64 * 64
+    out = np.zeros(n64 * K, np.int8)
+    n, k = np.meshgrid(np.arange(N), np.arange(K), indexing="ij")
+    off = ((n // 64) * (K // 64) + k // 64) * 4096 + ((n // 16) % 4) * 1024 + ((k // 16) % 4) * 256 + (n % 16) * 16 + k % 16
+    out[off.reshape(-1)] = W.reshape(-1)
+    return out
+
+
+@pytest.mark.parametrize("FR", [8, 16])
 @pytest.mark.parametrize("M,N,K", [(2600, 512, 384), (197 * 16, 768, 768), (2049, 192, 192), (4000, 320, 576), (197 * 12, 2304, 768)])
-def test_gemm_weight_fragment_layout(M, N, K):
-    """ivit_pack_weight_frags_i8 == the documented layout; the weights-in-registers kernel (IVIT_W_FRAGS) == the oracle for
-    all epilogues, row-major and block-layout A, block-layout output, partial token and channel tiles"""
+def test_gemm_weight_fragment_layout(M, N, K, FR):
+    """ivit_pack_weight_frags_i8 / ivit_pack_weight_frags16_i8 == the documented layouts; the weights-in-registers kernel in both
+    MFMA forms (IVIT_W_FRAGS: 32x32x32, IVIT_W_FRAGS16: 16x16x64) == the oracle for all epilogues, row-major and block-layout A,
+    block-layout output, partial token and channel tiles"""
     rng = np.random.default_rng(M + K + 1)
     A = rng.integers(-128, 128, size=(M, K)).astype(np.int8)
     W = rng.integers(-128, 128, size=(N, K)).astype(np.int8)
@@ -397,15 +410,15 @@ def test_gemm_weight_fragment_layout(M, N, K):
     At = torch.zeros(R16 * K, dtype=torch.int8, device=DEV)
     _lib.call("ivit_tile_operand_i8", _lib.ptr(dA), K, M, K, _lib.ptr(At), st())
     Wf = torch.full(((N + 63) // 64 * 64 * K,), 77, dtype=torch.int8, device=DEV)
-    _lib.call("ivit_pack_weight_frags_i8", _lib.ptr(dW), K, N, K, _lib.ptr(Wf), st())
-    assert np.array_equal(Wf.cpu().numpy(), _frag_layout_host(W))
+    _lib.call("ivit_pack_weight_frags_i8" if FR == 8 else "ivit_pack_weight_frags16_i8", _lib.ptr(dW), K, N, K, _lib.ptr(Wf), st())
+    assert np.array_equal(Wf.cpu().numpy(), _frag_layout_host(W) if FR == 8 else _frag16_layout_host(W))
     exp = orc.requant(orc.gemm_i8(A, W, b), m.astype(np.float64), e, 8)
     res = rng.integers(-128, 128, size=(M, N)).astype(np.int8)
     dres = dev(res)
     m1, e1 = dyadic(np.float32(0.7 * 2 ** -4), np.float32(2 ** -4))
     m2, e2 = dyadic(np.float32(2 ** -5), np.float32(2 ** -4))
     exp_res = orc.requant(exp, m1.astype(np.float64), e1, 8, z2=res.astype(np.int32), m2=m2.astype(np.float64), e2=e2)
-    for lay in (8, 9):
+    for lay in (FR, FR + 1):
         a_op = At if lay & 1 else dA
         out = torch.zeros(M, N, dtype=torch.int8, device=DEV)
         _lib.call("ivit_gemm_i8_requant_ex", _lib.ptr(a_op), K, _lib.ptr(Wf), K, _lib.ptr(db), _lib.ptr(md), _lib.ptr(ed),
@@ -420,7 +433,7 @@ def test_gemm_weight_fragment_layout(M, N, K):
         T, hd = 197, 64
         H = N // (3 * hd)
         outs = []
-        for lay in (0, 9):
+        for lay in (0, FR + 1):
             out = torch.zeros(3 * M * H * hd, dtype=torch.int8, device=DEV)
             _lib.call("ivit_gemm_i8_requant_qkv_ex", _lib.ptr(At if lay else dA), K, _lib.ptr(Wf if lay else dW), K, _lib.ptr(db),
                       _lib.ptr(md), _lib.ptr(ed), _lib.ptr(out), T, H, hd, M, N, K, lay, st())
@@ -428,11 +441,11 @@ def test_gemm_weight_fragment_layout(M, N, K):
         assert np.array_equal(outs[0], outs[1])
     outb = torch.zeros(R16 * N, dtype=torch.int8, device=DEV)
     _lib.call("ivit_gemm_i8_requant_ex", _lib.ptr(At), K, _lib.ptr(Wf), K, _lib.ptr(db), _lib.ptr(md), _lib.ptr(ed),
-              _lib.ptr(outb), N, M, N, K, 13, st())
+              _lib.ptr(outb), N, M, N, K, FR + 5, st())
     assert np.array_equal(outb.cpu().numpy(), _block_layout_host(exp.astype(np.int8)))
     with pytest.raises(_lib.IvitError, match="fragment-packed"):   # K / 64 must be a multiple of 3
         _lib.call("ivit_gemm_i8_requant_ex", _lib.ptr(dA), K, _lib.ptr(Wf), K, _lib.ptr(db), _lib.ptr(md), _lib.ptr(ed),
-                  _lib.ptr(out), N, M, N, 128, 8, st())
+                  _lib.ptr(out), N, M, N, 128, FR, st())
 
 
 @pytest.mark.parametrize("M,N,K", [(2600, 512, 384), (197 * 16, 3072, 768)])
