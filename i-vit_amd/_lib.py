@@ -50,6 +50,7 @@ SIGNATURES = {
     "ivit_layernorm_i8": [vp, i64, ci, ci, vp, vp, vp, vp, vp, i64, vp],
     "ivit_layernorm_i32_f32": [vp, i64, ci, ci, vp, vp, vp, i64, vp],
     "ivit_layernorm_f32_f32": [vp, i64, ci, ci, vp, ci, vp, vp, vp, i64, vp],
+    "ivit_layernorm_f32_f32_ex": [vp, i64, ci, ci, vp, ci, vp, vp, vp, i64, ci, vp],
     "ivit_shiftmax_f32_i8": [vp, i64, ci, ci, f32, vp, i64, vp],
     "ivit_shiftmax_f32_i16": [vp, i64, ci, ci, f32, ci, vp, i64, vp],
     "ivit_bgemm_pv_i16_i8": [vp, vp, vp, ci, ci, ci, ci, vp],

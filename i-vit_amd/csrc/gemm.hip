@@ -163,9 +163,7 @@ __global__ __launch_bounds__(NT) void gemm_i8_kernel(GemmArgs g)
                     int o[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const double p = (double)acc[i][j][4 * q + r] * Mc[r];
-                        const double tt = p + IVIT_MAGIC;
-                        o[r] = clamp_i32((int)(unsigned)__double_as_longlong(tt), -32768, 32767);
+                        o[r] = rne_clamp16((double)acc[i][j][4 * q + r] * Mc[r]);
                     }
                     int2 ow;
                     ow.x = (o[0] & 0xffff) | (o[1] << 16);

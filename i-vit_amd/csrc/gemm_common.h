@@ -99,6 +99,14 @@ IVIT_DEV void lds_wait(v4f& a, v4f& b) { asm volatile("s_waitcnt lgkmcnt(0)" : "
 IVIT_DEV void lds_wait(v4i& a) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a)); }
 IVIT_DEV void lds_wait(v2i& a, v2i& b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b)); }
 
+// clamp16(RNE(p)) for ANY double p: the magic-number conversion alone reads the low 32 bits and wraps for |p| >= 2^31 (a per-channel
+// multiplier above what a 16-bit output can hold); the reference saturates (torch.clamp on the float64 value, quant_utils.py:249)
+IVIT_DEV int rne_clamp16(double p)
+{
+    p = __builtin_fmin(__builtin_fmax(p, -32768.0), 32767.0);
+    return (int)(unsigned)__double_as_longlong(p + IVIT_MAGIC);
+}
+
 IVIT_DEV int pack4_i8(int a, int b, int c, int d)
 {
     return (a & 0xff) | ((b & 0xff) << 8) | ((c & 0xff) << 16) | ((d & 0xff) << 24);
@@ -543,7 +551,7 @@ IVIT_DEV void epilogue_rq16_res16(v16i (&acc)[2][TJ], const GemmArgs& g, char* c
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const double p = (double)acc[i][2 * rd + jj][4 * q + r] * Mc[r];
-                    o[r] = clamp_i32((int)(unsigned)__double_as_longlong(p + IVIT_MAGIC), -32768, 32767);
+                    o[r] = rne_clamp16(p);
                 }
                 v2i ow;
                 ow.x = (o[0] & 0xffff) | (o[1] << 16);
@@ -624,7 +632,7 @@ IVIT_DEV void epilogue_rq16_res16_small(v16i (&acc)[2][2], const GemmArgs& g, ch
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const double p = (double)acc[i][j][4 * q + r] * Mc[r];
-                o[r] = clamp_i32((int)(unsigned)__double_as_longlong(p + IVIT_MAGIC), -32768, 32767);
+                o[r] = rne_clamp16(p);
             }
             v2i ow;
             ow.x = (o[0] & 0xffff) | (o[1] << 16);

@@ -28,7 +28,8 @@ struct LnLitArgs {
     const float* s_ln;
     float* out;
     int64_t ldo;
-    int outer;     // the mean is taken over a strided (transposed) view: torch's outer-reduction order (rowsum.h)
+    int outer;     // > 0: the mean is taken over a transposed view whose contiguous extent is `outer` (row = .. * outer + column):
+                   // torch's outer-reduction order (rowsum.h)
 };
 
 // IVITIntLayerNorm.forward, ivit_modules.py:36-63, line by line
@@ -39,7 +40,7 @@ __global__ __launch_bounds__(NT) void layernorm_f32_f32_kernel(LnLitArgs a)
     for (int row = blockIdx.x * WPB + wave; row < a.rows; row += gridDim.x * WPB) {
         const float* xr = a.x + (int64_t)row * a.ldx;
         auto xint = [&](int c) { return xr[c] / a.s_in[a.n_s == 1 ? 0 : c]; };   // :36  x / scaling_factor
-        const float S = a.outer ? torch_outer_rowsum(xint, C) : torch_rowsum(xint, C, lane);
+        const float S = a.outer ? torch_outer_rowsum(xint, C, row % a.outer >= (a.outer & ~31)) : torch_rowsum(xint, C, lane);
         const float mean = S / (float)C;                                          // :37  mean = sum / C
         const int mean_int = (int)rintf(mean);                                    //      round_ste
         long long var = 0;
@@ -117,16 +118,23 @@ static inline int rows_grid(int64_t rows)
 
 }  // namespace
 
+IVIT_EXPORT int ivit_layernorm_f32_f32_ex(const float* x, int64_t ldx, int rows, int C, const float* s_in, int n_s,
+                                          const float* bias_int, const float* s_ln, float* out, int64_t ldo, int outer_mean,
+                                          ivit_stream_t stream)
+{
+    IVIT_REQUIRE(x && s_in && bias_int && s_ln && out, "ivit_layernorm_f32_f32: NULL operand");
+    IVIT_REQUIRE(rows > 0 && C > 0 && C <= 16384 && ldx >= C && ldo >= C && (n_s == 1 || n_s == C) && outer_mean >= 0 && (outer_mean == 0 || rows % outer_mean == 0),
+                 "ivit_layernorm_f32_f32: bad shape rows=%d C=%d n_s=%d", rows, C, n_s);
+    LnLitArgs a{x, ldx, rows, C, s_in, n_s, bias_int, s_ln, out, ldo, outer_mean};
+    hipLaunchKernelGGL(layernorm_f32_f32_kernel, dim3(rows_grid(rows)), dim3(NT), 0, ivit_stream(stream), a);
+    IVIT_CHECK_LAUNCH("ivit_layernorm_f32_f32");
+}
+
 IVIT_EXPORT int ivit_layernorm_f32_f32(const float* x, int64_t ldx, int rows, int C, const float* s_in, int n_s,
                                        const float* bias_int, const float* s_ln, float* out, int64_t ldo,
                                        ivit_stream_t stream)
 {
-    IVIT_REQUIRE(x && s_in && bias_int && s_ln && out, "ivit_layernorm_f32_f32: NULL operand");
-    IVIT_REQUIRE(rows > 0 && C > 0 && C <= 16384 && ldx >= C && ldo >= C && (n_s == 1 || n_s == C),
-                 "ivit_layernorm_f32_f32: bad shape rows=%d C=%d n_s=%d", rows, C, n_s);
-    LnLitArgs a{x, ldx, rows, C, s_in, n_s, bias_int, s_ln, out, ldo};
-    hipLaunchKernelGGL(layernorm_f32_f32_kernel, dim3(rows_grid(rows)), dim3(NT), 0, ivit_stream(stream), a);
-    IVIT_CHECK_LAUNCH("ivit_layernorm_f32_f32");
+    return ivit_layernorm_f32_f32_ex(x, ldx, rows, C, s_in, n_s, bias_int, s_ln, out, ldo, 0, stream);
 }
 
 IVIT_EXPORT int ivit_shiftmax_f32_i8(const float* x, int64_t ldx, int rows, int L, float s, int8_t* out, int64_t ldo,

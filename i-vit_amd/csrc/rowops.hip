@@ -12,6 +12,7 @@
 #include <limits.h>
 
 #include "common.h"
+#include "rowsum.h"
 
 // tests / A-B timing: 1 = always the wave-per-row LayerNorm kernel, 2 = the half-wave-per-row one wherever it exists
 // (ivit_debug_ln_wave_per_row)
@@ -62,6 +63,8 @@ struct LnArgs {
     const int8_t* remap;   // [256] k'(q) = trunc(phi(q)), indexed q + 128   (ivit_modules.py:38 .to(int32))
     const float* phi;      // [256] phi(q), indexed q + 128                  (the mean, :37, is taken over these)
     int abl;               // lab build: timing ablations (results wrong), always 0 in the product
+    int outer;             // compat, > 0: the reference reduces over a transposed view of contiguous extent `outer` (row = .. * outer +
+                           // column) -- torch's outer-reduction order
 };
 
 // Per-row statistics exactly as ivit_modules.py:36-51 computes them.
@@ -91,8 +94,10 @@ IVIT_DEV float ln_factor(long long var)
 // i goes to partial i % 32 in increasing i with a 4-level cascade, then rows, then the 8 lanes left to right; restated
 // and checked against torch in oracle/ivit_oracle.c ivo_torch_rowsum_f32).  Called by the whole wave for the rare rows
 // whose mean is an exact .5 tie, where this order decides the reference's result.  phi_lds: [256] floats.
-IVIT_DEV float torch_rowsum_phi(const int8_t* qrow, int C, const float* phi_lds, int lane)
+IVIT_DEV float torch_rowsum_phi(const int8_t* qrow, int C, const float* phi_lds, int lane, int outer = 0, int row = 0)
 {
+    if (outer)   // the reduced dimension is not the contiguous one (Swin patch embedding): rowsum.h torch_outer_rowsum
+        return torch_outer_rowsum([&](int i) { return phi_lds[(int)qrow[i] + 128]; }, C, row % outer >= (outer & ~31));
     const int vec_size = C >> 3, size_ilp = vec_size >> 2;
     float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
     if (lane < 32) {
@@ -270,7 +275,7 @@ __global__ __launch_bounds__(NT, (NJ <= 3 && !COMPAT ? 3 : NJ <= 8 ? 2 : 1)) voi
             while (tm) {                       // wave-uniform: rows decided by the float32 reduction order
                 const int rr = __builtin_ctzll(tm);
                 tm &= tm - 1;
-                const float S = torch_rowsum_phi(xin + (int64_t)(row0 + rr) * a.ldx, C, s_phi, lane);
+                const float S = torch_rowsum_phi(xin + (int64_t)(row0 + rr) * a.ldx, C, s_phi, lane, a.outer, row0 + rr);
                 const int fixed = (int)rintf(S / (float)C);     // ivit_modules.py:37
                 my_mean = (lane == rr) ? fixed : my_mean;
             }
@@ -702,7 +707,7 @@ __global__ __launch_bounds__(NT, (G == 4 && NJ <= 3 ? 5 : G == 8 && NJ <= 3 ? 4 
                 const int tl_ = __builtin_ctzll(tm);
                 tm &= tm - 1;
                 const int rr = tl_ / LPR;
-                const float S = torch_rowsum_phi(xin + (int64_t)(row0 + rr) * a.ldx, C, s_phi, lane);
+                const float S = torch_rowsum_phi(xin + (int64_t)(row0 + rr) * a.ldx, C, s_phi, lane, a.outer, row0 + rr);
                 const int fixed = (int)rintf(S / (float)C);     // ivit_modules.py:37
                 my_mean = (my_row == rr) ? fixed : my_mean;
             }
@@ -1481,7 +1486,7 @@ IVIT_EXPORT int ivit_layernorm_i8_ex(const int8_t* x, int64_t ldx, int rows, int
     IVIT_REQUIRE(out_blocks == 0 || (out_blocks == 1 && C % 64 == 0 && ldo == C && ((uintptr_t)out % 16 == 0) &&
                                      ((int64_t)rows + 15) * C < 2147483648ll),
                  "ivit_layernorm_i8_ex: block-layout output needs C %% 64 == 0, ldo == C and a buffer below 2 GiB");
-    LnArgs a{x, ldx, rows, C, bias_int, s_ln, m, e, out, ldo, out_blocks, nullptr, nullptr, g_ln_ablate};
+    LnArgs a{x, ldx, rows, C, bias_int, s_ln, m, e, out, ldo, out_blocks, nullptr, nullptr, g_ln_ablate, 0};
     hipStream_t st = ivit_stream(stream);
     // v2 where a row fills the wave (measured at 50 432 rows: C = 768 28.1 us against 30.3; C = 384 19.0 against 17.5 for the
     // half-wave form; at C = 96 -- Swin's patch norm -- only 24 of 64 lanes would hold data)
@@ -1517,8 +1522,10 @@ IVIT_EXPORT int ivit_layernorm_i8_ex(const int8_t* x, int64_t ldx, int rows, int
 
 IVIT_EXPORT int ivit_layernorm_i8_compat(const int8_t* x, int64_t ldx, int rows, int C, const float* bias_int,
                                          const float* s_ln, const uint32_t* m, const int32_t* e, const int8_t* remap,
-                                         const float* phi, int8_t* out, int64_t ldo, int out_blocks, ivit_stream_t stream)
+                                         const float* phi, int8_t* out, int64_t ldo, int flags, ivit_stream_t stream)
 {
+    const int out_blocks = flags & 1, outer = flags >> 8;     // IVIT_LN_OUT_BLOCKS, IVIT_LN_OUTER_MEAN(L)
+    IVIT_REQUIRE((flags & 0xfe) == 0 && outer >= 0 && (outer == 0 || rows % outer == 0), "ivit_layernorm_i8_compat: bad flags");
     IVIT_REQUIRE(x && out && bias_int && s_ln && m && e && remap && phi, "ivit_layernorm_i8_compat: NULL operand");
     IVIT_REQUIRE(rows > 0 && C >= 32 && C % 8 == 0 && C <= 4096, "ivit_layernorm_i8_compat: rows=%d C=%d unsupported", rows, C);
     IVIT_REQUIRE(ldx % 4 == 0 && ldo % 4 == 0 && ldx >= C && ldo >= C && ((uintptr_t)x % 4 == 0) &&
@@ -1530,7 +1537,7 @@ IVIT_EXPORT int ivit_layernorm_i8_compat(const int8_t* x, int64_t ldx, int rows,
     IVIT_REQUIRE(out_blocks == 0 || (out_blocks == 1 && C % 64 == 0 && ldo == C && ((uintptr_t)out % 16 == 0) &&
                                      ((int64_t)rows + 15) * C < 2147483648ll),
                  "ivit_layernorm_i8_compat: block-layout output needs C %% 64 == 0, ldo == C and a buffer below 2 GiB");
-    LnArgs a{x, ldx, rows, C, bias_int, s_ln, m, e, out, ldo, out_blocks, remap, phi, g_ln_ablate};
+    LnArgs a{x, ldx, rows, C, bias_int, s_ln, m, e, out, ldo, out_blocks, remap, phi, g_ln_ablate, outer};
     hipStream_t st = ivit_stream(stream);
     if (C >= 512 && C <= 1024 && g_ln_wave_per_row == 0) return launch_ln_v2<true>(a, st, "ivit_layernorm_i8_compat");
     const int nj = (C / 4 + 63) / 64;
@@ -1558,7 +1565,7 @@ IVIT_EXPORT int ivit_layernorm_i32_f32(const int32_t* x, int64_t ldx, int rows, 
 {
     IVIT_REQUIRE(x && out && bias_int && s_ln, "ivit_layernorm_i32_f32: NULL operand");
     IVIT_REQUIRE(rows > 0 && C > 0 && C <= 4096 && ldx >= C && ldo >= C, "ivit_layernorm_i32_f32: bad shape");
-    LnArgs a{x, ldx, rows, C, bias_int, s_ln, nullptr, nullptr, out, ldo, 0, nullptr, nullptr, 0};
+    LnArgs a{x, ldx, rows, C, bias_int, s_ln, nullptr, nullptr, out, ldo, 0, nullptr, nullptr, 0, 0};
     hipLaunchKernelGGL(layernorm_i32_f32_kernel, dim3(grid_for_rows(rows)), dim3(NT), 0, ivit_stream(stream), a);
     IVIT_CHECK_LAUNCH("ivit_layernorm_i32_f32");
 }

@@ -54,14 +54,17 @@ IVIT_DEV float torch_rowsum(F elem, int n, int lane)
 
 // The same sum when the reduced dimension is NOT the contiguous one of the tensor (a transposed view, e.g. the Swin patch embedding:
 // layers_quant.py:198 hands `x.flatten(2).transpose(1, 2)` through an elementwise QuantAct, which keeps the strides, to the
-// LayerNorm's x_int.mean(axis=2)).  ATen then takes vectorized_outer_sum -> multi_row_sum: every output column is one accumulator
-// lane of its own, and the reduced index alone runs through the 4-level cascade -- level_step = 2^max(4, ceil_log2(n) / 4)
-// elements added in sequence, each finished group folded into the next level.  This is the order of every column whenever the
-// contiguous extent is a multiple of 32 columns (4 vectors of 8 floats; Swin: 3136 tokens) and the iteration is not split
-// inside it -- TensorIterator runs serially below 32768 outputs (up to 10 images) and with thread counts whose chunks are
-// multiples of 32 columns (1, 2, 4, 8, 16 threads at batch 128).  Serial; every lane that calls it gets the same value.
+// LayerNorm's x_int.mean(axis=2)).  ATen then takes vectorized_outer_sum: every output column (an index of the contiguous
+// dimension, extent L) is an accumulator lane of its own.
+//   columns below 32 * (L / 32) (4 vectors of 8 floats at a time): multi_row_sum -- the reduced index alone runs through the
+//     4-level cascade, level_step = 2^max(4, ceil_log2(n) / 4) elements added in sequence, each finished group folded upwards;
+//   the remaining L % 32 columns (vector and scalar tail): row_sum -- four interleaved partial sums (element i to partial i % 4),
+//     each a cascade over n / 4 steps, the n % 4 last elements into partial 0, then ((p0 + p1) + p2) + p3.
+// This is the order whenever the iteration is not split inside the contiguous extent: TensorIterator runs serially below 32768
+// outputs, and with one thread (oracle/ivit_oracle.c ivo_torch_outer_rowsum_f32 is the restatement checked against torch).
+// Serial; every lane that calls it gets the same value.
 template <class F>
-IVIT_DEV float torch_outer_rowsum(F elem, int n)
+IVIT_DEV float torch_cascade_sum(F elem, int n)
 {
     int lg = 0;
     while ((1 << lg) < n) ++lg;
@@ -79,6 +82,19 @@ IVIT_DEV float torch_outer_rowsum(F elem, int n)
     for (; i < n; ++i) acc0 += elem(i);
     acc0 += acc1; acc0 += acc2; acc0 += acc3;
     return acc0;
+}
+
+template <class F>
+IVIT_DEV float torch_outer_rowsum(F elem, int n, bool tail_column)
+{
+    if (!tail_column) return torch_cascade_sum(elem, n);
+    const int n4 = n >> 2;
+    float p0 = torch_cascade_sum([&](int i) { return elem(4 * i); }, n4);
+    const float p1 = torch_cascade_sum([&](int i) { return elem(4 * i + 1); }, n4);
+    const float p2 = torch_cascade_sum([&](int i) { return elem(4 * i + 2); }, n4);
+    const float p3 = torch_cascade_sum([&](int i) { return elem(4 * i + 3); }, n4);
+    for (int i = 4 * n4; i < n; ++i) p0 += elem(i);
+    return ((p0 + p1) + p2) + p3;
 }
 
 }  // namespace

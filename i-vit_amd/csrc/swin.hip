@@ -142,6 +142,9 @@ struct Ln16Args {
     int8_t* out;
     int64_t ldo;
     WinMap map;
+    int outer;     // compat kernels, > 0: the reference takes the mean over a transposed view of contiguous extent `outer` (the first
+                   // LayerNorm behind the Swin patch embedding, whose layout travels through the elementwise QuantActs): torch's
+                   // outer-reduction order (rowsum.h torch_outer_rowsum), row = image * outer + column
 };
 
 __global__ __launch_bounds__(NT) void layernorm_i16_i8_kernel(Ln16Args a)
@@ -202,7 +205,7 @@ __global__ __launch_bounds__(NT) void layernorm_i16_i8_literal_kernel(Ln16LitArg
     for (int row = blockIdx.x * WPB + wave; row < a.rows; row += gridDim.x * WPB) {
         const int16_t* xr = a.x + (int64_t)row * C;
         auto xint = [&](int c) { return ((float)xr[c] * s_in) / s_in; };       // :36 on the float view q * s
-        const float S = torch_rowsum(xint, C, lane);
+        const float S = a.outer ? torch_outer_rowsum(xint, C, row % a.outer >= (a.outer & ~31)) : torch_rowsum(xint, C, lane);
         const int mean_int = (int)rintf(S / (float)C);                         // :37
         long long var = 0;
         for (int c = lane; c < C; c += 64) {
@@ -513,7 +516,13 @@ __global__ __launch_bounds__(NT) void layernorm_i16_i8_tiled_compat_kernel(Ln16A
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        {   // float32 row sums in torch's order: the two halves of the wave take two rows per round
+        if (a.outer) {   // transposed view in the reference: a lane sums one row in the outer-reduction order (serial cascade)
+            if (lane < RPW) {
+                const float* pr = s_phi[wave] + lane * C;
+                const int rw = min(row0 + lane, a.rows - 1);
+                s_sum[wave][lane] = torch_outer_rowsum([&](int i) { return pr[i]; }, C, rw % a.outer >= (a.outer & ~31));
+            }
+        } else {   // float32 row sums in torch's order: the two halves of the wave take two rows per round
             const int half = lane >> 5, l32 = lane & 31;
 #pragma unroll 1
             for (int r0 = 0; r0 < RPW; r0 += 2) {
@@ -934,7 +943,7 @@ IVIT_EXPORT int ivit_layernorm_i16_i8(const int16_t* x, int rows, int C, const f
                  "ivit_layernorm_i16_i8: bad operand");
     int rc = check_map("ivit_layernorm_i16_i8", rows, H, W, ws, shift);
     if (rc) return rc;
-    Ln16Args a{x, rows, C, bias_int, s_ln, m, e, out, ldo, WinMap{H, W, ws, shift}};
+    Ln16Args a{x, rows, C, bias_int, s_ln, m, e, out, ldo, WinMap{H, W, ws, shift}, 0};
     hipStream_t st = ivit_stream(stream);
     const bool tiled = C % 8 == 0 && C <= 1536 && ldo % 8 == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)out % 8 == 0) &&
                        ((uintptr_t)bias_int % 16 == 0) && ((uintptr_t)s_ln % 16 == 0) && ((uintptr_t)m % 16 == 0) &&
@@ -972,7 +981,10 @@ IVIT_EXPORT int ivit_layernorm_i16_i8_compat(const int16_t* x, int rows, int C, 
                  "ivit_layernorm_i16_i8_compat: bad operand");
     int rc = check_map("ivit_layernorm_i16_i8_compat", rows, H, W, ws, shift);
     if (rc) return rc;
-    Ln16Args b{x, rows, C, bias_int, s_ln, m, e, out, ldo, WinMap{H, W, ws, shift}};
+    const int outer = fast_division >> 8;     // IVIT_LN_OUTER_MEAN(L)
+    fast_division &= 255;
+    IVIT_REQUIRE(outer >= 0 && (outer == 0 || rows % outer == 0) && fast_division <= 1, "ivit_layernorm_i16_i8_compat: bad flags");
+    Ln16Args b{x, rows, C, bias_int, s_ln, m, e, out, ldo, WinMap{H, W, ws, shift}, outer};
     hipStream_t st = ivit_stream(stream);
     const bool tiled = fast_division && C % 8 == 0 && C <= 1536 && ldo % 8 == 0 && ((uintptr_t)x % 16 == 0) &&
                        ((uintptr_t)out % 8 == 0) && ((uintptr_t)bias_int % 16 == 0) && ((uintptr_t)s_ln % 16 == 0) &&

@@ -17,6 +17,8 @@ There is no fallback path: a missing libivit_hip.so or a kernel error raises.
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 
@@ -34,6 +36,9 @@ def _np(v):
 
 
 class IntViTEngine(GraphReplay):
+    # fragment-packed weights in the 16x16x64 MFMA order (False / IVIT_FRAGS16=0: the 32x32x32 order everywhere; A/B, tests)
+    frags16 = os.environ.get("IVIT_FRAGS16", "1") != "0"
+
     def __init__(self, float_state=None, ranges=None, embed_dim: int = 768, depth: int = 12, num_heads: int = 12,
                  device="cuda:0", max_batch: int = 256, source=None, family: str = "ivit", stream_bits: int = 8,
                  softmax_bits: int = 8, pos_bits: int = 8):
@@ -234,14 +239,19 @@ class IntViTEngine(GraphReplay):
                 lin["Wb"] = torch.empty_like(lin["W"])
                 _lib.call("ivit_tile_operand_i8", _lib.ptr(lin["W"]), lin["K"], lin["N"], lin["K"], _lib.ptr(lin["Wb"]),
                           self._stream())
-        # MFMA-fragment copies (IVIT_W_FRAGS): the weights-in-registers GEMM, 14-21 % faster than the LDS-DMA kernel on block-layout
-        # weights; needs K % 192 == 0, and its 256-channel tiles must not waste more than an eighth of their columns
+        # MFMA-fragment copies: the weights-in-registers GEMM, 14-21 % faster than the LDS-DMA kernel on block-layout weights; needs
+        # K % 192 == 0, and its 256-channel tiles must not waste more than an eighth of their columns.  IVIT_W_FRAGS16 (the
+        # v_mfma_i32_16x16x64_i8 form: the chip holds a higher clock on that shape, fc1 -7 %, fc2 -5 %) wherever the epilogue writes
+        # int8; the 16-bit-stream epilogue of proj / fc2 exists for the 32x32x32 form (IVIT_W_FRAGS) only
+        wide = {id(b[k]) for b in self.blocks for k in ("proj", "fc2")} if self.stream_bits == 16 else set()
         for lin in [self.patch] + [b[k] for b in self.blocks for k in ("qkv", "proj", "fc1", "fc2")]:
             N, K = lin["N"], lin["K"]
             lin["Wf"] = None
+            lin["Wf_bit"] = 8 if id(lin) in wide or not self.frags16 else 16
             if K % 192 == 0 and N % 64 == 0 and N >= 128 and (N + 255) // 256 * 256 * 8 <= N * 9:
                 lin["Wf"] = torch.empty((N + 63) // 64 * 64 * K, dtype=torch.int8, device=self.dev)
-                _lib.call("ivit_pack_weight_frags_i8", _lib.ptr(lin["W"]), K, N, K, _lib.ptr(lin["Wf"]), self._stream())
+                _lib.call("ivit_pack_weight_frags_i8" if lin["Wf_bit"] == 8 else "ivit_pack_weight_frags16_i8", _lib.ptr(lin["W"]), K, N, K,
+                          _lib.ptr(lin["Wf"]), self._stream())
         self.weight_frags = True      # False: block-layout weights through the LDS-DMA kernel (A/B timing)
         self.block_operands = True    # False: row-major activations / weights everywhere (tests, A/B timing)
         # which producers write their output (a GEMM A operand) in the block layout.  Measured per producer / consumer pair
@@ -284,7 +294,7 @@ class IntViTEngine(GraphReplay):
     def _w(self, lin, blocks):
         """(weight pointer, layout bit) -- the block-layout copy when the call goes to the persistent kernel"""
         if blocks and self.weight_frags and lin.get("Wf") is not None:
-            return _lib.ptr(lin["Wf"]), 8
+            return _lib.ptr(lin["Wf"]), lin["Wf_bit"]
         if blocks and lin["Wb"] is not None:
             return _lib.ptr(lin["Wb"]), 2
         return _lib.ptr(lin["W"]), 0
@@ -424,7 +434,7 @@ class IntViTEngine(GraphReplay):
                 g_buf = ws["f1"]
                 _lib.call("ivit_gemm_i8_requant_lut_ex", _lib.ptr(ws["h"]), C, _lib.ptr(f1["Wf"]), f1["K"], _lib.ptr(f1["b"]),
                           _lib.ptr(f1["m"]), _lib.ptr(f1["e"]), _lib.ptr(blk["gelu_lut"]), _lib.ptr(g_buf), 4 * C, M, f1["N"], f1["K"],
-                          8 | int(a_ln) | (4 if a_ge else 0), st)
+                          f1["Wf_bit"] | int(a_ln) | (4 if a_ge else 0), st)
             else:
                 self._gemm(ws["h"], C, f1, ws["f1"], 4 * C, M, st, a_blocks=a_ln, blocks=blk_l, out_blocks=a_ge)
                 tap(p + "mlp.qact_gelu", ws["f1"], (B, T, 4 * C), a_ge)
@@ -486,7 +496,7 @@ class IntViTEngine(GraphReplay):
                     probe.begin("gemm_resid", st)
                 _lib.call("ivit_gemm_i8_requant_i16_residual_i16_ex", _lib.ptr(A), lda, _lib.ptr(lin["Wf"] if frags else lin["W"]), lin["K"],
                           _lib.ptr(lin["b"]), _lib.ptr(lin["m"]), _lib.ptr(lin["e"]), _lib.ptr(res), C, r[0], r[1], r[2], r[3], _lib.ptr(out),
-                          C, M, C, lin["K"], 8 if frags else 0, st)
+                          C, M, C, lin["K"], lin["Wf_bit"] if frags else 0, st)
                 if probe is not None:
                     probe.end("gemm_resid", st, (M, C, lin["K"]))
                 return
@@ -518,7 +528,7 @@ class IntViTEngine(GraphReplay):
                 # I-BERT GELU + mlp.qact1 as a byte map in the fc1 epilogue (see forward)
                 _lib.call("ivit_gemm_i8_requant_lut_ex", _lib.ptr(ws["h"]), C, _lib.ptr(f1["Wf"]), f1["K"], _lib.ptr(f1["b"]),
                           _lib.ptr(f1["m"]), _lib.ptr(f1["e"]), _lib.ptr(blk["gelu_lut"]), _lib.ptr(ws["f1"]), 4 * C, M, f1["N"], f1["K"],
-                          8, st)
+                          f1["Wf_bit"], st)
             else:
                 self._gemm(ws["h"], C, f1, ws["f1"], 4 * C, M, st, a_blocks=False, blocks=big, out_blocks=False)
                 _lib.call("ivit_shiftgelu_lut_i8_ex", _lib.ptr(ws["f1"]), 4 * C, M, 4 * C, _lib.ptr(blk["gelu_lut"]),

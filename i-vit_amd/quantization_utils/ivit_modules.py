@@ -37,14 +37,24 @@ class IVITIntLayerNorm(nn.LayerNorm):
         _, bias_int, s_ln = self._cache
         # the literal kernel: x / scaling_factor, the float32 mean in torch's reduction order, .to(int32), ... (:36-63) for
         # any input scale (a calibrated, non power-of-two scale makes x / s a non-integer float, see csrc/literal.hip)
+        # x_int.mean(axis=2) (:37) over a TRANSPOSED view (the Swin patch embedding, layers_quant.py:198: the reduced dimension is
+        # not the contiguous one) runs through ATen's outer-reduction cascade; rows whose mean is an exact .5 tie depend on it
+        outer = 0
+        if x.dim() >= 2 and x.stride(-1) != 1 and x.shape[-1] > 1:
+            if x.dim() != 3 or x.stride(1) != 1 or x.stride(2) != x.shape[1] or x.stride(0) != x.shape[1] * x.shape[2]:
+                raise NotImplementedError("IVITIntLayerNorm over a strided last dimension: only the [B, L, C] transpose of a "
+                                          "contiguous [B, C, L] tensor (the patch embedding) is restated")
+            outer = x.shape[1]       # contiguous extent of the view
         xin = x.contiguous().float()
         s_in = scaling_factor.reshape(-1).contiguous().float()
         assert s_in.numel() in (1, C)
         out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
-        _lib.call("ivit_layernorm_f32_f32", _lib.ptr(xin), C, xin.numel() // C, C, _lib.ptr(s_in), s_in.numel(),
-                  _lib.ptr(bias_int), _lib.ptr(s_ln), _lib.ptr(out), C, _st())
+        _lib.call("ivit_layernorm_f32_f32_ex", _lib.ptr(xin), C, xin.numel() // C, C, _lib.ptr(s_in), s_in.numel(),
+                  _lib.ptr(bias_int), _lib.ptr(s_ln), _lib.ptr(out), C, outer, _st())
         self.bias_integer = bias_int                            # :59
         self.norm_scaling_factor = s_ln                         # :64
+        if outer:     # the reference's output is a chain of elementwise ops on x_int: it keeps the input's (transposed) strides
+            out = torch.empty_like(x, dtype=torch.float32).copy_(out)
         return out, s_ln
 
 

@@ -286,7 +286,10 @@ class QuantAct(nn.Module):
         xa = x_act.detach().contiguous().float()
         mm = torch.empty(2, dtype=torch.float32, device=xa.device)
         _lib.call("ivit_minmax_f32", _lib.ptr(xa), xa.numel(), _lib.ptr(mm), _st())
-        x_min, x_max = mm[0], mm[1]
+        self._observe_update(mm[0], mm[1])
+
+    def _observe_update(self, x_min, x_max):
+        """the reference's update of its range by one observation (quant_modules.py:346-360)"""
         if torch.eq(self.x_min, self.x_max).all():
             self.x_min = self.x_min + x_min
             self.x_max = self.x_max + x_max
@@ -300,6 +303,7 @@ class QuantAct(nn.Module):
 
     def forward(self, x, pre_act_scaling_factor=None, identity=None, identity_scaling_factor=None,
                 specified_min=None, specified_max=None):
+        identity_in = identity
         if self.running_stat:
             self._observe(x if identity is None else identity + x)
         x_min = self.x_min if specified_min is None else specified_min
@@ -339,7 +343,15 @@ class QuantAct(nn.Module):
             q = torch.empty(z.shape, dtype=torch.int32, device=x.device)
             _lib.call("ivit_requant_i32", _lib.ptr(z), z.numel() // C, C, _lib.ptr(m), _lib.ptr(e), n_me,
                       _lib.ptr(z2), _lib.ptr(m2), _lib.ptr(e2), n2, bits, _lib.ptr(q), _st())
-        return to_float(q, self.act_scaling_factor), self.act_scaling_factor
+        y = to_float(q, self.act_scaling_factor)
+        # Memory layout of the result, as torch gives it to the reference's chain of elementwise ops: the strides of a dense
+        # permuted input are kept, and the two-operand form ends in `output1 + output` (quant_utils.py:245) with the IDENTITY's
+        # term first, whose layout wins.  A consumer whose float32 reduction order depends on the layout (IVITIntLayerNorm behind
+        # the Swin patch embedding's transpose, layers_quant.py:198-201, and every LayerNorm of Swin's first stage) must see it.
+        lay = identity_in if (identity_in is not None and identity_in.shape == x.shape) else x
+        if not lay.is_contiguous() and y.shape == lay.shape:
+            y = torch.empty_like(lay, dtype=torch.float32).copy_(y)
+        return y, self.act_scaling_factor
 
 
 # ----------------------------------------------------------------------------- QuantMatMul

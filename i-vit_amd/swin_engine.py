@@ -311,9 +311,9 @@ class IntSwinEngine(GraphReplay):
         _lib.call("ivit_gemm_i8_requant_ex", _lib.ptr(A), lda, w, lin["K"], _lib.ptr(lin["b"]),
                   _lib.ptr(lin["m"]), _lib.ptr(lin["e"]), _lib.ptr(out), ldo, M, lin["N"], lin["K"], lay, st)
 
-    def _ln16(self, x, rows, C, ln, out, ldo, st, H=0, W=0, ws=0, shift=0):
+    def _ln16(self, x, rows, C, ln, out, ldo, st, H=0, W=0, ws=0, shift=0, outer=0):
         if ln["s_in"] is not None:       # natural input scale: the literal kernel (csrc/swin.hip)
-            _lib.call("ivit_layernorm_i16_i8_compat", _lib.ptr(x), rows, C, ln["s_in"], ln["fast_div"], _lib.ptr(ln["bias"]), _lib.ptr(ln["s"]),
+            _lib.call("ivit_layernorm_i16_i8_compat", _lib.ptr(x), rows, C, ln["s_in"], ln["fast_div"] | (outer << 8), _lib.ptr(ln["bias"]), _lib.ptr(ln["s"]),
                       _lib.ptr(ln["m"]), _lib.ptr(ln["e"]), _lib.ptr(out), ldo, H, W, ws, shift, st)
             return
         _lib.call("ivit_layernorm_i16_i8", _lib.ptr(x), rows, C, _lib.ptr(ln["bias"]), _lib.ptr(ln["s"]),
@@ -360,7 +360,7 @@ class IntSwinEngine(GraphReplay):
         if ln["remap"] is not None:
             _lib.call("ivit_layernorm_i8_compat", _lib.ptr(ws["pe"]), C0, M, C0, _lib.ptr(ln["bias"]), _lib.ptr(ln["s"]),
                       _lib.ptr(ln["m"]), _lib.ptr(ln["e"]), _lib.ptr(ln["remap"]), _lib.ptr(ln["phi"]), _lib.ptr(ws["pn"]), C0,
-                      0, st)
+                      (M // B) << 8, st)   # IVIT_LN_OUTER_MEAN(L): the reference reduces over the transposed view of layers_quant.py:198
         else:
             _lib.call("ivit_layernorm_i8", _lib.ptr(ws["pe"]), C0, M, C0, _lib.ptr(ln["bias"]), _lib.ptr(ln["s"]),
                       _lib.ptr(ln["m"]), _lib.ptr(ln["e"]), _lib.ptr(ws["pn"]), C0, st)
@@ -381,7 +381,12 @@ class IntSwinEngine(GraphReplay):
                 perm = None
                 if taps is not None:
                     perm = torch.from_numpy(window_row_map(B, H, W, win, shift)).to(self.dev)
-                self._ln16(x, M, C, blk["ln1"], ws["h"], ld, st, H, W, win, shift)
+                # every LayerNorm of stage 0 still sees the patch embedding's transposed layout in the reference: elementwise ops keep
+                # the strides of layers_quant.py:198's view, and the residual QuantActs add `identity + x` with the identity (the
+                # strided stream) as the first operand, whose layout torch then gives the sum; only the patch merging's cat makes the
+                # stream contiguous.  Their float32 means run in torch's outer-reduction order (IVIT_LN_OUTER_MEAN)
+                outer = H * W if li == 0 else 0
+                self._ln16(x, M, C, blk["ln1"], ws["h"], ld, st, H, W, win, shift, outer=outer)
                 tap(p + "qact1", ws["h"], M, C, ld, perm)
                 q = blk["qkv"]
                 qw, qlay = self._w(q, M)
@@ -424,7 +429,7 @@ class IntSwinEngine(GraphReplay):
                     _lib.call("ivit_residual_requant_i16", _lib.ptr(ws["acc"]), 32, _lib.ptr(pj["m"]), _lib.ptr(pj["e"]),
                               r[0], r[1], _lib.ptr(x), r[2], r[3], _lib.ptr(x2), M, C, H, W, win, shift, st)
                 tap(p + "qact2", x2, M, C)
-                self._ln16(x2, M, C, blk["ln2"], ws["h"], ld, st)
+                self._ln16(x2, M, C, blk["ln2"], ws["h"], ld, st, outer=outer)
                 tap(p + "qact3", ws["h"], M, C, ld)
                 self._gemm(ws["h"], ld, blk["fc1"], ws["f1"], 4 * C, M, st)
                 tap(p + "mlp.qact_gelu", ws["f1"], M, 4 * C)

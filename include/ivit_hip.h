@@ -216,7 +216,7 @@ int ivit_attention_fused_i8_compat(const int8_t* qkv, int8_t* out, int batch, in
                                    const uint32_t* exp2d, int out_blocks, ivit_stream_t stream);
 
 /* The same with the table also in BAND form, staged per query tile in LDS (the fast path; exp2d may then be NULL):
- * band[(qmax+128)*band_w + j] = exp_int of (qmax, q = qmax - j) for j < band_w, band_w a multiple of 16 in [16, 256] chosen
+ * band[(qmax+128)*band_w + j] = exp_int of (qmax, q = qmax - j) for j < band_w, band_w a multiple of 16 in [16, 128] (the staged rows must fit the 64 KiB of LDS a launch gets by default) chosen
  * by the caller such that entry band_w - 1 is already the saturated value (the exponent's argument is clamped at n*x0,
  * ivit_modules.py:155, so every larger distance gives the same entry); i-vit_amd/prepare.py shiftexp_band. */
 int ivit_attention_fused_i8_compat_band(const int8_t* qkv, int8_t* out, int batch, int heads, int tokens, int head_dim,
@@ -251,8 +251,11 @@ int ivit_layernorm_i8_ex(const int8_t* x, int64_t ldx, int rows, int C, const fl
  * (i-vit_amd/prepare.py phi_tables).  C % 8 == 0, C >= 32. */
 int ivit_layernorm_i8_compat(const int8_t* x, int64_t ldx, int rows, int C, const float* bias_int, const float* s_ln,
                              const uint32_t* m, const int32_t* e, const int8_t* remap /* [256] */,
-                             const float* phi /* [256] */, int8_t* out, int64_t ldo, int out_blocks,
+                             const float* phi /* [256] */, int8_t* out, int64_t ldo, int flags,
                              ivit_stream_t stream);
+#define IVIT_LN_OUT_BLOCKS 1              /* `flags` of ivit_layernorm_i8_compat: `out` in IVIT_LAYOUT_BLOCKS */
+#define IVIT_LN_OUTER_MEAN(L) ((L) << 8)  /* tie rows in torch's outer-reduction order for a transposed view of contiguous extent L
+                                           * (see ivit_layernorm_f32_f32_ex): the Swin patch embedding */
 
 /* module-level form: int32 input (8 or 16 bit values), float32 output y*s_ln (ivit_modules.py:63) */
 int ivit_layernorm_i32_f32(const int32_t* x, int64_t ldx, int rows, int C, const float* bias_int,
@@ -264,6 +267,15 @@ int ivit_layernorm_i32_f32(const int32_t* x, int64_t ldx, int rows, int C, const
  * truncating .to(int32).  Equals ivit_layernorm_i32_f32 on round(x/s) when s is a power of two. */
 int ivit_layernorm_f32_f32(const float* x, int64_t ldx, int rows, int C, const float* s_in, int n_s,
                            const float* bias_int, const float* s_ln, float* out, int64_t ldo, ivit_stream_t stream);
+/* outer_mean = L > 0: the caller's tensor reaches the reference's `x_int.mean(axis=2)` as a TRANSPOSED view (the reduced dimension
+ * is not the contiguous one: the Swin patch embedding, layers_quant.py:198-201, whose elementwise QuantAct keeps the strides of
+ * `x.flatten(2).transpose(1, 2)`); L = extent of the contiguous dimension (tokens per image), rows % L == 0, row = image * L +
+ * column.  ATen then sums every row with its outer-reduction order (csrc/rowsum.h: one cascade over the reduced index for
+ * columns below 32 * (L / 32), four interleaved cascades for the last L % 32 columns) instead of the 32-partial-sum order of a
+ * contiguous row; rows whose mean is an exact .5 tie come out differently.  `x` itself is still passed row-contiguous. */
+int ivit_layernorm_f32_f32_ex(const float* x, int64_t ldx, int rows, int C, const float* s_in, int n_s,
+                              const float* bias_int, const float* s_ln, float* out, int64_t ldo, int outer_mean,
+                              ivit_stream_t stream);
 
 /* ---- ShiftGELU -----------------------------------------------------------------------------
  * IVITIntGELU.forward (ivit_modules.py:89-126, n = 23, output_bit = 8) on rows of L int8 values
@@ -344,7 +356,9 @@ int ivit_bgemm_qk_i8(const int8_t* Q, const int8_t* K, int32_t* S, int batch, in
                      ivit_stream_t stream);
 int ivit_bgemm_pv_i8(const int8_t* P, const int8_t* V, int32_t* O, int batch, int Tq, int Tk, int D,
                      ivit_stream_t stream);
-/* P of more than 8 bits (Shiftmax with output_bit up to 16: values <= 32767, a row sums to ~2^15 so |acc| < 2^23) */
+/* P of more than 8 bits.  CONTRACT: P is a softmax output -- every row of P sums to at most 2^15 + Tk (Shiftmax with output_bit
+ * up to 16), so |acc| <= 128 * (2^15 + Tk) < 2^23; arbitrary int16 P would overflow the int32 accumulator from Tk = 512 on and is
+ * not checked (for wider or unbounded P use ivit_bgemm_pv_i32_i8, which takes and checks a bound) */
 int ivit_bgemm_pv_i16_i8(const int16_t* P, const int8_t* V, int32_t* O, int batch, int Tq, int Tk, int D,
                          ivit_stream_t stream);
 /* P as int32 with |P| <= p_absmax (I-BERT's softmax with output_bit = 16 reaches 2^15 on a one-hot row, ibert_modules.py:314);
@@ -398,7 +412,9 @@ int ivit_layernorm_i16_i8(const int16_t* x, int rows, int C, const float* bias_i
  * over those values in torch's CPU reduction order, truncating .to(int32), ivit_modules.py:36-38).  fast_division = 1: the
  * caller has verified (exhaustively over the 65 536 inputs, prepare.markstein_division_ok) that the 3-instruction quotient by
  * the invariant s_in -- q0 = x*r, e = fma(-s, q0, x), fma(e, r, q0) with r = RN(1/s_in) -- is the correctly rounded one for this
- * s_in, which enables the tiled kernel; 0: the literal one-wave-per-row kernel with IEEE divisions. */
+ * s_in, which enables the tiled kernel; 0: the literal one-wave-per-row kernel with IEEE divisions.  fast_division |
+ * IVIT_LN_OUTER_MEAN(L): the reference takes this mean over a transposed view of contiguous extent L (see
+ * ivit_layernorm_f32_f32_ex: Swin's first norm1, whose input still carries the patch embedding's layout). */
 int ivit_layernorm_i16_i8_compat(const int16_t* x, int rows, int C, float s_in, int fast_division, const float* bias_int,
                                  const float* s_ln, const uint32_t* m, const int32_t* e, int8_t* out, int64_t ldo, int H, int W,
                                  int ws, int shift, ivit_stream_t stream);

@@ -360,7 +360,10 @@ def gen_swin(tag="swin_tiny"):
 
 def gen_swin_natural(tag):
     """Swin-T with its ranges AS CALIBRATED (two batches, EMA), frozen: logits / top-1 / tap digests of the reference.
-    There is no compat oracle for Swin; the fixture pins the mirror's module path (literal float kernels) on the GPU."""
+    There is no compat oracle for Swin; the fixture pins the mirror's module path (literal float kernels) and the fused engine on
+    the GPU.  The patch-embed LayerNorm reduces over a transposed view (layers_quant.py:198-201): its exact-tie rows (counted
+    into the meta record) are decided by ATen's outer-reduction order, which is deterministic at this batch -- the golden forward
+    is repeated with 1 and with 4 threads and must give the same digests."""
     sq = _import_swin()
     factory, wseed, cseeds, cb, iseed, nimg = "swin_tiny_patch4_window7_224", 21, (201, 211), 2, 2001, 2
     model = getattr(sq, factory)(pretrained=False)
@@ -389,15 +392,32 @@ def gen_swin_natural(tag):
     for name, mod in model.named_modules():
         if isinstance(mod, (rq.QuantAct, rq.IVITIntSoftmax, rq.IVITIntGELU)) and name != "act_out":
             mod.register_forward_hook(hook(name))
+    cap = {}
+    model.patch_embed.norm.register_forward_pre_hook(lambda mod, inp: cap.__setitem__("ln_in", (inp[0].detach().clone(), inp[1].detach().clone(), inp[0].stride())))
     imgs = synth.make_images(nimg, iseed)
     y = model(torch.from_numpy(imgs))
+    # the reference against itself: other thread counts, same digests (TensorIterator runs this reduction serially below 32768 outputs)
+    first = {n: crc(t) for n, t in taps.items()}
+    nthreads = torch.get_num_threads()
+    for nt in (1, 4):
+        torch.set_num_threads(nt)
+        y2 = model(torch.from_numpy(imgs))
+        assert torch.equal(y, y2) and all(first[n] == crc(taps[n]) for n in first), f"the reference differs from itself with {nt} threads"
+    torch.set_num_threads(nthreads)
+    xin, sin, strides = cap["ln_in"]
+    assert strides[-1] != 1, "patch_embed.norm no longer sees a transposed view"
+    rs = torch.round(xin / sin).to(torch.int64).sum(dim=2)
+    Cn = xin.shape[2]
+    tie_rows = int(((rs % Cn) == Cn // 2).sum())
+    print(f"[{tag}] patch_embed.norm: input strides {tuple(strides)}, {tie_rows} of {rs.numel()} rows are exact ties of the mean")
     s_head = (model.head.fc_scaling_factor * model.qact3.act_scaling_factor).float()
     logits_int = torch.round(y / s_head).to(torch.int64).numpy().astype(np.int32)
     names = sorted(taps)
     out = {
         "meta": np.array(json.dumps(dict(tag=tag, factory=factory, weight_seed=wseed, calib_seeds=list(cseeds), calib_batch=cb,
                                          image_seed=iseed, n_images=nimg, qkv_gain=synth.QKV_GAIN, regime="natural",
-                                         torch=torch.__version__))),
+                                         patch_norm_tie_rows=tie_rows, patch_norm_rows=int(rs.numel()),
+                                         reproducible_with_threads=[1, 4, nthreads], torch=torch.__version__))),
         "range_names": np.array(list(ranges)),
         "range_bits": np.array([bitsof[n] for n in ranges], np.int32),
         "x_min": np.array([v[0] for v in ranges.values()], np.float32),
@@ -881,6 +901,69 @@ def gen_ibert_natural(tag="deit_tiny_ibert_natural"):
     print(f"[{tag}] wrote fixtures; LayerNorm shifts {sorted(set(shifts.values()))}; top1 = {out['top1'].tolist()}")
 
 
+CALIB_TRACE_PLAN = {
+    # tag: (factory, operator family, weight seed, calibration seeds, calibration batch) -- the plans of the *_natural fixtures
+    "deit_tiny_natural": ("deit_tiny_patch16_224", "ivit", 11, (101, 111, 121), 4),
+    "deit_small_natural": ("deit_small_patch16_224", "ivit", 12, (102, 112), 4),
+    "deit_tiny_ibert_natural": ("deit_tiny_patch16_224", "ibert", 11, (101, 111), 4),
+}
+
+
+def gen_calib_trace():
+    """The reference's calibration, step by step (quant_modules.py:310-360; scripts/inference.py:33-91 runs exactly these
+    forwards): for every calibration batch and every QuantAct, the raw (min, max) it observed over its float input and the range
+    it held after its update (first batch: initialise; later: EMA with momentum 0.95).  tests/golden/calib_trace.npz; the GPU
+    test drives the module mirror through the same batches with each QuantAct forced to the reference's post-update range, so
+    that both sides quantise alike, and compares what the mirror OBSERVES and what its update rule MAKES of the observation."""
+    out = {}
+    for tag, (factory, fam, wseed, cseeds, cb) in CALIB_TRACE_PLAN.items():
+        model = getattr(ref_models, factory)(pretrained=False, gelu_type=fam, softmax_type=fam, layernorm_type=fam)
+        fs = synth.make_float_state(factory, wseed)
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in fs.items()}, strict=False)
+        model.eval()
+        qacts = [(n, m) for n, m in model.named_modules() if isinstance(m, rq.QuantAct)]
+        raw, post, order = {}, {}, []
+
+        def pre(name):
+            def fn(mod, args, kwargs):
+                x = args[0]
+                identity = args[2] if len(args) > 2 else kwargs.get("identity")
+                xa = x if identity is None else identity + x                     # quant_modules.py:310
+                raw.setdefault(name, []).append((float(xa.data.min()), float(xa.data.max())))
+                if name not in order:
+                    order.append(name)
+            return fn
+
+        def after(name):
+            def fn(mod, args, outp):
+                post.setdefault(name, []).append((float(mod.x_min), float(mod.x_max)))
+            return fn
+
+        for n, m in qacts:
+            m.register_forward_pre_hook(pre(n), with_kwargs=True)
+            m.register_forward_hook(after(n))
+        for cs in cseeds:
+            model(torch.from_numpy(synth.make_images(cb, cs)))
+        names = [n for n, _ in qacts]
+        assert set(order) == set(names) and all(len(raw[n]) == len(cseeds) for n in names)
+        z = np.load(os.path.join(GOLD, tag + ".npz"), allow_pickle=True)
+        assert names == [str(x) for x in z["range_names"]]
+        fin = np.array([post[n][-1] for n in names], np.float32)
+        assert np.array_equal(fin[:, 0], z["x_min"]) and np.array_equal(fin[:, 1], z["x_max"]), "trace != the fixture's final ranges"
+        out[tag + "/names"] = np.array(names)
+        out[tag + "/call_order"] = np.array(order)
+        out[tag + "/raw"] = np.array([[raw[n][b] for n in names] for b in range(len(cseeds))], np.float32)      # [batch, qact, 2]
+        out[tag + "/post"] = np.array([[post[n][b] for n in names] for b in range(len(cseeds))], np.float32)
+        out[tag + "/meta"] = np.array(json.dumps(dict(factory=factory, family=fam, weight_seed=wseed, calib_seeds=list(cseeds),
+                                                      calib_batch=cb, momentum=0.95, torch=torch.__version__)))
+        if fam == "ibert":
+            lns = [(n, m) for n, m in model.named_modules() if isinstance(m, rq.IBERTIntLayerNorm)]
+            out[tag + "/ln_names"] = np.array([n for n, _ in lns])
+            out[tag + "/ln_shift"] = np.array([float(m.shift) for _, m in lns], np.float32)
+        print(f"[calib_trace] {tag}: {len(names)} QuantActs x {len(cseeds)} batches")
+    np.savez_compressed(os.path.join(GOLD, "calib_trace.npz"), **out)
+
+
 def gen_schema():
     """state_dict keys and shapes of the reference's DeiT and Swin models (the on-disk checkpoint format)"""
     out = {}
@@ -911,6 +994,8 @@ if __name__ == "__main__":
             gen_compat_ops()
         elif w == "ibert_ops":
             gen_ibert_ops()
+        elif w == "calib_trace":
+            gen_calib_trace()
         elif w == "schema":
             gen_schema()
         elif w in ("deit_tiny_ibert_natural", "deit_tiny_ibert_w16all"):

@@ -1,0 +1,18 @@
+#!/bin/bash
+# round 3, GPU batch c: full GPU suite with the 16x16x64 GEMM form as the engine default + the Swin natural-scale end-to-end test,
+# bench A/B of the two fragment forms on one box
+set -e
+cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/r03c; mkdir -p $O
+export TMPDIR=/tmp
+timeout -k 10 900 python -m pytest tests -m gpu -x -q > $O/gpu_tests.log 2>&1 || { tail -60 $O/gpu_tests.log; exit 1; }
+tail -3 $O/gpu_tests.log
+for i in 1 2; do
+IVIT_FRAGS16=0 timeout -k 10 300 python bench.py --steps 50 --warmup 10 --no-cpu-baseline > $O/bench_f32_$i.json 2>> $O/bench.err
+timeout -k 10 300 python bench.py --steps 50 --warmup 10 --no-cpu-baseline > $O/bench_f16_$i.json 2>> $O/bench.err
+done
+python - <<'PY'
+import json,glob
+for f in sorted(glob.glob("gpurun_out/r03c/bench_f*.json")):
+    d=json.loads(open(f).read().strip().splitlines()[-1]); print(f, d["ms_per_step"], d["value"], d["roofline"]["avg_launch_ms_raw"], d["roofline"]["frac"])
+PY

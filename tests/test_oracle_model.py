@@ -96,6 +96,29 @@ def test_compat_gelu_and_shiftmax_kat(ckat):
         assert np.array_equal(orc.shiftmax_compat(ckat[c + "q"].astype(np.int32), ckat[c + "s"]), ckat[c + "out"]), ci
 
 
+def test_torch_outer_rowsum_equals_torch_on_a_transposed_view():
+    """the order csrc/rowsum.h torch_outer_rowsum / ivo_torch_outer_rowsum_f32 restate IS what this torch build does for
+    `x.mean(axis=2)` over a [B, L, C] view with strides (L*C, 1, L) (the Swin patch embedding): bitwise on order-sensitive data,
+    for the Swin geometry (C = 96, L = 3136) and other sizes, and different from the contiguous-row order on the same numbers"""
+    import torch
+    rng = np.random.default_rng(7)
+    differs = 0
+    for C, L in ((96, 3136), (96, 64), (192, 784), (128, 32), (48, 96), (768, 64), (1000, 32), (96, 50), (384, 196), (97, 77)):
+        x = (rng.standard_normal((2, C, L)) * rng.uniform(1, 1e4, size=(2, C, 1))).astype(np.float32)
+        xt = torch.from_numpy(x).transpose(1, 2)                 # [B, L, C], strides (C*L, 1, L)
+        assert xt.stride(-1) != 1
+        got = xt.sum(dim=2).numpy()
+        rows = x.transpose(0, 2, 1).reshape(-1, C)               # the same rows, contiguous
+        step = max(1, len(rows) // 400)
+        idx = np.concatenate([np.arange(0, len(rows), step), np.arange(max(0, L - 40), L)])      # incl. the tail columns of image 0
+        exp = np.array([orc.torch_outer_rowsum(rows[i], (i % L) >= (L // 32) * 32) for i in idx], np.float32)
+        assert np.array_equal(got.reshape(-1)[idx].view(np.int32), exp.view(np.int32)), (C, L)
+        inner = np.array([orc.torch_rowsum(r) for r in rows[:200]], np.float32)
+        differs += int((inner.view(np.int32) != got.reshape(-1)[:200].view(np.int32)).sum())
+        assert np.array_equal(torch.from_numpy(rows[:200].copy()).sum(dim=1).numpy().view(np.int32), inner.view(np.int32))
+    assert differs > 0
+
+
 def test_torch_rowsum_order_is_not_plain_left_to_right():
     """the restated reduction order is observable: it differs from a sequential float32 sum on fuzzy near-integers"""
     rng = np.random.default_rng(5)

@@ -65,6 +65,44 @@ def test_two_rank_gloo_allgather_matches_single_process():
     assert np.array_equal(got, exp.numpy())
 
 
+def _worker_uneven(rank, world, port, n_images, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(1)
+    all_imgs = torch.randint(0, 50, (n_images, 3, 2, 2), generator=g).float()
+    bounds = [shard_bounds(n_images, world, r) for r in range(world)]
+    lo, hi = bounds[rank]
+    dp = DataParallelTop1(StubEngine(), world, counts=[b - a for a, b in bounds])
+    out = dp.step(all_imgs[lo:hi])
+    if rank == 0:
+        q.put(out.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_uneven_shards_1025_images():
+    """config 4's global batch does not have to divide by the world size: 1025 images over 2 ranks = 513 + 512
+    (parallel.shard_bounds); the shorter shard is padded for the ONE all-gather and the padding cut out again"""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    n = 1025
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_uneven, args=(r, 2, port, n, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    g = torch.Generator().manual_seed(1)
+    all_imgs = torch.randint(0, 50, (n, 3, 2, 2), generator=g).float()
+    _, _, exp = StubEngine()(all_imgs)
+    assert got.shape == (n,) and np.array_equal(got, exp.numpy())
+
+
 def test_single_rank_is_identity():
     x = torch.arange(5, dtype=torch.int32)
     assert gather_top1(x, 1) is x
@@ -87,6 +125,9 @@ def test_bench_launcher_spawns_ranks_gloo_stub():
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["config"]["global_batch"] == 16 and d["value"] > 0
+    # the config-4 path of the same command: 33 images over 2 ranks (17 + 16), one padded all-gather per step
+    assert d["config4"]["per_rank_batch"] == 17 and d["config4"]["scaling"] == "strong" and d["config4"]["images_per_s"] > 0
+    assert "host_affinity" in d
 
 
 def test_bench_launcher_propagates_failure():
