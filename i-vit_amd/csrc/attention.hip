@@ -556,7 +556,7 @@ IVIT_EXPORT int ivit_attention_fused_i8_wide(const int8_t* qkv, int8_t* out, int
                                      ((int64_t)batch * tokens + 15) * heads * head_dim < 2147483648ll),
                  "ivit_attention_fused_i8_ex: bad output layout (block-layout buffers stay below 2 GiB)");
     IVIT_REQUIRE((uintptr_t)exp2d % 4 == 0, "ivit_attention_fused_i8_compat: misaligned exponent table");
-    IVIT_REQUIRE(band_w == 0 || (band && band_w >= 16 && band_w <= 128 && band_w % 16 == 0 && (uintptr_t)band % 16 == 0),
+    IVIT_REQUIRE(band_w == 0 || (band && band_w >= 16 && band_w <= 256 && band_w % 16 == 0 && (uintptr_t)band % 16 == 0),
                  "ivit_attention_fused_i8_compat_band: band table must be 16-byte aligned, width a multiple of 16 in [16, 256]");
     AttnArgs a{};
     a.abl = (g_ln_ablate >> 20) & 31;
@@ -611,7 +611,7 @@ IVIT_EXPORT int ivit_attention_fused_i8_ibert_wide(const int8_t* qkv, int8_t* ou
 {
     IVIT_REQUIRE(softmax_bits == 8 || softmax_bits == 16, "ivit_attention_fused_i8_ibert_wide: softmax_bits must be 8 or 16");
     IVIT_REQUIRE(qkv && out && table && batch > 0 && heads > 0, "ivit_attention_fused_i8_ibert: bad operand");
-    IVIT_REQUIRE(band_w == 0 || (band && band_w >= 16 && band_w <= 128 && band_w % 16 == 0 && (uintptr_t)band % 16 == 0),
+    IVIT_REQUIRE(band_w == 0 || (band && band_w >= 16 && band_w <= 256 && band_w % 16 == 0 && (uintptr_t)band % 16 == 0),
                  "ivit_attention_fused_i8_ibert: band table must be 16-byte aligned, width a multiple of 16 in [16, 256]");
     if (head_dim != HD || tokens <= 16 * (NKT - 1) || tokens >= KP) {
         ivit_set_error("ivit_attention_fused_i8_ibert: unsupported geometry head_dim=%d tokens=%d (need 64, 193..207)", head_dim, tokens);

@@ -593,6 +593,7 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_wreg_kernel(GemmArgs g)
     const unsigned smem_base = (unsigned)(__UINTPTR_TYPE__)(lptr_t)smem;
     const unsigned abase[2] = {smem_base + (S16 ? (unsigned)lane * 16u : (unsigned)swz(l31, h)),
                                smem_base + (S16 ? (unsigned)lane * 16u : (unsigned)swz(l31, 2 + h))};
+    unsigned long long tv[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // ABL & 2048: stamps kept in registers until the tile ends
     unsigned long long* stamp = nullptr;   // ABL & 16: [block][tile < 4][32]: tile start, loop start, loop end, epilogue end, step starts
 
     auto table_issue = [&](int n0) {
@@ -614,6 +615,10 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_wreg_kernel(GemmArgs g)
             const int bits = __float_as_int(mf);
             lh.x = ((double)mf > M) ? __int_as_float(bits - 1) : mf;
             lh.y = ((double)mf < M) ? __int_as_float(bits + 1) : mf;
+            if constexpr (S16) {   // two more float32 steps on either side: see epilogue_i8_16 (no range test on the accumulator)
+                lh.x = __int_as_float(__float_as_int(lh.x) - 2);
+                lh.y = __int_as_float(__float_as_int(lh.y) + 2);
+            }
         }
         int tid_w = tid;       // opaque: no loop-invariant address part is carried (and spilled) across the main loop
         asm volatile("" : "+v"(tid_w));
@@ -683,7 +688,7 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_wreg_kernel(GemmArgs g)
             constexpr bool LAST = decltype(last_tag)::value;
             constexpr int ST = decltype(stage_tag)::value;
             if constexpr (ABL & 16)
-                if (stamp && kt < 12) stamp[4 + kt] = __builtin_amdgcn_s_memtime();
+                if (!(ABL & 2048) && stamp && kt < 12) stamp[4 + kt] = __builtin_amdgcn_s_memtime();
             load_frags(stage_tag, I1{}, af1);
             wait_frags(af0);
             __builtin_amdgcn_sched_barrier(0);
@@ -799,7 +804,7 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_wreg_kernel(GemmArgs g)
         }
         load_frags(I0{}, I0{}, af0);
         if constexpr (ABL & 16)
-            if (stamp) stamp[1] = __builtin_amdgcn_s_memtime();
+            { if constexpr (ABL & 2048) tv[1] = __builtin_amdgcn_s_memtime(); else if (stamp) stamp[1] = __builtin_amdgcn_s_memtime(); }
         int kt = 0;
         for (; kt + 3 < nk; kt += 3) {
             step(kt, wr0, wr1, wr2, T{}, F{}, I0{});
@@ -810,7 +815,7 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_wreg_kernel(GemmArgs g)
         step(kt + 1, wr1, wr2, wr0, F{}, F{}, I1{});
         step(kt + 2, wr2, wr0, wr1, F{}, T{}, I2{});
         if constexpr (ABL & 16)
-            if (stamp) stamp[2] = __builtin_amdgcn_s_memtime();
+            { if constexpr (ABL & 2048) tv[2] = __builtin_amdgcn_s_memtime(); else if (stamp) stamp[2] = __builtin_amdgcn_s_memtime(); }
         // every wave's reads of every stage returned before the barrier of the last step: the ring is free
         const bool more = nxt.m0 >= 0;   // uniform
         if (more) prefetch(nxt);
@@ -856,9 +861,9 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_wreg_kernel(GemmArgs g)
             asm volatile("" : "+v"(tid_o));
             if constexpr (S16) {
                 static_assert(!S16 || EPI != EPI_RQ16_RES16, "the 16-bit epilogue exists for the 32x32 form only");
-                epilogue_i8_16<EPI, 2 * TJ, BIG_NT, (ABL & 64), WR_CH, Hook>(acc16, g, cs, tab, cur.m0, cur.n0, 64 * wave, tid_o, (tid_o >> 4) & 3,
+                epilogue_i8_16<EPI, 2 * TJ, BIG_NT, (ABL & (64 | 2048 | 4096)), WR_CH, Hook>(acc16, g, cs, tab, cur.m0, cur.n0, 64 * wave, tid_o, (tid_o >> 4) & 3,
                                                                           tid_o & 15, hook,
-                                                                          g.lut ? reinterpret_cast<const unsigned char*>(smem + WR_LUT) : nullptr);
+                                                                          g.lut ? reinterpret_cast<const unsigned char*>(smem + WR_LUT) : nullptr, (ABL & 2048) ? tv : nullptr);
             } else if constexpr (EPI == EPI_RQ16_RES16)
                 epilogue_rq16_res16<TJ, BIG_NT, Hook>(acc, g, cs, cur.m0, cur.n0, 64 * wave, tid_o, (tid_o >> 5) & 1, tid_o & 31, hook);
             else
@@ -881,8 +886,12 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_wreg_kernel(GemmArgs g)
         char* tab_next = smem + WR_RING + WR_CS + ((it + 1) & 1) * WR_TAB;
         const WrWork nxt = wr_work(g, it + 1, b, G);
         if constexpr (ABL & 16) {
-            stamp = (tid == 0 && it < 4) ? reinterpret_cast<unsigned long long*>(const_cast<int8_t*>(g.res)) + (blockIdx.x * 4 + it) * 32 : nullptr;
-            if (stamp) {
+            unsigned long long* sbase = (ABL & 2048) ? g.stamp : reinterpret_cast<unsigned long long*>(const_cast<int8_t*>(g.res));
+            stamp = (tid == 0 && it < 4) ? sbase + (blockIdx.x * 4 + it) * 32 : nullptr;
+            if constexpr (ABL & 2048) {    // deferred form: nothing is stored before the tile ends (a store in flight would join the
+                tv[0] = __builtin_amdgcn_s_memtime();   // counted vmcnt waits of the main loop and the vmcnt(0) of the epilogue)
+                tv[7] = __builtin_amdgcn_s_memrealtime();
+            } else if (stamp) {
                 stamp[0] = __builtin_amdgcn_s_memtime();
                 stamp[16] = __builtin_amdgcn_s_memrealtime();   // constant 100 MHz: the shader clock follows from the pair
             }
@@ -890,7 +899,14 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_wreg_kernel(GemmArgs g)
         if (cur.half) run(T{}, cur, nxt, tab, tab_next, it == 0);
         else run(F{}, cur, nxt, tab, tab_next, it == 0);
         if constexpr (ABL & 16)
-            if (stamp) stamp[3] = __builtin_amdgcn_s_memtime();
+            {
+                if constexpr (ABL & 2048) {
+                    if (stamp) {
+                        stamp[0] = tv[0]; stamp[1] = tv[1]; stamp[2] = tv[2]; stamp[3] = __builtin_amdgcn_s_memtime();
+                        stamp[20] = tv[4]; stamp[21] = tv[5]; stamp[22] = tv[6]; stamp[16] = tv[7];
+                    }
+                } else if (stamp) stamp[3] = __builtin_amdgcn_s_memtime();
+            }
         cur = nxt;
     }
 }
@@ -937,6 +953,9 @@ int launch_gemm(GemmArgs& g, const char* name, ivit_stream_t stream)
     }
     g.flags = g_debug_flags & (31 | 128 | 256 | 512);
     g.flags2 = g_debug_flags2;
+#if IVIT_LAB
+    g.stamp = reinterpret_cast<unsigned long long*>(g_stamp_buf);
+#endif
     const bool blocks = g.a_blocks || g.w_blocks;
     if (blocks && !g.w_frags) {
         IVIT_REQUIRE(EPI != EPI_I32 && EPI != EPI_RQ16 && g.M >= 2048 && g.N >= BCH && !g_force_small,
@@ -974,6 +993,21 @@ int launch_gemm(GemmArgs& g, const char* name, ivit_stream_t stream)
 #endif
             if (g.w_frags == 2) {     // IVIT_W_FRAGS16: the v_mfma_i32_16x16x64_i8 form
                 if constexpr (EPI != EPI_RQ16_RES16) {
+#if IVIT_LAB
+                    if constexpr (EPI == EPI_RQ || EPI == EPI_RESID) {
+                        if ((g_debug_flags2 & 256) && g.stamp) {   // stamped timeline (scripts/wreg_timeline.py --s16)
+                            if (EPI == EPI_RESID && g.res_f32) hipLaunchKernelGGL((gemm_i8_wreg_kernel<EPI, 16 | 2048 | 4096, true>), grid, dim3(BIG_NT), 0, ivit_stream(stream), g);
+                            else hipLaunchKernelGGL((gemm_i8_wreg_kernel<EPI, 16 | 2048, true>), grid, dim3(BIG_NT), 0, ivit_stream(stream), g);
+                            IVIT_CHECK_LAUNCH(name);
+                        }
+                    }
+#endif
+                    if constexpr (EPI == EPI_RESID) {
+                        if (g.res_f32) {     // ABL bit 12: the residual QuantAct on float32 fmas (residual_f32_form)
+                            hipLaunchKernelGGL((gemm_i8_wreg_kernel<EPI, 4096, true>), grid, dim3(BIG_NT), 0, ivit_stream(stream), g);
+                            IVIT_CHECK_LAUNCH(name);
+                        }
+                    }
                     hipLaunchKernelGGL((gemm_i8_wreg_kernel<EPI, 0, true>), grid, dim3(BIG_NT), 0, ivit_stream(stream), g);
                     IVIT_CHECK_LAUNCH(name);
                 } else {
@@ -1116,6 +1150,29 @@ IVIT_EXPORT int ivit_gemm_i8_requant(const int8_t* A, int64_t lda, const int8_t*
     return ivit_gemm_i8_requant_ex(A, lda, W, ldw, bias, m, e, out, ldo, M, N, K, 0, stream);
 }
 
+// EPI_RESID: can both two-operand products run as one float32 fma each?  RNE(k * float(M)) (computed as the kernel does, one
+// fused multiply-add against 1.5 * 2^23) is compared with RNE(k * M) in float64 for every int8 k: 512 evaluations per launch.
+static void residual_f32_form(GemmArgs& g)
+{
+    g.Mf_main = (float)g.M_main;
+    g.Mf_res = (float)g.M_res;
+    g.res_f32 = 0;
+    if (!(g.M_main > 0.0 && g.M_res > 0.0 && g.M_main < 16384.0 && g.M_res < 16384.0)) return;
+    const double Md[2] = {g.M_main, g.M_res};
+    const float Mf[2] = {g.Mf_main, g.Mf_res};
+    for (int t = 0; t < 2; ++t)
+        for (int k = -128; k <= 127; ++k) {
+            const float tf = __builtin_fmaf((float)k, Mf[t], 12582912.0f);
+            int bits;
+            __builtin_memcpy(&bits, &tf, 4);
+            const double td = __builtin_fma((double)k, Md[t], IVIT_MAGIC);
+            long long lb;
+            __builtin_memcpy(&lb, &td, 8);
+            if (bits - 0x4B400000 != (int)(unsigned)lb) return;
+        }
+    g.res_f32 = 1;
+}
+
 IVIT_EXPORT int ivit_gemm_i8_requant_residual_ex(const int8_t* A, int64_t lda, const int8_t* W, int64_t ldw,
                                               const int32_t* bias, const uint32_t* m, const int32_t* e,
                                               const int8_t* res, int64_t ldr, uint32_t m_main, int32_t e_main,
@@ -1127,6 +1184,7 @@ IVIT_EXPORT int ivit_gemm_i8_requant_residual_ex(const int8_t* A, int64_t lda, c
     g.out = out; g.ldo = ldo; g.res = res; g.ldr = ldr; g.M = M; g.N = N; g.K = K;
     g.M_main = ivit_dyadic_to_double(m_main, e_main);
     g.M_res = ivit_dyadic_to_double(m_res, e_res);
+    residual_f32_form(g);
     IVIT_REQUIRE(g.M_main < 1048576.0 && g.M_res < 1048576.0,
                  "ivit_gemm_i8_requant_residual_ex: residual multiplier >= 2^20 is outside the int8 fast path");
     g.a_blocks = layouts & 1; g.w_blocks = (layouts >> 1) & 1; g.w_frags = (layouts & 16) ? 2 : ((layouts >> 3) & 1);

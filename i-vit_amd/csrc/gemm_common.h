@@ -61,6 +61,9 @@ struct GemmArgs {
     const int8_t* res;
     int64_t ldr;
     double M_main, M_res;
+    float Mf_main, Mf_res;   // EPI_RESID: float32 images of M_main / M_res, and
+    int res_f32;             // 1: RNE(k * Mf) == RNE(k * M) for all 256 int8 k, both multipliers (verified by the launcher): the
+                             //    residual QuantAct runs on two float32 fmas per output instead of two float64 ones
     int M, N, K;
     int tokens, heads, head_dim;
     int tiles_m, tiles_n;
@@ -72,6 +75,7 @@ struct GemmArgs {
     int a_blocks, w_blocks;   // operand in the block layout (common.h: ivit_block_offset); persistent kernel only
     int out_blocks;           // EPI_RQ: the int8 output in the block layout (row length N): it is the next GEMM's A operand
     int w_frags;              // W is the MFMA-fragment copy (ivit_pack_weight_frags_i8): the weights-in-registers kernel
+    unsigned long long* stamp;   // lab build only: timeline buffer of the stamped kernel forms (ivit_debug_set_stamp_buffer)
     int flags2;               // lab build only (ivit_debug_set_gemm_flags2): cache policies of the epilogue's stores / residual loads
     const int8_t* lut;        // EPI_RQ, weights-in-registers kernel: out = lut[q + 128] applied to every requantised byte (an
                               // elementwise int8 -> int8 operator behind the QuantAct, e.g. I-BERT GELU + mlp.qact1), or NULL
@@ -185,26 +189,35 @@ struct NoHook {
 // Phase 2 of the int8 epilogues: the staged tile Cs[token][channel] (row stride CH + 4) -> 16-byte row-contiguous chunks: optional
 // residual QuantAct, optional head-major remap or byte map, store.  Called by every thread right after its phase-1 LDS writes.
 template <int EPI, int TOK, int NTHREADS, int ABL, int CH, typename Hook>
-IVIT_DEV void epilogue_phase2(const GemmArgs& g, char* smem, int m0, int n0, int tid, const Hook& hook, const unsigned char* lut_lds)
+IVIT_DEV void epilogue_phase2(const GemmArgs& g, char* smem, int m0, int n0, int tid, const Hook& hook, const unsigned char* lut_lds,
+                              unsigned long long* st = nullptr)
 {
     constexpr int CSS = CH + 4;
     constexpr int CPR = CH / 16;
     unsigned long long t_p1 = 0, t_sync = 0;
-    if constexpr (ABL & 512) t_p1 = __builtin_amdgcn_s_memtime();
+    if constexpr (ABL & (512 | 2048)) t_p1 = __builtin_amdgcn_s_memtime();
     // Phase 2 work items of this thread: NIT chunks (token row tl, 16-byte column chunk cc).  The residual loads go out BEFORE the
     // barrier (the accumulators are dead, their registers free), so their latency runs under the barrier wait and the LDS reads.
     constexpr int NIT = TOK * CPR / NTHREADS;
     int4 rv[NIT];
     int4 rw[EPI == EPI_RESID16 ? NIT : 1][2];   // 16 int16 residual values per chunk
+    // A tile that lies inside the matrix (all but the last token panel / channel tile) needs no per-chunk clamping or bounds test,
+    // and its chunk addresses are one base plus a uniform step per `it` (the thread's rows are NTHREADS / CPR apart): the address
+    // arithmetic and the exec-mask juggling were ~20 of the ~30 instructions a chunk of the plain int8 epilogue costs, at one
+    // VALU instruction per ~8 cycles beside the co-resident workgroup's MFMA stream.
+    const bool interior = (m0 + TOK <= g.M) && (n0 + CH <= g.N);     // uniform
+    constexpr int RPI = NTHREADS / CPR;                              // rows between a thread's consecutive chunks
+    static_assert(NTHREADS % CPR == 0, "a thread keeps its chunk column");
     if constexpr (EPI == EPI_RESID || EPI == EPI_RESID16) {
         if constexpr (!(ABL & 16)) {
+            const int8_t* rbase = g.res + (int64_t)(m0 + tid / CPR) * g.ldr + (n0 + 16 * (tid % CPR));
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const int q = tid + NTHREADS * it;
                 const int tl = q / CPR, cc = q % CPR;
                 const int t = min(m0 + tl, g.M - 1), cn = min(n0 + 16 * cc, g.N - 16);
                 if constexpr (EPI == EPI_RESID) {
-                    rv[it] = load16_sel(g.res + (int64_t)t * g.ldr + cn, g.flags2);
+                    rv[it] = load16_sel(interior ? rbase + (int64_t)(it * RPI) * g.ldr : g.res + (int64_t)t * g.ldr + cn, g.flags2);
                 } else {
                     const int4* rp = reinterpret_cast<const int4*>(reinterpret_cast<const int16_t*>(g.res) + (int64_t)t * g.ldr + cn);
                     rw[it][0] = rp[0];
@@ -224,7 +237,8 @@ IVIT_DEV void epilogue_phase2(const GemmArgs& g, char* smem, int m0, int n0, int
             d[4] = t_p1; d[5] = t_sync;
         }
     }
-    if constexpr (ABL & 16) return;
+    if constexpr ((ABL & 16) && !(ABL & 2048)) return;
+    if constexpr (ABL & 2048) { st[4] = t_p1; st[5] = __builtin_amdgcn_s_memtime(); }
 
     int8_t* out = reinterpret_cast<int8_t*>(g.out);
     int v[NIT][4];
@@ -242,6 +256,13 @@ IVIT_DEV void epilogue_phase2(const GemmArgs& g, char* smem, int m0, int n0, int
         v[it][0] = vv[it][0].x; v[it][1] = vv[it][0].y; v[it][2] = vv[it][1].x; v[it][3] = vv[it][1].y;
     }
     hook.consume();
+    if constexpr (ABL & 2048) st[6] = __builtin_amdgcn_s_memtime();
+    const bool oblk = (EPI == EPI_RQ) && g.out_blocks;
+    const int64_t off0 = oblk ? (int64_t)block_off(block_row(m0 + tid / CPR, g.N), block_col(n0 + 16 * (tid % CPR)))
+                              : (int64_t)(m0 + tid / CPR) * g.ldo + (n0 + 16 * (tid % CPR));
+    const int64_t ostep = oblk ? (int64_t)(RPI / 16) * (g.N >> 6) * 1024 : (int64_t)RPI * g.ldo;     // uniform
+    float magic_v = 12582912.0f;      // 1.5 * 2^23 in a VGPR (the residual form's fmas take their multiplier from an SGPR)
+    asm volatile("" : "+v"(magic_v));
     // EPI_QKV addressing state (see below)
     constexpr int qkv_rows_per_it = NTHREADS / CPR;
     int qkv_b = 0, qkv_tok = 0;
@@ -268,9 +289,33 @@ IVIT_DEV void epilogue_phase2(const GemmArgs& g, char* smem, int m0, int n0, int
                 }
             }
         }
-        if (t >= g.M || cn >= g.N) continue;
+        if (!interior && (t >= g.M || cn >= g.N)) continue;
         if constexpr (EPI == EPI_RESID) {
             const int rr[4] = {rv[it].x, rv[it].y, rv[it].z, rv[it].w};
+            if constexpr (ABL & 4096) {   // kernel form chosen by the launcher when g.res_f32.  RNE(k * M) as ONE float32 fma against 1.5 * 2^23 per product: the float's low bits are the
+                               // integer, and the launcher has checked all 256 int8 inputs of both multipliers against the
+                               // float64 evaluation (the epilogue's VALU instructions issue at ~1 per 8 cycles beside the
+                               // co-resident workgroup's MFMA stream: 11 -> 7 instructions per output byte)
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    unsigned o[4];
+#pragma unroll
+                    for (int bb = 0; bb < 4; ++bb) {
+                        const float kf = (float)(int)(int8_t)(v[it][d] >> (8 * bb));
+                        const float xf = (float)(int)(int8_t)(rr[d] >> (8 * bb));
+                        // plain v_fma_f32 through asm: left to itself the compiler packs the pair into v_pk_fma_f32, which costs more
+                        // than two scalar fmas beside an MFMA stream (cdna guide, 'packed f32 VALU')
+                        float f1, f2;
+                        asm("v_fma_f32 %0, %1, %2, %3" : "=v"(f1) : "v"(kf), "s"(g.Mf_main), "v"(magic_v));
+                        asm("v_fma_f32 %0, %1, %2, %3" : "=v"(f2) : "v"(xf), "s"(g.Mf_res), "v"(magic_v));
+                        // quant_utils.py:229-245: two rounded products, then the sum; + 128 so that the clamp leaves an unsigned byte
+                        o[bb] = (unsigned)clamp_i32((int)((unsigned)__float_as_int(f1) + (unsigned)__float_as_int(f2) - 2u * 0x4B400000u), -128, 127);
+                    }
+                    const unsigned w01 = __builtin_amdgcn_perm(o[1], o[0], 0x0c0c0400u);
+                    const unsigned w23 = __builtin_amdgcn_perm(o[3], o[2], 0x04000c0cu);
+                    v[it][d] = (int)(w01 | w23);
+                }
+            } else {
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
                 int o[4];
@@ -283,6 +328,7 @@ IVIT_DEV void epilogue_phase2(const GemmArgs& g, char* smem, int m0, int n0, int
                     o[bb] = clamp_i32(sres, -128, 127);
                 }
                 v[it][d] = pack4_i8(o[0], o[1], o[2], o[3]);
+            }
             }
         }
         if constexpr (EPI == EPI_RESID16) {
@@ -327,6 +373,8 @@ IVIT_DEV void epilogue_phase2(const GemmArgs& g, char* smem, int m0, int n0, int
                 qkv_tok = t - qkv_b * g.tokens;
             }
             off = (int64_t)(unsigned)(qkv_col + ((qkv_b * g.heads * g.tokens + qkv_tok) * g.head_dim));   // 32-bit: the launcher checks 3*M*heads*head_dim < 2^31
+        } else if (interior && RPI % 16 == 0) {     // base + uniform step (a block row is 16 token rows: RPI / 16 block rows per `it`)
+            off = off0 + (int64_t)it * ostep;
         } else {
             off = (EPI == EPI_RQ && g.out_blocks) ? (int64_t)block_off(block_row(t, g.N), block_col(cn)) : (int64_t)t * g.ldo + cn;
         }
@@ -447,7 +495,7 @@ IVIT_DEV void epilogue_i8(v16i (&acc)[TI][TJ], const GemmArgs& g, char* smem, co
 // phase 2 is shared.
 template <int EPI, int NJ, int NTHREADS, int ABL, int CH, typename Hook>
 IVIT_DEV void epilogue_i8_16(v4i (&acc)[4][NJ], const GemmArgs& g, char* smem, const char* rq_lds, int m0, int n0, int wch, int tid,
-                             int g4, int l15, const Hook& hook, const unsigned char* lut_lds)
+                             int g4, int l15, const Hook& hook, const unsigned char* lut_lds, unsigned long long* st = nullptr)
 {
     static_assert(NJ % 4 == 0, "batches of four token sub-tiles");
     __builtin_amdgcn_s_setprio(2);
@@ -471,9 +519,13 @@ IVIT_DEV void epilogue_i8_16(v4i (&acc)[4][NJ], const GemmArgs& g, char* smem, c
         const float hi[4] = {lh01.y, lh01.w, lh23.y, lh23.w};
 #pragma unroll
         for (int jb = 0; jb < NJ; jb += 4) {
+            // The table holds brackets WIDENED by two float32 steps on either side of M (table_write of the S16 kernel): then
+            // a' * lo <= acc * M <= a' * hi also for the a' = fl(acc) of an accumulator beyond 2^24 ((1 - 2^-24)(1 + 2^-23) > 1), and
+            // no range test is needed: products beyond the int8 range saturate the clamp on either side whatever their rounding
+            // (the bit pattern of t is monotone in acc * M over the whole int32 range), so a certificate that fails there only
+            // sends the batch to the exact path.
             int b[4][4];
             unsigned unc = 0;
-            float amax = 0.0f;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -482,10 +534,9 @@ IVIT_DEV void epilogue_i8_16(v4i (&acc)[4][NJ], const GemmArgs& g, char* smem, c
                     const int tl = __float_as_int(__builtin_fmaf(a, lo[r], 12582912.0f));
                     const int th = __float_as_int(__builtin_fmaf(a, hi[r], 12582912.0f));
                     asm("v_sad_u32 %0, %1, %2, %3" : "=v"(unc) : "v"(tl), "v"(th), "v"(unc));
-                    amax = fmaxf(amax, fabsf(a));
                     b[j][r] = clamp_i32(tl, 0x4B400000 - 128, 0x4B400000 + 127);  // low byte = int8 result
                 }
-            const bool bad = (unc != 0) | (amax >= 4194304.0f);
+            const bool bad = unc != 0;
             if (__builtin_amdgcn_ballot_w64(bad) != 0) {  // rare: exact float64 evaluation of the batch (quant_utils.py:229-230)
                 const int c0 = min(n0 + cl, g.N - 4);
                 const uint4 m4 = *reinterpret_cast<const uint4*>(g.m + c0);
@@ -509,7 +560,7 @@ IVIT_DEV void epilogue_i8_16(v4i (&acc)[4][NJ], const GemmArgs& g, char* smem, c
         }
         __builtin_amdgcn_sched_barrier(0);
     }
-    epilogue_phase2<EPI, 16 * NJ, NTHREADS, ABL, CH, Hook>(g, smem, m0, n0, tid, hook, lut_lds);
+    epilogue_phase2<EPI, 16 * NJ, NTHREADS, ABL, CH, Hook>(g, smem, m0, n0, tid, hook, lut_lds, st);
 }
 
 // ---- 16-bit epilogue of the weights-in-registers kernel (EPI_RQ16_RES16).  A wave owns 64 of the tile's 256 channels x 32 TJ

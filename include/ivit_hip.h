@@ -216,7 +216,7 @@ int ivit_attention_fused_i8_compat(const int8_t* qkv, int8_t* out, int batch, in
                                    const uint32_t* exp2d, int out_blocks, ivit_stream_t stream);
 
 /* The same with the table also in BAND form, staged per query tile in LDS (the fast path; exp2d may then be NULL):
- * band[(qmax+128)*band_w + j] = exp_int of (qmax, q = qmax - j) for j < band_w, band_w a multiple of 16 in [16, 128] (the staged rows must fit the 64 KiB of LDS a launch gets by default) chosen
+ * band[(qmax+128)*band_w + j] = exp_int of (qmax, q = qmax - j) for j < band_w, band_w a multiple of 16 in [16, 256] (4 x 16 x (band_w + 4) x 4 bytes of dynamic LDS on top of 31 KiB static: 97 KiB at 256, within the 160 KiB of a CU; launches above 64 KiB are covered by test_attention_fused_compat) chosen
  * by the caller such that entry band_w - 1 is already the saturated value (the exponent's argument is clamped at n*x0,
  * ivit_modules.py:155, so every larger distance gives the same entry); i-vit_amd/prepare.py shiftexp_band. */
 int ivit_attention_fused_i8_compat_band(const int8_t* qkv, int8_t* out, int batch, int heads, int tokens, int head_dim,

@@ -60,7 +60,7 @@ for name in names:
                       _lib.ptr(out), 197, N // 192, 64, M, N, K, LAY, _lib.stream_ptr())
         elif RESID:   # the fused residual QuantAct form (attn.proj, mlp.fc2)
             _lib.call("ivit_gemm_i8_requant_residual_ex", _lib.ptr(a_), K, _lib.ptr(w_), K, _lib.ptr(b), _lib.ptr(m), _lib.ptr(e),
-                      _lib.ptr(resid_t), N, 1503238554, 31, 1073741824, 32, _lib.ptr(out), N, M, N, K, LAY, _lib.stream_ptr())
+                      _lib.ptr(resid_t), N, 1610612736, 31, 1073741824, 32, _lib.ptr(out), N, M, N, K, LAY, _lib.stream_ptr())
         else:
             _lib.call("ivit_gemm_i8_requant_ex", _lib.ptr(a_), K, _lib.ptr(w_), K, _lib.ptr(b), _lib.ptr(m), _lib.ptr(e), _lib.ptr(out),
                       N, M, N, K, LAY, _lib.stream_ptr())

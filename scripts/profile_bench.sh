@@ -7,7 +7,7 @@ set -e
 T=$1
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp; export TMPDIR=/tmp
-B="python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline $BENCH_ARGS"   # e.g. BENCH_ARGS="--bitwidth 16 --operators ibert"
+B="python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras $BENCH_ARGS"   # e.g. BENCH_ARGS="--bitwidth 16 --operators ibert"
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$T -- $B > $R/gpurun_out/prof_$T.log 2>&1
 echo "stats done"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_${T}_fetch -- $B > $R/gpurun_out/pmc_${T}_fetch.log 2>&1

@@ -418,17 +418,22 @@ def test_gemm_weight_fragment_layout(M, N, K, FR):
     m1, e1 = dyadic(np.float32(0.7 * 2 ** -4), np.float32(2 ** -4))
     m2, e2 = dyadic(np.float32(2 ** -5), np.float32(2 ** -4))
     exp_res = orc.requant(exp, m1.astype(np.float64), e1, 8, z2=res.astype(np.int32), m2=m2.astype(np.float64), e2=e2)
+    # a main multiplier one step below 1/2 (m = 2^30 - 1, e = 31): float32 rounds it to 1/2 and 3 * M crosses a rounding boundary,
+    # so the launcher's exhaustive check rejects the float32 form of the residual QuantAct and the float64 form runs
+    m3, e3 = np.array([(1 << 30) - 1], np.uint32), np.array([31], np.int32)
+    exp_res64 = orc.requant(exp, m3.astype(np.float64), e3, 8, z2=res.astype(np.int32), m2=m2.astype(np.float64), e2=e2)
     for lay in (FR, FR + 1):
         a_op = At if lay & 1 else dA
         out = torch.zeros(M, N, dtype=torch.int8, device=DEV)
         _lib.call("ivit_gemm_i8_requant_ex", _lib.ptr(a_op), K, _lib.ptr(Wf), K, _lib.ptr(db), _lib.ptr(md), _lib.ptr(ed),
                   _lib.ptr(out), N, M, N, K, lay, st())
         assert np.array_equal(out.cpu().numpy().astype(np.int32), exp), lay
-        out = torch.zeros(M, N, dtype=torch.int8, device=DEV)
-        _lib.call("ivit_gemm_i8_requant_residual_ex", _lib.ptr(a_op), K, _lib.ptr(Wf), K, _lib.ptr(db), _lib.ptr(md),
-                  _lib.ptr(ed), _lib.ptr(dres), N, int(m1[0]), int(e1[0]), int(m2[0]), int(e2[0]), _lib.ptr(out), N, M, N, K,
-                  lay, st())
-        assert np.array_equal(out.cpu().numpy().astype(np.int32), exp_res), lay
+        for (ma, ea, want) in ((m1, e1, exp_res), (m3, e3, exp_res64)):
+            out = torch.zeros(M, N, dtype=torch.int8, device=DEV)
+            _lib.call("ivit_gemm_i8_requant_residual_ex", _lib.ptr(a_op), K, _lib.ptr(Wf), K, _lib.ptr(db), _lib.ptr(md),
+                      _lib.ptr(ed), _lib.ptr(dres), N, int(ma[0]), int(ea[0]), int(m2[0]), int(e2[0]), _lib.ptr(out), N, M, N, K,
+                      lay, st())
+            assert np.array_equal(out.cpu().numpy().astype(np.int32), want), (lay, int(ma[0]))
     if M % 197 == 0 and N % 192 == 0:     # head-major q/k/v epilogue
         T, hd = 197, 64
         H = N // (3 * hd)
