@@ -564,20 +564,26 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_wreg_kernel(GemmArgs g)
         wsrc = g.W + (int64_t)cg * nk * 4096 + (unsigned)lane_o * 16u;
     };
     const int kstep_a = g.a_blocks ? 1024 : BK;
+    // The sources are RUNNING pointers: every issue advances its pointer in place to the next K step (the pieces of a work item are
+    // issued strictly in K order), so no `base + kt * step` temporary pair lives beside the 64-bit bases in the main loop.
     auto issue_dma = [&](int kt, int i) {
-        __builtin_amdgcn_global_load_lds((gptr_t)(asrc[i] + kt * kstep_a),
-                                         (lptr_t)(smem + (kt % WR_STAGES) * WR_STAGE + 1024 * (wave + 4 * i)), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)asrc[i], (lptr_t)(smem + (kt % WR_STAGES) * WR_STAGE + 1024 * (wave + 4 * i)), 16, 0, 0);
+        asrc[i] += kstep_a;
     };
     // weight fragments of K step kt into buffer wr[.]: piece p = 2 i + ks (channel sub-tile i, K half ks) is 1 KB at p * 1024.
     // Per-lane 64-bit addresses (an SGPR base + lane offset form depends on the compiler keeping the base in SGPRs, which it
     // does not under register pressure)
     v4i wr0[4], wr1[4], wr2[4];
     auto issue_w = [&](v4i (&wr)[4], int kt, int p) {
-        const int8_t* src = wsrc + (int64_t)kt * 4096;
+        (void)kt;
+        const int8_t* src = wsrc;
         if (p == 0) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(wr[0]) : "v"(src));
         if (p == 1) asm volatile("global_load_dwordx4 %0, %1, off offset:1024" : "=v"(wr[1]) : "v"(src));
         if (p == 2) asm volatile("global_load_dwordx4 %0, %1, off offset:2048" : "=v"(wr[2]) : "v"(src));
-        if (p == 3) asm volatile("global_load_dwordx4 %0, %1, off offset:3072" : "=v"(wr[3]) : "v"(src));
+        if (p == 3) {
+            asm volatile("global_load_dwordx4 %0, %1, off offset:3072" : "=v"(wr[3]) : "v"(src));
+            wsrc += 4096;     // the next K step's four pieces
+        }
     };
     // what goes out ahead of a work item: stage 0, weight buffer 0, stage 1 (the item's own first step issues weight buffer 1)
     auto prefetch = [&](const WrWork& w) {
@@ -677,7 +683,17 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_wreg_kernel(GemmArgs g)
             }
         };
         v16i acc[S16 ? 1 : 2][S16 ? 1 : TJ];      // 32x32 form: channel sub-tile i (32) x token sub-tile j (32)
-        v4i acc16[S16 ? 4 : 1][S16 ? 2 * TJ : 1];  // S16: channel sub-tile i (16) x token sub-tile j (16)
+        // S16: channel sub-tile i (16) x token sub-tile j (16).  The MFMAs are issued through inline asm with the accumulator TIED
+        // (destination = source C): as builtin calls the register allocator kept moving the 32 four-register tiles around (82 of
+        // 288 MFMAs not in place, ~200 v_mov_b64, and the kernel over its register budget).  What the compiler no longer does for
+        // these instructions, and why that is sound here: (a) MFMA -> MFMA on the same accumulator: a tile gets ONE MFMA per K
+        // step, 31 others lie between two of its updates; (b) operands come from ds_read / global_load behind explicit s_waitcnt
+        // (memory results need no VALU-to-MFMA wait states), the bias preload is VALU moves > 10 instructions before the first
+        // MFMA; (c) the first VALU read of an accumulator is in the epilogue, behind the s_nop pair after the loop.
+        v4i acc16[S16 ? 4 : 1][S16 ? 2 * TJ : 1];
+        auto mfma16 = [&](v4i& c, const v4i& a, const v4i& b) {
+            asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+        };
         // K step kt on weight buffer wc (current), wn (next: waited for here), wf (the one after: loaded here)
         using I0 = std::integral_constant<int, 0>;
         using I1 = std::integral_constant<int, 1>;
@@ -697,7 +713,7 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_wreg_kernel(GemmArgs g)
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < TJ; ++j) {
-                        if constexpr (!(ABL & 8)) acc16[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wc[i], af0[j], acc16[i][j], 0, 0, 0);
+                        if constexpr (!(ABL & 8)) mfma16(acc16[i][j], wc[i], af0[j]);
                         else asm volatile("" : "+v"(acc16[i][j]) : "v"(wc[i]), "v"(af0[j]));
                         if constexpr (ISSUE) {   // NP + 4 loads of K step kt + 2: one behind every other MFMA (full tile: 16 MFMAs,
                             const int n = TJ * i + j;   // six loads), behind each of the first five (half tile: 8 MFMAs, five loads)
@@ -738,7 +754,7 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_wreg_kernel(GemmArgs g)
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < TJ; ++j) {
-                        if constexpr (!(ABL & 8)) acc16[i][TJ + j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wc[i], af1[j], acc16[i][TJ + j], 0, 0, 0);
+                        if constexpr (!(ABL & 8)) mfma16(acc16[i][TJ + j], wc[i], af1[j]);
                         else asm volatile("" : "+v"(acc16[i][TJ + j]) : "v"(wc[i]), "v"(af1[j]));
                     }
             } else {
@@ -859,7 +875,13 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_wreg_kernel(GemmArgs g)
         } else {
             int tid_o = tid;   // opaque: the epilogue's per-thread addresses are computed here, not carried through the main loop
             asm volatile("" : "+v"(tid_o));
-            if constexpr (S16) {
+            if constexpr (S16) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");     // MFMA results -> VALU reads: see mfma16 (c)
+            if constexpr (S16 && (EPI == EPI_RQ || EPI == EPI_RESID || EPI == EPI_QKV) && !(ABL & 8192)) {
+                // straight from the registers (lane transpose, no LDS staging); ABL bit 13: the staged form below (A/B, lab)
+                epilogue_direct_16<EPI, 2 * TJ, (ABL & (64 | 2048 | 4096)), Hook>(acc16, g, tab, cur.m0, cur.n0, 64 * wave, (tid_o >> 4) & 3, tid_o & 15, hook,
+                                                                               g.lut ? reinterpret_cast<const unsigned char*>(smem + WR_LUT) : nullptr,
+                                                                               (ABL & 2048) ? tv : nullptr);
+            } else if constexpr (S16) {
                 static_assert(!S16 || EPI != EPI_RQ16_RES16, "the 16-bit epilogue exists for the 32x32 form only");
                 epilogue_i8_16<EPI, 2 * TJ, BIG_NT, (ABL & (64 | 2048 | 4096)), WR_CH, Hook>(acc16, g, cs, tab, cur.m0, cur.n0, 64 * wave, tid_o, (tid_o >> 4) & 3,
                                                                           tid_o & 15, hook,
@@ -993,11 +1015,24 @@ int launch_gemm(GemmArgs& g, const char* name, ivit_stream_t stream)
 #endif
             if (g.w_frags == 2) {     // IVIT_W_FRAGS16: the v_mfma_i32_16x16x64_i8 form
                 if constexpr (EPI != EPI_RQ16_RES16) {
+                    // its epilogue addresses residual and output with 32-bit byte offsets
+                    IVIT_REQUIRE(((int64_t)g.M + 16) * (EPI == EPI_QKV ? g.N : g.ldo) < 4294967296ll &&
+                                     (EPI != EPI_RESID || ((int64_t)g.M + 16) * g.ldr < 4294967296ll),
+                                 "%s: IVIT_W_FRAGS16 addresses its output (and residual) with 32-bit offsets: operand of 4 GiB or more", name);
 #if IVIT_LAB
                     if constexpr (EPI == EPI_RQ || EPI == EPI_RESID) {
                         if ((g_debug_flags2 & 256) && g.stamp) {   // stamped timeline (scripts/wreg_timeline.py --s16)
                             if (EPI == EPI_RESID && g.res_f32) hipLaunchKernelGGL((gemm_i8_wreg_kernel<EPI, 16 | 2048 | 4096, true>), grid, dim3(BIG_NT), 0, ivit_stream(stream), g);
                             else hipLaunchKernelGGL((gemm_i8_wreg_kernel<EPI, 16 | 2048, true>), grid, dim3(BIG_NT), 0, ivit_stream(stream), g);
+                            IVIT_CHECK_LAUNCH(name);
+                        }
+                    }
+#endif
+#if IVIT_LAB
+                    if constexpr (EPI == EPI_RQ || EPI == EPI_RESID || EPI == EPI_QKV) {
+                        if (g_debug_flags2 & 512) {     // A/B: the LDS-staged epilogue instead of the direct one (scripts/gemm_ab.py 0:512)
+                            if (EPI == EPI_RESID && g.res_f32) hipLaunchKernelGGL((gemm_i8_wreg_kernel<EPI, 8192 | 4096, true>), grid, dim3(BIG_NT), 0, ivit_stream(stream), g);
+                            else hipLaunchKernelGGL((gemm_i8_wreg_kernel<EPI, 8192, true>), grid, dim3(BIG_NT), 0, ivit_stream(stream), g);
                             IVIT_CHECK_LAUNCH(name);
                         }
                     }

@@ -563,6 +563,206 @@ IVIT_DEV void epilogue_i8_16(v4i (&acc)[4][NJ], const GemmArgs& g, char* smem, c
     epilogue_phase2<EPI, 16 * NJ, NTHREADS, ABL, CH, Hook>(g, smem, m0, n0, tid, hook, lut_lds, st);
 }
 
+// ---- the same epilogue WITHOUT the LDS round trip (EPI_RQ row-major or block layout, EPI_RESID, EPI_QKV).
+// After phase 1 a lane (g4, l15) holds, for token 16 j + l15, one dword per channel sub-tile i: bytes 16 i + 4 g4 .. + 3 of the
+// wave's 64 channels.  The four lanes of a token (g4 = 0..3) hold a 4 x 4 matrix of dwords [g4][i]; transposed across those lanes --
+// two v_permlane32_swap, two v_permlane16_swap, as in attention.hip's output path -- lane g4 ends with the 16 CONTIGUOUS bytes
+// 16 g4 .. 16 g4 + 15 of the token's 64-byte row segment: one 16-byte store per lane and token sub-tile, a wave instruction covers
+// 16 rows x 64 bytes (one whole 1 KB block of the block layout; one (image, head) row group of the head-major q/k/v layout).
+// The staged form spent 32 ds_write_b32, 16 ds_read2_b32, a workgroup barrier (1.5-2 K cycles of skew in the residual form) and
+// per-chunk address arithmetic on the same bytes; its VALU and LDS instructions issue at one per ~8 cycles beside the co-resident
+// workgroup's MFMA stream (profiles/r03g_wreg16_timeline.txt, r03i_epilogue_probe.txt), so what is not issued is what is saved.
+// The residual QuantAct works on the transposed chunk against a 16-byte residual load of the same row segment.
+IVIT_DEV void residual_chunk_f32(int (&v)[4], const int4& res, float Mf_main, float Mf_res, float magic_v)
+{
+    const int rr[4] = {res.x, res.y, res.z, res.w};
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        unsigned o[4];
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) {
+            const float kf = (float)(int)(int8_t)(v[d] >> (8 * bb));
+            const float xf = (float)(int)(int8_t)(rr[d] >> (8 * bb));
+            float f1, f2;      // plain v_fma_f32 through asm: see epilogue_phase2
+            asm("v_fma_f32 %0, %1, %2, %3" : "=v"(f1) : "v"(kf), "s"(Mf_main), "v"(magic_v));
+            asm("v_fma_f32 %0, %1, %2, %3" : "=v"(f2) : "v"(xf), "s"(Mf_res), "v"(magic_v));
+            o[bb] = (unsigned)clamp_i32((int)((unsigned)__float_as_int(f1) + (unsigned)__float_as_int(f2) - 2u * 0x4B400000u), -128, 127);
+        }
+        v[d] = (int)(__builtin_amdgcn_perm(o[1], o[0], 0x0c0c0400u) | __builtin_amdgcn_perm(o[3], o[2], 0x04000c0cu));
+    }
+}
+
+IVIT_DEV void residual_chunk_f64(int (&v)[4], const int4& res, double M_main, double M_res)
+{
+    const int rr[4] = {res.x, res.y, res.z, res.w};
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        int o[4];
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) {
+            const int k3 = (int)(int8_t)(v[d] >> (8 * bb));
+            const int xr = (int)(int8_t)(rr[d] >> (8 * bb));
+            o[bb] = clamp_i32(requant_exact(k3, M_main) + requant_exact(xr, M_res), -128, 127);   // quant_utils.py:229-245
+        }
+        v[d] = pack4_i8(o[0], o[1], o[2], o[3]);
+    }
+}
+
+template <int EPI, int NJ, int ABL, typename Hook>
+IVIT_DEV void epilogue_direct_16(v4i (&acc)[4][NJ], const GemmArgs& g, const char* rq_lds, int m0, int n0, int wch, int g4, int l15,
+                                 const Hook& hook, const unsigned char* lut_lds, unsigned long long* st = nullptr)
+{
+    static_assert(NJ % 4 == 0 && (EPI == EPI_RQ || EPI == EPI_RESID || EPI == EPI_QKV), "direct epilogue: int8 outputs");
+    __builtin_amdgcn_s_setprio(2);
+    hook.issue();
+    const unsigned rq_a = lds_addr(rq_lds) + 8u * (unsigned)(wch + 4 * g4);
+    const int ncol = n0 + wch;                      // first of this wave's 64 channels (uniform)
+    const bool col_ok = ncol < g.N;                 // N % 64 == 0: a wave is in or out as a whole
+    const int c = ncol + 16 * g4;                   // this lane's 16-byte chunk column
+    // Phase A: per batch of four token sub-tiles, requantise (all four channel sub-tiles) and pack; the batch's accumulators are
+    // dead then, and its residual chunks are requested into the registers they leave.  Phase B: transpose, residual QuantAct,
+    // store -- batch 0 runs under the flight of batch 1's residual loads; the next work item's table (hook.consume: vmcnt(0) for its
+    // loads, issued before this epilogue) is written between the two batches.
+    constexpr int NB = NJ / 4;
+    unsigned D[NB][4][4];     // [batch][i][j]: bytes 16 i + 4 g4 .. + 3 of token 16 (4 batch + j) + l15
+    int4 rv[EPI == EPI_RESID ? NB : 1][4];
+    v4f lhbuf[2][2];
+    lds_read16_async(lhbuf[0][0], rq_a);
+    lds_read16_async(lhbuf[0][1], rq_a + 16u);
+#pragma unroll
+    for (int bi = 0; bi < NB; ++bi) {
+        const int jb = 4 * bi;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int sidx = jb + i;                        // position in the sequence of table reads
+            v4f& lh01 = lhbuf[sidx & 1][0];                 // lo0 hi0 lo1 hi1
+            v4f& lh23 = lhbuf[sidx & 1][1];                 // lo2 hi2 lo3 hi3
+            lds_wait(lh01, lh23);
+            if (sidx + 1 < NJ) {
+                const unsigned nxt = rq_a + 8u * (unsigned)(16 * ((i + 1) & 3));
+                lds_read16_async(lhbuf[(sidx + 1) & 1][0], nxt);
+                lds_read16_async(lhbuf[(sidx + 1) & 1][1], nxt + 16u);
+            }
+            const float lo[4] = {lh01.x, lh01.z, lh23.x, lh23.z};
+            const float hi[4] = {lh01.y, lh01.w, lh23.y, lh23.w};
+            int b[4][4];
+            unsigned unc = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float a = (float)acc[i][jb + j][r];
+                    const int tl = __float_as_int(__builtin_fmaf(a, lo[r], 12582912.0f));
+                    const int th = __float_as_int(__builtin_fmaf(a, hi[r], 12582912.0f));
+                    asm("v_sad_u32 %0, %1, %2, %3" : "=v"(unc) : "v"(tl), "v"(th), "v"(unc));
+                    b[j][r] = clamp_i32(tl, 0x4B400000 - 128, 0x4B400000 + 127);  // low byte = int8 result
+                }
+            if (__builtin_amdgcn_ballot_w64(unc != 0) != 0) {  // rare: exact float64 evaluation of the batch (quant_utils.py:229-230)
+                const int c0 = min(ncol + 16 * i + 4 * g4, g.N - 4);
+                const uint4 m4 = *reinterpret_cast<const uint4*>(g.m + c0);
+                const int4 e4 = *reinterpret_cast<const int4*>(g.e + c0);
+                const double Mc[4] = {dyadic_mult(m4.x, e4.x), dyadic_mult(m4.y, e4.y), dyadic_mult(m4.z, e4.z), dyadic_mult(m4.w, e4.w)};
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const double t = (double)acc[i][jb + j][r] * Mc[r] + IVIT_MAGIC;
+                        b[j][r] = clamp_i32((int)(unsigned)__double_as_longlong(t), -128, 127);
+                    }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                D[bi][i][j] = __builtin_amdgcn_perm((unsigned)b[j][1], (unsigned)b[j][0], 0x0c0c0400u) |
+                              __builtin_amdgcn_perm((unsigned)b[j][3], (unsigned)b[j][2], 0x04000c0cu);
+        }
+        if constexpr (EPI == EPI_RESID) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int t = min(m0 + 16 * (jb + j) + l15, g.M - 1);
+                rv[bi][j] = load16_sel(g.res + ((unsigned)t * (unsigned)g.ldr + (unsigned)min(c, g.N - 16)), g.flags2);   // 32-bit offsets: launcher
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // (derived only now: during phase A every register is taken)
+    int8_t* const out = reinterpret_cast<int8_t*>(g.out);
+    float magic_v = 12582912.0f;
+    asm volatile("" : "+v"(magic_v));
+    // ---- store addressing: offset of (row m0 + l15, column c), and what 16 more rows add
+    unsigned off0, ostep;                           // 32-bit byte offsets (the launcher checks that the operands stay below 4 GiB)
+    int q_b = 0, q_tok = 0;                         // EPI_QKV: image / token of row m0 + l15
+    if constexpr (EPI == EPI_QKV) {
+        const int cc = min(c, g.N - 16);
+        const int cdim = g.heads * g.head_dim;
+        const int which = cc / cdim, rem = cc - which * cdim;
+        const int hh = rem / g.head_dim, d0 = rem - hh * g.head_dim;
+        const int nb = g.M / g.tokens;
+        off0 = (unsigned)(((which * nb * g.heads + hh) * g.tokens) * g.head_dim + d0);   // 32-bit range checked by the launcher
+        ostep = 0;
+        const int t0 = min(m0 + l15, g.M - 1);
+        q_b = t0 / g.tokens;
+        q_tok = t0 - q_b * g.tokens;
+    } else if (EPI == EPI_RQ && g.out_blocks) {
+        off0 = block_off(block_row(m0 + l15, g.N), block_col(min(c, g.N - 16)));
+        ostep = (unsigned)(g.N >> 6) * 1024u;
+    } else {
+        off0 = (unsigned)(m0 + l15) * (unsigned)g.ldo + (unsigned)c;
+        ostep = 16u * (unsigned)g.ldo;
+    }
+    if constexpr (ABL & 2048) st[4] = __builtin_amdgcn_s_memtime();
+#pragma unroll
+    for (int bi = 0; bi < NB; ++bi) {
+        const int jb = 4 * bi;
+        if (bi == NB - 1) {
+            if constexpr (ABL & 2048) st[5] = __builtin_amdgcn_s_memtime();
+            hook.consume();
+            if constexpr (ABL & 2048) st[6] = __builtin_amdgcn_s_memtime();
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            typedef unsigned v2u __attribute__((ext_vector_type(2)));
+            // 4 x 4 dword transpose over the token's four lanes: lane g4 <- dwords [0..3][g4]
+            const v2u ab = __builtin_amdgcn_permlane32_swap(D[bi][0][j], D[bi][2][j], false, false);
+            const v2u cd = __builtin_amdgcn_permlane32_swap(D[bi][1][j], D[bi][3][j], false, false);
+            const v2u ac = __builtin_amdgcn_permlane16_swap(ab.x, cd.x, false, false);
+            const v2u bd = __builtin_amdgcn_permlane16_swap(ab.y, cd.y, false, false);
+            int v[4] = {(int)ac.x, (int)ac.y, (int)bd.x, (int)bd.y};
+            if constexpr (EPI == EPI_RESID) {
+                if constexpr (ABL & 4096) residual_chunk_f32(v, rv[bi][j], g.Mf_main, g.Mf_res, magic_v);
+                else residual_chunk_f64(v, rv[bi][j], g.M_main, g.M_res);
+            }
+            if constexpr (EPI == EPI_RQ) {
+                if (lut_lds) {      // uniform: a 256-entry int8 -> int8 map (LDS) over the 16 bytes of the chunk
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        const unsigned u = (unsigned)v[d] ^ 0x80808080u;      // q + 128 per byte
+                        v[d] = (int)((unsigned)lut_lds[u & 255] | ((unsigned)lut_lds[(u >> 8) & 255] << 8) |
+                                     ((unsigned)lut_lds[(u >> 16) & 255] << 16) | ((unsigned)lut_lds[u >> 24] << 24));
+                    }
+                }
+            }
+            const int t = m0 + 16 * (jb + j) + l15;
+            unsigned off;
+            if constexpr (EPI == EPI_QKV) {
+                if (jb + j > 0) {       // 16 rows further: at most one image boundary when an image has at least 16 tokens
+                    if (g.tokens >= 16) {
+                        q_tok += 16;
+                        if (q_tok >= g.tokens) { q_tok -= g.tokens; ++q_b; }
+                    } else {
+                        const int tt = min(t, g.M - 1);
+                        q_b = tt / g.tokens;
+                        q_tok = tt - q_b * g.tokens;
+                    }
+                }
+                off = off0 + (unsigned)((q_b * g.heads * g.tokens + q_tok) * g.head_dim);
+            } else {
+                off = off0 + (unsigned)(jb + j) * ostep;
+            }
+            if (col_ok && t < g.M) store16_sel(out + off, make_int4(v[0], v[1], v[2], v[3]), g.flags2);
+        }
+    }
+}
+
 // ---- 16-bit epilogue of the weights-in-registers kernel (EPI_RQ16_RES16).  A wave owns 64 of the tile's 256 channels x 32 TJ
 // tokens; a lane holds, per accumulator quad, 4 consecutive channels of one token.  Straight from the registers that is one
 // 8-byte access per lane into 32 different rows per instruction -- measured ~75 us per launch over the int8 epilogue, the
