@@ -8,6 +8,7 @@ import torch.nn as nn
 
 from .. import _lib
 from ..prepare import LayerNormParams, f32
+from . import lazy
 from .quant_modules import _dev_table, _st, narrow_i8, to_float, to_int32
 
 
@@ -28,6 +29,21 @@ class IVITIntLayerNorm(nn.LayerNorm):
         pass
 
     def forward(self, x, scaling_factor=None):
+        if isinstance(x, lazy.QT):
+            s_in = lazy.host_of(scaling_factor)
+            if x.q8 is not None and s_in is not None and s_in.size == 1:
+                def build():
+                    lp = LayerNormParams(self.weight.detach().cpu().numpy(), self.bias.detach().cpu().numpy(), f32(1.0))
+                    self.bias_integer = _dev_table(lp.bias_int, x.device)       # :59
+                    s = lazy.QS.make(lp.s_ln, x.device)
+                    self.norm_scaling_factor = s.as_subclass(torch.Tensor)      # :64
+                    return s
+                s_ln = lazy._cache(self, ("s_ln", self.weight._version, self.bias._version, str(x.device)), build)
+                return lazy.pending("ln", self, x.shape, x.device, (x,), (scaling_factor,), s_ln)
+            x = x.to_float()
+        return self._slow(x, scaling_factor)
+
+    def _slow(self, x, scaling_factor=None):
         C = x.shape[-1]
         key = (self.weight._version, self.bias._version, x.device)
         if self._cache is None or self._cache[0] != key:
@@ -75,6 +91,17 @@ class IVITIntGELU(nn.Module):
         pass
 
     def forward(self, x, scaling_factor=None):
+        if isinstance(x, lazy.QT):
+            s_in = lazy.host_of(scaling_factor)
+            if x.q8 is not None and s_in is not None and s_in.size == 1:
+                s = lazy._cache(self, ("s_out", s_in.tobytes(), str(x.device)),
+                                lambda: lazy.QS.make(f32(s_in[0] * f32(1 / 2 ** (self.output_bit - 1))), x.device))   # :121,124
+                self.act_scaling_factor = s.as_subclass(torch.Tensor)
+                return lazy.pending("gelu", self, x.shape, x.device, (x,), (scaling_factor,), s)
+            x = x.to_float()
+        return self._slow(x, scaling_factor)
+
+    def _slow(self, x, scaling_factor=None):
         L = x.shape[-1]
         k8 = narrow_i8(to_int32(x, scaling_factor, trunc=True), "IVITIntGELU input")   # :106-107
         out = torch.empty(x.shape, dtype=torch.int32, device=x.device)
@@ -103,6 +130,15 @@ class IVITIntSoftmax(nn.Module):
         pass
 
     def forward(self, x, scaling_factor):
+        if isinstance(x, lazy.QT):
+            if isinstance(x.node, lazy.Scores) and not x.views and self.output_bit == 8 and scaling_factor is x.node.s_out_qs:
+                s = lazy._cache(self, ("s_out", str(x.device)), lambda: lazy.QS.make(f32(1 / 2 ** (self.output_bit - 1)), x.device))  # :176
+                self.act_scaling_factor = s.as_subclass(torch.Tensor)
+                return lazy.QT.wrap(x.shape, x.device, node=lazy.Probs(x, self)), s
+            x = x.to_float()
+        return self._slow(x, scaling_factor)
+
+    def _slow(self, x, scaling_factor):
         L = x.shape[-1]
         # the literal kernel: the reference discards its .to(int32) (:166) and runs the float32 sequence on x / s itself
         # (Swin's masked scores, swin_quant.py:151-156, included), csrc/literal.hip

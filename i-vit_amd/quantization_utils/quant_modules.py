@@ -21,6 +21,7 @@ import torch.nn as nn
 
 from .. import _lib
 from ..prepare import LinearParams, dyadic, f32, sym_scale
+from . import lazy
 
 
 # ----------------------------------------------------------------------------- device helpers
@@ -223,15 +224,29 @@ class QuantLinear(nn.Linear):
             W8 = _dev_table(W8h, dev)
             b32 = None if b32h is None else _dev_table(b32h, dev)
             s_acc = _dev_table(lp.s_acc, dev)
-            # buffers the reference overwrites on every call (quant_modules.py:211-220)
-            self.fc_scaling_factor = _dev_table(lp.sw, dev)
-            self.weight_integer = _dev_table(lp.W8, dev).float().reshape(self.weight.shape)
-            if b32 is not None:
-                self.bias_integer = b32.float()
+            self._publish(lp, dev)
             self._cache = (key, W8, b32, s_acc)
         return self._cache[1:]
 
+    def _publish(self, lp, dev):
+        """buffers the reference overwrites on every call (quant_modules.py:211-220)"""
+        self.fc_scaling_factor = _dev_table(lp.sw, dev)
+        self.weight_integer = _dev_table(lp.W8, dev).float().reshape(self.weight.shape)
+        if lp.b32 is not None:
+            self.bias_integer = _dev_table(lp.b32, dev).float()
+
     def forward(self, x, prev_act_scaling_factor=None):
+        if isinstance(x, lazy.QT):
+            s_in = lazy.host_of(prev_act_scaling_factor)
+            if x.q8 is not None and s_in is not None and s_in.size == 1 and self.in_features % 64 == 0:
+                # int8-carrying input of a frozen model: nothing runs here; the QuantAct behind launches GEMM + requantisation
+                c = lazy.linear_consts(self, s_in, x.device)
+                return lazy.pending("linear", self, (*x.shape[:-1], self.out_features), x.device, (x,),
+                                    (prev_act_scaling_factor,), c["s_acc"])
+            x = x.to_float()
+        return self._slow(x, prev_act_scaling_factor)
+
+    def _slow(self, x, prev_act_scaling_factor=None):
         assert prev_act_scaling_factor is not None and prev_act_scaling_factor.shape == (1,)
         W8, b32, s_acc = self._params(float(prev_act_scaling_factor.item()))
         K, N = self.in_features, self.out_features
@@ -301,8 +316,51 @@ class QuantAct(nn.Module):
             self.x_min = self.x_min * mo + x_min * (1 - mo)
             self.x_max = self.x_max * mo + x_max * (1 - mo)
 
+    def _frozen_scale(self, device):
+        """(s_out on the host, QS, plain scale tensor) of a fixed QuantAct, recomputed only when its range buffers change"""
+        key = (id(self.x_min), self.x_min._version, id(self.x_max), self.x_max._version, str(device))
+        c = self.__dict__.get("_frozen")
+        if c is None or c[0] != key:
+            s_out = sym_scale(float(self.x_min.reshape(-1)[0]), float(self.x_max.reshape(-1)[0]), self.activation_bit)
+            qs = lazy.QS.make(s_out, device)
+            c = self.__dict__["_frozen"] = (key, f32(s_out), qs, qs.as_subclass(torch.Tensor), (self.x_min, self.x_max))
+        return c[1], c[2], c[3]
+
+    def _fast(self, x, pre_sf, identity, identity_sf):
+        """frozen 8-bit QuantAct of an int8-carrying forward (lazy.py): int8 out, one fused launch, nothing read back"""
+        if pre_sf is None:
+            if isinstance(x, lazy.QT) or identity is not None or not x.is_cuda:
+                return None
+            s_out, qs, plain = self._frozen_scale(x.device)
+            xin = x.detach().contiguous().float()
+            q8 = torch.empty(xin.shape, dtype=torch.int8, device=x.device)
+            _lib.call("ivit_quantize_input_f32_i8", _lib.ptr(xin), _lib.ptr(q8), xin.numel(), float(f32(1.0) / s_out), _st())
+            self.act_scaling_factor = plain
+            return lazy.QT.wrap(q8.shape, x.device, q8=q8, scale=qs), qs
+        if not isinstance(x, lazy.QT):
+            return None
+        s_out, qs, plain = self._frozen_scale(x.device)
+        r = lazy.resolve(self, x, pre_sf, identity, identity_sf, s_out, qs)
+        if r is None:
+            return None
+        self.act_scaling_factor = plain
+        return r, qs
+
     def forward(self, x, pre_act_scaling_factor=None, identity=None, identity_scaling_factor=None,
                 specified_min=None, specified_max=None):
+        if (lazy.active() and not self.running_stat and self.activation_bit == 8 and specified_min is None
+                and specified_max is None):
+            r = self._fast(x, pre_act_scaling_factor, identity, identity_scaling_factor)
+            if r is not None:
+                return r
+        if isinstance(x, lazy.QT):
+            x = x.to_float()
+        if isinstance(identity, lazy.QT):
+            identity = identity.to_float()
+        return self._slow(x, pre_act_scaling_factor, identity, identity_scaling_factor, specified_min, specified_max)
+
+    def _slow(self, x, pre_act_scaling_factor=None, identity=None, identity_scaling_factor=None,
+              specified_min=None, specified_max=None):
         identity_in = identity
         if self.running_stat:
             self._observe(x if identity is None else identity + x)
@@ -369,6 +427,19 @@ class QuantMatMul(nn.Module):
         pass
 
     def forward(self, A, pre_act_scaling_factor_A, B, pre_act_scaling_factor_B):
+        if isinstance(A, lazy.QT) or isinstance(B, lazy.QT):
+            sa, sb = lazy.host_of(pre_act_scaling_factor_A), lazy.host_of(pre_act_scaling_factor_B)
+            if (isinstance(A, lazy.QT) and isinstance(B, lazy.QT) and sa is not None and sb is not None and sa.size == 1
+                    and sb.size == 1 and A.shape[:-2] == B.shape[:-2] and A.shape[-1] == B.shape[-2]):
+                s = pre_act_scaling_factor_A * pre_act_scaling_factor_B
+                self.act_scaling_factor = s.as_subclass(torch.Tensor)
+                return lazy.pending("matmul", self, (*A.shape[:-1], B.shape[-1]), A.device, (A, B),
+                                    (pre_act_scaling_factor_A, pre_act_scaling_factor_B), s)
+            A = A.to_float() if isinstance(A, lazy.QT) else A
+            B = B.to_float() if isinstance(B, lazy.QT) else B
+        return self._slow(A, B, pre_act_scaling_factor_A, pre_act_scaling_factor_B)
+
+    def _slow(self, A, B, pre_act_scaling_factor_A, pre_act_scaling_factor_B):
         a32 = to_int32(A, pre_act_scaling_factor_A)
         b8 = narrow_i8(to_int32(B, pre_act_scaling_factor_B), "QuantMatMul B")  # to_int32 makes B contiguous [.., K, N]
         Tq, Kd = A.shape[-2], A.shape[-1]
@@ -417,7 +488,27 @@ class QuantConv2d(nn.Conv2d):
     def unfix(self):
         pass
 
+    def _publish(self, lp, dev):
+        self.conv_scaling_factor = _dev_table(lp.sw, dev)
+        self.weight_integer = _dev_table(lp.W8, dev).float().reshape(self.weight.shape)
+        self.bias_integer = _dev_table(lp.b32, dev).float()
+
     def forward(self, x, pre_act_scaling_factor=None):
+        if isinstance(x, lazy.QT):
+            s_in = lazy.host_of(pre_act_scaling_factor)
+            kh, kw = self.kernel_size
+            K = self.in_channels * kh * kw
+            if (x.q8 is not None and s_in is not None and s_in.size == 1 and K % 64 == 0 and self.groups == 1
+                    and self.dilation == (1, 1) and self.bias is not None and x.dim() == 4
+                    and kh == kw == self.stride[0] == self.stride[1] and self.padding == (0, 0)
+                    and x.shape[2] % kh == 0 and x.shape[3] % kw == 0):
+                c = lazy.linear_consts(self, s_in, x.device)
+                shape = (x.shape[0], self.out_channels, x.shape[2] // kh, x.shape[3] // kw)
+                return lazy.pending("conv", self, shape, x.device, (x,), (pre_act_scaling_factor,), c["s_acc"].view(1, -1, 1, 1))
+            x = x.to_float()
+        return self._slow(x, pre_act_scaling_factor)
+
+    def _slow(self, x, pre_act_scaling_factor=None):
         kh, kw = self.kernel_size
         if not (kh == kw == self.stride[0] == self.stride[1] and self.padding == (0, 0) and self.groups == 1
                 and self.dilation == (1, 1)):
@@ -431,9 +522,7 @@ class QuantConv2d(nn.Conv2d):
             dev = x.device
             self._cache = (key, _dev_table(_pad_cols(lp.W8, _pad_k(lp.K)), dev), _dev_table(lp.b32, dev),
                            _dev_table(lp.s_acc, dev))
-            self.conv_scaling_factor = _dev_table(lp.sw, dev)
-            self.weight_integer = _dev_table(lp.W8, dev).float().reshape(self.weight.shape)
-            self.bias_integer = self._cache[2].float()
+            self._publish(lp, dev)
         _, W8, b32, s_acc = self._cache
         g = H // kh
         K = _pad_k(Cin * kh * kw)

@@ -102,9 +102,12 @@ class IntSwinEngine(GraphReplay):
             d["Wf"] = None
             N = d["N"]
             if Kp % 192 == 0 and N % 64 == 0 and N >= 128 and (N + 255) // 256 * 256 * 8 <= N * 9:
-                # MFMA-fragment copy (IVIT_W_FRAGS): the weights-in-registers GEMM (stage 1 fc1, stage 2 qkv / fc1, all of stage 3)
+                # MFMA-fragment copy: the weights-in-registers GEMM (stage 1 fc1, stage 2 qkv / fc1, all of stage 3).  The
+                # 16x16x64 order (IVIT_W_FRAGS16) except for attn.proj, whose fused 16-bit epilogue exists for the 32x32x32 form only
+                d["Wf_bit"] = 8 if name.endswith("attn.proj") else 16
                 d["Wf"] = torch.empty((N + 63) // 64 * 64 * Kp, dtype=torch.int8, device=self.dev)
-                _lib.call("ivit_pack_weight_frags_i8", _lib.ptr(d["W"]), Kp, N, Kp, _lib.ptr(d["Wf"]), _lib.stream_ptr())
+                _lib.call("ivit_pack_weight_frags_i8" if d["Wf_bit"] == 8 else "ivit_pack_weight_frags16_i8", _lib.ptr(d["W"]), Kp, N, Kp,
+                          _lib.ptr(d["Wf"]), _lib.stream_ptr())
             return lp, d
 
         def lin_dev(name, s_in, s_out):
@@ -301,7 +304,7 @@ class IntSwinEngine(GraphReplay):
     def _w(lin, M):
         """(weight pointer, layouts) -- the block-layout copy when the call goes to the persistent kernel"""
         if lin.get("Wf") is not None and M >= 2048:
-            return _lib.ptr(lin["Wf"]), 8
+            return _lib.ptr(lin["Wf"]), lin["Wf_bit"]
         if lin["Wb"] is not None and M >= 2048:
             return _lib.ptr(lin["Wb"]), 2
         return _lib.ptr(lin["W"]), 0
@@ -412,7 +415,7 @@ class IntSwinEngine(GraphReplay):
                 pj = blk["proj"]
                 r = blk["res1"]
                 if fuse_proj:
-                    w_, lay = (_lib.ptr(pj["Wf"]), 8) if (M >= 2048 and pj.get("Wf") is not None) else (_lib.ptr(pj["W"]), 0)
+                    w_, lay = (_lib.ptr(pj["Wf"]), pj["Wf_bit"]) if (M >= 2048 and pj.get("Wf") is not None) else (_lib.ptr(pj["W"]), 0)
                     _lib.call("ivit_gemm_i8_requant_i16_residual_i16_ex", _lib.ptr(ws["ao"]), ld, w_, pj["K"], _lib.ptr(pj["b"]),
                               _lib.ptr(pj["m"]), _lib.ptr(pj["e"]), _lib.ptr(x), C, r[0], r[1], r[2], r[3], _lib.ptr(x2), C, M, C,
                               pj["K"], lay, st)

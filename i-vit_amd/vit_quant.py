@@ -17,6 +17,7 @@ from torch import nn
 from .dispatch import EngineDispatch
 from .layers_quant import DropPath, Mlp, PatchEmbed, trunc_normal_
 from .quantization_utils import (QuantAct, QuantLinear, QuantMatMul, get_gelu, get_layernorm, get_softmax)
+from .quantization_utils import lazy
 
 __all__ = ["deit_tiny_patch16_224", "deit_small_patch16_224", "deit_base_patch16_224", "vit_base_patch16_224",
            "vit_large_patch16_224", "VisionTransformer"]
@@ -195,9 +196,11 @@ class VisionTransformer(EngineDispatch, nn.Module):
             return logits_f32.clone()
         if not self.is_frozen():
             self.invalidate_engine()     # running-stat QuantActs replace their range buffers: any snapshot is stale
-        x, s = self.forward_features(x)
-        x, _ = self.head(x, s)
-        return x
+        # a frozen I-ViT model run module by module carries int8 between its modules (quantization_utils/lazy.py)
+        with lazy.scope(x.is_cuda and not self.training and self.op_types == ("ivit",) * 3 and self.is_frozen()):
+            x, s = self.forward_features(x)
+            x, _ = self.head(x, s)
+        return x.to_float() if isinstance(x, lazy.QT) else x
 
 
 def _factory(embed_dim, depth, num_heads, name):

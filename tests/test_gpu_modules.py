@@ -970,3 +970,100 @@ def test_ibert_natural_scale_module_path_matches_reference():
     li = np.rint(y.cpu().numpy().astype(np.float64) / z["head_scale"].astype(np.float64)).astype(np.int32)
     assert np.array_equal(li, z["logits_int32"])
     assert np.array_equal(y.argmax(dim=1).cpu().numpy(), z["top1"])
+
+
+# ----------------------------------------------------------------------------------- int8-carrying module path (lazy.py)
+@pytest.mark.parametrize("tag", ["deit_tiny", "deit_tiny_natural", "deit_small_natural", "deit_base", "vit_base"])
+def test_frozen_module_path_carries_int8_and_never_syncs(tag):
+    """The reference's call protocol (vit_quant.py:61-90, 142-155, 285-312: QuantLinear, QuantAct, IVITIntLayerNorm, ... one by
+    one) on a frozen model, with every device -> host read-back an ERROR (torch.cuda.set_sync_debug_mode): int8 payloads move
+    between the modules, each QuantAct launches one fused integer kernel, all (m, e) pairs and tables come from host-side scales
+    cached at the warm-up forward.  Float logits bitwise and every QuantAct tap of the reference's goldens."""
+    import zlib
+    from ivit_amd.quantization_utils import lazy
+    model, meta, z = load_model(tag)
+    model.use_engine = False
+    n = min(meta["n_images"], 4)
+    imgs = torch.from_numpy(synth.make_images(meta["n_images"], meta["image_seed"])[:n]).to(DEV)
+    with torch.no_grad():
+        model(imgs)                      # warm-up: integer weights, (m, e) pairs and tables are derived and cached
+    taps = {}
+
+    def hook(name):
+        def fn(mod, inp, outp):
+            y = outp[0]
+            if isinstance(y, lazy.QT) and y.q8 is not None:
+                taps[name] = y.q8.clone()
+        return fn
+
+    handles = [mod.register_forward_hook(hook(name)) for name, mod in model.named_modules() if isinstance(mod, q.QuantAct)]
+    lazy.STATS.update(fused=0, materialised=0)
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        with torch.no_grad():
+            y = model(imgs)
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    for h in handles:
+        h.remove()
+    depth = len(model.blocks)
+    # per block: LN, qkv, attention, proj, residual, LN, fc1, GELU, fc2, residual; stem: patch GEMM, cls/pos assembly; tail: LN
+    assert lazy.STATS["fused"] == 10 * depth + 3, lazy.STATS
+    assert lazy.STATS["materialised"] == 1, lazy.STATS          # the logits, at the model's boundary
+    if "regime" not in meta:
+        assert np.array_equal(bits(y), z["logits_f32_bits"][:n])
+    else:     # ranges as calibrated: the reference's float logits come out of a float GEMM; its INT32 logits are the contract
+        from ivit_amd.prepare import LinearParams, sym_scale
+        hs = LinearParams(model.head.weight.detach().cpu().numpy(), model.head.bias.detach().cpu().numpy(),
+                          sym_scale(float(model.qact2.x_min), float(model.qact2.x_max))).s_acc
+        li = np.rint(y.cpu().numpy().astype(np.float64) / hs.astype(np.float64)).astype(np.int32)
+        assert np.array_equal(li, z["logits_int32"][:n])
+    assert np.array_equal(y.argmax(dim=1).cpu().numpy(), z["top1"][:n])
+    gold = dict(zip([str(x) for x in z["tap_names"]], z["tap_crc32"]))
+    if n == meta["n_images"]:
+        checked = [name for name in taps if name in gold]
+        bad = [name for name in checked
+               if zlib.crc32(np.ascontiguousarray(taps[name].cpu().numpy().astype(np.int32)).tobytes()) != int(gold[name])]
+        assert not bad, bad[:6]
+        assert len(checked) >= 7 * depth + 3
+
+
+def test_int8_carrying_path_falls_back_to_floats_where_a_caller_looks():
+    """anything that is not the model's own call protocol sees the float tensor the reference's module returns: a forward hook
+    doing arithmetic on a QuantAct output, an unfrozen QuantAct in the middle of the model, IVIT_LAZY=0"""
+    from ivit_amd.quantization_utils import lazy
+    model, meta, z = load_model("deit_tiny")
+    model.use_engine = False
+    imgs = torch.from_numpy(synth.make_images(2, meta["image_seed"])).to(DEV)
+    seen = {}
+
+    def hook(mod, inp, outp):
+        y, s = outp
+        seen["q"] = torch.round(y / s).to(torch.int32)        # plain torch arithmetic on the output
+        seen["type"] = type(y)
+    h = model.blocks[3].qact2.register_forward_hook(hook)
+    with torch.no_grad():
+        y = model(imgs)
+    h.remove()
+    assert seen["type"] is lazy.QT and int(seen["q"].abs().max()) <= 128
+    assert np.array_equal(bits(y), z["logits_f32_bits"][:2])
+    old = lazy.ENABLED
+    try:
+        lazy.ENABLED = False
+        with torch.no_grad():
+            y0 = model(imgs)
+    finally:
+        lazy.ENABLED = old
+    assert np.array_equal(bits(y0), z["logits_f32_bits"][:2])
+    # softmax / GELU / matmul outputs read as floats from inside the pending chain
+    got = {}
+    hs = [model.blocks[0].attn.int_softmax.register_forward_hook(lambda m, i, o: got.__setitem__("p", (o[0] / o[1]).amax())),
+          model.blocks[0].mlp.act.register_forward_hook(lambda m, i, o: got.__setitem__("g", (o[0] * 1.0).abs().amax())),
+          model.blocks[0].attn.matmul_2.register_forward_hook(lambda m, i, o: got.__setitem__("pv", o[0].float().abs().amax()))]
+    with torch.no_grad():
+        y1 = model(imgs)
+    for h in hs:
+        h.remove()
+    assert 0 < float(got["p"]) <= 128 and float(got["g"]) > 0 and float(got["pv"]) > 0
+    assert np.array_equal(bits(y1), z["logits_f32_bits"][:2])

@@ -280,3 +280,41 @@ def test_operator_signatures_match_reference_dropin_fixture(golden_dir):
         compatible(sig(obj.forward), spec["forward"], name + ".forward")
         for m in spec["methods"]:
             assert callable(getattr(obj, m, None)), (name, m)
+
+
+def test_int8_carrying_tensor_mechanics():
+    """quantization_utils/lazy.py on the CPU (no kernel runs): a QT answers shape questions like the float tensor it stands for,
+    the model files' shape operations act on its int8 payload or are recorded on its pending node, a QS carries its host value
+    through `* python scalar` in float32, and anything else materialises `integer * scale`."""
+    import torch
+    import torch.nn.functional as F
+    from ivit_amd.quantization_utils import lazy
+    QT, QS = lazy.QT, lazy.QS
+    rng = np.random.default_rng(3)
+    q = torch.from_numpy(rng.integers(-128, 128, (2, 5, 24), dtype=np.int8))
+    s = QS.make(0.03, "cpu")
+    x = QT.wrap(q.shape, q.device, q8=q, scale=s)
+    assert x.shape == (2, 5, 24) and x.dim() == 3 and x.dtype == torch.float32 and not x.is_cuda and x.numel() == 240
+    a, b, c = x.reshape(2, 5, 3, 2, 4).permute(2, 0, 3, 1, 4).unbind(0)              # vit_quant.py:66-68
+    assert isinstance(a, QT) and a.shape == (2, 2, 5, 4) and torch.equal(b.q8, q.reshape(2, 5, 3, 2, 4).permute(2, 0, 3, 1, 4)[1])
+    assert b.transpose(-2, -1).shape == (2, 2, 4, 5)
+    f = x.to_float()
+    assert f.dtype == torch.float32 and torch.equal(f, q.float() * np.float32(0.03))
+    assert F.dropout(x, 0.1, False) is x
+    y = x * 0.125
+    assert isinstance(y, QT) and y.q8 is x.q8 and y.scale.host[0] == np.float32(0.03) * np.float32(0.125)
+    assert type(x + 1) is torch.Tensor and torch.equal(x + 1, f + 1)                  # not part of the protocol: floats
+    s2 = s * 0.125
+    assert isinstance(s2, QS) and (s * 0.125) is s2 and s2.host[0] == np.float32(0.03) * np.float32(0.125)
+    assert float(s2) == float(np.float32(0.03) * np.float32(0.125))
+    assert s.view(1, -1).host is s.host and type(s + s) is torch.Tensor
+    # a pending node: the views are recorded and replayed on the materialised tensor
+    n = QT.wrap(x.shape, "cpu", node=lazy.Scaled(x, 2.0))
+    v = n[:, 0]
+    assert v.shape == (2, 24) and torch.equal(v.to_float(), (f * 2.0)[:, 0])
+    t1, t2 = n.transpose(1, 2).unbind(0)
+    assert t2.shape == (24, 5) and torch.equal(t2.to_float(), (f * 2.0).transpose(1, 2)[1])
+    with lazy.scope(True):
+        cat = torch.cat((torch.ones(2, 1, 24), x), dim=1)                             # vit_quant.py:293
+    assert isinstance(cat, QT) and cat.shape == (2, 6, 24) and torch.equal(cat.to_float(), torch.cat((torch.ones(2, 1, 24), f), 1))
+    assert not lazy.active()
