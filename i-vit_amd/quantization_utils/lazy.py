@@ -126,8 +126,16 @@ class QT(torch.Tensor):
     @staticmethod
     def wrap(shape, device, q8=None, scale=None, node=None, views=()):
         r = torch.Tensor._make_wrapper_subclass(QT, tuple(shape), dtype=torch.float32, device=device, requires_grad=False)
-        r.q8, r.scale, r.node, r.views = q8, scale, node, tuple(views)
+        r._q8, r.scale, r.node, r.views = q8, scale, node, tuple(views)
         return r
+
+    @property
+    def q8(self):
+        """the int8 payload; a deferred requantising GEMM (Requant) is launched the first time anybody asks for it"""
+        if self._q8 is None and isinstance(self.node, Requant):
+            self._q8 = self.apply_views(self.node.force())
+            self.node, self.views = None, ()
+        return self._q8
 
     # -- materialisation: the float tensor the reference's module would have returned
     def to_float(self):
@@ -165,16 +173,16 @@ class QT(torch.Tensor):
             def fn(t, _f=func, _r=rest, _k=kwargs):
                 return _f(t, *_r, **_k)
 
-            if self.q8 is not None:
-                out = fn(self.q8)
+            if self._q8 is not None:
+                out = fn(self._q8)
                 if isinstance(out, (tuple, list)):
                     return tuple(QT.wrap(o.shape, o.device, q8=o, scale=self.scale) for o in out)
                 return QT.wrap(out.shape, out.device, q8=out, scale=self.scale)
             meta = fn(torch.empty(self.shape, device="meta"))
             if isinstance(meta, (tuple, list)):
-                return tuple(QT.wrap(m.shape, self.device, node=self.node, views=self.views + ((lambda t, _fn=fn, _i=i: _fn(t)[_i]),))
-                             for i, m in enumerate(meta))
-            return QT.wrap(meta.shape, self.device, node=self.node, views=self.views + (fn,))
+                return tuple(QT.wrap(m.shape, self.device, scale=self.scale, node=self.node,
+                                     views=self.views + ((lambda t, _fn=fn, _i=i: _fn(t)[_i]),)) for i, m in enumerate(meta))
+            return QT.wrap(meta.shape, self.device, scale=self.scale, node=self.node, views=self.views + (fn,))
         if name in ("dropout", "dropout_", "feature_dropout", "alpha_dropout") and self is not None:
             training = kwargs.get("training", args[2] if len(args) > 2 else kwargs.get("train", True))
             if not training:
@@ -285,6 +293,18 @@ def linear_consts(lin, s_in, device):
     return _cache(lin, ("lin", lin.weight._version, None if lin.bias is None else lin.bias._version, _key(s_in), str(device)), build)
 
 
+def _gemm_me(lin, s_in, s_out, device):
+    """device (m, e) tables of the per-channel requantisation s_acc -> s_out, or None outside the kernels' contract (e < 31)"""
+    c = linear_consts(lin, s_in, device)
+
+    def build():
+        m, e = dyadic(c["lp"].s_acc, s_out)
+        if np.any(e < 31):
+            return None
+        return _dev(m.view(np.int32), device), _dev(e, device)
+    return _cache(lin, ("rq", _key(s_in, s_out), str(device)), build)
+
+
 def gemm_requant(lin, a8, s_in, s_out, device):
     """a8 [M, K] int8 contiguous -> int8 [M, N]: GEMM + per-channel requantisation to s_out in one kernel; None if outside the
     kernels' contract"""
@@ -292,13 +312,7 @@ def gemm_requant(lin, a8, s_in, s_out, device):
     N, K = c["N"], c["K"]
     if K % 64 != 0 or N % 16 != 0:
         return None
-
-    def build():
-        m, e = dyadic(c["lp"].s_acc, s_out)
-        if np.any(e < 31):
-            return None
-        return _dev(m.view(np.int32), device), _dev(e, device)
-    me = _cache(lin, ("rq", _key(s_in, s_out), str(device)), build)
+    me = _gemm_me(lin, s_in, s_out, device)
     if me is None:
         return None
     M = a8.shape[0]
@@ -317,6 +331,11 @@ def resolve(qact, x, pre_sf, identity, identity_sf, s_out, s_out_qs):
         return None
     node = x.node
     out = None
+    if isinstance(node, Requant) and x._q8 is None and identity is not None and not x.views:
+        out = node.with_residual(identity, host_of(identity_sf), s_in, s_out, device)
+        if out is not None:
+            STATS["fused"] += 1
+            return QT.wrap(out.shape, device, q8=out, scale=s_out_qs)
     if x.q8 is not None:
         if identity is None:
             return None
@@ -344,6 +363,13 @@ def resolve(qact, x, pre_sf, identity, identity_sf, s_out, s_out_qs):
                 else:
                     a8 = q8_contig(node.inputs[0])
                     a8 = None if a8 is None else a8.reshape(-1, a8.shape[-1])
+            if (a8 is not None and node.kind == "linear" and not x.views and a8.shape[0] >= 2048
+                    and linear_consts(node.mod, s_a, device)["Wf"] is not None):
+                # not launched yet: if the next QuantAct adds a residual (Block.qact2 / qact4, vit_quant.py:147,153) the GEMM,
+                # this requantisation and that one are ONE kernel; any other consumer launches the GEMM as it is
+                rq = Requant(node.mod, a8, s_a, s_out, node.shape, s_out_qs)
+                if rq.ok:
+                    return QT.wrap(x.shape, device, scale=s_out_qs, node=rq)
             o = gemm_requant(node.mod, a8, s_a, s_out, device) if a8 is not None else None
             if o is not None:
                 sh = node.shape
@@ -356,7 +382,7 @@ def resolve(qact, x, pre_sf, identity, identity_sf, s_out, s_out_qs):
             out = _resolve_attention(node, s_in, s_out, device)
             if out is None:      # the first matmul of the attention chain: stays pending as the Shiftmax input
                 base = node.inputs[0]
-                if isinstance(base, QT) and base.q8 is not None and not x.views:
+                if isinstance(base, QT) and not x.views:
                     return QT.wrap(x.shape, device, node=Scores(x, pre_sf, s_out, s_out_qs, qact))
     elif isinstance(node, Scaled) and identity is None and not x.views:
         return QT.wrap(x.shape, device, node=Scores(x, pre_sf, s_out, s_out_qs, qact))
@@ -365,6 +391,66 @@ def resolve(qact, x, pre_sf, identity, identity_sf, s_out, s_out_qs):
     STATS["fused"] += 1
     out = x.apply_views(out)
     return QT.wrap(out.shape, device, q8=out, scale=s_out_qs)
+
+
+class Requant(Node):
+    """a linear + its 8-bit QuantAct, not launched yet (see resolve)"""
+
+    def __init__(self, lin, a8, s_a, s_out, shape, s_out_qs):
+        self.lin, self.a8, self.s_a, self.s_out, self.shape, self.s_out_qs = lin, a8, s_a, s_out, shape, s_out_qs
+        self.ok = _gemm_me(lin, s_a, s_out, a8.device) is not None
+        self.out = None
+
+    def force(self):
+        if self.out is None:
+            STATS["fused"] += 1
+            self.out = gemm_requant(self.lin, self.a8, self.s_a, self.s_out, self.a8.device).view(*self.shape)
+        return self.out
+
+    def head_major(self, q, kT, v):
+        """q, k^T and v of vit_quant.py:66-70 as recorded views of THIS linear's output [B, N, 3 H hd]: the GEMM writes them head-major
+        ([3, B, H, N, hd], what the attention kernel reads) itself -> that tensor; None if the views are anything else"""
+        if self.out is not None or len(self.shape) != 3 or any(t._q8 is not None or t.node is not self for t in (q, kT, v)):
+            return None
+        B, N, C3 = self.shape
+        base = torch.empty(self.shape, dtype=torch.int8, device="meta")
+        mq, mk, mv = q.apply_views(base), kT.apply_views(base).transpose(-2, -1), v.apply_views(base)
+        if mq.dim() != 4:
+            return None
+        H, hd = mq.shape[1], mq.shape[3]
+        C = H * hd
+        if 3 * C != C3 or hd != 64 or N > 207 or any(tuple(m.shape) != (B, H, N, hd) or m.stride() != (N * C3, hd, C3, 1)
+                                                     or m.storage_offset() != i * C for i, m in enumerate((mq, mk, mv))):
+            return None
+        device = self.a8.device
+        c = linear_consts(self.lin, self.s_a, device)
+        me = _gemm_me(self.lin, self.s_a, self.s_out, device)
+        if c["Wf"] is None or c["K"] != C:
+            return None
+        hm = torch.empty(3, B, H, N, hd, dtype=torch.int8, device=device)
+        _lib.call("ivit_gemm_i8_requant_qkv_ex", _lib.ptr(self.a8), c["K"], _lib.ptr(c["Wf"]), c["K"], _lib.ptr(c["b"]), _lib.ptr(me[0]),
+                  _lib.ptr(me[1]), _lib.ptr(hm), N, H, hd, B * N, C3, c["K"], 16, _st())
+        STATS["fused"] += 1
+        return hm
+
+    def to_float(self):
+        return self.force().to(torch.float32) * self.s_out_qs.as_subclass(torch.Tensor).reshape(-1)[0]
+
+    def with_residual(self, identity, s_id, s_in, s_out2, device):
+        """out = clamp8(RNE(RNE(acc * M) * m1 / 2^e1) + RNE(identity * m2 / 2^e2)): ivit_gemm_i8_requant_residual_ex"""
+        i8 = q8_contig(identity)
+        c = linear_consts(self.lin, self.s_a, device)
+        N, K = c["N"], c["K"]
+        if (i8 is None or s_id is None or s_id.size != 1 or s_in.size != 1 or s_in[0] != f32(self.s_out) or c["Wf"] is None
+                or tuple(i8.shape) != tuple(self.shape)):
+            return None
+        me = _gemm_me(self.lin, self.s_a, self.s_out, device)
+        (m1, e1), (m2, e2) = dyadic(s_in, s_out2), dyadic(s_id, s_out2)
+        M = self.a8.shape[0]
+        out = torch.empty(M, N, dtype=torch.int8, device=device)
+        _lib.call("ivit_gemm_i8_requant_residual_ex", _lib.ptr(self.a8), K, _lib.ptr(c["Wf"]), K, _lib.ptr(c["b"]), _lib.ptr(me[0]),
+                  _lib.ptr(me[1]), _lib.ptr(i8), N, int(m1[0]), int(e1[0]), int(m2[0]), int(e2[0]), _lib.ptr(out), N, M, N, K, 16, _st())
+        return out.view(*self.shape)
 
 
 class Scores(Node):
@@ -450,7 +536,7 @@ def _resolve_gelu(node, s_g_out, s_out, device):
 def _resolve_attention(node, s_pv, s_out, device):
     """matmul_2(probs, v) behind qact2, where probs = Shiftmax(qact_attn1(matmul_1(q, k^T) * scale)): the fused attention kernel"""
     P, v = node.inputs
-    if not (isinstance(P, QT) and isinstance(P.node, Probs) and not P.views and isinstance(v, QT) and v.q8 is not None):
+    if not (isinstance(P, QT) and isinstance(P.node, Probs) and not P.views and isinstance(v, QT)):
         return None
     sc_qt = P.node.x
     sc = sc_qt.node
@@ -462,16 +548,22 @@ def _resolve_attention(node, s_pv, s_out, device):
     if s_mm is None or not np.array_equal(sc.s_in, s_mm if scaled is None else (s_mm * f32(scaled.c)).astype(f32)):
         return None
     q, kT = mm.inputs
-    if not (isinstance(q, QT) and q.q8 is not None and isinstance(kT, QT) and kT.q8 is not None):
+    if not (isinstance(q, QT) and isinstance(kT, QT)):
         return None
-    q8, k8, v8 = q.q8, kT.q8.transpose(-2, -1), v.q8
-    if q8.dim() != 4 or q8.shape != k8.shape or q8.shape != v8.shape or q8.shape[-1] != 64 or q8.shape[-2] > 207:
-        return None
-    B, H, T, hd = q8.shape
-    hm = torch.empty(3, B, H, T, hd, dtype=torch.int8, device=device)
-    hm[0].copy_(q8)
-    hm[1].copy_(k8)
-    hm[2].copy_(v8)
+    hm = q.node.head_major(q, kT, v) if isinstance(q.node, Requant) else None
+    if hm is not None:
+        B, H, T, hd = hm.shape[1:]
+    else:
+        if q.q8 is None or kT.q8 is None or v.q8 is None:
+            return None
+        q8, k8, v8 = q.q8, kT.q8.transpose(-2, -1), v.q8
+        if q8.dim() != 4 or q8.shape != k8.shape or q8.shape != v8.shape or q8.shape[-1] != 64 or q8.shape[-2] > 207:
+            return None
+        B, H, T, hd = q8.shape
+        hm = torch.empty(3, B, H, T, hd, dtype=torch.int8, device=device)
+        hm[0].copy_(q8)
+        hm[1].copy_(k8)
+        hm[2].copy_(v8)
     s_S, s_at = sc.s_in, sc.s_out
     if s_S.size != 1 or s_pv.size != 1:
         return None

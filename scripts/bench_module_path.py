@@ -16,6 +16,9 @@ imgs = torch.from_numpy(synth.make_images(min(B, 16), 99)).to(DEV)
 imgs = imgs.repeat((B + imgs.shape[0] - 1) // imgs.shape[0], 1, 1, 1)[:B].contiguous()
 
 
+HOST = {}
+
+
 def timed(model, n=5):
     with torch.no_grad():
         model(imgs)
@@ -23,6 +26,7 @@ def timed(model, n=5):
         t0 = time.perf_counter()
         for _ in range(n):
             model(imgs)
+        HOST["ms"] = (time.perf_counter() - t0) / n * 1e3      # time to ISSUE the forwards (no read-back on a sync-free path)
         torch.cuda.synchronize()
     return (time.perf_counter() - t0) / n * 1e3
 
@@ -37,7 +41,13 @@ for fam in FAMS:
     if not ENGINE_ONLY:
         model.use_engine = False
         ms = timed(model)
-        print(f"{fam:5s} module path  batch {B}: {ms:8.2f} ms / forward  ({B / ms * 1e3:8.0f} img/s)", flush=True)
+        print(f"{fam:5s} module path  batch {B}: {ms:8.2f} ms / forward  ({B / ms * 1e3:8.0f} img/s), host issue time {HOST['ms']:.2f} ms", flush=True)
+        if os.environ.get("IVIT_KERNEL_SPLIT"):
+            from torch.profiler import profile, ProfilerActivity
+            with torch.no_grad(), profile(activities=[ProfilerActivity.CUDA]) as prof:
+                model(imgs)
+                torch.cuda.synchronize()
+            print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=16, max_name_column_width=70), flush=True)
     model.use_engine = True
     print(f"{fam:5s} engine       batch {B}: {timed(model, 10):8.2f} ms / forward  (reason if not taken: {model.engine_unsupported_reason()})", flush=True)
     if os.environ.get("IVIT_KERNEL_SPLIT"):   # per-kernel time of the engine forward (torch profiler)

@@ -996,17 +996,21 @@ def test_frozen_module_path_carries_int8_and_never_syncs(tag):
                 taps[name] = y.q8.clone()
         return fn
 
-    handles = [mod.register_forward_hook(hook(name)) for name, mod in model.named_modules() if isinstance(mod, q.QuantAct)]
     lazy.STATS.update(fused=0, materialised=0)
     torch.cuda.synchronize()
     torch.cuda.set_sync_debug_mode("error")
     try:
         with torch.no_grad():
             y = model(imgs)
+            stats = dict(lazy.STATS)
+            handles = [mod.register_forward_hook(hook(name)) for name, mod in model.named_modules() if isinstance(mod, q.QuantAct)]
+            y2 = model(imgs)             # the same with a hook looking at every QuantAct's payload
     finally:
         torch.cuda.set_sync_debug_mode("default")
     for h in handles:
         h.remove()
+    lazy.STATS.update(stats)
+    assert torch.equal(y, y2)
     depth = len(model.blocks)
     # per block: LN, qkv, attention, proj, residual, LN, fc1, GELU, fc2, residual; stem: patch GEMM, cls/pos assembly; tail: LN
     assert lazy.STATS["fused"] == 10 * depth + 3, lazy.STATS
@@ -1067,3 +1071,27 @@ def test_int8_carrying_path_falls_back_to_floats_where_a_caller_looks():
         h.remove()
     assert 0 < float(got["p"]) <= 128 and float(got["g"]) > 0 and float(got["pv"]) > 0
     assert np.array_equal(bits(y1), z["logits_f32_bits"][:2])
+
+
+def test_int8_module_path_fuses_the_residual_gemm_at_large_batch():
+    """DeiT-B, 12 images (2364 token rows: the weights-in-registers GEMM applies): attn.proj -> attn.qact3 -> Block.qact2 and
+    mlp.fc2 -> mlp.qact2 -> Block.qact4 are ONE kernel each (ivit_gemm_i8_requant_residual_ex), 8 launches per block; logits
+    bitwise equal to the fused engine's and, on the golden images inside the batch, to the reference's"""
+    from ivit_amd.quantization_utils import lazy
+    model, meta, z = load_model("deit_base")
+    n = meta["n_images"]
+    imgs = np.concatenate([synth.make_images(12 - n, 515), synth.make_images(n, meta["image_seed"])])
+    imgs = torch.from_numpy(imgs).to(DEV)
+    with torch.no_grad():
+        ye = model(imgs)                 # fused engine
+        model.use_engine = False
+        model(imgs)
+        lazy.STATS.update(fused=0, materialised=0)
+        torch.cuda.set_sync_debug_mode("error")
+        try:
+            ym = model(imgs)
+        finally:
+            torch.cuda.set_sync_debug_mode("default")
+    assert lazy.STATS == {"fused": 8 * len(model.blocks) + 3, "materialised": 1}, lazy.STATS
+    assert torch.equal(ye, ym)
+    assert np.array_equal(bits(ym)[12 - n:], z["logits_f32_bits"])
