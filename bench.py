@@ -346,7 +346,7 @@ def worker(args):
         macs = [float(M) * N * K for _, _, (M, N, K), _ in rows]
         avg_ms = sum(ms) / len(ms)
         achieved = 2.0 * sum(macs) / (sum(ms) * 1e-3) / 1e12
-        traffic, traffic_src = (None, None) if args.bitwidth != 8 else pmc_traffic(("gemm_i8_wreg_kernel<1, 0>", "gemm_i8_wreg_kernel<1>", "gemm_i8_pers_kernel<1, 0>", "gemm_i8_pers_kernel<1>"))   # names as profiled
+        traffic, traffic_src = (None, None) if args.bitwidth != 8 else pmc_traffic(("gemm_i8_wreg_kernel<1, 4096, true>", "gemm_i8_wreg_kernel<1, 0, true>", "gemm_i8_wreg_kernel<1, 0>", "gemm_i8_wreg_kernel<1>", "gemm_i8_pers_kernel<1, 0>", "gemm_i8_pers_kernel<1>"))   # names as profiled
         roof = {"bound": "mfma", "kernel": "gemm_i8_wreg_kernel<EPI_RESID> (attn.proj + mlp.fc2, residual QuantAct fused)" if args.bitwidth == 8
                 else "gemm_i8_wreg_kernel<EPI_RQ16_RES16> (attn.proj + mlp.fc2, 16-bit QuantAct + 16-bit residual QuantAct fused)",
                 "achieved": round(achieved, 1), "peak": INT8_PEAK_TOPS, "unit": "TFLOP/s",

@@ -12,5 +12,12 @@ for c in $CFGS; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${T}_cfg$c -- python3 $R/scripts/bench_configs.py $c > $R/gpurun_out/prof_${T}_cfg$c.log 2>&1
   echo "config $c stats done"
 done
+# separate counter passes (FETCH_SIZE, WRITE_SIZE: one counter per run, kernel-trace only) for the configs in $PMC_CFGS
+for c in $PMC_CFGS; do
+  for k in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --kernel-trace --pmc $k --output-format csv -d $R/gpurun_out/pmc_${T}_cfg${c}_$k -- python3 $R/scripts/bench_configs.py $c > $R/gpurun_out/pmc_${T}_cfg${c}_$k.log 2>&1
+    echo "config $c $k done"
+  done
+done
 python3 $R/scripts/bench_configs.py --graph 1 2 3 4 5 > $R/gpurun_out/${T}_configs.jsonl 2> $R/gpurun_out/${T}_configs.err
 echo "throughput lines done"
