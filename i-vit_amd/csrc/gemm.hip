@@ -1055,7 +1055,7 @@ int launch_gemm(GemmArgs& g, const char* name, ivit_stream_t stream)
     }
     if constexpr (EPI != EPI_I32 && EPI != EPI_RQ16 && EPI != EPI_RQ16_RES16) {
 #if IVIT_LAB
-        if (EPI <= EPI_QKV && !blocks && (g_debug_flags & (31 | 32 | 128 | 256 | 512 | 1024 | 8192 | 4194304 | 8388608))) {   // a lab form was asked for (tests, scripts)
+        if (EPI <= EPI_QKV && !blocks && (g_debug_flags & (31 | 128 | 256 | 512 | 1024))) {   // a lab form was asked for (tests, scripts)
             int rc = IVIT_OK;
             if (ivit_gemm_lab_launch(EPI, &g, name, stream, &rc)) return rc;
         }

@@ -15,13 +15,9 @@ extern "C" {
 int ivit_debug_force_small_gemm(int on);
 /* Perf-ablation hook for scripts/gemm_ablate.py (bit 0: skip the in-loop DMA, bit 1: skip the MFMAs,
  * bit 2: skip the epilogue, ...); results are WRONG whenever flags & 1023 != 0.  Bits that keep results correct
- * (A/B timing): 32 the 256x256-tile kernel, 64 no start stagger, 1024 the relaunch-per-tile form instead of the
- * persistent one, 2048 split a sparse last round of tiles into half tiles, 4096 one workgroup per CU, 8192 the
- * deep-ring (5-stage, one workgroup per CU) kernel, 32768 per-CU turn-taking of the main loops, bits 16-21 start delay
- * of the second co-resident workgroup in ~1K-cycle units, bit 22 the persistent 256x256 kernel, bit 23 the ping-pong
- * kernel (its ablations reuse bits 16-18: no exact fallback / no in-loop requantisation / no phase 2; bit 24 forces
- * four units per K step; bit 25 writes time stamps into the stamp buffer), bit 26 a 256-workgroup grid of the
- * persistent kernel without the LDS blocker (two-stream probe). */
+ * (A/B timing): 64 no start stagger, 1024 the relaunch-per-tile form instead of the persistent one, 2048 split a sparse last
+ * round of tiles into half tiles, 4096 one workgroup per CU, 32768 per-CU turn-taking of the main loops, bits 16-21 start delay of the second co-resident workgroup in
+ * ~1K-cycle units, bit 26 a 256-workgroup grid of the persistent kernel without the LDS blocker (two-stream probe). */
 int ivit_debug_set_gemm_flags(int flags);
 /* Second flag word: A/B of cache policies in the GEMM epilogue (results stay correct).  Bits 0-1: policy of the int8 output
  * stores (0 plain, 1 nt, 2 sc1, 3 sc0 sc1); bit 2: the residual operand is read with nt loads. */

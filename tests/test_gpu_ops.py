@@ -289,7 +289,7 @@ def test_gemm_both_kernels_agree():
             _lib.call("ivit_debug_force_small_gemm", force)
             run()
         _lib.call("ivit_debug_force_small_gemm", 0)
-        for flags in (1024, 2048, 4096, 8192, 32, 4194304, 8388608):   # relaunch form; tail split; one workgroup per CU; deep ring; 256x256; persistent 256x256
+        for flags in (1024, 2048, 4096):   # relaunch form; tail split; one workgroup per CU
             _lib.call("ivit_debug_set_gemm_flags", flags)
             run()
     assert all(np.array_equal(outs[0], o) for o in outs[1:])
