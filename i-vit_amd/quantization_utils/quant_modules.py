@@ -6,8 +6,10 @@ Same class names, constructor arguments, registered buffers (state_dict keys, SU
 files and checkpoints apply unchanged.  Tensors crossing a module boundary are the reference's
 float32 ``value = integer * scale`` views; inside, each module converts to integers, runs the
 integer kernel through the C ABI (``ivit_*`` in include/ivit_hip.h) and converts back.  This is the
-compatibility path (one launch per conversion); ``VisionTransformer.forward`` of a frozen model
-takes the fused int8 engine (engine.py) instead.
+compatibility path (one launch per conversion: calibration, I-BERT operators, non-8-bit widths, Swin);
+``VisionTransformer.forward`` of a frozen model takes the fused int8 engine (engine.py) instead, and a
+frozen I-ViT model that is called module by module anyway carries int8 between the modules (lazy.py:
+the ``forward`` of each class below hands over to it, ``_slow`` is the ordinary path).
 
 Scales are read back to the host to derive the dyadic (m, e) pairs exactly as batch_frexp does
 (quant_utils.py:151-175); that is what the reference itself does on every call (numpy + Decimal).
