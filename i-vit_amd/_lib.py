@@ -38,6 +38,8 @@ SIGNATURES = {
     "ivit_untile_operand_i8": [vp, i64, ci, vp, i64, vp],
     "ivit_gemm_i8_requant_ex": [vp, i64, vp, i64, vp, vp, vp, vp, i64, ci, ci, ci, ci, vp],
     "ivit_gemm_i8_requant_residual_ex": [vp, i64, vp, i64, vp, vp, vp, vp, i64, u32, i32, u32, i32, vp, i64, ci, ci, ci, ci, vp],
+    "ivit_gemm_i8_requant_gelu_ex": [vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, i64, ci, ci, ci, ci, vp],
+    "ivit_gemm_gelu_workspace_bytes": [ci, vp],
     "ivit_gemm_i8_requant_qkv_ex": [vp, i64, vp, i64, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp],
     "ivit_gemm_i8_requant_residual_i16": [vp, i64, vp, i64, vp, vp, vp, vp, i64, u32, i32, u32, i32, vp, i64, ci, ci, ci, vp],
     "ivit_gemm_i8_requant_lut_ex": [vp, i64, vp, i64, vp, vp, vp, vp, vp, i64, ci, ci, ci, ci, vp],

@@ -878,9 +878,13 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_wreg_kernel(GemmArgs g)
             if constexpr (S16) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");     // MFMA results -> VALU reads: see mfma16 (c)
             if constexpr (S16 && (EPI == EPI_RQ || EPI == EPI_RESID || EPI == EPI_QKV) && !(ABL & 8192)) {
                 // straight from the registers (lane transpose, no LDS staging); ABL bit 13: the staged form below (A/B, lab)
-                epilogue_direct_16<EPI, 2 * TJ, (ABL & (64 | 2048 | 4096)), Hook>(acc16, g, tab, cur.m0, cur.n0, 64 * wave, (tid_o >> 4) & 3, tid_o & 15, hook,
+                epilogue_direct_16<EPI, 2 * TJ, (ABL & (64 | 2048 | 4096 | 32768)), Hook>(acc16, g, tab, cur.m0, cur.n0, 64 * wave, (tid_o >> 4) & 3, tid_o & 15, hook,
                                                                                g.lut ? reinterpret_cast<const unsigned char*>(smem + WR_LUT) : nullptr,
                                                                                (ABL & 2048) ? tv : nullptr);
+                if constexpr ((ABL & 32768) != 0) {      // ShiftGELU of a token panel by the workgroup that completes it (staging region: free here)
+                    __builtin_amdgcn_s_setprio(0);
+                    gelu_panel_phase<BIG_NT>(g, cs, cur.m0, cur.half, tid_o);
+                }
             } else if constexpr (S16) {
                 static_assert(!S16 || EPI != EPI_RQ16_RES16, "the 16-bit epilogue exists for the 32x32 form only");
                 epilogue_i8_16<EPI, 2 * TJ, BIG_NT, (ABL & (64 | 2048 | 4096)), WR_CH, Hook>(acc16, g, cs, tab, cur.m0, cur.n0, 64 * wave, tid_o, (tid_o >> 4) & 3,
@@ -1037,6 +1041,12 @@ int launch_gemm(GemmArgs& g, const char* name, ivit_stream_t stream)
                         }
                     }
 #endif
+                    if constexpr (EPI == EPI_RQ) {
+                        if (g.gelu_ws) {     // ABL bit 15: ShiftGELU + mlp.qact1 applied per completed token panel (gelu_panel_phase)
+                            hipLaunchKernelGGL((gemm_i8_wreg_kernel<EPI, 32768, true>), grid, dim3(BIG_NT), 0, ivit_stream(stream), g);
+                            IVIT_CHECK_LAUNCH(name);
+                        }
+                    }
                     if constexpr (EPI == EPI_RESID) {
                         if (g.res_f32) {     // ABL bit 12: the residual QuantAct on float32 fmas (residual_f32_form)
                             hipLaunchKernelGGL((gemm_i8_wreg_kernel<EPI, 4096, true>), grid, dim3(BIG_NT), 0, ivit_stream(stream), g);
@@ -1176,6 +1186,30 @@ IVIT_EXPORT int ivit_gemm_i8_requant_lut_ex(const int8_t* A, int64_t lda, const 
     IVIT_REQUIRE(!g.out_blocks || (N % 64 == 0 && ldo == N && ((int64_t)M + 15) * N < 2147483648ll),
                  "ivit_gemm_i8_requant_lut_ex: block-layout output needs N %% 64 == 0, ldo == N and a buffer below 2 GiB");
     return launch_gemm<EPI_RQ>(g, "ivit_gemm_i8_requant_lut_ex", stream);
+}
+
+IVIT_EXPORT int ivit_gemm_gelu_workspace_bytes(int M, int64_t* bytes)
+{
+    IVIT_REQUIRE(M > 0 && bytes, "ivit_gemm_gelu_workspace_bytes: M > 0 and a result pointer");
+    const int64_t panels = ((int64_t)M + WR_TOK - 1) / WR_TOK;
+    *bytes = panels * (int64_t)sizeof(int);
+    return IVIT_OK;
+}
+
+IVIT_EXPORT int ivit_gemm_i8_requant_gelu_ex(const int8_t* A, int64_t lda, const int8_t* W, int64_t ldw, const int32_t* bias,
+                                             const uint32_t* m, const int32_t* e, const int8_t* gelu_lut, void* workspace,
+                                             int8_t* out, int64_t ldo, int M, int N, int K, int layouts, ivit_stream_t stream)
+{
+    GemmArgs g{};
+    g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.m = m; g.e = e;
+    g.out = out; g.ldo = ldo; g.M = M; g.N = N; g.K = K; g.gelu_lut = gelu_lut; g.gelu_ws = static_cast<int*>(workspace);
+    g.a_blocks = layouts & 1; g.out_blocks = (layouts >> 2) & 1; g.w_frags = (layouts & 16) ? 2 : 0;
+    IVIT_REQUIRE(gelu_lut && workspace && ((uintptr_t)workspace % 4 == 0) && (layouts & ~(1 | 4 | 16)) == 0 && g.w_frags == 2,
+                 "ivit_gemm_i8_requant_gelu_ex: needs the table, the workspace and IVIT_W_FRAGS16 (| IVIT_A_BLOCKS | IVIT_OUT_BLOCKS)");
+    IVIT_REQUIRE(N <= 4096, "ivit_gemm_i8_requant_gelu_ex: N = %d, at most 4096 channels per token", N);
+    IVIT_REQUIRE(!g.out_blocks || (N % 64 == 0 && ldo == N && ((int64_t)M + 15) * N < 2147483648ll),
+                 "ivit_gemm_i8_requant_gelu_ex: block-layout output needs N %% 64 == 0, ldo == N and a buffer below 2 GiB");
+    return launch_gemm<EPI_RQ>(g, "ivit_gemm_i8_requant_gelu_ex", stream);
 }
 
 IVIT_EXPORT int ivit_gemm_i8_requant(const int8_t* A, int64_t lda, const int8_t* W, int64_t ldw, const int32_t* bias,

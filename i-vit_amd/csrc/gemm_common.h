@@ -79,6 +79,11 @@ struct GemmArgs {
     int flags2;               // lab build only (ivit_debug_set_gemm_flags2): cache policies of the epilogue's stores / residual loads
     const int8_t* lut;        // EPI_RQ, weights-in-registers kernel: out = lut[q + 128] applied to every requantised byte (an
                               // elementwise int8 -> int8 operator behind the QuantAct, e.g. I-BERT GELU + mlp.qact1), or NULL
+    // EPI_RQ, 16x16x64 weights-in-registers kernel, ABL bit 15 (ivit_gemm_i8_requant_gelu_ex, EXPERIMENTAL): ShiftGELU + mlp.qact1
+    // behind the QuantAct, applied by the workgroup that completes a token panel (gelu_panel_phase)
+    const int8_t* gelu_lut;   // [256][256] (row max + 128, k + 128) -> int8: the table of ivit_shiftgelu_build_lut_ex
+    int* gelu_ws;             // caller-owned arrival counters of the 128-token panels [tiles_m]: zero before the first use, left
+                              // zero by every launch
 };
 
 IVIT_DEV int nk_of(const GemmArgs& g) { return g.K / 64; }
@@ -127,10 +132,13 @@ IVIT_DEV void store16_pol(void* p, int4 v)
 {
     typedef int v4i_ __attribute__((ext_vector_type(4)));
     const v4i_ d = {v.x, v.y, v.z, v.w};
+    // (lab A/B of cache policies only.  The s_nop: the data comes straight out of v_permlane16_swap / v_permlane32_swap in
+    // epilogue_direct_16; the compiler's hazard recognizer puts wait states in front of its own VMEM instructions but does not look
+    // into inline asm.)
     if constexpr (POL == 0) *reinterpret_cast<int4*>(p) = v;
-    else if constexpr (POL == 1) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(d) : "memory");
-    else if constexpr (POL == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(d) : "memory");
-    else asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(d) : "memory");
+    else if constexpr (POL == 1) asm volatile("s_nop 7\n\tglobal_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(d) : "memory");
+    else if constexpr (POL == 2) asm volatile("s_nop 7\n\tglobal_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(d) : "memory");
+    else asm volatile("s_nop 7\n\tglobal_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(d) : "memory");
 }
 IVIT_DEV void store16_sel(void* p, int4 v, int pol)
 {
@@ -624,6 +632,8 @@ IVIT_DEV void epilogue_direct_16(v4i (&acc)[4][NJ], const GemmArgs& g, const cha
     // store -- batch 0 runs under the flight of batch 1's residual loads; the next work item's table (hook.consume: vmcnt(0) for its
     // loads, issued before this epilogue) is written between the two batches.
     constexpr int NB = NJ / 4;
+    constexpr bool GELU = (ABL & 32768) != 0;     // the tile is read back by the workgroup that completes its panel (gelu_panel_phase)
+    static_assert(!GELU || EPI == EPI_RQ, "the fused ShiftGELU follows a plain requantising epilogue");
     unsigned D[NB][4][4];     // [batch][i][j]: bytes 16 i + 4 g4 .. + 3 of token 16 (4 batch + j) + l15
     int4 rv[EPI == EPI_RESID ? NB : 1][4];
     v4f lhbuf[2][2];
@@ -758,9 +768,120 @@ IVIT_DEV void epilogue_direct_16(v4i (&acc)[4][NJ], const GemmArgs& g, const cha
             } else {
                 off = off0 + (unsigned)(jb + j) * ostep;
             }
-            if (col_ok && t < g.M) store16_sel(out + off, make_int4(v[0], v[1], v[2], v[3]), g.flags2);
+            if constexpr (GELU) {
+                // written through to memory (sc1 = device scope): read back by whichever workgroup completes the panel, possibly on
+                // another XCD.  Two 64-bit atomic stores, not an inline-asm 128-bit one: compiler-visible, so its hazard and
+                // s_waitcnt bookkeeping cover them
+                if (col_ok && t < g.M) {
+                    long long* q = reinterpret_cast<long long*>(out + off);
+                    __hip_atomic_store(q, (long long)(((unsigned long long)(unsigned)v[1] << 32) | (unsigned)v[0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(q + 1, (long long)(((unsigned long long)(unsigned)v[3] << 32) | (unsigned)v[2]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            } else {
+                if (col_ok && t < g.M) store16_sel(out + off, make_int4(v[0], v[1], v[2], v[3]), g.flags2);
+            }
         }
     }
+}
+
+// ---- EXPERIMENTAL (measured slower than GEMM + table pass; no engine uses it): ShiftGELU + mlp.qact1 behind
+// mlp.fc1 + mlp.qact_gelu inside the GEMM that produces its input (ivit_modules.py:105-126).
+// The map of a byte depends on the maximum over ALL N outputs of its token (the exponent's argument is k - max), and a token's N
+// channels are N / 256 tiles of N / 256 different workgroups.  So: every tile writes its requantised bytes through to memory and
+// counts itself in at its 128-token panel; the workgroup whose arrival completes the panel reads the panel's 128 x N bytes back,
+// takes the row maxima, and maps the rows in place.  Nobody waits for anybody: a workgroup either finds the panel complete or
+// leaves.  Visibility across XCDs (one L2 each): sc1 stores, all acknowledged (s_waitcnt vmcnt(0)) and written back (release)
+// before the arrival is counted; the completing workgroup reads with sc1 loads.  The counters are left as they were found (zero).
+template <int NTHREADS>
+IVIT_DEV void gelu_panel_phase(const GemmArgs& g, char* lds, int m0, int half, int tid)
+{
+    typedef int v4i_ __attribute__((ext_vector_type(4)));
+    constexpr int RG = 4;                          // rows per wave and step: RG x N / 1024 16-byte chunks in flight per lane
+    constexpr int MAXC = 4;                        // 16-byte chunks per lane and row: N <= 4096
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's tile stores have been acknowledged
+    __syncthreads();
+    int* flag = reinterpret_cast<int*>(lds);
+    const int panel = m0 >> 7, mp = panel << 7;
+    int* cnt = g.gelu_ws + panel;
+    if (tid == 0) {
+        const int inc = half ? 1 : 2;
+        const int old = __hip_atomic_fetch_add(cnt, inc, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        flag[0] = (old + inc == 2 * g.tiles_n) ? 1 : 0;
+    }
+    __syncthreads();
+    if (flag[0] == 0) return;                      // uniform: the panel is not complete (or another workgroup completes it)
+#if IVIT_LAB
+    if (g.flags2 & 0x1000) {      // timing ablation: count, but leave the panel unmapped (results wrong)
+        if (tid == 0) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+#endif
+    const int lane = tid & 63, wave = tid >> 6;
+    unsigned char* tab = reinterpret_cast<unsigned char*>(lds) + 64 + wave * (RG * 256);
+    int8_t* const out = reinterpret_cast<int8_t*>(g.out);
+    const int nch = g.N >> 4;                      // 16-byte chunks per row (N % 64 == 0)
+    constexpr int RPW = 128 / (NTHREADS / 64);     // rows per wave
+    for (int rs = 0; rs < RPW; rs += RG) {
+        const int r0 = mp + wave * RPW + rs;
+        if (r0 >= g.M) break;                      // uniform
+        v4i_ w[RG][MAXC];
+        unsigned off[RG][MAXC];
+#pragma unroll
+        for (int r = 0; r < RG; ++r) {
+            const int row = min(r0 + r, g.M - 1);
+            const BlockRow br = block_row(row, g.N);
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c) {
+                w[r][c] = (v4i_){0, 0, 0, 0};
+                const int ch = min(lane + 64 * c, nch - 1);
+                off[r][c] = g.out_blocks ? block_off(br, block_col(16 * ch)) : (unsigned)row * (unsigned)g.ldo + 16u * (unsigned)ch;
+                if (64 * c < nch) {                // uniform.  (An inline-asm 128-bit sc1 load here returned wrong first dwords now and
+                                                   // then: the compiler reuses these registers for the mapped output and knows nothing of
+                                                   // a load it cannot see.  Compiler-visible atomic loads, twice as many, are exact.)
+                    const long long* q = reinterpret_cast<const long long*>(out + off[r][c]);
+                    const long long lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const long long hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    w[r][c] = (v4i_){(int)lo, (int)(lo >> 32), (int)hi, (int)(hi >> 32)};
+                }
+            }
+        }
+        // the rows' maxima from the bytes themselves, then their table slices
+#pragma unroll
+        for (int r = 0; r < RG; ++r) {
+            int km = -128;
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c) {
+                if (64 * c >= nch) continue;
+                if (lane + 64 * c < nch) {
+#pragma unroll
+                    for (int d = 0; d < 4; ++d)
+                        km = max(max(km, (int)(int8_t)(w[r][c][d])), max((int)(int8_t)(w[r][c][d] >> 8), max((int)(int8_t)(w[r][c][d] >> 16), w[r][c][d] >> 24)));
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) km = max(km, __shfl_xor(km, o));
+            reinterpret_cast<int*>(tab + 256 * r)[lane] = reinterpret_cast<const int*>(g.gelu_lut + (int64_t)(km + 128) * 256)[lane];
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < RG; ++r) {
+            const unsigned char* tb = tab + 256 * r;
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c) {
+                if (64 * c >= nch) continue;       // uniform
+                int o[4];
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const unsigned u = (unsigned)w[r][c][d] ^ 0x80808080u;      // k + 128 per byte
+                    o[d] = (int)((unsigned)tb[u & 255] | ((unsigned)tb[(u >> 8) & 255] << 8) | ((unsigned)tb[(u >> 16) & 255] << 16) |
+                                 ((unsigned)tb[u >> 24] << 24));
+                }
+                if (lane + 64 * c < nch && r0 + r < g.M) *reinterpret_cast<int4*>(out + off[r][c]) = make_int4(o[0], o[1], o[2], o[3]);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();           // every lane has read its slices before the next step overwrites them
+    }
+    if (tid == 0) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---- 16-bit epilogue of the weights-in-registers kernel (EPI_RQ16_RES16).  A wave owns 64 of the tile's 256 channels x 32 TJ

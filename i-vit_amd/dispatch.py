@@ -96,11 +96,20 @@ class EngineDispatch:
         self._engine = (device, fp, eng)
         return eng
 
+    def _reason_cached(self):
+        """engine_unsupported_reason(), re-evaluated only when a QuantAct's width changed (it builds 4 * depth dictionaries; this
+        predicate runs on every forward, and a DeiT-T batch-1 forward is 0.7 ms)"""
+        key = tuple(int(m.activation_bit) for _, m in self._quant_acts())
+        c = self.__dict__.get("_reason_cache")
+        if c is None or c[0] != key:
+            c = self.__dict__["_reason_cache"] = (key, self.engine_unsupported_reason())
+        return c[1]
+
     def takes_engine(self, x: torch.Tensor) -> bool:
         if getattr(self, "_io_stat_hooks", False) and _qm.io_stats_enabled():
             return False      # attach_io_stat_hooks: the collector's hooks sit on the sub-modules, which the fused engine never calls
         return (self.use_engine and not self.training and x.is_cuda and self.is_frozen()
-                and self.engine_unsupported_reason() is None)
+                and self._reason_cached() is None)
 
     def ranges(self):
         return {n: (float(m.x_min.reshape(-1)[0]), float(m.x_max.reshape(-1)[0]))

@@ -453,6 +453,87 @@ def test_gemm_weight_fragment_layout(M, N, K, FR):
                   _lib.ptr(out), N, M, N, 128, FR, st())
 
 
+def _gelu_ws(M):
+    return torch.zeros((M + 127) // 128, dtype=torch.int32, device=DEV)
+
+
+@pytest.mark.parametrize("M,N,K", [(2600, 768, 192), (197 * 16, 3072, 768), (2049, 1024, 192), (4000, 1792, 576)])
+def test_gemm_requant_gelu_fused(M, N, K):
+    """ivit_gemm_i8_requant_gelu_ex: the (row max, k) -> int8 table of ShiftGELU + mlp.qact1 applied inside the GEMM that produces
+    k, by the workgroup that completes a 128-token panel == the oracle's GEMM + requant followed by the table with the maximum over
+    the whole row; row-major and block-layout operands / output, partial token panels and channel tiles; the workspace is left zero
+    and serves the next launch"""
+    rng = np.random.default_rng(M + N + 11)
+    A = rng.integers(-128, 128, size=(M, K)).astype(np.int8)
+    W = rng.integers(-128, 128, size=(N, K)).astype(np.int8)
+    b = rng.integers(-50000, 50000, size=N).astype(np.int32)
+    m, e = rand_me(rng, N, -17, -11)
+    md, ed = me_dev(m, e)
+    lut = rng.integers(-128, 128, size=(256, 256)).astype(np.int8)
+    k8 = orc.requant(orc.gemm_i8(A, W, b), m.astype(np.float64), e, 8)
+    rmax = k8.max(axis=1)
+    assert len(np.unique(rmax)) > 20 and rmax.max() <= 127          # many different table rows in play
+    exp = lut[rmax[:, None] + 128, k8 + 128]
+    dA, dW, db, dl = dev(A), dev(W), dev(b), dev(lut)
+    R16 = (M + 15) // 16 * 16
+    At = torch.zeros(R16 * K, dtype=torch.int8, device=DEV)
+    _lib.call("ivit_tile_operand_i8", _lib.ptr(dA), K, M, K, _lib.ptr(At), st())
+    Wf = torch.zeros((N + 63) // 64 * 64 * K, dtype=torch.int8, device=DEV)
+    _lib.call("ivit_pack_weight_frags16_i8", _lib.ptr(dW), K, N, K, _lib.ptr(Wf), st())
+    ws = _gelu_ws(M)
+    nb = np.zeros(1, np.int64)
+    _lib.call("ivit_gemm_gelu_workspace_bytes", M, nb.ctypes.data_as(C.c_void_p))
+    assert int(nb[0]) == ws.numel() * 4
+    for lay in (16, 17, 16 | 4, 17 | 4, 16):
+        blocks = bool(lay & 4)
+        out = torch.zeros(R16 * N if blocks else M * N, dtype=torch.int8, device=DEV)
+        _lib.call("ivit_gemm_i8_requant_gelu_ex", _lib.ptr(At if lay & 1 else dA), K, _lib.ptr(Wf), K, _lib.ptr(db), _lib.ptr(md),
+                  _lib.ptr(ed), _lib.ptr(dl), _lib.ptr(ws), _lib.ptr(out), N, M, N, K, lay, st())
+        got = out.cpu().numpy()
+        want = _block_layout_host(exp) if blocks else exp.reshape(-1)
+        assert np.array_equal(got[:want.size], want), (lay, int((got[:want.size] != want).sum()))
+        assert int(ws.abs().max()) == 0, lay         # left as found
+    with pytest.raises(_lib.IvitError, match="IVIT_W_FRAGS16"):
+        _lib.call("ivit_gemm_i8_requant_gelu_ex", _lib.ptr(dA), K, _lib.ptr(dW), K, _lib.ptr(db), _lib.ptr(md), _lib.ptr(ed),
+                  _lib.ptr(dl), _lib.ptr(ws), _lib.ptr(out), N, M, N, K, 0, st())
+
+
+def test_gemm_requant_gelu_fused_headline_shape():
+    """mlp.fc1 of DeiT-B at batch 256 (50 432 x 3072 x 768, block layouts, 394 panels of 12 channel tiles on 512 workgroups, half
+    tiles in the last round) with the real ShiftGELU table: ten launches in a row on one workspace, each equal to
+    ivit_gemm_i8_requant_ex + ivit_shiftgelu_lut_i8_ex in place"""
+    M, N, K = 256 * 197, 3072, 768
+    g = torch.Generator(device="cpu").manual_seed(5)
+    A = torch.randint(-128, 128, (M, K), dtype=torch.int8, generator=g).to(DEV)
+    W = torch.randint(-128, 128, (N, K), dtype=torch.int8, generator=g)
+    W[:, ::3] //= 8                                    # accumulators that leave a spread of row maxima after the requantisation
+    W = W.to(DEV)
+    b = torch.randint(-50000, 50000, (N,), dtype=torch.int32, generator=g).to(DEV)
+    rng = np.random.default_rng(3)
+    m, e = rand_me(rng, N, -17, -13)
+    md, ed = me_dev(m, e)
+    s_g = np.float32(0.0517)
+    mg, eg = dyadic(np.float32(s_g * np.float32(1 / 128)), np.float32(0.011))
+    lut = torch.empty(65536, dtype=torch.int8, device=DEV)
+    _lib.call("ivit_shiftgelu_build_lut_ex", float(s_g), int(mg[0]), int(eg[0]), None, _lib.ptr(lut), st())
+    At = torch.zeros(M * K, dtype=torch.int8, device=DEV)
+    _lib.call("ivit_tile_operand_i8", _lib.ptr(A), K, M, K, _lib.ptr(At), st())
+    Wf = torch.zeros(N * K, dtype=torch.int8, device=DEV)
+    _lib.call("ivit_pack_weight_frags16_i8", _lib.ptr(W), K, N, K, _lib.ptr(Wf), st())
+    ref = torch.zeros(M * N, dtype=torch.int8, device=DEV)
+    _lib.call("ivit_gemm_i8_requant_ex", _lib.ptr(At), K, _lib.ptr(Wf), K, _lib.ptr(b), _lib.ptr(md), _lib.ptr(ed), _lib.ptr(ref), N,
+              M, N, K, 16 | 1 | 4, st())
+    _lib.call("ivit_shiftgelu_lut_i8_ex", _lib.ptr(ref), N, M, N, _lib.ptr(lut), _lib.ptr(ref), N, 1 | 2, st())
+    assert len(torch.unique(ref)) > 30
+    ws = _gelu_ws(M)
+    for it in range(10):
+        out = torch.full((M * N,), 3, dtype=torch.int8, device=DEV)
+        _lib.call("ivit_gemm_i8_requant_gelu_ex", _lib.ptr(At), K, _lib.ptr(Wf), K, _lib.ptr(b), _lib.ptr(md), _lib.ptr(ed),
+                  _lib.ptr(lut), _lib.ptr(ws), _lib.ptr(out), N, M, N, K, 16 | 1 | 4, st())
+        assert torch.equal(out, ref), (it, int((out != ref).sum()))
+        assert int(ws.abs().max()) == 0
+
+
 @pytest.mark.parametrize("M,N,K", [(2600, 512, 384), (197 * 16, 3072, 768)])
 def test_gemm_requant_output_map(M, N, K):
     """ivit_gemm_i8_requant_lut_ex: a 256-entry int8 -> int8 map applied to every requantised output in the epilogue of the
