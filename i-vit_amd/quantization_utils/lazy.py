@@ -35,13 +35,21 @@ from ..prepare import (LayerNormParams, LinearParams, dyadic, f32, phi_tables, q
                        sym_scale)
 
 ENABLED = os.environ.get("IVIT_LAZY", "1") != "0"
-_ACTIVE = [0]
+_ACTIVE = [1 if os.environ.get("IVIT_LAZY") == "always" else 0]
 STATS = {"fused": 0, "materialised": 0}     # fused launches at a QuantAct / float tensors materialised, since the last reset
 
 
 def active() -> bool:
     """inside `with lazy.scope(True):` -- the model mirror opens it around the module-by-module forward of a frozen I-ViT model"""
     return _ACTIVE[0] > 0
+
+
+def enable_everywhere(on: bool = True):
+    """Frozen 8-bit QuantActs carry int8 wherever they are called from -- for callers that drive the modules themselves, e.g. the
+    reference's own models/vit_quant.py imported on top of this package.  The mirror's VisionTransformer.forward
+    opens the scope by itself; nothing else does by default (Swin's LayerNorms depend on the memory layout of their float inputs,
+    DESIGN.md section 2, which an int8 payload does not carry).  Same as IVIT_LAZY=always in the environment."""
+    _ACTIVE[0] = max(_ACTIVE[0], 1) if on else 0
 
 
 class scope:

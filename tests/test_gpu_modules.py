@@ -1095,3 +1095,48 @@ def test_int8_module_path_fuses_the_residual_gemm_at_large_batch():
     assert lazy.STATS == {"fused": 8 * len(model.blocks) + 3, "materialised": 1}, lazy.STATS
     assert torch.equal(ye, ym)
     assert np.array_equal(bits(ym)[12 - n:], z["logits_f32_bits"])
+
+
+def test_int8_carrying_path_for_a_caller_that_drives_the_modules_itself():
+    """the literal drop-in scenario: somebody else's forward (here: the reference's forward_features / forward bodies, vit_quant.py:285-312,
+    written out against the sub-modules) calls the modules one by one.  With lazy.enable_everywhere() the frozen QuantActs carry int8
+    there too, the result is a tensor that materialises the reference's float logits when looked at, and nothing is read back"""
+    from ivit_amd.quantization_utils import lazy
+    model, meta, z = load_model("deit_small")
+    imgs = torch.from_numpy(synth.make_images(meta["n_images"], meta["image_seed"])).to(DEV)
+
+    def reference_forward(m, x):                       # vit_quant.py:285-312
+        B = x.shape[0]
+        x, s = m.qact_input(x)
+        x, s = m.patch_embed(x, s)
+        cls = m.cls_token.expand(B, -1, -1)
+        x = torch.cat((cls, x), dim=1)
+        xp, sp = m.qact_pos(m.pos_embed)
+        x, s = m.qact1(x, s, xp, sp)
+        x = m.pos_drop(x)
+        for blk in m.blocks:
+            x, s = blk(x, s)
+        x, s = m.norm(x, s)
+        x = x[:, 0]
+        x, s = m.qact2(x, s)
+        x = m.pre_logits(x)
+        x, s = m.head(x, s)
+        return x
+
+    lazy.enable_everywhere(True)
+    try:
+        with torch.no_grad():
+            reference_forward(model, imgs)             # warm-up
+            lazy.STATS.update(fused=0, materialised=0)
+            torch.cuda.set_sync_debug_mode("error")
+            try:
+                y = reference_forward(model, imgs)
+            finally:
+                torch.cuda.set_sync_debug_mode("default")
+        assert isinstance(y, lazy.QT) and lazy.STATS["materialised"] == 0 and lazy.STATS["fused"] == 10 * len(model.blocks) + 3
+        top1 = y.argmax(dim=1)                         # looking at it: the float logits
+        assert np.array_equal(top1.cpu().numpy(), z["top1"])
+        assert np.array_equal(bits(y + 0.0), z["logits_f32_bits"])
+    finally:
+        lazy.enable_everywhere(False)
+    assert not lazy.active()
