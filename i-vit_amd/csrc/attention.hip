@@ -77,8 +77,8 @@ IVIT_DEV int kswz(int r, int c) { return r * HD + (((c + 2 * ((r >> 2) & 1)) & 3
 // staged in LDS like mode 1), row sum in torch's float32 reduction order
 // PB: width of the softmax output (softmax_bw, vit_quant.py:184): 8, or 16 -- probabilities up to 2^15 as three 7-bit planes
 // (p = c + 128 b + 16384 a), one P.V MFMA set per plane (the a plane only when a wave has such a score)
-template <int MODE, int PB = 8>
-__global__ __launch_bounds__(NT, 3) void attention_kernel(AttnArgs a)
+template <int MODE, int PB = 8, int OCC = (PB == 8 ? 4 : 3)>
+__global__ __launch_bounds__(NT, OCC) void attention_kernel(AttnArgs a)
 {
     __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
     extern __shared__ __attribute__((aligned(16))) unsigned band_lds[];   // [4 waves][16 queries][band_w + BAND_PAD], compat only
@@ -489,7 +489,7 @@ __global__ __launch_bounds__(NT, 3) void attention_kernel(AttnArgs a)
 
 // Workgroups per (image, head).  Every workgroup stages K and V^T of its head in LDS (~3 us) and walks query tiles (13 at
 // T = 197: 4 per wave, ~3.5 us each); `slots` workgroups are resident at once.  With batch * heads a multiple of the slots one
-// workgroup per head is right (DeiT-B b256: 3072 = 4 rounds of 768); a launch that fills only part of a round is bound by that
+// workgroup per head is right (DeiT-B b256: 3072 = 3 rounds of 1024; 4 of 768 before round 3); a launch that fills only part of a round is bound by that
 // walk -- DeiT-S b64 (384 heads) took a whole round's 17 us -- so the tiles are dealt out among 2 or 4 workgroups per head when
 // the model below says the launch gets shorter (each stages K / V^T itself: L2 hits).
 int attention_parts(int batch_heads, int tokens, int slots)
@@ -581,7 +581,10 @@ IVIT_EXPORT int ivit_attention_fused_i8_wide(const int8_t* qkv, int8_t* out, int
         if (x <= 15 * a.x0) { a.ksat = i; break; }
     }
     const size_t band_lds_bytes = band_w ? (size_t)4 * 16 * (band_w + BAND_PAD) * sizeof(unsigned) : 0;
-    a.parts = attention_parts(batch * heads, tokens, band_w ? 512 : 768);
+    {   // resident workgroups: 4 per CU for 8-bit probabilities (128 VGPRs), 3 for the 16-bit planes; the band rows add dynamic LDS
+        const int by_regs = softmax_bits == 16 ? 3 : 4, by_lds = (int)(163840 / (SMEM_BYTES + 512 + band_lds_bytes));
+        a.parts = attention_parts(batch * heads, tokens, 256 * (by_regs < by_lds ? by_regs : by_lds));
+    }
     const dim3 grid(batch * heads * a.parts), blk(NT);
     hipStream_t st = ivit_stream(stream);
     if (softmax_bits == 16) {
@@ -591,6 +594,7 @@ IVIT_EXPORT int ivit_attention_fused_i8_wide(const int8_t* qkv, int8_t* out, int
     } else {
         if (band_w) hipLaunchKernelGGL(attention_kernel<1>, grid, blk, band_lds_bytes, st, a);
         else if (exp2d) hipLaunchKernelGGL(attention_kernel<2>, grid, blk, 0, st, a);
+        else if (IVIT_LAB && (g_ln_ablate & (1 << 25))) hipLaunchKernelGGL((attention_kernel<0, 8, 3>), grid, blk, 0, st, a);   // lab A/B: three workgroups per CU as before round 3
         else hipLaunchKernelGGL(attention_kernel<0>, grid, blk, 0, st, a);
     }
     IVIT_CHECK_LAUNCH("ivit_attention_fused_i8");
@@ -632,7 +636,10 @@ IVIT_EXPORT int ivit_attention_fused_i8_ibert_wide(const int8_t* qkv, int8_t* ou
     a.band = reinterpret_cast<const unsigned*>(band);
     a.band_w = band_w;
     const size_t band_lds_bytes = band_w ? (size_t)4 * 16 * (band_w + BAND_PAD) * sizeof(unsigned) : 0;
-    a.parts = attention_parts(batch * heads, tokens, band_w ? 512 : 768);
+    {
+        const int by_regs = softmax_bits == 16 ? 3 : 4, by_lds = (int)(163840 / (SMEM_BYTES + 512 + band_lds_bytes));
+        a.parts = attention_parts(batch * heads, tokens, 256 * (by_regs < by_lds ? by_regs : by_lds));
+    }
     if (softmax_bits == 16) {
         if (band_w) hipLaunchKernelGGL((attention_kernel<4, 16>), dim3(batch * heads * a.parts), dim3(NT), band_lds_bytes, ivit_stream(stream), a);
         else hipLaunchKernelGGL((attention_kernel<3, 16>), dim3(batch * heads * a.parts), dim3(NT), 0, ivit_stream(stream), a);
