@@ -77,7 +77,9 @@ IVIT_DEV int kswz(int r, int c) { return r * HD + (((c + 2 * ((r >> 2) & 1)) & 3
 // staged in LDS like mode 1), row sum in torch's float32 reduction order
 // PB: width of the softmax output (softmax_bw, vit_quant.py:184): 8, or 16 -- probabilities up to 2^15 as three 7-bit planes
 // (p = c + 128 b + 16384 a), one P.V MFMA set per plane (the a plane only when a wave has such a score)
-template <int MODE, int PB = 8, int OCC = (PB == 8 ? 4 : 3)>
+// GENT ("general T", Shiftmax modes only): any token count up to 207 -- every key tile takes the masked path of the last one
+// (keys >= T carry the sentinel), all 13 key tiles are still walked: for geometries other than 14 x 14 patches, not tuned.
+template <int MODE, int PB = 8, int OCC = (PB == 8 ? 4 : 3), bool GENT = false>
 __global__ __launch_bounds__(NT, OCC) void attention_kernel(AttnArgs a)
 {
     __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
@@ -162,7 +164,7 @@ __global__ __launch_bounds__(NT, OCC) void attention_kernel(AttnArgs a)
             for (int r = 0; r < 4; ++r) {
                 // |S| <= 64*128*128 = 2^20, m < 2^32: the product is exact in float64
                 int nk = (IVIT_LAB && (a.abl & 1)) ? (acc[r] & 127) : clamp_i32(requant_exact(acc[r], -a.Ms), -127, 128);
-                if (kt == NKT - 1) nk = (16 * kt + 4 * g + r < T) ? nk : 1000;
+                if (GENT || kt == NKT - 1) nk = (16 * kt + 4 * g + r < T) ? nk : 1000;
                 s[kt][r] = nk;
                 nmin = min(nmin, nk);
             }
@@ -194,7 +196,7 @@ __global__ __launch_bounds__(NT, OCC) void attention_kernel(AttnArgs a)
                 for (int r = 0; r < 4; ++r) {
                     const int nk = s[kt][r];
                     unsigned e = slice[min(nk + rmax, W - 1)];     // the 1000 sentinel of the padding keys clamps, too
-                    if (kt == NKT - 1) e = (nk == 1000) ? 0u : e;
+                    if (GENT || kt == NKT - 1) e = (nk == 1000) ? 0u : e;
                     s[kt][r] = (int)e;
                     esum += e;
                 }
@@ -301,7 +303,7 @@ __global__ __launch_bounds__(NT, OCC) void attention_kernel(AttnArgs a)
                 for (int r = 0; r < 4; ++r) {
                     const int nk = s[kt][r];
                     unsigned e = row2d[-min(nk, 128)];
-                    if (kt == NKT - 1) e = (nk == 1000) ? 0u : e;
+                    if (GENT || kt == NKT - 1) e = (nk == 1000) ? 0u : e;
                     s[kt][r] = (int)e;
                     esum += e;
                 }
@@ -311,7 +313,7 @@ __global__ __launch_bounds__(NT, OCC) void attention_kernel(AttnArgs a)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 unsigned e, ef;
-                if (kt == NKT - 1) {
+                if (GENT || kt == NKT - 1) {
                     const int idx = min(rmax + s[kt][r], 255);
                     e = lut[idx];
                     ef = lut[256 + idx];
@@ -544,8 +546,8 @@ IVIT_EXPORT int ivit_attention_fused_i8_wide(const int8_t* qkv, int8_t* out, int
     IVIT_REQUIRE(softmax_bits == 8 || softmax_bits == 16, "ivit_attention_fused_i8_wide: softmax_bits must be 8 or 16");
     IVIT_REQUIRE(qkv && out, "ivit_attention_fused_i8: NULL operand");
     IVIT_REQUIRE(batch > 0 && heads > 0, "ivit_attention_fused_i8: empty batch");
-    if (head_dim != HD || tokens <= 16 * (NKT - 1) || tokens > KP) {
-        ivit_set_error("ivit_attention_fused_i8: unsupported geometry head_dim=%d tokens=%d (need 64, 193..208)",
+    if (head_dim != HD || tokens < 1 || tokens > KP) {
+        ivit_set_error("ivit_attention_fused_i8: unsupported geometry head_dim=%d tokens=%d (need 64, 1..208)",
                        head_dim, tokens);
         return IVIT_ERR_UNSUPPORTED;
     }
@@ -587,6 +589,18 @@ IVIT_EXPORT int ivit_attention_fused_i8_wide(const int8_t* qkv, int8_t* out, int
     }
     const dim3 grid(batch * heads * a.parts), blk(NT);
     hipStream_t st = ivit_stream(stream);
+    if (tokens <= 16 * (NKT - 1)) {      // fewer than 193 tokens: the general-T form
+        if (softmax_bits == 16) {
+            if (band_w) hipLaunchKernelGGL((attention_kernel<1, 16, 3, true>), grid, blk, band_lds_bytes, st, a);
+            else if (exp2d) hipLaunchKernelGGL((attention_kernel<2, 16, 3, true>), grid, blk, 0, st, a);
+            else hipLaunchKernelGGL((attention_kernel<0, 16, 3, true>), grid, blk, 0, st, a);
+        } else {
+            if (band_w) hipLaunchKernelGGL((attention_kernel<1, 8, 4, true>), grid, blk, band_lds_bytes, st, a);
+            else if (exp2d) hipLaunchKernelGGL((attention_kernel<2, 8, 4, true>), grid, blk, 0, st, a);
+            else hipLaunchKernelGGL((attention_kernel<0, 8, 4, true>), grid, blk, 0, st, a);
+        }
+        IVIT_CHECK_LAUNCH("ivit_attention_fused_i8");
+    }
     if (softmax_bits == 16) {
         if (band_w) hipLaunchKernelGGL((attention_kernel<1, 16>), grid, blk, band_lds_bytes, st, a);
         else if (exp2d) hipLaunchKernelGGL((attention_kernel<2, 16>), grid, blk, 0, st, a);

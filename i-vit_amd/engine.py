@@ -26,7 +26,6 @@ from . import _lib
 from .graph import GraphReplay
 from .prepare import (IMAGENET_MEAN, IMAGENET_STD, LayerNormParams, dyadic, f32, input_lut_u8, markstein_division_ok, pad_head, phi_is_identity, phi_tables, quant_sym,
                       requant_host, shiftexp2d, shiftexp_band)
-from .synth import IMG_SIZE, NUM_PATCHES, NUM_TOKENS, PATCH
 
 
 def _np(v):
@@ -41,11 +40,18 @@ class IntViTEngine(GraphReplay):
 
     def __init__(self, float_state=None, ranges=None, embed_dim: int = 768, depth: int = 12, num_heads: int = 12,
                  device="cuda:0", max_batch: int = 256, source=None, family: str = "ivit", stream_bits: int = 8,
-                 softmax_bits: int = 8, pos_bits: int = 8):
+                 softmax_bits: int = 8, pos_bits: int = 8, img_size: int = 224, patch_size: int = 16):
         """float_state: name -> float32 array (the reference's state_dict names, SURVEY Appendix D);
         ranges: QuantAct name -> (x_min, x_max) of the frozen model.  Alternatively `source`: any object with the
         FloatSource interface of export.py (e.g. export.ExportSource: integer parameters + scale table, no floats)."""
         self.C, self.D, self.H = embed_dim, depth, num_heads
+        # geometry (vit_quant.py:158-166: img_size, patch_size): square images, non-overlapping patches.  The patch GEMM steps K in
+        # 64-byte slabs and the fused attention kernel holds a whole Shiftmax row of at most 207 keys in four lanes
+        self.IMG, self.P = int(img_size), int(patch_size)
+        if self.IMG % self.P or (3 * self.P * self.P) % 64 or (self.IMG // self.P) ** 2 + 1 > 207:
+            raise ValueError(f"geometry {self.IMG} / {self.P}: needs img_size % patch_size == 0, 3 * patch_size^2 % 64 == 0 and at most 207 tokens")
+        self.NP = (self.IMG // self.P) ** 2
+        self.T = self.NP + 1
         # operator family of LayerNorm / Softmax / GELU: "ivit" (I-ViT: IVITIntLayerNorm, Shiftmax, ShiftGELU) or "ibert" (the
         # fork's default, ibert_modules.py: literal float32 sequences on fl(q * s), any activation scale)
         if family not in ("ivit", "ibert"):
@@ -71,7 +77,7 @@ class IntViTEngine(GraphReplay):
             from .export import FloatSource
             source = FloatSource({k: _np(v) for k, v in float_state.items()}, ranges)
         C, H, hd = self.C, self.H, self.hd
-        T = NUM_TOKENS
+        T = self.T
         s = source.act_scale
 
         def dev(a, dtype=None):
@@ -270,19 +276,19 @@ class IntViTEngine(GraphReplay):
         return _lib.stream_ptr()
 
     def _alloc(self, B):
-        C, T = self.C, NUM_TOKENS
+        C, T = self.C, self.T
         M = B * T
         M16 = (M + 15) // 16 * 16   # block-layout operands pad their rows to a multiple of 16
         i8 = dict(dtype=torch.int8, device=self.dev)
         self.ws = dict(
-            a0=torch.empty(B * NUM_PATCHES, 3 * PATCH * PATCH, **i8),
-            pe=torch.empty(B * NUM_PATCHES, C, **i8),
+            a0=torch.empty(B * self.NP, 3 * self.P * self.P, **i8),
+            pe=torch.empty(B * self.NP, C, **i8),
             x=torch.empty(M, C, **i8), x2=torch.empty(M, C, **i8), h=torch.empty(M16, C, **i8),
             qkv=torch.empty(3 * M * C, **i8), ao=torch.empty(M16, C, **i8),
             f1=torch.empty(M16, 4 * C, **i8), g=torch.empty(M16, 4 * C, **i8), untile=torch.empty(M, 4 * C, **i8),
             cls=torch.empty(B, C, **i8),
             **({} if self.stream_bits == 8 else dict(
-                pe16=torch.empty(B * NUM_PATCHES, C, dtype=torch.int16, device=self.dev),
+                pe16=torch.empty(B * self.NP, C, dtype=torch.int16, device=self.dev),
                 x16=torch.empty(M, C, dtype=torch.int16, device=self.dev), y16=torch.empty(M, C, dtype=torch.int16, device=self.dev),
                 k16=torch.empty(M, C, dtype=torch.int16, device=self.dev),
                 cls16=torch.empty(B, C, dtype=torch.int16, device=self.dev))),
@@ -359,10 +365,10 @@ class IntViTEngine(GraphReplay):
         if images.dtype == torch.uint8:
             if self.input_lut is None:
                 self.set_input_normalisation()
-            _lib.call("ivit_quantize_patchify_u8_i8", _lib.ptr(images), _lib.ptr(ws["a0"]), 3 * PATCH * PATCH, B, 3, IMG_SIZE, PATCH,
+            _lib.call("ivit_quantize_patchify_u8_i8", _lib.ptr(images), _lib.ptr(ws["a0"]), 3 * self.P * self.P, B, 3, self.IMG, self.P,
                       _lib.ptr(self.input_lut), st)
         else:
-            _lib.call("ivit_quantize_patchify_f32_i8", _lib.ptr(images), _lib.ptr(ws["a0"]), B, 3, IMG_SIZE, PATCH, self.inv_s0, st)
+            _lib.call("ivit_quantize_patchify_f32_i8", _lib.ptr(images), _lib.ptr(ws["a0"]), B, 3, self.IMG, self.P, self.inv_s0, st)
 
     # ------------------------------------------------------------------ forward
     def forward(self, images: torch.Tensor, taps: dict | None = None):
@@ -371,12 +377,12 @@ class IntViTEngine(GraphReplay):
         next call.  `taps` (debug/tests) receives clones of intermediate int8 tensors."""
         assert images.is_cuda and images.dtype in (torch.float32, torch.uint8) and images.is_contiguous()
         B = images.shape[0]
-        assert images.shape[1:] == (3, IMG_SIZE, IMG_SIZE) and 0 < B <= self.max_batch
+        assert images.shape[1:] == (3, self.IMG, self.IMG) and 0 < B <= self.max_batch
         if self.stream_bits == 16:
             if taps is not None:
                 raise NotImplementedError("taps are not recorded on the 16-bit-stream path")
             return self._forward16(images)
-        C, H, hd, T = self.C, self.H, self.hd, NUM_TOKENS
+        C, H, hd, T = self.C, self.H, self.hd, self.T
         M = B * T
         ws = self.ws
         st = self._stream()
@@ -394,9 +400,9 @@ class IntViTEngine(GraphReplay):
                 taps[name] = t.reshape(-1)[: int(np.prod(shape))].view(shape).clone()
 
         self._patchify(images, B, st)
-        self._gemm(ws["a0"], 3 * PATCH * PATCH, self.patch, ws["pe"], C, B * NUM_PATCHES, st,
-                   blocks=bool(self.block_operands) and B * NUM_PATCHES >= 2048 and C >= 128)
-        tap("patch_embed.qact", ws["pe"], (B, NUM_PATCHES, C))
+        self._gemm(ws["a0"], 3 * self.P * self.P, self.patch, ws["pe"], C, B * self.NP, st,
+                   blocks=bool(self.block_operands) and B * self.NP >= 2048 and C >= 128)
+        tap("patch_embed.qact", ws["pe"], (B, self.NP, C))
         _lib.call("ivit_embed_assemble_i8", _lib.ptr(ws["pe"]), _lib.ptr(self.pos_add), _lib.ptr(self.cls_row),
                   self.embed_me[0], self.embed_me[1], _lib.ptr(ws["x"]), B, T, C, st)
         tap("qact1", ws["x"], (B, T, C))
@@ -474,14 +480,14 @@ class IntViTEngine(GraphReplay):
         projection / fc2 GEMMs requantise their accumulators to 16 bits per channel (attn.qact3 / mlp.qact2 at 16 bits) and the
         residual QuantActs are the 16-bit two-operand kernel; qkv / fc1 / attention / GELU are the int8 kernels unchanged."""
         B = images.shape[0]
-        ws, C, H, hd, T = self.ws, self.C, self.H, self.hd, NUM_TOKENS
+        ws, C, H, hd, T = self.ws, self.C, self.H, self.hd, self.T
         M = B * T
         st = self._stream()
         big = bool(self.block_operands) and M >= 2048 and C % 64 == 0
         self._patchify(images, B, st)
         pt = self.patch
-        _lib.call("ivit_gemm_i8_requant_i16", _lib.ptr(ws["a0"]), 3 * PATCH * PATCH, _lib.ptr(pt["W"]), pt["K"], _lib.ptr(pt["b"]),
-                  _lib.ptr(pt["m"]), _lib.ptr(pt["e"]), _lib.ptr(ws["pe16"]), C, B * NUM_PATCHES, C, pt["K"], st)
+        _lib.call("ivit_gemm_i8_requant_i16", _lib.ptr(ws["a0"]), 3 * self.P * self.P, _lib.ptr(pt["W"]), pt["K"], _lib.ptr(pt["b"]),
+                  _lib.ptr(pt["m"]), _lib.ptr(pt["e"]), _lib.ptr(ws["pe16"]), C, B * self.NP, C, pt["K"], st)
         _lib.call("ivit_embed_assemble_i16", _lib.ptr(ws["pe16"]), _lib.ptr(self.pos_add), _lib.ptr(self.cls_row),
                   self.embed_me[0], self.embed_me[1], _lib.ptr(ws["x16"]), B, T, C, st)
         x = ws["x16"]

@@ -158,8 +158,11 @@ class VisionTransformer(EngineDispatch, nn.Module):
             return f"operator family {self.op_types} (fused engine: all three operators 'ivit', or all three 'ibert')"
         if self.embed_dim // self.num_heads != 64 or self.embed_dim % 64:
             return "head_dim != 64"
-        if self.geometry != (224, 16, 3, 4.0, True, None):
-            return f"geometry {self.geometry} (fused engine: 224x224, patch 16, 3 channels, mlp_ratio 4, qkv bias)"
+        img, patch = self.geometry[0], self.geometry[1]
+        if (self.geometry[2:] != (3, 4.0, True, None) or not isinstance(img, int) or not isinstance(patch, int) or img % patch
+                or (3 * patch * patch) % 64 or (img // patch) ** 2 + 1 > 207):
+            return (f"geometry {self.geometry} (fused engine: square images, 3 channels, img_size % patch_size == 0, "
+                    "3 * patch_size^2 % 64 == 0, at most 207 tokens, mlp_ratio 4, qkv bias)")
         if self.num_classes <= 0:
             return "no classification head"
         # every QuantAct of the DeiT / ViT engine is 8 bit, except the 16-bit one inside IBERTIntSoftmax (ibert_modules.py:247) ...
@@ -187,6 +190,7 @@ class VisionTransformer(EngineDispatch, nn.Module):
         from .engine import IntViTEngine
         return IntViTEngine(dict(self.state_dict()), self.ranges(), self.embed_dim, self.depth, self.num_heads,
                             device=device, max_batch=max_batch, family=self.op_types[0],
+                            img_size=self.geometry[0], patch_size=self.geometry[1],
                             **dict(zip(("stream_bits", "softmax_bits", "pos_bits"),
                                        self._engine_widths if self.engine_unsupported_reason() is None else (8, 8, 8))))
 

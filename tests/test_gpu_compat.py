@@ -116,7 +116,7 @@ def test_shiftgelu_compat_table(ckat):
 
 
 @pytest.mark.parametrize("B,H,T,s_at", [(2, 3, 197, 0.3127), (1, 6, 197, 0.11873), (1, 2, 208, 0.9113), (1, 1, 193, 0.2113),
-                                        (1, 2, 197, 0.0571)])
+                                        (1, 2, 197, 0.0571), (1, 2, 101, 0.2113), (2, 1, 50, 0.11873)])
 @pytest.mark.parametrize("form", ["band_in_lds", "full_table_gather"])
 def test_attention_fused_compat(B, H, T, s_at, form):
     rng = np.random.default_rng(200 + B * H + T)

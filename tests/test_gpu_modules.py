@@ -1140,3 +1140,40 @@ def test_int8_carrying_path_for_a_caller_that_drives_the_modules_itself():
     finally:
         lazy.enable_everywhere(False)
     assert not lazy.active()
+
+
+@pytest.mark.parametrize("img,patch", [(160, 16), (224, 32), (96, 8)])
+def test_engine_other_geometries_equal_the_module_path(img, patch):
+    """VisionTransformer(img_size, patch_size) of the reference is parametric (vit_quant.py:158-197): the fused engine takes square
+    geometries with 3 * patch^2 % 64 == 0 and at most 207 tokens (101, 50 and 145 tokens here), calibrated on the GPU, and equals
+    the literal module-by-module path bit for bit (float round trip per module, IVIT_LAZY off) as well as the int8-carrying one"""
+    from ivit_amd.quantization_utils import lazy
+    torch.manual_seed(img + patch)
+    model = ivit.VisionTransformer(img_size=img, patch_size=patch, embed_dim=192, depth=3, num_heads=3, mlp_ratio=4, qkv_bias=True,
+                                   num_classes=40).to(DEV).eval()
+    with torch.no_grad():
+        for p in model.parameters():          # wider weights than the init's 0.02: activations that use their ranges
+            if p.dim() > 1:
+                p.mul_(3.0)
+        g = torch.Generator(device="cpu").manual_seed(5)
+        calib = torch.randn(6, 3, img, img, generator=g).to(DEV)
+        model(calib)
+        model(calib.flip(0) * 0.7)
+    ivit.freeze_model(model)
+    assert model.engine_unsupported_reason() is None, model.engine_unsupported_reason()
+    x = torch.randn(5, 3, img, img, generator=g).to(DEV)
+    with torch.no_grad():
+        ye = model(x)
+        assert model._engine is not None and model._engine[2].T == (img // patch) ** 2 + 1
+        model.use_engine = False
+        yl = model(x)
+        old = lazy.ENABLED
+        try:
+            lazy.ENABLED = False
+            ym = model(x)
+        finally:
+            lazy.ENABLED = old
+    assert torch.equal(ye, ym) and torch.equal(yl, ym)
+    assert len(torch.unique(ye.argmax(dim=1))) > 1
+    bad = ivit.VisionTransformer(img_size=224, patch_size=14, embed_dim=192, depth=1, num_heads=3)
+    assert "geometry" in bad.engine_unsupported_reason()
