@@ -1073,12 +1073,13 @@ def test_int8_carrying_path_falls_back_to_floats_where_a_caller_looks():
     assert np.array_equal(bits(y1), z["logits_f32_bits"][:2])
 
 
-def test_int8_module_path_fuses_the_residual_gemm_at_large_batch():
+@pytest.mark.parametrize("tag", ["deit_base", "deit_base_natural"])
+def test_int8_module_path_fuses_the_residual_gemm_at_large_batch(tag):
     """DeiT-B, 12 images (2364 token rows: the weights-in-registers GEMM applies): attn.proj -> attn.qact3 -> Block.qact2 and
     mlp.fc2 -> mlp.qact2 -> Block.qact4 are ONE kernel each (ivit_gemm_i8_requant_residual_ex), 8 launches per block; logits
     bitwise equal to the fused engine's and, on the golden images inside the batch, to the reference's"""
     from ivit_amd.quantization_utils import lazy
-    model, meta, z = load_model("deit_base")
+    model, meta, z = load_model(tag)
     n = meta["n_images"]
     imgs = np.concatenate([synth.make_images(12 - n, 515), synth.make_images(n, meta["image_seed"])])
     imgs = torch.from_numpy(imgs).to(DEV)
@@ -1094,7 +1095,9 @@ def test_int8_module_path_fuses_the_residual_gemm_at_large_batch():
             torch.cuda.set_sync_debug_mode("default")
     assert lazy.STATS == {"fused": 8 * len(model.blocks) + 3, "materialised": 1}, lazy.STATS
     assert torch.equal(ye, ym)
-    assert np.array_equal(bits(ym)[12 - n:], z["logits_f32_bits"])
+    if "regime" not in meta:
+        assert np.array_equal(bits(ym)[12 - n:], z["logits_f32_bits"])
+    assert np.array_equal(ym.argmax(dim=1).cpu().numpy()[12 - n:], z["top1"])
 
 
 def test_int8_carrying_path_for_a_caller_that_drives_the_modules_itself():
