@@ -1180,3 +1180,47 @@ def test_engine_other_geometries_equal_the_module_path(img, patch):
     assert len(torch.unique(ye.argmax(dim=1))) > 1
     bad = ivit.VisionTransformer(img_size=224, patch_size=14, embed_dim=192, depth=1, num_heads=3)
     assert "geometry" in bad.engine_unsupported_reason()
+
+
+def test_int8_module_path_with_the_reference_attention_forward(monkeypatch):
+    """the reference's Attention.forward slices q, k, v by INDEXING the permuted view (vit_quant.py:65-72: qkv[0], qkv[1], qkv[2]) where
+    the mirror unbinds it: the recorded views replay to the same strides, so the head-major GEMM epilogue and the fused attention
+    still apply (8 launches per block at >= 2048 token rows) and the logits stay bitwise"""
+    from ivit_amd.quantization_utils import lazy
+    import ivit_amd.vit_quant as vq
+
+    def attention_forward(self, x, act_scaling_factor):            # vit_quant.py:61-90, line by line
+        B, N, C = x.shape
+        x, act_scaling_factor = self.qkv(x, act_scaling_factor)
+        x, act_scaling_factor_1 = self.qact1(x, act_scaling_factor)
+        qkv = x.reshape(B, N, 3, self.num_heads, C // self.num_heads).permute(2, 0, 3, 1, 4)
+        q, k, v = (qkv[0], qkv[1], qkv[2])
+        attn, act_scaling_factor = self.matmul_1(q, act_scaling_factor_1, k.transpose(-2, -1), act_scaling_factor_1)
+        attn = attn * self.scale
+        act_scaling_factor = act_scaling_factor * self.scale
+        attn, act_scaling_factor = self.qact_attn1(attn, act_scaling_factor)
+        attn, act_scaling_factor = self.int_softmax(attn, act_scaling_factor)
+        attn = self.attn_drop(attn)
+        x, act_scaling_factor = self.matmul_2(attn, act_scaling_factor, v, act_scaling_factor_1)
+        x = x.transpose(1, 2).reshape(B, N, C)
+        x, act_scaling_factor = self.qact2(x, act_scaling_factor)
+        x, act_scaling_factor = self.proj(x, act_scaling_factor)
+        x, act_scaling_factor = self.qact3(x, act_scaling_factor)
+        x = self.proj_drop(x)
+        return x, act_scaling_factor
+
+    model, meta, z = load_model("deit_base")
+    n = meta["n_images"]
+    imgs = torch.from_numpy(np.concatenate([synth.make_images(12 - n, 77), synth.make_images(n, meta["image_seed"])])).to(DEV)
+    model.use_engine = False
+    monkeypatch.setattr(vq.Attention, "forward", attention_forward)
+    with torch.no_grad():
+        model(imgs)
+        lazy.STATS.update(fused=0, materialised=0)
+        torch.cuda.set_sync_debug_mode("error")
+        try:
+            y = model(imgs)
+        finally:
+            torch.cuda.set_sync_debug_mode("default")
+    assert lazy.STATS == {"fused": 8 * len(model.blocks) + 3, "materialised": 1}, lazy.STATS
+    assert np.array_equal(bits(y)[12 - n:], z["logits_f32_bits"])
