@@ -16,6 +16,7 @@ import torch.nn as nn
 
 from .. import _lib
 from ..prepare import EPS32, dyadic, f32
+from . import lazy
 from .quant_modules import QuantAct, _dev_table, _st, to_float, to_int32
 
 
@@ -81,6 +82,19 @@ class IBERTIntLayerNorm(nn.Module):
         self.overflow_handling = True
 
     def forward(self, x, scaling_factor=None, exponents=None):
+        if isinstance(x, lazy.QT):
+            s_in = lazy.host_of(scaling_factor)
+            if x.q8 is not None and s_in is not None and s_in.size == 1 and not self.overflow_handling:
+                def build():      # the scale this module returns: sqrt(C) / 2^30 * gamma (:145-153)
+                    C_ = x.shape[-1]
+                    sf = f32(np.sqrt(f32(C_)).astype(np.float32) / f32(2 ** 30))
+                    return lazy.QS.make((sf * self.weight.detach().cpu().numpy().astype(np.float32)).astype(np.float32), x.device)
+                s_ln = lazy._cache(self, ("s_ln", self.weight._version, str(x.device)), build)
+                return lazy.pending("ibln", self, x.shape, x.device, (x,), (scaling_factor,), s_ln)
+            x = x.to_float()
+        return self._slow(x, scaling_factor, exponents)
+
+    def _slow(self, x, scaling_factor=None, exponents=None):
         C = x.shape[-1]
         key = (self.weight._version, self.bias._version, x.device)
         if self._cache is None or self._cache[0] != key:
@@ -135,6 +149,15 @@ class IBERTIntGELU(nn.Module):
         return gelu_constants(s)
 
     def forward(self, x, scaling_factor=None):
+        if isinstance(x, lazy.QT):
+            s_in = lazy.host_of(scaling_factor)
+            if x.q8 is not None and s_in is not None and s_in.size == 1:
+                so = lazy._cache(self, ("s_out", s_in.tobytes(), str(x.device)), lambda: lazy.QS.make(f32(self.constants(s_in[0])[3]), x.device))
+                return lazy.pending("ibgelu", self, x.shape, x.device, (x,), (scaling_factor,), so)
+            x = x.to_float()
+        return self._slow(x, scaling_factor)
+
+    def _slow(self, x, scaling_factor=None):
         s = float(scaling_factor.reshape(-1)[0])
         b_int, c_int, shift_int, s_out = self.constants(s)
         xin = x.contiguous().float()
@@ -165,6 +188,15 @@ class IBERTIntSoftmax(nn.Module):
         pass
 
     def forward(self, x, scaling_factor):
+        if isinstance(x, lazy.QT):
+            if (isinstance(x.node, lazy.Scores) and not x.views and self.output_bit == 8 and not self.act.running_stat
+                    and scaling_factor is x.node.s_out_qs):
+                so = lazy._cache(self, ("s_out", str(x.device)), lambda: lazy.QS.make(f32(2 / 2 ** self.output_bit), x.device))   # :317
+                return lazy.QT.wrap(x.shape, x.device, node=lazy.Probs(x, self)), so
+            x = x.to_float()
+        return self._slow(x, scaling_factor)
+
+    def _slow(self, x, scaling_factor):
         s = f32(float(scaling_factor.reshape(-1)[0]))
         L = x.shape[-1]
         x0_int, b_int, c_int, exp_sf = softmax_constants(s, -1.0, 1.0)[:4]         # :277-294 (the range-dependent ones below)

@@ -384,8 +384,12 @@ def resolve(qact, x, pre_sf, identity, identity_sf, s_out, s_out_qs):
                 out = o.view(*sh) if node.kind == "linear" else o.view(sh[0], sh[2], sh[3], sh[1]).permute(0, 3, 1, 2)
         elif node.kind == "ln":
             out = _resolve_ln(node, s_out, device)
+        elif node.kind == "ibln":
+            out = _resolve_ibert_ln(node, s_out, device)
         elif node.kind == "gelu":
             out = _resolve_gelu(node, s_in, s_out, device)
+        elif node.kind == "ibgelu":
+            out = _resolve_ibert_gelu(node, s_in, s_out, device)
         elif node.kind == "matmul":
             out = _resolve_attention(node, s_in, s_out, device)
             if out is None:      # the first matmul of the attention chain: stays pending as the Shiftmax input
@@ -521,6 +525,53 @@ def _resolve_ln(node, s_out, device):
     return out
 
 
+def _resolve_ibert_ln(node, s_out, device):
+    """IBERTIntLayerNorm (ibert_modules.py:126-153) + the QuantAct behind it on int8: ivit_ibert_layernorm_i8 (csrc/ibert.hip), which
+    works on fl(q * s_in) literally -- any input scale"""
+    ln, x = node.mod, node.inputs[0]
+    x8 = q8_contig(x)
+    s_in = host_of(node.scales[0])
+    if x8 is None or s_in is None or s_in.size != 1 or ln.overflow_handling:
+        return None
+    C = x8.shape[-1]
+
+    def build():
+        lp = LayerNormParams(ln.weight.detach().cpu().numpy(), ln.bias.detach().cpu().numpy(), s_out)
+        return dict(bias=_dev(lp.bias_int, device), s=_dev(lp.s_ln, device), m=_dev(lp.m.view(np.int32), device), e=_dev(lp.e, device),
+                    shift_pow2=float(2.0 ** float(ln.shift.reshape(-1)[0])))
+    try:
+        c = _cache(ln, ("ibln", ln.weight._version, ln.bias._version, id(ln.shift), ln.shift._version, _key(s_out), str(device)), build)
+    except ValueError:
+        return None
+    out = torch.empty_like(x8)
+    _lib.call("ivit_ibert_layernorm_i8", _lib.ptr(x8), C, x8.numel() // C, C, float(s_in[0]), _lib.ptr(c["bias"]), _lib.ptr(c["s"]),
+              c["shift_pow2"], _lib.ptr(c["m"]), _lib.ptr(c["e"]), _lib.ptr(out), C, 0, _st())
+    return out
+
+
+def _resolve_ibert_gelu(node, s_g_out, s_out, device):
+    """IBERTIntGELU (ibert_modules.py:205-232) + mlp.qact1: a map of the input byte alone, as a table (ivit_ibert_gelu_build_lut;
+    replicated over the row-maximum axis of the ShiftGELU table format).  The GELU's output scale is negative: requant(z, s) ==
+    requant(-z, -s), handled inside the table build"""
+    x8 = q8_contig(node.inputs[0])
+    s_g = host_of(node.scales[0])
+    if x8 is None or s_g is None or s_g.size != 1:
+        return None
+
+    def build():
+        from .ibert_modules import gelu_constants
+        gb, gc, gsh, gso = gelu_constants(s_g[0])
+        mg, eg = dyadic(abs(f32(gso)), s_out)
+        lut = torch.empty(65536, dtype=torch.int8, device=device)
+        _lib.call("ivit_ibert_gelu_build_lut", float(s_g[0]), gb, gc, gsh, float(gso), int(mg[0]), int(eg[0]), _lib.ptr(lut), _st())
+        return lut
+    lut = _cache(node.mod, ("ibgelu", _key(s_g, s_out), str(device)), build)
+    L = x8.shape[-1]
+    out = torch.empty_like(x8)
+    _lib.call("ivit_shiftgelu_lut_i8_ex", _lib.ptr(x8), L, x8.numel() // L, L, _lib.ptr(lut), _lib.ptr(out), L, 0, _st())
+    return out
+
+
 def _resolve_gelu(node, s_g_out, s_out, device):
     x8 = q8_contig(node.inputs[0])
     s_g = host_of(node.scales[0])
@@ -575,6 +626,32 @@ def _resolve_attention(node, s_pv, s_out, device):
     s_S, s_at = sc.s_in, sc.s_out
     if s_S.size != 1 or s_pv.size != 1:
         return None
+    sm = P.node.mod
+    if type(sm).__name__ == "IBERTIntSoftmax":
+        # IBERTIntSoftmax (ibert_modules.py:237-319): exp_int after its internal 16-bit QuantAct as a (row max, q) table, row sum in
+        # torch's float32 order inside the kernel (attention.hip MODE 3 / 4); the kernel holds 193 .. 207 tokens
+        if not (192 < T < 208) or sm.output_bit != 8 or sm.act.running_stat:
+            return None
+
+        def build_ib():
+            from .ibert_modules import softmax_constants
+            lo, hi = float(sm.act.x_min.reshape(-1)[0]), float(sm.act.x_max.reshape(-1)[0])
+            x0i, bi, ci, exp_sf, act_sf, ma, ea = softmax_constants(s_at, lo, hi)
+            tab = torch.empty(65536, dtype=torch.float32, device=device)
+            _lib.call("ivit_ibert_softmax_build_table", float(s_at), x0i, bi, ci, float(exp_sf), float(act_sf), ma, ea, _lib.ptr(tab), _st())
+            ms, mo = dyadic(s_S, s_at), dyadic(s_pv, s_out)
+            d = dict(ms=(int(ms[0][0]), int(ms[1][0])), mo=(int(mo[0][0]), int(mo[1][0])), tab=tab, band=None, band_w=0)
+            band, bw = shiftexp_band(tab.cpu().numpy().view(np.uint32).reshape(256, 256))
+            if bw and bw <= 128:
+                d.update(band=_dev(band.view(np.float32), device), band_w=bw)
+            sm.act.act_scaling_factor = torch.full((1,), float(act_sf), dtype=torch.float32, device=device)
+            return d
+        a = _cache(sc.qact, ("ibattn", _key(s_S, np.asarray(s_at), s_pv, np.asarray(s_out)), id(sm.act.x_min), sm.act.x_min._version,
+                             id(sm.act.x_max), sm.act.x_max._version, str(device)), build_ib)
+        out = torch.empty(B * T, H * hd, dtype=torch.int8, device=device)
+        _lib.call("ivit_attention_fused_i8_ibert", _lib.ptr(hm), _lib.ptr(out), B, H, T, hd, a["ms"][0], a["ms"][1], a["mo"][0], a["mo"][1],
+                  _lib.ptr(a["tab"]), _lib.ptr(a["band"]), a["band_w"], 0, _st())
+        return out.view(B, T, H, hd).permute(0, 2, 1, 3)
 
     def build():
         ms, mo = dyadic(s_S, s_at), dyadic(s_pv, s_out)

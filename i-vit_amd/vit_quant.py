@@ -201,7 +201,7 @@ class VisionTransformer(EngineDispatch, nn.Module):
         if not self.is_frozen():
             self.invalidate_engine()     # running-stat QuantActs replace their range buffers: any snapshot is stale
         # a frozen I-ViT model run module by module carries int8 between its modules (quantization_utils/lazy.py)
-        with lazy.scope(x.is_cuda and not self.training and self.op_types == ("ivit",) * 3 and self.is_frozen()):
+        with lazy.scope(x.is_cuda and not self.training and self.op_types in (("ivit",) * 3, ("ibert",) * 3) and self.is_frozen()):
             x, s = self.forward_features(x)
             x, _ = self.head(x, s)
         return x.to_float() if isinstance(x, lazy.QT) else x

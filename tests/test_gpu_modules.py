@@ -973,7 +973,8 @@ def test_ibert_natural_scale_module_path_matches_reference():
 
 
 # ----------------------------------------------------------------------------------- int8-carrying module path (lazy.py)
-@pytest.mark.parametrize("tag", ["deit_tiny", "deit_tiny_natural", "deit_small_natural", "deit_base", "vit_base"])
+@pytest.mark.parametrize("tag", ["deit_tiny", "deit_tiny_natural", "deit_small_natural", "deit_base", "vit_base", "deit_tiny_ibert",
+                                 "deit_tiny_ibert_natural"])
 def test_frozen_module_path_carries_int8_and_never_syncs(tag):
     """The reference's call protocol (vit_quant.py:61-90, 142-155, 285-312: QuantLinear, QuantAct, IVITIntLayerNorm, ... one by
     one) on a frozen model, with every device -> host read-back an ERROR (torch.cuda.set_sync_debug_mode): int8 payloads move
