@@ -20,8 +20,8 @@ round trips, for a FROZEN model (every QuantAct fixed):
 Every (m, e) pair, table and integer weight is derived on the host from host-side scales and cached per module, so after the
 first (warm-up) forward a frozen forward reads nothing back from the device: it runs under
 `torch.cuda.set_sync_debug_mode("error")` and can be captured into a HIP graph (tests/test_gpu_modules.py).
-Covers the I-ViT operator family at 8-bit QuantAct widths (the reference's default configuration); other configurations
-take the ordinary module path through the materialisation rule above.
+Covers the I-ViT and the I-BERT operator families (ivit_modules.py, ibert_modules.py) at 8-bit QuantAct widths; other configurations
+(16-bit widths, mixed families, Swin) take the ordinary module path through the materialisation rule above.
 """
 from __future__ import annotations
 
