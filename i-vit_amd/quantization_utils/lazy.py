@@ -273,6 +273,8 @@ def q8_contig(x):
 def _cache(mod, key, build):
     c = mod.__dict__.setdefault("_lazy_cache", {})
     if key not in c:
+        if len(c) >= 64:       # a model whose ranges keep changing (re-calibrated and re-frozen again and again): start over
+            c.clear()
         c[key] = build()
     return c[key]
 
