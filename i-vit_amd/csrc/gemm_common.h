@@ -686,10 +686,18 @@ IVIT_DEV void epilogue_direct_16(v4i (&acc)[4][NJ], const GemmArgs& g, const cha
                               __builtin_amdgcn_perm((unsigned)b[j][3], (unsigned)b[j][2], 0x04000c0cu);
         }
         if constexpr (EPI == EPI_RESID) {
+            // ALL residual chunks are requested as soon as the first batch's accumulators are dead (64 registers free, 16 of them
+            // for its packed results): requested batch by batch, the last batch's loads were only one batch of phase B old when
+            // hook.consume() drained vmcnt -- 3.4 K cycles of a 15 K cycle epilogue spent waiting for them (stamped timeline)
+            const bool batchwise = IVIT_LAB && (g.flags2 & 1024);      // lab A/B: the former order
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int t = min(m0 + 16 * (jb + j) + l15, g.M - 1);
-                rv[bi][j] = load16_sel(g.res + ((unsigned)t * (unsigned)g.ldr + (unsigned)min(c, g.N - 16)), g.flags2);   // 32-bit offsets: launcher
+            for (int b2 = 0; b2 < NB; ++b2) {
+                if (batchwise ? b2 != bi : bi != 0) continue;         // uniform
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int t = min(m0 + 16 * (4 * b2 + j) + l15, g.M - 1);
+                    rv[b2][j] = load16_sel(g.res + ((unsigned)t * (unsigned)g.ldr + (unsigned)min(c, g.N - 16)), g.flags2);   // 32-bit offsets: launcher
+                }
             }
         }
         __builtin_amdgcn_sched_barrier(0);
