@@ -42,7 +42,7 @@ for name in names:
     s = stamps.cpu().numpy().reshape(512, 4, 32)
     nb = 256 if one else 512
     print(f"== {name} N={N} K={K} {'16x16x64' if S16 else '32x32x32'} {'residual epilogue' if RESID else 'int8 epilogue'}")
-    for it in (0, 1):
+    for it in (0, 1, 2):
         t = s[:nb, it]
         ok = t[:, 3] > 0
         t = t[ok]
@@ -54,7 +54,15 @@ for name in names:
         if it + 1 < 4:
             nxt = s[:nb, it + 1, 0][ok]
             good = nxt > 0
-            print(f"   tile start to next tile start {np.median((nxt - t[:, 0])[good]):.0f}")
+            if good.any():
+                print(f"   tile start to next tile start {np.median((nxt - t[:, 0])[good]):.0f}")
+    # whole launch: first tile start to the last tile end, per workgroup, by the number of tiles it ran
+    ntl = (s[:nb, :, 3] > 0).sum(axis=1)
+    for k in (2, 3):
+        sel = ntl == k
+        if sel.any():
+            span = s[:nb, :, 3].max(axis=1)[sel] - s[:nb, 0, 0][sel]
+            print(f"workgroups with {k} tiles: {sel.sum()}, first start to last end: median {np.median(span):.0f} cycles")
     ok = (s[:nb, 3, 0] > 0)
     dt = (s[:nb, 3, 0] - s[:nb, 0, 0]).astype(np.float64)[ok]
     dr = (s[:nb, 3, 16] - s[:nb, 0, 16]).astype(np.float64)[ok]
