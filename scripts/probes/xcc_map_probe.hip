@@ -42,6 +42,12 @@ int main(int argc, char** argv)
         printf("\n  b = 256..271: ");
         for (int b = 256; b < 272 && b < grid; ++b) printf("%u ", h[b] & 15u);
         printf("\n");
+        // which workgroups share a CU?  key = (XCC_ID, HW_ID.se_id, sh_id, cu_id)
+        auto cu_key = [&](int b) { const unsigned hw = h[b] >> 8; return ((h[b] & 15u) << 16) | (hw & 0xff00u); };
+        int pair_half = 0, pair_next = 0;
+        for (int b = 0; b + grid / 2 < grid; ++b) pair_half += cu_key(b) == cu_key(b + grid / 2);
+        for (int b = 0; b + 8 < grid; b += 16) pair_next += cu_key(b) == cu_key(b + 8);
+        printf("  workgroups b and b + grid/2 on the same CU: %d of %d;  b and b + 8 on the same CU: %d of %d\n", pair_half, grid / 2, pair_next, grid / 16);
     }
     return 0;
 }
