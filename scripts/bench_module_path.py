@@ -48,6 +48,18 @@ for fam in FAMS:
                 model(imgs)
                 torch.cuda.synchronize()
             print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=16, max_name_column_width=70), flush=True)
+        # the same forward captured once and replayed (nothing in it reads back): the host's launch work drops out
+        with torch.no_grad():
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                model(imgs)
+            g.replay()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                g.replay()
+            torch.cuda.synchronize()
+            print(f"{fam:5s} module path  batch {B}, HIP-graph replay: {(time.perf_counter() - t0) / 10 * 1e3:8.2f} ms / forward", flush=True)
     model.use_engine = True
     print(f"{fam:5s} engine       batch {B}: {timed(model, 10):8.2f} ms / forward  (reason if not taken: {model.engine_unsupported_reason()})", flush=True)
     if os.environ.get("IVIT_KERNEL_SPLIT"):   # per-kernel time of the engine forward (torch profiler)

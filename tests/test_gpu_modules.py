@@ -1225,3 +1225,27 @@ def test_int8_module_path_with_the_reference_attention_forward(monkeypatch):
             torch.cuda.set_sync_debug_mode("default")
     assert lazy.STATS == {"fused": 8 * len(model.blocks) + 3, "materialised": 1}, lazy.STATS
     assert np.array_equal(bits(y)[12 - n:], z["logits_f32_bits"])
+
+
+def test_int8_module_path_replays_from_a_hip_graph():
+    """no read-back means the module-by-module forward of a frozen model can be captured once and replayed (torch.cuda.CUDAGraph =
+    a HIP graph): same logits, new input through the static buffer"""
+    model, meta, z = load_model("deit_small")
+    model.use_engine = False
+    n = meta["n_images"]
+    static_in = torch.from_numpy(synth.make_images(n, 4321)).to(DEV)
+    with torch.no_grad():
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                model(static_in)              # warm-up: constants cached, allocator primed
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            static_out = model(static_in)
+        static_in.copy_(torch.from_numpy(synth.make_images(n, meta["image_seed"])).to(DEV))
+        graph.replay()
+        torch.cuda.synchronize()
+    assert np.array_equal(bits(static_out), z["logits_f32_bits"])
+    assert np.array_equal(static_out.argmax(dim=1).cpu().numpy(), z["top1"])
