@@ -1184,31 +1184,25 @@ def test_engine_other_geometries_equal_the_module_path(img, patch):
 
 
 def test_int8_module_path_with_the_reference_attention_forward(monkeypatch):
-    """the reference's Attention.forward slices q, k, v by INDEXING the permuted view (vit_quant.py:65-72: qkv[0], qkv[1], qkv[2]) where
-    the mirror unbinds it: the recorded views replay to the same strides, so the head-major GEMM epilogue and the fused attention
+    """the reference's Attention.forward takes q, k, v by INDEXING the permuted view (vit_quant.py:65-72) where the mirror unbinds it: the recorded views replay to the same strides, so the head-major GEMM epilogue and the fused attention
     still apply (8 launches per block at >= 2048 token rows) and the logits stay bitwise"""
     from ivit_amd.quantization_utils import lazy
     import ivit_amd.vit_quant as vq
 
-    def attention_forward(self, x, act_scaling_factor):            # vit_quant.py:61-90, line by line
-        B, N, C = x.shape
-        x, act_scaling_factor = self.qkv(x, act_scaling_factor)
-        x, act_scaling_factor_1 = self.qact1(x, act_scaling_factor)
-        qkv = x.reshape(B, N, 3, self.num_heads, C // self.num_heads).permute(2, 0, 3, 1, 4)
-        q, k, v = (qkv[0], qkv[1], qkv[2])
-        attn, act_scaling_factor = self.matmul_1(q, act_scaling_factor_1, k.transpose(-2, -1), act_scaling_factor_1)
-        attn = attn * self.scale
-        act_scaling_factor = act_scaling_factor * self.scale
-        attn, act_scaling_factor = self.qact_attn1(attn, act_scaling_factor)
-        attn, act_scaling_factor = self.int_softmax(attn, act_scaling_factor)
-        attn = self.attn_drop(attn)
-        x, act_scaling_factor = self.matmul_2(attn, act_scaling_factor, v, act_scaling_factor_1)
-        x = x.transpose(1, 2).reshape(B, N, C)
-        x, act_scaling_factor = self.qact2(x, act_scaling_factor)
-        x, act_scaling_factor = self.proj(x, act_scaling_factor)
-        x, act_scaling_factor = self.qact3(x, act_scaling_factor)
-        x = self.proj_drop(x)
-        return x, act_scaling_factor
+    def attention_forward(self, tokens, s_tokens):
+        """the same module calls as the mirror's Attention.forward, with q, k, v taken by integer indexing of the permuted view"""
+        batch, n_tok, width = tokens.shape
+        heads = self.num_heads
+        packed, s_packed = self.qact1(*self.qkv(tokens, s_tokens))
+        by_role = packed.reshape(batch, n_tok, 3, heads, width // heads).permute(2, 0, 3, 1, 4)
+        query, key, value = by_role[0], by_role[1], by_role[2]                 # indexing, not unbind
+        scores, s_scores = self.matmul_1(query, s_packed, key.transpose(-2, -1), s_packed)
+        scores, s_scores = self.qact_attn1(scores * self.scale, s_scores * self.scale)
+        probs, s_probs = self.int_softmax(scores, s_scores)
+        ctx, s_ctx = self.matmul_2(self.attn_drop(probs), s_probs, value, s_packed)
+        ctx, s_ctx = self.qact2(ctx.transpose(1, 2).reshape(batch, n_tok, width), s_ctx)
+        out, s_out = self.qact3(*self.proj(ctx, s_ctx))
+        return self.proj_drop(out), s_out
 
     model, meta, z = load_model("deit_base")
     n = meta["n_images"]
