@@ -1539,7 +1539,9 @@ IVIT_EXPORT int ivit_layernorm_i8_compat(const int8_t* x, int64_t ldx, int rows,
                  "ivit_layernorm_i8_compat: block-layout output needs C %% 64 == 0, ldo == C and a buffer below 2 GiB");
     LnArgs a{x, ldx, rows, C, bias_int, s_ln, m, e, out, ldo, out_blocks, remap, phi, g_ln_ablate, outer};
     hipStream_t st = ivit_stream(stream);
-    if (C >= 512 && C <= 1024 && g_ln_wave_per_row == 0) return launch_ln_v2<true>(a, st, "ivit_layernorm_i8_compat");
+    // C < 512 as well (Swin's patch norm, C = 96, 401 408 rows at batch 128: 255 us in the one-row-per-wave kernel below, whose waves
+    // are three-quarters idle at that width): the grouped kernel keeps 8 / 16 rows per wave in flight whatever the width
+    if (C <= 1024 && g_ln_wave_per_row == 0) return launch_ln_v2<true>(a, st, "ivit_layernorm_i8_compat");
     const int nj = (C / 4 + 63) / 64;
     const int resident = 256 * (nj <= 8 ? 2 : 1);                   // = the kernel's __launch_bounds__ occupancy
     int grid = grid_for_rows(rows, nj <= 3 ? 8 : nj <= 4 ? 4 : 1);
