@@ -537,8 +537,10 @@ __global__ __launch_bounds__(NT, NJ <= 3 ? 4 : 3) void layernorm_i8_pair_kernel(
 //   * channels outer, rows inner in the element chain: one set of constants serves 16 rows; results overwrite the row
 //     registers, a row with an uncertified element (~1 %) is re-read and redone literally.
 // Arithmetic identical to layernorm_i8_kernel (same certificate, same literal fallback, same COMPAT handling).
+// (COMPAT at groups of 8: three workgroups per CU -- at four the remap tables' extra registers spilled six dwords; natural-scale
+// DeiT-B b256 6.95 -> 6.90 ms)
 template <int NJ, bool COMPAT, int G>
-__global__ __launch_bounds__(NT, (G == 4 && NJ <= 3 ? 5 : G == 8 && NJ <= 3 ? 4 : NJ <= 1 ? 4 : NJ <= 3 ? 3 : 2)) void layernorm_i8_v2_kernel(LnArgs a)
+__global__ __launch_bounds__(NT, (G == 4 && NJ <= 3 ? 5 : G == 8 && NJ <= 3 ? (COMPAT ? 3 : 4) : NJ <= 1 ? 4 : NJ <= 3 ? 3 : 2)) void layernorm_i8_v2_kernel(LnArgs a)
 {
     static_assert(G == 4 || G == 8 || G == 16, "G");
     typedef unsigned v2u __attribute__((ext_vector_type(2)));
