@@ -112,6 +112,8 @@ LAB_SIGNATURES = {
     "ivit_debug_set_gemm_flags2": [ci],
     "ivit_debug_ln_wave_per_row": [ci],
     "ivit_debug_ln_ablate": [ci],
+    "ivit_debug_ln_stream_cfg": [ci],
+    "ivit_debug_ln_stamp_buffer": [vp],
     "ivit_debug_set_stamp_buffer": [vp],
 }
 LAB_PATH = os.path.join(_HERE, "libivit_hip_lab.so")
@@ -181,6 +183,8 @@ class lab_session:
         L.ivit_debug_set_gemm_flags2(0)
         L.ivit_debug_ln_wave_per_row(0)
         L.ivit_debug_ln_ablate(0)
+        L.ivit_debug_ln_stream_cfg(0)
+        L.ivit_debug_ln_stamp_buffer(None)
         _use_lab = self.prev
         return False
 

@@ -19,9 +19,12 @@
 #if IVIT_LAB
 int g_ln_wave_per_row = 0;
 int g_ln_ablate = 0;     // lab build only (ivit_debug_ln_ablate): 1 no element chain, 2 no statistics, 4 no stores, 8 no table build
+int g_ln_stream_cfg = 0; // lab build only (ivit_debug_ln_stream_cfg): ring depth / workgroups per CU of the streaming kernel
+unsigned long long* g_ln_stamps = nullptr;   // lab build only (ivit_debug_ln_stamp_buffer): 8 x s_memrealtime per wave of the streaming kernel
 #else
 constexpr int g_ln_wave_per_row = 0;
 constexpr int g_ln_ablate = 0;
+constexpr int g_ln_stream_cfg = 0;
 #endif
 
 namespace {
@@ -65,6 +68,9 @@ struct LnArgs {
     int abl;               // lab build: timing ablations (results wrong), always 0 in the product
     int outer;             // compat, > 0: the reference reduces over a transposed view of contiguous extent `outer` (row = .. * outer +
                            // column) -- torch's outer-reduction order
+#if IVIT_LAB
+    unsigned long long* stamps;   // lab build: wave timeline of the streaming kernel (nullptr = none)
+#endif
 };
 
 // Per-row statistics exactly as ivit_modules.py:36-51 computes them.
@@ -825,6 +831,8 @@ __global__ __launch_bounds__(NT, (G == 4 && NJ <= 3 ? 5 : G == 8 && NJ <= 3 ? (C
     }
 }
 
+#include "ln_stream.h"
+
 __global__ __launch_bounds__(NT) void layernorm_i32_f32_kernel(LnArgs a)
 {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: row addresses in SALU
@@ -1471,6 +1479,18 @@ IVIT_EXPORT int ivit_debug_ln_ablate(int bits)
     g_ln_ablate = bits;
     return IVIT_OK;
 }
+
+IVIT_EXPORT int ivit_debug_ln_stream_cfg(int cfg)
+{
+    g_ln_stream_cfg = cfg;
+    return IVIT_OK;
+}
+
+IVIT_EXPORT int ivit_debug_ln_stamp_buffer(void* buf)
+{
+    g_ln_stamps = reinterpret_cast<unsigned long long*>(buf);
+    return IVIT_OK;
+}
 #endif
 
 IVIT_EXPORT int ivit_layernorm_i8_ex(const int8_t* x, int64_t ldx, int rows, int C, const float* bias_int,
@@ -1489,10 +1509,18 @@ IVIT_EXPORT int ivit_layernorm_i8_ex(const int8_t* x, int64_t ldx, int rows, int
                                      ((int64_t)rows + 15) * C < 2147483648ll),
                  "ivit_layernorm_i8_ex: block-layout output needs C %% 64 == 0, ldo == C and a buffer below 2 GiB");
     LnArgs a{x, ldx, rows, C, bias_int, s_ln, m, e, out, ldo, out_blocks, nullptr, nullptr, g_ln_ablate, 0};
+#if IVIT_LAB
+    a.stamps = g_ln_stamps;
+#endif
     hipStream_t st = ivit_stream(stream);
     // v2 where a row fills the wave (measured at 50 432 rows: C = 768 28.1 us against 30.3; C = 384 19.0 against 17.5 for the
     // half-wave form; at C = 96 -- Swin's patch norm -- only 24 of 64 lanes would hold data)
-    if (C >= 512 && C <= 1024 && g_ln_wave_per_row == 0) return launch_ln_v2<false>(a, st, "ivit_layernorm_i8");
+    // the streaming kernel (ln_stream.h) for the ViT widths from ~12 MB of rows (below, its fixed costs -- four workgroups per
+    // CU, the constants table before the first row -- lose against the kernels below: 12 608 x 384 10.5 vs 8.7 us, r04e);
+    // lab form 3: never, lab form 4: wherever it applies
+    if (((g_ln_wave_per_row == 0 && ln_stream_pays(a)) || g_ln_wave_per_row == 4) && ln_stream_takes(a))
+        return launch_ln_stream<false>(a, st, "ivit_layernorm_i8", g_ln_stream_cfg);
+    if (C >= 512 && C <= 1024 && (g_ln_wave_per_row == 0 || g_ln_wave_per_row >= 3)) return launch_ln_v2<false>(a, st, "ivit_layernorm_i8");
     // half a wave per row (constants in LDS, 3 * C floats) where it is the faster form: measured 17.5 vs 20.7 us at
     // C = 384 and 14.0 vs 14.9 us at C = 192, but 36 vs 30 us at C = 768 (rows = 50 432)
     if ((C <= 384 || g_ln_wave_per_row == 2) && C <= 1536 && g_ln_wave_per_row != 1) {
@@ -1540,10 +1568,15 @@ IVIT_EXPORT int ivit_layernorm_i8_compat(const int8_t* x, int64_t ldx, int rows,
                                      ((int64_t)rows + 15) * C < 2147483648ll),
                  "ivit_layernorm_i8_compat: block-layout output needs C %% 64 == 0, ldo == C and a buffer below 2 GiB");
     LnArgs a{x, ldx, rows, C, bias_int, s_ln, m, e, out, ldo, out_blocks, remap, phi, g_ln_ablate, outer};
+#if IVIT_LAB
+    a.stamps = g_ln_stamps;
+#endif
     hipStream_t st = ivit_stream(stream);
     // C < 512 as well (Swin's patch norm, C = 96, 401 408 rows at batch 128: 255 us in the one-row-per-wave kernel below, whose waves
     // are three-quarters idle at that width): the grouped kernel keeps 8 / 16 rows per wave in flight whatever the width
-    if (C <= 1024 && g_ln_wave_per_row == 0) return launch_ln_v2<true>(a, st, "ivit_layernorm_i8_compat");
+    if (((g_ln_wave_per_row == 0 && ln_stream_pays(a)) || g_ln_wave_per_row == 4) && ln_stream_takes(a))
+        return launch_ln_stream<true>(a, st, "ivit_layernorm_i8_compat", g_ln_stream_cfg);
+    if (C <= 1024 && (g_ln_wave_per_row == 0 || g_ln_wave_per_row >= 3)) return launch_ln_v2<true>(a, st, "ivit_layernorm_i8_compat");
     const int nj = (C / 4 + 63) / 64;
     const int resident = 256 * (nj <= 8 ? 2 : 1);                   // = the kernel's __launch_bounds__ occupancy
     int grid = grid_for_rows(rows, nj <= 3 ? 8 : nj <= 4 ? 4 : 1);
@@ -1570,6 +1603,9 @@ IVIT_EXPORT int ivit_layernorm_i32_f32(const int32_t* x, int64_t ldx, int rows, 
     IVIT_REQUIRE(x && out && bias_int && s_ln, "ivit_layernorm_i32_f32: NULL operand");
     IVIT_REQUIRE(rows > 0 && C > 0 && C <= 4096 && ldx >= C && ldo >= C, "ivit_layernorm_i32_f32: bad shape");
     LnArgs a{x, ldx, rows, C, bias_int, s_ln, nullptr, nullptr, out, ldo, 0, nullptr, nullptr, 0, 0};
+#if IVIT_LAB
+    a.stamps = nullptr;
+#endif
     hipLaunchKernelGGL(layernorm_i32_f32_kernel, dim3(grid_for_rows(rows)), dim3(NT), 0, ivit_stream(stream), a);
     IVIT_CHECK_LAUNCH("ivit_layernorm_i32_f32");
 }

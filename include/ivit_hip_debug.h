@@ -25,9 +25,18 @@ int ivit_debug_set_gemm_flags2(int flags);
 /* Diagnostic timeline buffer (8 x uint64 per workgroup) for the stamped build (flags = 512); scripts/gemm_timeline.py */
 int ivit_debug_set_stamp_buffer(void* buf);
 
-/* ivit_layernorm_i8 kernel form: 0 = automatic (half a wave per row for C <= 384, a wave per row above), 1 = always a
- * wave per row, 2 = half a wave per row wherever it exists (C <= 1536): parity tests of both forms, A/B timing */
+/* ivit_layernorm_i8 kernel form: 0 = automatic (the streaming kernel of ln_stream.h for C = 192 / 384 / 512 / 768 / 1024,
+ * else half a wave per row for C <= 384, the grouped kernel up to 1024, a wave per row above), 1 = always a wave per row,
+ * 2 = half a wave per row wherever it exists (C <= 1536), 3 = the automatic choice without the streaming kernel (rounds 2-3),
+ * 4 = the streaming kernel wherever it applies, whatever the size: parity tests of every form, A/B timing */
 int ivit_debug_ln_wave_per_row(int on);
+
+/* streaming LayerNorm kernel, A/B timing (results stay correct): bits 0-3 ring depth (2, 3, 6; else the default 4; C = 768
+ * only), bits 4-7 workgroups per CU (1-4; 0 = the default 2); scripts/ln_ablate.py */
+int ivit_debug_ln_stream_cfg(int cfg);
+/* wave timeline of the streaming LayerNorm kernel: 8 x uint64 per wave (s_memrealtime, 100 MHz: entry, table ready, slots 0-2 of
+ * the first round computed, -, all stores done, groups of the wave); NULL = off; scripts/ln_timeline.py */
+int ivit_debug_ln_stamp_buffer(void* buf);
 
 /* timing ablations of the default int8 LayerNorm kernel (results WRONG when non-zero): 1 no element chain, 2 no row
  * statistics, 4 no stores, 8 no per-workgroup table build; correct results: bits 4-5 = 1 / 2 / 3 force groups of 8 rows (oversubscribed

@@ -1,0 +1,11 @@
+#!/bin/bash
+# round 4, batch i: whole GPU suite with the streaming LayerNorm as the default; LN A/B at every config shape; bench line
+set -eu
+cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/r4i; mkdir -p $O
+timeout -k 10 1100 python -m pytest tests -m gpu -x -q > $O/gpu_tests.log 2>&1 || { tail -60 $O/gpu_tests.log; exit 1; }
+tail -3 $O/gpu_tests.log
+timeout -k 10 600 python scripts/ln_ab.py > $O/ln_ab.txt 2>&1 || { tail -40 $O/ln_ab.txt; exit 1; }
+cat $O/ln_ab.txt
+timeout -k 10 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench.json 2> $O/bench.err || { tail -20 $O/bench.err; exit 1; }
+cat $O/bench.json

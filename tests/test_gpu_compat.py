@@ -46,6 +46,17 @@ def ckat(golden_dir):
     return np.load(os.path.join(golden_dir, "compat_kat.npz"))
 
 
+@pytest.fixture(params=[0, 4, 3], ids=["product", "lab_streaming", "lab_grouped"])
+def ln_form(request):
+    """the product library's own choice of LayerNorm kernel, and the streaming / grouped kernels forced through the lab build"""
+    if request.param == 0:
+        yield 0
+        return
+    with _lib.lab_session():
+        _lib.call("ivit_debug_ln_wave_per_row", request.param)
+        yield request.param
+
+
 def _ln_compat(q, s_in, gamma, beta, s_out, blocks=0):
     lp = LayerNormParams(gamma, beta, s_out)
     remap, phi = phi_tables(s_in)
@@ -57,7 +68,7 @@ def _ln_compat(q, s_in, gamma, beta, s_out, blocks=0):
     return out[:rows].cpu().numpy().astype(np.int32)
 
 
-def test_layernorm_compat_kat(ckat):
+def test_layernorm_compat_kat(ckat, ln_form):
     """the reference's IVITIntLayerNorm + QuantAct on q*s inputs; every other row is an exact .5 tie of the mean"""
     for ci in ckat["ln_cases"]:
         c = f"ln{ci}_"
@@ -68,7 +79,7 @@ def test_layernorm_compat_kat(ckat):
 
 @pytest.mark.parametrize("rows,Cn,s", [(4000, 768, 0.0371), (3001, 192, 0.11873), (999, 384, 0.0052341), (50, 1024, 0.3127),
                                         (2000, 1536, 0.0371), (300, 96, 0.0371)])
-def test_layernorm_compat_random_vs_oracle(rows, Cn, s):
+def test_layernorm_compat_random_vs_oracle(rows, Cn, s, ln_form):
     rng = np.random.default_rng(rows + Cn)
     s = np.float32(s)
     q = np.clip(np.rint(rng.normal(rng.normal(0, 10, size=(rows, 1)), rng.uniform(1, 50, size=(rows, 1)),

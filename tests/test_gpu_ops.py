@@ -589,7 +589,7 @@ def test_producers_write_block_layout():
     rm = torch.empty(rows, Cn, dtype=torch.int8, device=DEV)
     _lib.call("ivit_layernorm_i8", *args, _lib.ptr(rm), Cn, st())
     v = valid_bytes(rows, Cn)
-    for form in (0, 1, 2):   # product library; lab: a wave per row, half a wave per row
+    for form in (0, 1, 2, 3, 4):   # product library; lab: a wave per row, half a wave per row, grouped, streaming
         bl = torch.zeros((rows + 15) // 16 * 16 * Cn, dtype=torch.int8, device=DEV)
         if form == 0:
             _lib.call("ivit_layernorm_i8_ex", *args, _lib.ptr(bl), Cn, 1, st())
@@ -793,10 +793,11 @@ def test_layernorm_random_vs_oracle(rows, Cn, ln_form):
     assert np.array_equal(got, exp), f"{(got != exp).sum()} of {got.size} differ"
 
 
-@pytest.fixture(params=[0, 2, 1], ids=["product", "lab_half_wave_per_row", "lab_wave_per_row"])
+@pytest.fixture(params=[0, 4, 3, 2, 1], ids=["product", "lab_streaming", "lab_grouped", "lab_half_wave_per_row", "lab_wave_per_row"])
 def ln_form(request):
-    """the product library's own choice of int8 LayerNorm kernel, and both forms forced through the lab build: half a wave
-    per row (C <= 1536) and a wave per row"""
+    """the product library's own choice of int8 LayerNorm kernel, and every form forced through the lab build: the streaming
+    kernel of round 4 wherever it applies (the product takes it from ~12 MB of rows), the grouped kernel of rounds 2-3, half
+    a wave per row (C <= 1536) and a wave per row"""
     if request.param == 0:
         yield 0
         return
@@ -845,6 +846,41 @@ def test_layernorm_certificate_regimes(regime, Cn, ln_form):
               _lib.ptr(dev(lp.s_ln)), _lib.ptr(md), _lib.ptr(ed), _lib.ptr(out), Cn, st())
     got = out.cpu().numpy().astype(np.int32)
     assert np.array_equal(got, exp), f"{regime}: {(got != exp).sum()} of {got.size} differ"
+
+
+@pytest.mark.parametrize("Cn", [192, 768])
+def test_layernorm_newton_shortcut_rows(Cn, ln_form):
+    """ln_stream.h evaluates the reference's ten Newton steps (ivit_modules.py:45-49) as floor(sqrt(var)) where that is provably
+    the same, and literally for rows with var < 142 883 or var + 1 a perfect square (where the recurrence has not converged / ends
+    on either of two values): rows of all three kinds, the rare kind collected from a large random draw"""
+    rng = np.random.default_rng(Cn)
+    n = 300000 if Cn == 192 else 60000
+    sig = rng.uniform(8, 45, size=(n, 1))
+    k = np.clip(np.rint(rng.normal(rng.normal(0, 6, size=(n, 1)), sig, size=(n, Cn))), -128, 127).astype(np.int8)
+    ki = k.astype(np.int64)
+    s1 = ki.sum(1)
+    mean = np.rint((s1.astype(np.float32) / np.float32(Cn))).astype(np.int64)
+    var = (ki * ki).sum(1) - 2 * mean * s1 + Cn * mean * mean
+    r = np.floor(np.sqrt(var.astype(np.float64))).astype(np.int64)
+    special = np.nonzero((r + 1) ** 2 - 1 == var)[0]
+    small = np.nonzero(var < 142883)[0][:1500]
+    rest = np.nonzero((var >= 142883) & ((r + 1) ** 2 - 1 != var))[0][:1500]
+    assert len(special) >= 20 and len(small) >= 100 and len(rest) >= 100, (len(special), len(small), len(rest))
+    k = k[rng.permutation(np.concatenate([special, small, rest]))]
+    rows = len(k)
+    gamma = rng.uniform(0.5, 1.5, size=Cn).astype(np.float32)
+    beta = rng.normal(0, 0.1, size=Cn).astype(np.float32)
+    y, s_ln, _ = orc.layernorm(k.astype(np.int32), gamma, beta)
+    s_out = np.float32(2.0 ** np.ceil(np.log2(np.abs(y * s_ln).max() / 127 * 0.8)))
+    m, e = orc.dyadic(s_ln, s_out)
+    exp = orc.requant(orc.roundtrip(y, s_ln), m, e, 8)
+    lp = _ln_host(gamma, beta, s_out)
+    out = torch.empty(rows, Cn, dtype=torch.int8, device=DEV)
+    md, ed = me_dev(lp.m, lp.e)
+    _lib.call("ivit_layernorm_i8", _lib.ptr(dev(k)), Cn, rows, Cn, _lib.ptr(dev(lp.bias_int)),
+              _lib.ptr(dev(lp.s_ln)), _lib.ptr(md), _lib.ptr(ed), _lib.ptr(out), Cn, st())
+    got = out.cpu().numpy().astype(np.int32)
+    assert np.array_equal(got, exp), f"{(got != exp).sum()} of {got.size} differ"
 
 
 # ----------------------------------------------------------------------------------- GELU
