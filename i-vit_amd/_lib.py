@@ -38,8 +38,6 @@ SIGNATURES = {
     "ivit_untile_operand_i8": [vp, i64, ci, vp, i64, vp],
     "ivit_gemm_i8_requant_ex": [vp, i64, vp, i64, vp, vp, vp, vp, i64, ci, ci, ci, ci, vp],
     "ivit_gemm_i8_requant_residual_ex": [vp, i64, vp, i64, vp, vp, vp, vp, i64, u32, i32, u32, i32, vp, i64, ci, ci, ci, ci, vp],
-    "ivit_gemm_i8_requant_gelu_ex": [vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, i64, ci, ci, ci, ci, vp],
-    "ivit_gemm_gelu_workspace_bytes": [ci, vp],
     "ivit_gemm_i8_requant_qkv_ex": [vp, i64, vp, i64, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp],
     "ivit_gemm_i8_requant_residual_i16": [vp, i64, vp, i64, vp, vp, vp, vp, i64, u32, i32, u32, i32, vp, i64, ci, ci, ci, vp],
     "ivit_gemm_i8_requant_lut_ex": [vp, i64, vp, i64, vp, vp, vp, vp, vp, i64, ci, ci, ci, ci, vp],
@@ -114,6 +112,8 @@ LAB_SIGNATURES = {
     "ivit_debug_ln_ablate": [ci],
     "ivit_debug_ln_stream_cfg": [ci],
     "ivit_debug_ln_stamp_buffer": [vp],
+    "ivit_gemm_i8_requant_gelu_ex": [vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, i64, ci, ci, ci, ci, vp],
+    "ivit_gemm_gelu_workspace_bytes": [ci, vp],
     "ivit_debug_set_stamp_buffer": [vp],
 }
 LAB_PATH = os.path.join(_HERE, "libivit_hip_lab.so")

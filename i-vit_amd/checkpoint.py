@@ -23,7 +23,9 @@ TAGS = {"deit_tiny": "deit_tiny_patch16_224", "deit_small": "deit_small_patch16_
         "deit_base": "deit_base_patch16_224", "vit_base": "vit_base_patch16_224",
         "swin_tiny": "swin_tiny_patch4_window7_224", "deit_tiny_ibert": "deit_tiny_patch16_224",
         "deit_tiny_natural": "deit_tiny_patch16_224", "deit_tiny_w16": "deit_tiny_patch16_224", "deit_tiny_w16all": "deit_tiny_patch16_224", "deit_tiny_ibert_w16all": "deit_tiny_patch16_224", "swin_tiny_natural": "swin_tiny_patch4_window7_224", "deit_small_natural": "deit_small_patch16_224",
-        "deit_base_natural": "deit_base_patch16_224", "deit_tiny_ibert_natural": "deit_tiny_patch16_224"}
+        "deit_base_natural": "deit_base_patch16_224", "deit_tiny_ibert_natural": "deit_tiny_patch16_224",
+        "vit_large": "vit_large_patch16_224", "vit_large_natural": "vit_large_patch16_224",
+        "swin_small": "swin_small_patch4_window7_224", "swin_small_natural": "swin_small_patch4_window7_224"}
 
 
 def load_fixture(tag: str):

@@ -1041,7 +1041,7 @@ int launch_gemm(GemmArgs& g, const char* name, ivit_stream_t stream)
                         }
                     }
 #endif
-                    if constexpr (EPI == EPI_RQ) {
+                    if constexpr (EPI == EPI_RQ && IVIT_LAB != 0) {
                         if (g.gelu_ws) {     // ABL bit 15: ShiftGELU + mlp.qact1 applied per completed token panel (gelu_panel_phase)
                             hipLaunchKernelGGL((gemm_i8_wreg_kernel<EPI, 32768, true>), grid, dim3(BIG_NT), 0, ivit_stream(stream), g);
                             IVIT_CHECK_LAUNCH(name);
@@ -1188,6 +1188,7 @@ IVIT_EXPORT int ivit_gemm_i8_requant_lut_ex(const int8_t* A, int64_t lda, const 
     return launch_gemm<EPI_RQ>(g, "ivit_gemm_i8_requant_lut_ex", stream);
 }
 
+#if IVIT_LAB     // the fc1 + ShiftGELU experiment (include/ivit_hip_debug.h): lab library only
 IVIT_EXPORT int ivit_gemm_gelu_workspace_bytes(int M, int64_t* bytes)
 {
     IVIT_REQUIRE(M > 0 && bytes, "ivit_gemm_gelu_workspace_bytes: M > 0 and a result pointer");
@@ -1211,6 +1212,7 @@ IVIT_EXPORT int ivit_gemm_i8_requant_gelu_ex(const int8_t* A, int64_t lda, const
                  "ivit_gemm_i8_requant_gelu_ex: block-layout output needs N %% 64 == 0, ldo == N and a buffer below 2 GiB");
     return launch_gemm<EPI_RQ>(g, "ivit_gemm_i8_requant_gelu_ex", stream);
 }
+#endif
 
 IVIT_EXPORT int ivit_gemm_i8_requant(const int8_t* A, int64_t lda, const int8_t* W, int64_t ldw, const int32_t* bias,
                                      const uint32_t* m, const int32_t* e, int8_t* out, int64_t ldo, int M, int N,

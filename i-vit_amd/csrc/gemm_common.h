@@ -813,7 +813,7 @@ IVIT_DEV void gelu_panel_phase(const GemmArgs& g, char* lds, int m0, int half, i
     int* cnt = g.gelu_ws + panel;
     if (tid == 0) {
         const int inc = half ? 1 : 2;
-        const int old = __hip_atomic_fetch_add(cnt, inc, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        const int old = __hip_atomic_fetch_add(cnt, inc, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);   // acquire too: the completing workgroup reads the other tiles next
         flag[0] = (old + inc == 2 * g.tiles_n) ? 1 : 0;
     }
     __syncthreads();

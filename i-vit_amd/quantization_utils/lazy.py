@@ -27,6 +27,9 @@ from __future__ import annotations
 
 import os
 
+import threading
+import warnings
+
 import numpy as np
 import torch
 
@@ -35,13 +38,16 @@ from ..prepare import (LayerNormParams, LinearParams, dyadic, f32, phi_tables, q
                        sym_scale)
 
 ENABLED = os.environ.get("IVIT_LAZY", "1") != "0"
-_ACTIVE = [1 if os.environ.get("IVIT_LAZY") == "always" else 0]
+_ALWAYS = [os.environ.get("IVIT_LAZY") == "always"]      # enable_everywhere(): process-wide, independent of any open scope
+_TLS = threading.local()                                  # .depth: open `scope(True)` blocks of THIS thread; .mat: nested to_float calls
 STATS = {"fused": 0, "materialised": 0}     # fused launches at a QuantAct / float tensors materialised, since the last reset
+_WARNED = set()
 
 
 def active() -> bool:
-    """inside `with lazy.scope(True):` -- the model mirror opens it around the module-by-module forward of a frozen I-ViT model"""
-    return _ACTIVE[0] > 0
+    """inside `with lazy.scope(True):` (this thread) -- the model mirror opens it around the module-by-module forward of a frozen
+    I-ViT model -- or after enable_everywhere()"""
+    return ENABLED and (_ALWAYS[0] or getattr(_TLS, "depth", 0) > 0)
 
 
 def enable_everywhere(on: bool = True):
@@ -49,7 +55,7 @@ def enable_everywhere(on: bool = True):
     reference's own models/vit_quant.py imported on top of this package.  The mirror's VisionTransformer.forward
     opens the scope by itself; nothing else does by default (Swin's LayerNorms depend on the memory layout of their float inputs,
     DESIGN.md section 2, which an int8 payload does not carry).  Same as IVIT_LAZY=always in the environment."""
-    _ACTIVE[0] = max(_ACTIVE[0], 1) if on else 0
+    _ALWAYS[0] = bool(on)       # never touches the scope depth: switching it off inside an open scope leaves the scope intact
 
 
 class scope:
@@ -57,10 +63,10 @@ class scope:
         self.on = bool(on) and ENABLED
 
     def __enter__(self):
-        _ACTIVE[0] += int(self.on)
+        _TLS.depth = getattr(_TLS, "depth", 0) + int(self.on)
 
     def __exit__(self, *exc):
-        _ACTIVE[0] -= int(self.on)
+        _TLS.depth = getattr(_TLS, "depth", 0) - int(self.on)
         return False
 
 
@@ -146,14 +152,30 @@ class QT(torch.Tensor):
         return self._q8
 
     # -- materialisation: the float tensor the reference's module would have returned
-    def to_float(self):
+    def to_float(self, boundary=False):
+        """`boundary`: the model hands its result to the caller (the one materialisation a forward is meant to have).  Any other
+        outermost call means something inside the model looked at a float tensor -- correct, but that module then runs the float
+        round trips the int8-carrying path exists to avoid: one warning per kind of producer (and lazy.STATS counts them all)."""
         STATS["materialised"] += 1
-        if self.q8 is not None:
-            return self.q8.to(torch.float32) * self.scale.as_subclass(torch.Tensor).reshape(-1)[0]
-        t = self.node.to_float()
-        for fn in self.views:
-            t = fn(t)
-        return t
+        depth = getattr(_TLS, "mat", 0)
+        if depth == 0 and not boundary:
+            what = "int8 payload" if self._q8 is not None else type(self.node).__name__ + (
+                f"({self.node.kind})" if hasattr(self.node, "kind") else "")
+            if what not in _WARNED:
+                _WARNED.add(what)
+                warnings.warn(f"ivit_amd.lazy: an int8-carrying activation ({what}) was materialised as float32 inside the model; the "
+                              "modules behind it run their float form (about 30x slower per module) -- see lazy.STATS", RuntimeWarning,
+                              stacklevel=2)
+        _TLS.mat = depth + 1
+        try:
+            if self.q8 is not None:
+                return self.q8.to(torch.float32) * self.scale.as_subclass(torch.Tensor).reshape(-1)[0]
+            t = self.node.to_float()
+            for fn in self.views:
+                t = fn(t)
+            return t
+        finally:
+            _TLS.mat = depth
 
     def apply_views(self, t):
         for fn in self.views:
@@ -312,7 +334,10 @@ def _gemm_me(lin, s_in, s_out, device):
         if np.any(e < 31):
             return None
         return _dev(m.view(np.int32), device), _dev(e, device)
-    return _cache(lin, ("rq", _key(s_in, s_out), str(device)), build)
+    # keyed on the weight / bias versions as linear_consts is: an in-place weight edit under unchanged ranges rebuilds W8 and
+    # s_acc there, and the per-channel multipliers must follow (round-3 advisor finding: they did not)
+    return _cache(lin, ("rq", lin.weight._version, None if lin.bias is None else lin.bias._version, _key(s_in, s_out), str(device)),
+                  build)
 
 
 def gemm_requant(lin, a8, s_in, s_out, device):

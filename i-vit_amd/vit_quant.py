@@ -204,7 +204,7 @@ class VisionTransformer(EngineDispatch, nn.Module):
         with lazy.scope(x.is_cuda and not self.training and self.op_types in (("ivit",) * 3, ("ibert",) * 3) and self.is_frozen()):
             x, s = self.forward_features(x)
             x, _ = self.head(x, s)
-        return x.to_float() if isinstance(x, lazy.QT) else x
+        return x.to_float(boundary=True) if isinstance(x, lazy.QT) else x
 
 
 def _factory(embed_dim, depth, num_heads, name):

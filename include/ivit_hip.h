@@ -121,23 +121,6 @@ int ivit_gemm_i8_requant_lut_ex(const int8_t* A, int64_t lda, const int8_t* W, i
                                 const uint32_t* m, const int32_t* e, const int8_t* lut, int8_t* out, int64_t ldo,
                                 int M, int N, int K, int layouts, ivit_stream_t stream);
 
-/* EXPERIMENTAL -- measured SLOWER than the two launches it replaces ("ShiftGELU stays a pass of its own"); kept,
- * bit-exact and tested, as the record of that experiment; the engines do not call it.
- * mlp.fc1 + mlp.qact_gelu + ShiftGELU + mlp.qact1 in ONE launch (layers_quant.py:141-146; ivit_modules.py:105-126):
- *   k   = clamp8(RNE(acc * m[n] / 2^e[n]))                  as ivit_gemm_i8_requant_ex
- *   out = gelu_lut[(max_n k[t][:] + 128) * 256 + (k + 128)]   the table of ivit_shiftgelu_build_lut(_ex): ShiftGELU with the row
- *                                                             maximum over all N outputs of token t, requantised by mlp.qact1
- * = ivit_gemm_i8_requant_ex followed by ivit_shiftgelu_lut_i8_ex in place, bit for bit: every channel tile counts itself in at
- * its 128-token panel and the workgroup that completes a panel reads it back, takes the row maxima and maps it
- * (gemm_common.h: gelu_panel_phase).  Needs the weights-in-registers kernel: layouts contains IVIT_W_FRAGS16 (M >= 2048,
- * K % 192 == 0, N % 64 == 0, 128 <= N <= 4096), optionally IVIT_A_BLOCKS / IVIT_OUT_BLOCKS.
- * `workspace`: ivit_gemm_gelu_workspace_bytes(M) bytes = 4 * ceil(M / 128), owned by the caller, ZERO before the first launch;
- * every launch leaves it zero again (launches that share a workspace must not overlap). */
-int ivit_gemm_gelu_workspace_bytes(int M, int64_t* bytes);
-int ivit_gemm_i8_requant_gelu_ex(const int8_t* A, int64_t lda, const int8_t* W, int64_t ldw, const int32_t* bias,
-                                 const uint32_t* m, const int32_t* e, const int8_t* gelu_lut, void* workspace,
-                                 int8_t* out, int64_t ldo, int M, int N, int K, int layouts, ivit_stream_t stream);
-
 /* as above, then the two-operand QuantAct of the residual connection
  * (vit_quant.py:147,153; quant_utils.py:232-245):
  *   k = clamp8(RNE(acc * m[n] / 2^e[n]))

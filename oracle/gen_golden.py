@@ -234,6 +234,7 @@ MODEL_PLAN = {
     "deit_small": ("deit_small_patch16_224", 12, 102, 4, 1002, 4, False),
     "deit_base": ("deit_base_patch16_224", 13, 103, 4, 1003, 4, False),
     "vit_base": ("vit_base_patch16_224", 14, 104, 2, 1004, 2, False),
+    "vit_large": ("vit_large_patch16_224", 15, 105, 2, 1005, 2, False),     # round 4: the widest factory (vit_quant.py:391-406)
     # the fork's default operator family (vit_quant.py:188-190), same synthetic weights as deit_tiny
     "deit_tiny_ibert": ("deit_tiny_patch16_224", 11, 101, 4, 1001, 4, False),
 }
@@ -352,6 +353,17 @@ def _import_swin():
     return sq
 
 
+SWIN_PLAN = {
+    # tag: (factory, weight seed, calibration seed, calibration batch, image seed, n golden images)
+    "swin_tiny": ("swin_tiny_patch4_window7_224", 21, 201, 2, 2001, 3),
+    "swin_small": ("swin_small_patch4_window7_224", 22, 202, 2, 2002, 2),    # round 4 (swin_quant.py:588-606): 18 blocks in stage 2
+}
+SWIN_NATURAL_PLAN = {
+    "swin_tiny_natural": ("swin_tiny_patch4_window7_224", 21, (201, 211), 2, 2001, 2),
+    "swin_small_natural": ("swin_small_patch4_window7_224", 22, (202, 212), 2, 2002, 2),
+}
+
+
 def gen_swin(tag="swin_tiny"):
     if tag.endswith("_natural"):
         return gen_swin_natural(tag)
@@ -365,7 +377,7 @@ def gen_swin_natural(tag):
     into the meta record) are decided by ATen's outer-reduction order, which is deterministic at this batch -- the golden forward
     is repeated with 1 and with 4 threads and must give the same digests."""
     sq = _import_swin()
-    factory, wseed, cseeds, cb, iseed, nimg = "swin_tiny_patch4_window7_224", 21, (201, 211), 2, 2001, 2
+    factory, wseed, cseeds, cb, iseed, nimg = SWIN_NATURAL_PLAN[tag]
     model = getattr(sq, factory)(pretrained=False)
     for mod in model.modules():                                                            # shim 4
         if isinstance(mod, rq.QuantLinear) and mod.bias is None:
@@ -436,7 +448,7 @@ def gen_swin_pow2(tag="swin_tiny"):
     harness-side shims of SURVEY Appendix E (tkinter stub, Int* aliases, bias-free QuantLinear weight_function) --
     reference files untouched."""
     sq = _import_swin()
-    factory, wseed, cseed, cb, iseed, nimg = "swin_tiny_patch4_window7_224", 21, 201, 2, 2001, 3
+    factory, wseed, cseed, cb, iseed, nimg = SWIN_PLAN[tag]
     cfg = synth.SWIN_CONFIGS[factory]
     t0 = time.time()
     model = getattr(sq, factory)(pretrained=False)
@@ -588,6 +600,7 @@ NATURAL_PLAN = {
     "deit_tiny_natural": ("deit_tiny_patch16_224", 11, (101, 111, 121), 4, 1001, 8),
     "deit_small_natural": ("deit_small_patch16_224", 12, (102, 112), 4, 1002, 4),
     "deit_base_natural": ("deit_base_patch16_224", 13, (103, 113), 2, 1003, 2),
+    "vit_large_natural": ("vit_large_patch16_224", 15, (105, 115), 2, 1005, 2),
 }
 
 

@@ -1034,6 +1034,36 @@ def test_frozen_module_path_carries_int8_and_never_syncs(tag):
         assert len(checked) >= 7 * depth + 3
 
 
+def test_int8_carrying_path_follows_an_in_place_weight_edit():
+    """A frozen model whose weights are edited IN PLACE while every QuantAct range stays byte-identical: the integer weights, the
+    accumulator scales AND the per-channel (m, e) multipliers of the fused GEMMs must all be rebuilt (round-3 advisor finding: the
+    multipliers were cached without the weight version).  The int8-carrying path against the float module path (IVIT_LAZY=0)."""
+    import warnings
+    from ivit_amd.quantization_utils import lazy
+    model, meta, z = load_model("deit_tiny")
+    model.use_engine = False
+    imgs = torch.from_numpy(synth.make_images(2, meta["image_seed"])).to(DEV)
+    with torch.no_grad():
+        y_before = model(imgs)
+        g = torch.Generator(device="cpu").manual_seed(5)
+        for lin in (model.blocks[2].attn.proj, model.blocks[5].mlp.fc1, model.blocks[7].attn.qkv):
+            # per-channel rescaling changes fc_scaling_factor per channel, i.e. every (m, e); ranges are untouched (frozen)
+            scale = (0.5 + torch.rand(lin.weight.shape[0], 1, generator=g)).to(DEV)
+            lin.weight.mul_(scale)
+            lin.bias.mul_(scale.reshape(-1))
+        y_lazy = model(imgs)
+        old = lazy.ENABLED
+        try:
+            lazy.ENABLED = False
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                y_float = model(imgs)
+        finally:
+            lazy.ENABLED = old
+    assert not torch.equal(y_before, y_lazy), "the edit changed nothing: the test has no teeth"
+    assert np.array_equal(bits(y_lazy), bits(y_float)), "stale constants on the int8-carrying path after an in-place weight edit"
+
+
 def test_int8_carrying_path_falls_back_to_floats_where_a_caller_looks():
     """anything that is not the model's own call protocol sees the float tensor the reference's module returns: a forward hook
     doing arithmetic on a QuantAct output, an unfrozen QuantAct in the middle of the model, IVIT_LAZY=0"""
@@ -1048,8 +1078,9 @@ def test_int8_carrying_path_falls_back_to_floats_where_a_caller_looks():
         seen["q"] = torch.round(y / s).to(torch.int32)        # plain torch arithmetic on the output
         seen["type"] = type(y)
     h = model.blocks[3].qact2.register_forward_hook(hook)
-    with torch.no_grad():
-        y = model(imgs)
+    lazy._WARNED.clear()
+    with torch.no_grad(), pytest.warns(RuntimeWarning, match="materialised as float32 inside the model"):
+        y = model(imgs)          # one warning per kind of producer: the caller is told that this forward left the int8 path
     h.remove()
     assert seen["type"] is lazy.QT and int(seen["q"].abs().max()) <= 128
     assert np.array_equal(bits(y), z["logits_f32_bits"][:2])

@@ -457,9 +457,16 @@ def _gelu_ws(M):
     return torch.zeros((M + 127) // 128, dtype=torch.int32, device=DEV)
 
 
+@pytest.fixture
+def lab_library():
+    """the lab build of the library (include/ivit_hip_debug.h): entry points that are not part of the product"""
+    with _lib.lab_session():
+        yield
+
+
 @pytest.mark.parametrize("M,N,K", [(2600, 768, 192), (197 * 16, 3072, 768), (2049, 1024, 192), (4000, 1792, 576)])
-def test_gemm_requant_gelu_fused(M, N, K):
-    """ivit_gemm_i8_requant_gelu_ex: the (row max, k) -> int8 table of ShiftGELU + mlp.qact1 applied inside the GEMM that produces
+def test_gemm_requant_gelu_fused(M, N, K, lab_library):
+    """ivit_gemm_i8_requant_gelu_ex (lab library: the experiment of round 3, never part of an engine): the (row max, k) -> int8 table of ShiftGELU + mlp.qact1 applied inside the GEMM that produces
     k, by the workgroup that completes a 128-token panel == the oracle's GEMM + requant followed by the table with the maximum over
     the whole row; row-major and block-layout operands / output, partial token panels and channel tiles; the workspace is left zero
     and serves the next launch"""
@@ -498,7 +505,7 @@ def test_gemm_requant_gelu_fused(M, N, K):
                   _lib.ptr(dl), _lib.ptr(ws), _lib.ptr(out), N, M, N, K, 0, st())
 
 
-def test_gemm_requant_gelu_fused_headline_shape():
+def test_gemm_requant_gelu_fused_headline_shape(lab_library):
     """mlp.fc1 of DeiT-B at batch 256 (50 432 x 3072 x 768, block layouts, 394 panels of 12 channel tiles on 512 workgroups, half
     tiles in the last round) with the real ShiftGELU table: ten launches in a row on one workspace, each equal to
     ivit_gemm_i8_requant_ex + ivit_shiftgelu_lut_i8_ex in place"""

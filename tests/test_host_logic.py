@@ -318,3 +318,33 @@ def test_int8_carrying_tensor_mechanics():
         cat = torch.cat((torch.ones(2, 1, 24), x), dim=1)                             # vit_quant.py:293
     assert isinstance(cat, QT) and cat.shape == (2, 6, 24) and torch.equal(cat.to_float(), torch.cat((torch.ones(2, 1, 24), f), 1))
     assert not lazy.active()
+
+
+def test_lazy_scope_depth_is_per_thread_and_survives_enable_everywhere():
+    """quantization_utils/lazy.py: `enable_everywhere(False)` inside an open scope must not corrupt the scope depth (round-3
+    advisor finding: it reset the counter, the scope's exit then drove it to -1 and the int8-carrying path stayed off for the
+    rest of the process), and a scope opened on one thread is not seen by another."""
+    import threading
+    from ivit_amd.quantization_utils import lazy
+    if not lazy.ENABLED:
+        pytest.skip("IVIT_LAZY=0")
+    assert not lazy.active()
+    with lazy.scope(True):
+        assert lazy.active()
+        lazy.enable_everywhere(True)
+        lazy.enable_everywhere(False)
+        assert lazy.active()                      # the scope is still open
+        seen = []
+        t = threading.Thread(target=lambda: seen.append(lazy.active()))
+        t.start(); t.join()
+        assert seen == [False]                    # another thread: no scope of its own
+    assert not lazy.active()
+    with lazy.scope(True):                        # and the next scope works as the first did
+        assert lazy.active()
+    assert not lazy.active()
+    lazy.enable_everywhere(True)
+    try:
+        assert lazy.active()
+    finally:
+        lazy.enable_everywhere(False)
+    assert not lazy.active()
