@@ -486,7 +486,7 @@ constexpr int WR_TAB = WR_CH * 12;                          // float2 lohi[256];
 constexpr int WR_LUT = WR_RING + WR_CS + 2 * WR_TAB;        // 256-byte output map (GemmArgs::lut)
 constexpr int WR_SMEM = WR_LUT + 256;                       // 62.75 KiB: two workgroups per CU
 
-struct WrWork { int m0, n0, half; };   // m0 < 0: none
+struct WrWork { int m0, n0, half; };   // m0 < 0: none; half: 0 full tile (128 tok x 256 ch), 1 half tile (64 x 256), 2 narrow tile (128 x 128)
 
 IVIT_DEV WrWork wr_tile(const GemmArgs& g, int t)
 {
@@ -494,7 +494,7 @@ IVIT_DEV WrWork wr_tile(const GemmArgs& g, int t)
     const int q8 = nblk >> 3, r8 = nblk & 7, xcd = t & 7;
     const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (t >> 3);
     const int tm = lid / g.tiles_n, tn = lid - tm * g.tiles_n;
-    return WrWork{tm * WR_TOK, tn * WR_CH, 0};
+    return g.narrow ? WrWork{tm * WR_TOK, tn * (WR_CH / 2), 2} : WrWork{tm * WR_TOK, tn * WR_CH, 0};
 }
 
 // Work item i of workgroup b (grid G).  Tiles [0, split_from) are full tiles, tile t with workgroup t % G.  The remaining R
@@ -516,6 +516,13 @@ IVIT_DEV WrWork wr_work(const GemmArgs& g, int i, int b, int G)
 }
 
 // ABL (lab build only): 1 no epilogue, 2 no weight loads in the loop, 4 no DMA in the loop, 8 no MFMA, 16 time stamps
+//
+// Narrow tiles (GemmArgs::narrow, round 4; S16 only): 128 tokens x 128 channels per work item, wave w = channel group w & 1
+// x token half w >> 1, i.e. every wave does a half tile's arithmetic (64 ch x 64 tok, 16 accumulator tiles) on a full tile's
+// token stage (all four waves fill it: two DMA pieces each) and its own channel group's weights (the two waves of a group
+// load the same 4 KB per K step; the second hits L2).  For widths that 256-channel tiles fit badly (N = 384, 1152, 576 ...:
+// DeiT-S, Swin stages 1-2) and for launches with fewer 256-channel tiles than the chip has workgroup slots (DeiT-S at batch 64:
+// 150-600 tiles on 512 slots), where the per-tile serial time, not throughput, sets the kernel's duration.
 //
 // S16: the same tile on v_mfma_i32_16x16x64_i8 (IVIT_W_FRAGS16) instead of v_mfma_i32_32x32x32_i8.  Same cycles per K step (32
 // instructions of 16 cycles against 16 of 32), same registers (32 accumulator tiles of 4), same bytes -- but under the power
@@ -560,7 +567,7 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_wreg_kernel(GemmArgs g)
                 asrc[i] = g.A + (int64_t)min((w.m0 >> 4) + piece, ((g.M + 15) >> 4) - 1) * (g.K >> 6) * 1024 + pos * 16u;
             }
         }
-        const int cg = min((w.n0 >> 6) + wave, ((g.N + 63) >> 6) - 1);
+        const int cg = min((w.n0 >> 6) + (w.half == 2 ? (wave & 1) : wave), ((g.N + 63) >> 6) - 1);
         wsrc = g.W + (int64_t)cg * nk * 4096 + (unsigned)lane_o * 16u;
     };
     const int kstep_a = g.a_blocks ? 1024 : BK;
@@ -589,11 +596,11 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_wreg_kernel(GemmArgs g)
     auto prefetch = [&](const WrWork& w) {
         set_sources(w);
         issue_dma(0, 0);
-        if (!w.half) issue_dma(0, 1);
+        if (w.half != 1) issue_dma(0, 1);
 #pragma unroll
         for (int p = 0; p < 4; ++p) issue_w(wr0, 0, p);
         issue_dma(1, 0);
-        if (!w.half) issue_dma(1, 1);
+        if (w.half != 1) issue_dma(1, 1);
     };
 
     const unsigned smem_base = (unsigned)(__UINTPTR_TYPE__)(lptr_t)smem;
@@ -632,11 +639,17 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_wreg_kernel(GemmArgs g)
         reinterpret_cast<int*>(tab + WR_CH * 8)[tid_w] = r.bias;
     };
 
-    // One work item: a full tile (128 tokens: 4 token sub-tiles per wave) or a half tile (64 tokens: 2).
-    auto run = [&](auto half_tag, const WrWork& cur, const WrWork& nxt, char* tab, char* tab_next, bool first) {
-        constexpr bool HALF = decltype(half_tag)::value;
-        constexpr int TJ = HALF ? 2 : 4;
+    // One work item: a full tile (128 tokens: 4 token sub-tiles per wave), a half tile (64 tokens: 2), or a narrow tile (128
+    // tokens x 128 channels: 2 token sub-tiles per wave out of the wave's token half, DMA as for a full tile).
+    auto run = [&](auto mode_tag, const WrWork& cur, const WrWork& nxt, char* tab, char* tab_next, bool first) {
+        constexpr int MODE = decltype(mode_tag)::value;
+        constexpr bool HALF = MODE == 1, NARROW = MODE == 2;
+        static_assert(!NARROW || S16, "narrow tiles exist for the 16x16x64 form only");
+        constexpr int TJ = MODE ? 2 : 4;
         constexpr int NP = HALF ? 1 : 2;          // DMA pieces per wave and K step
+        const int wch = NARROW ? 64 * (wave & 1) : 64 * wave;          // this wave's channels inside the tile
+        const int wtok = NARROW ? 64 * (wave >> 1) : 0;                // ... and its first token
+        const unsigned abase_s16 = abase[0] + (NARROW ? (unsigned)(wave >> 1) * 4096u : 0u);
         v4i af0[TJ], af1[TJ];
         // 32x32 form: K half ks of the TJ token sub-tiles of 32;  S16: token sub-tiles TJ ks .. TJ ks + TJ - 1 of 16, all 64 K bytes
         auto load_frags = [&](auto stage_tag, auto ks_tag, v4i (&af)[TJ]) {
@@ -644,11 +657,11 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_wreg_kernel(GemmArgs g)
             constexpr unsigned stage_off = (unsigned)(ST * WR_STAGE);
             if constexpr (S16) {   // one base register (lane * 16), everything else in the offset field
                 constexpr int O = ST * WR_STAGE + ks * TJ * 1024;
-                lds_read16_async_off<O>(af[0], abase[0]);
-                lds_read16_async_off<O + 1024>(af[1], abase[0]);
+                lds_read16_async_off<O>(af[0], abase_s16);
+                lds_read16_async_off<O + 1024>(af[1], abase_s16);
                 if constexpr (TJ == 4) {
-                    lds_read16_async_off<O + 2048>(af[2], abase[0]);
-                    lds_read16_async_off<O + 3072>(af[3], abase[0]);
+                    lds_read16_async_off<O + 2048>(af[2], abase_s16);
+                    lds_read16_async_off<O + 3072>(af[3], abase_s16);
                 }
             } else {
                 const unsigned aa = abase[ks] + stage_off;
@@ -676,7 +689,9 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_wreg_kernel(GemmArgs g)
                     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
                                  : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]), "+v"(wn[0]), "+v"(wn[1]), "+v"(wn[2]), "+v"(wn[3])::"memory");
             } else {
-                if constexpr (INFLIGHT)
+                if constexpr (INFLIGHT && NARROW)
+                    asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" : "+v"(af[0]), "+v"(af[1]), "+v"(wn[0]), "+v"(wn[1]), "+v"(wn[2]), "+v"(wn[3])::"memory");
+                else if constexpr (INFLIGHT)
                     asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" : "+v"(af[0]), "+v"(af[1]), "+v"(wn[0]), "+v"(wn[1]), "+v"(wn[2]), "+v"(wn[3])::"memory");
                 else
                     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(af[0]), "+v"(af[1]), "+v"(wn[0]), "+v"(wn[1]), "+v"(wn[2]), "+v"(wn[3])::"memory");
@@ -716,9 +731,9 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_wreg_kernel(GemmArgs g)
                         if constexpr (!(ABL & 8)) mfma16(acc16[i][j], wc[i], af0[j]);
                         else asm volatile("" : "+v"(acc16[i][j]) : "v"(wc[i]), "v"(af0[j]));
                         if constexpr (ISSUE) {   // NP + 4 loads of K step kt + 2: one behind every other MFMA (full tile: 16 MFMAs,
-                            const int n = TJ * i + j;   // six loads), behind each of the first five (half tile: 8 MFMAs, five loads)
-                            const int u = HALF ? n : (n >> 1);
-                            if (HALF || (n & 1) == 0) {
+                            const int n = TJ * i + j;   // six loads), behind each of the first five / six (half / narrow tile: 8 MFMAs)
+                            const int u = MODE ? n : (n >> 1);
+                            if (MODE || (n & 1) == 0) {
                                 if (u < NP) { if constexpr (!(ABL & 4)) issue_dma(kt + 2, u); }
                                 else if (u < NP + 4) { if constexpr (!(ABL & 2)) issue_w(wf, kt + 2, u - NP); }
                             }
@@ -776,7 +791,7 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_wreg_kernel(GemmArgs g)
         // wait here.  (An unconditional counted wait would also drain the epilogue's stores: vmcnt counts them too.)
         if (first) {
             if constexpr (HALF) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // full and narrow tiles: two DMA pieces + four weight pieces newer
         }
         asm volatile("" : "+v"(wr0[0]), "+v"(wr0[1]), "+v"(wr0[2]), "+v"(wr0[3])::"memory");
         __builtin_amdgcn_s_barrier();     // everyone's stage 0; table visible
@@ -784,7 +799,7 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_wreg_kernel(GemmArgs g)
         if constexpr (S16) {   // lane (g4, l15): channels 64 wave + 16 i + 4 g4 + r of register r
             int lane_b = lane;     // opaque: the address is derived here, not carried through the tile loop (it was spilled)
             asm volatile("" : "+v"(lane_b));
-            const unsigned ba = lds_addr(tab) + (unsigned)(WR_CH * 8 + 4 * (64 * wave + 4 * (lane_b >> 4)));
+            const unsigned ba = lds_addr(tab) + (unsigned)(WR_CH * 8 + 4 * (wch + 4 * (lane_b >> 4)));
             v4i bq[4];
             lds_read16_async_off<0>(bq[0], ba);
             lds_read16_async_off<64>(bq[1], ba);
@@ -878,7 +893,7 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_wreg_kernel(GemmArgs g)
             if constexpr (S16) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");     // MFMA results -> VALU reads: see mfma16 (c)
             if constexpr (S16 && (EPI == EPI_RQ || EPI == EPI_RESID || EPI == EPI_QKV) && !(ABL & 8192)) {
                 // straight from the registers (lane transpose, no LDS staging); ABL bit 13: the staged form below (A/B, lab)
-                epilogue_direct_16<EPI, 2 * TJ, (ABL & (64 | 2048 | 4096 | 32768)), Hook>(acc16, g, tab, cur.m0, cur.n0, 64 * wave, (tid_o >> 4) & 3, tid_o & 15, hook,
+                epilogue_direct_16<EPI, 2 * TJ, (ABL & (64 | 2048 | 4096 | 32768)), Hook>(acc16, g, tab, cur.m0 + wtok, cur.n0, wch, (tid_o >> 4) & 3, tid_o & 15, hook,
                                                                                g.lut ? reinterpret_cast<const unsigned char*>(smem + WR_LUT) : nullptr,
                                                                                (ABL & 2048) ? tv : nullptr);
                 if constexpr ((ABL & 32768) != 0) {      // ShiftGELU of a token panel by the workgroup that completes it (staging region: free here)
@@ -922,8 +937,14 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_wreg_kernel(GemmArgs g)
                 stamp[16] = __builtin_amdgcn_s_memrealtime();   // constant 100 MHz: the shader clock follows from the pair
             }
         }
-        if (cur.half) run(T{}, cur, nxt, tab, tab_next, it == 0);
-        else run(F{}, cur, nxt, tab, tab_next, it == 0);
+        if constexpr (S16 && (EPI == EPI_RQ || EPI == EPI_RESID || EPI == EPI_QKV) && !(ABL & (8192 | 32768 | 16))) {
+            if (cur.half == 2) run(std::integral_constant<int, 2>{}, cur, nxt, tab, tab_next, it == 0);
+            else if (cur.half) run(std::integral_constant<int, 1>{}, cur, nxt, tab, tab_next, it == 0);
+            else run(std::integral_constant<int, 0>{}, cur, nxt, tab, tab_next, it == 0);
+        } else {
+            if (cur.half) run(std::integral_constant<int, 1>{}, cur, nxt, tab, tab_next, it == 0);
+            else run(std::integral_constant<int, 0>{}, cur, nxt, tab, tab_next, it == 0);
+        }
         if constexpr (ABL & 16)
             {
                 if constexpr (ABL & 2048) {
@@ -997,13 +1018,25 @@ int launch_gemm(GemmArgs& g, const char* name, ivit_stream_t stream)
         if constexpr (EPI != EPI_I32 && EPI != EPI_RQ16) {
             g.tiles_m = (g.M + WR_TOK - 1) / WR_TOK;
             g.tiles_n = (g.N + WR_CH - 1) / WR_CH;
+            // Narrow tiles (128 x 128, wr_tile): built in round 4 for the widths 256-channel tiles fit badly and for launches with few
+            // tiles, measured at every GEMM shape of the BASELINE configs (scripts/gemm_narrow_ab.py, profiles/r04f_*) and SLOWER
+            // nearly everywhere (x 1.08 - 1.44; DeiT-S attn.proj -5 %, Swin stage-1 qkv equal): a wave's 16 MFMAs per K step carry the
+            // same barrier, waits and six loads as 32.  What did pay is running the 256-channel tiles at N = 384 / 1152 / 576 at all
+            // (padding of 25 / 10 / 11 %) instead of the LDS-DMA kernel: DeiT-S b64 proj 17 -> 11 us.  Lab flags2 bit 13 selects them.
+            g.narrow = 0;
+            if constexpr (EPI == EPI_RQ || EPI == EPI_RESID || EPI == EPI_QKV) {
+                if (IVIT_LAB && g.w_frags == 2 && !g.lut && !g.gelu_ws && (g_debug_flags2 & 8192) && !(g_debug_flags2 & (256 | 512))) {
+                    g.narrow = 1;
+                    g.tiles_n = (g.N + WR_CH / 2 - 1) / (WR_CH / 2);
+                }
+            }
             const int ntiles = g.tiles_m * g.tiles_n;
             // A sparse last round (R tiles on 512 slots) runs as 2R half tiles of 64 tokens (wr_work) when every half tile still
             // finds a CU of its own (2R <= 256): fc1 at the headline shape, R = 120, 144 -> 136 us.  Beyond that two half tiles
             // share a CU while a lone full tile has one to itself and runs nearly twice as fast: measured slower (N = 768,
             // R = 158: proj 53.8 -> 60.5 us, fc2 124 -> 135 us with the residual epilogue).  Lab bit 27: off, bit 11: up to 2R <= 512.
             const int rounds = ntiles / 512, R = ntiles - rounds * 512;
-            const bool split = rounds > 0 && R > 0 && 2 * R <= ((g_debug_flags & 2048) ? 512 : 256) && !(g_debug_flags & 134217728);
+            const bool split = !g.narrow && rounds > 0 && R > 0 && 2 * R <= ((g_debug_flags & 2048) ? 512 : 256) && !(g_debug_flags & 134217728);
             g.split_from = split ? rounds * 512 : ntiles;
             const dim3 grid(ntiles < 512 ? ntiles : 512);
 #if IVIT_LAB

@@ -72,6 +72,7 @@ struct GemmArgs {
     int cu_turns;       // persistent kernel: 1 = co-resident workgroups alternate main loops through the per-CU token
     int stagger_units;  // persistent kernel: start delay of the second co-resident workgroup, in s_sleep(16) (~1K cycle) units
     int split_from;  // persistent kernel: tiles [split_from, tiles_m*tiles_n) are processed as two half tiles each
+    int narrow;      // weights-in-registers kernel (16x16x64 form): 1 = 128 token x 128 channel work items (gemm.hip wr_tile)
     int a_blocks, w_blocks;   // operand in the block layout (common.h: ivit_block_offset); persistent kernel only
     int out_blocks;           // EPI_RQ: the int8 output in the block layout (row length N): it is the next GEMM's A operand
     int w_frags;              // W is the MFMA-fragment copy (ivit_pack_weight_frags_i8): the weights-in-registers kernel

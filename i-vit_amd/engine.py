@@ -254,7 +254,8 @@ class IntViTEngine(GraphReplay):
             N, K = lin["N"], lin["K"]
             lin["Wf"] = None
             lin["Wf_bit"] = 8 if id(lin) in wide or not self.frags16 else 16
-            if K % 192 == 0 and N % 64 == 0 and N >= 128 and (N + 255) // 256 * 256 * 8 <= N * 9:
+            # (the 16x16x64 form has 128-channel work items for the widths 256-channel tiles fit badly, round 4: any N % 64 == 0)
+            if K % 192 == 0 and N % 64 == 0 and N >= 128 and (lin["Wf_bit"] == 16 or (N + 255) // 256 * 256 * 8 <= N * 9):
                 lin["Wf"] = torch.empty((N + 63) // 64 * 64 * K, dtype=torch.int8, device=self.dev)
                 _lib.call("ivit_pack_weight_frags_i8" if lin["Wf_bit"] == 8 else "ivit_pack_weight_frags16_i8", _lib.ptr(lin["W"]), K, N, K,
                           _lib.ptr(lin["Wf"]), self._stream())

@@ -306,7 +306,8 @@ def _key(*hosts):
 
 
 def _frag_ok(N, K):
-    return K % 192 == 0 and N % 64 == 0 and N >= 128 and (N + 255) // 256 * 256 * 8 <= N * 9
+    """the weights-in-registers GEMM on v_mfma_i32_16x16x64_i8 (256- or 128-channel work items, chosen by the launcher)"""
+    return K % 192 == 0 and N % 64 == 0 and N >= 128
 
 
 def linear_consts(lin, s_in, device):

@@ -101,10 +101,13 @@ class IntSwinEngine(GraphReplay):
                 _lib.call("ivit_tile_operand_i8", _lib.ptr(d["W"]), Kp, d["N"], Kp, _lib.ptr(d["Wb"]), _lib.stream_ptr())
             d["Wf"] = None
             N = d["N"]
-            if Kp % 192 == 0 and N % 64 == 0 and N >= 128 and (N + 255) // 256 * 256 * 8 <= N * 9:
-                # MFMA-fragment copy: the weights-in-registers GEMM (stage 1 fc1, stage 2 qkv / fc1, all of stage 3).  The
-                # 16x16x64 order (IVIT_W_FRAGS16) except for attn.proj, whose fused 16-bit epilogue exists for the 32x32x32 form only
-                d["Wf_bit"] = 8 if name.endswith("attn.proj") else 16
+            wf_bit = 8 if name.endswith("attn.proj") else 16
+            narrow_ok = name.endswith(("attn.qkv", "mlp.fc1"))      # int8 epilogues; mlp.fc2 (16-bit residual epilogue) has full tiles only
+            if Kp % 192 == 0 and N % 64 == 0 and N >= 128 and (narrow_ok or (N + 255) // 256 * 256 * 8 <= N * 9):
+                # MFMA-fragment copy: the weights-in-registers GEMM (qkv / fc1 of stages 1-3, all of stage 3).  The 16x16x64
+                # order (IVIT_W_FRAGS16; 128-channel work items where 256-channel tiles fit badly, round 4) except for attn.proj,
+                # whose fused 16-bit epilogue exists for the 32x32x32 form only
+                d["Wf_bit"] = wf_bit
                 d["Wf"] = torch.empty((N + 63) // 64 * 64 * Kp, dtype=torch.int8, device=self.dev)
                 _lib.call("ivit_pack_weight_frags_i8" if d["Wf_bit"] == 8 else "ivit_pack_weight_frags16_i8", _lib.ptr(d["W"]), Kp, N, Kp,
                           _lib.ptr(d["Wf"]), _lib.stream_ptr())

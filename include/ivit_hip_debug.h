@@ -20,7 +20,8 @@ int ivit_debug_force_small_gemm(int on);
  * ~1K-cycle units, bit 26 a 256-workgroup grid of the persistent kernel without the LDS blocker (two-stream probe). */
 int ivit_debug_set_gemm_flags(int flags);
 /* Second flag word: A/B of cache policies in the GEMM epilogue (results stay correct).  Bits 0-1: policy of the int8 output
- * stores (0 plain, 1 nt, 2 sc1, 3 sc0 sc1); bit 2: the residual operand is read with nt loads. */
+ * stores (0 plain, 1 nt, 2 sc1, 3 sc0 sc1); bit 2: the residual operand is read with nt loads; bit 13: narrow (128 x 128) work items of
+ * the weights-in-registers kernel (16x16x64 form; measured slower than its 128 x 256 tiles, scripts/gemm_narrow_ab.py). */
 int ivit_debug_set_gemm_flags2(int flags);
 /* Diagnostic timeline buffer (8 x uint64 per workgroup) for the stamped build (flags = 512); scripts/gemm_timeline.py */
 int ivit_debug_set_stamp_buffer(void* buf);

@@ -393,12 +393,27 @@ def _frag16_layout_host(W):
     return out
 
 
+@pytest.fixture(params=["auto", "narrow"])
+def wreg_tiles(request):
+    """work items of the weights-in-registers GEMM (16x16x64 form): the product's 128 x 256 tiles, or the 128 x 128 work items of
+    the lab build (include/ivit_hip_debug.h flags2 bit 13: built and measured in round 4, slower, kept for A/B)"""
+    if request.param == "auto":
+        yield "auto"
+        return
+    with _lib.lab_session():
+        _lib.call("ivit_debug_set_gemm_flags2", 8192)
+        yield request.param
+
+
 @pytest.mark.parametrize("FR", [8, 16])
-@pytest.mark.parametrize("M,N,K", [(2600, 512, 384), (197 * 16, 768, 768), (2049, 192, 192), (4000, 320, 576), (197 * 12, 2304, 768)])
-def test_gemm_weight_fragment_layout(M, N, K, FR):
+@pytest.mark.parametrize("M,N,K", [(2600, 512, 384), (197 * 16, 768, 768), (2049, 192, 192), (4000, 320, 576), (197 * 12, 2304, 768),
+                                   (197 * 64, 384, 384), (197 * 20, 1152, 384), (5000, 576, 192)])
+def test_gemm_weight_fragment_layout(M, N, K, FR, wreg_tiles):
     """ivit_pack_weight_frags_i8 / ivit_pack_weight_frags16_i8 == the documented layouts; the weights-in-registers kernel in both
-    MFMA forms (IVIT_W_FRAGS: 32x32x32, IVIT_W_FRAGS16: 16x16x64) == the oracle for all epilogues, row-major and block-layout A,
-    block-layout output, partial token and channel tiles"""
+    MFMA forms (IVIT_W_FRAGS: 32x32x32, IVIT_W_FRAGS16: 16x16x64; the latter with 128 x 256 and with 128 x 128 work items) == the
+    oracle for all epilogues, row-major and block-layout A, block-layout output, partial token and channel tiles"""
+    if FR == 8 and wreg_tiles != "auto":
+        pytest.skip("narrow tiles exist for the 16x16x64 form only")
     rng = np.random.default_rng(M + K + 1)
     A = rng.integers(-128, 128, size=(M, K)).astype(np.int8)
     W = rng.integers(-128, 128, size=(N, K)).astype(np.int8)

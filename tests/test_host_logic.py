@@ -348,3 +348,43 @@ def test_lazy_scope_depth_is_per_thread_and_survives_enable_everywhere():
     finally:
         lazy.enable_everywhere(False)
     assert not lazy.active()
+
+
+def test_bench_numa_cpus_of_gpu_on_a_fake_sysfs_tree(tmp_path, monkeypatch):
+    """bench.numa_cpus_of_gpu (the ranks of `bench.py --gpus N` pin themselves to their GPU's NUMA node): PCI order = HIP order,
+    HIP_VISIBLE_DEVICES remaps, numa_node = -1 / a node outside the affinity mask / a missing tree say WHY there is no answer"""
+    import bench
+    root = tmp_path / "sys"
+
+    def gpu(card, bdf, node, vendor="0x1002", cls="0x120000"):
+        dev = root / "devices" / "pci0000:00" / bdf
+        dev.mkdir(parents=True)
+        (dev / "vendor").write_text(vendor + "\n"); (dev / "class").write_text(cls + "\n"); (dev / "numa_node").write_text(f"{node}\n")
+        d = root / "class" / "drm" / card
+        d.mkdir(parents=True)
+        (d / "device").symlink_to(dev)
+
+    gpu("card1", "0000:85:00.0", 1)           # enumerated second by HIP (higher bus address)
+    gpu("card0", "0000:05:00.0", 0)
+    gpu("card2", "0000:03:00.0", 0, vendor="0x1a03", cls="0x030000")      # the BMC's VGA: not an AMD GPU
+    gpu("card3", "0000:c5:00.0", -1)
+    for node, cpus in ((0, "0-3,16-19"), (1, "4-7")):
+        n = root / "devices" / "system" / "node" / f"node{node}"
+        n.mkdir(parents=True)
+        (n / "cpulist").write_text(cpus + "\n")
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES", raising=False); monkeypatch.delenv("ROCR_VISIBLE_DEVICES", raising=False)
+    every = set(range(32))
+    assert bench.numa_cpus_of_gpu(0, str(root), every) == {0, 1, 2, 3, 16, 17, 18, 19}
+    assert bench.numa_cpus_of_gpu(1, str(root), every) == {4, 5, 6, 7}
+    assert bench.numa_cpus_of_gpu(0, str(root), {2, 3, 4}) == {2, 3}            # clipped to the affinity mask
+    why = []
+    assert bench.numa_cpus_of_gpu(2, str(root), every, why) is None and "numa_node = -1" in why[0]
+    why = []
+    assert bench.numa_cpus_of_gpu(5, str(root), every, why) is None and "3 GPU(s)" in why[0]
+    why = []
+    assert bench.numa_cpus_of_gpu(1, str(root), {0, 1}, why) is None and "affinity mask" in why[0]
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "1,0")
+    assert bench.numa_cpus_of_gpu(0, str(root), every) == {4, 5, 6, 7}
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    why = []
+    assert bench.numa_cpus_of_gpu(0, str(tmp_path / "nothing"), every, why) is None and "no AMD GPU" in why[0]
