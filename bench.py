@@ -167,11 +167,14 @@ def numa_cpus_of_gpu(local_rank, sysfs="/sys", allowed=None, why=None):
         devs = []
         for d in glob.glob(os.path.join(sysfs, "class/drm/card[0-9]*/device")):
             real = os.path.realpath(d)
-            with open(os.path.join(real, "vendor")) as f:
-                if f.read().strip() != "0x1002":
-                    continue
-            with open(os.path.join(real, "class")) as f:
-                cls = f.read().strip()
+            try:
+                with open(os.path.join(real, "vendor")) as f:
+                    if f.read().strip() != "0x1002":
+                        continue
+                with open(os.path.join(real, "class")) as f:
+                    cls = f.read().strip()
+            except OSError:
+                continue      # not a PCI function (round 4: the driver's box lists /sys/devices/platform/amdgpu_xcp_NN partition nodes)
             if not (cls.startswith("0x03") or cls.startswith("0x12")):      # display controller / processing accelerator
                 continue
             devs.append(real)

@@ -61,6 +61,7 @@ struct AttnArgs {
     // I-BERT softmax (MODE 3): exp_int after the internal QuantAct(16), as the float32 the reference sums and multiplies, for
     // every (row max, q): [256][256], built by ivit_ibert_softmax_build_table
     const float* ib_table;
+    float nMs32;  // RQ32 kernels: -Ms as float32 (a power of two: the float32 product with a score accumulator is exact)
     int parts;  // workgroups per (image, head): the query tiles are dealt out among them (small batches: batch * heads << CUs)
     int abl;   // lab build: 1 no score requant, 2 no table lookups, 4 no probability products, 8 no P.V + output, 16 one query tile per wave
 };
@@ -79,9 +80,19 @@ IVIT_DEV int kswz(int r, int c) { return r * HD + (((c + 2 * ((r >> 2) & 1)) & 3
 // (p = c + 128 b + 16384 a), one P.V MFMA set per plane (the a plane only when a wave has such a score)
 // GENT ("general T", Shiftmax modes only): any token count up to 207 -- every key tile takes the masked path of the last one
 // (keys >= T carry the sentinel), all 13 key tiles are still walked: for geometries other than 14 x 14 patches, not tuned.
-template <int MODE, int PB = 8, int OCC = (PB == 8 ? 4 : 3), bool GENT = false>
+// RQ32 (MODE 0, PB 8): the requantisation of the scores in float32 -- one v_cvt_f32_i32 + one v_fma_f32 against the magic constant
+// instead of v_cvt_f64_i32 + v_fma_f64 (4 + 4 cycles per wave instruction against 3.2 + 2, profiles/r04_valu_price_list.txt) --
+// when the multiplier Ms is a power of two (every scale of the power-of-two regime is, and head_dim^-0.5 = 1/8): |S| <= 2^20 is
+// exact in float32, S * Ms is exact, the fma rounds once, to nearest even at integer granularity, exactly as the float64 path.
+// The scores are then carried with the magic constant's exponent bits in place (RQ_OFF + nk): differences and minima commute
+// with the offset, so the table index nk + rmax needs no correction.
+constexpr int RQ_OFF = 0x4B400000;
+template <int MODE, int PB = 8, int OCC = (PB == 8 ? 4 : 3), bool GENT = false, bool RQ32 = false>
 __global__ __launch_bounds__(NT, OCC) void attention_kernel(AttnArgs a)
 {
+    static_assert(!RQ32 || (MODE == 0 && PB == 8), "RQ32: Shiftmax with a power-of-two input scale, 8-bit probabilities");
+    constexpr int SOFF = RQ32 ? RQ_OFF : 0;       // offset the (negated) scores are carried with
+    constexpr int PADK = SOFF + 1000;             // sentinel of the padding keys
     __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
     extern __shared__ __attribute__((aligned(16))) unsigned band_lds[];   // [4 waves][16 queries][band_w + BAND_PAD], compat only
     const int T = a.tokens;
@@ -101,21 +112,37 @@ __global__ __launch_bounds__(NT, OCC) void attention_kernel(AttnArgs a)
         reinterpret_cast<float*>(smem + LUT_OFF)[256 + tid] = (float)e0;   // same address + 1 KB: one more ds_read, one cvt fewer per score
     }
 
-    // ---- K tile [key][64]; rows >= T are never consumed unmasked
-    for (int q = tid; q < T * 4; q += NT) {
-        int r = q >> 2, c = q & 3;
-        v4i v = *reinterpret_cast<const v4i*>(kg + (int64_t)r * HD + 16 * c);
-        *reinterpret_cast<v4i*>(smem + kswz(r, c)) = v;
+    // ---- K tile [key][64]; rows >= T are never consumed unmasked.  ALL of a thread's K and V chunks are requested before the
+    //      first is written to LDS (T <= 208: at most 4 K chunks and one V work item of 4 chunks per thread): one memory latency
+    //      per workgroup instead of one per loop iteration (round 4: a staging-only launch took 24 us = 8 us per round of
+    //      workgroups, profiles/r04g_*)
+    static_assert(KP * 4 <= 4 * NT && (KP / 4) * 4 <= NT, "staging: four K chunks and one V work item per thread");
+    v4i kst[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = min(tid + NT * i, T * 4 - 1);
+        kst[i] = *reinterpret_cast<const v4i*>(kg + (int64_t)(q >> 2) * HD + 16 * (q & 3));
     }
     // ---- V transposed: Vt[d][chunk j = 4s + g'][byte 4t + r] = V[key = 64s + 16t + 4g' + r][d], chunk j of row d
     //      stored at position j ^ (d & 15).  One work item = 4 consecutive keys x 16 d: the 4x4 byte blocks are
     //      transposed in registers (v_perm_b32), so every LDS write is a whole dword (4 keys of one d).
-    for (int q = tid; q < ((T + 3) >> 2) * 4; q += NT) {
-        const int kg4 = q >> 2, c = q & 3;      // keys 4*kg4 .. 4*kg4+3, d = 16c .. 16c+15
-        v4i v[4];
+    const bool v_item = tid < ((T + 3) >> 2) * 4;
+    v4i vst[4];
+    {
+        const int kg4 = min(tid, ((T + 3) >> 2) * 4 - 1) >> 2, c = tid & 3;
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-            v[r] = *reinterpret_cast<const v4i*>(vg + (int64_t)min(4 * kg4 + r, T - 1) * HD + 16 * c);
+            vst[r] = *reinterpret_cast<const v4i*>(vg + (int64_t)min(4 * kg4 + r, T - 1) * HD + 16 * c);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = tid + NT * i;
+        if (q < T * 4) *reinterpret_cast<v4i*>(smem + kswz(q >> 2, q & 3)) = kst[i];
+    }
+    if (v_item) {
+        const int q = tid;
+        const int kg4 = q >> 2, c = q & 3;      // keys 4*kg4 .. 4*kg4+3, d = 16c .. 16c+15
+        v4i (&v)[4] = vst;
         const int key0 = 4 * kg4;
         const int j = 4 * (key0 >> 6) + ((key0 >> 2) & 3);
         const int boff = 4 * ((key0 >> 4) & 3);
@@ -145,16 +172,19 @@ __global__ __launch_bounds__(NT, OCC) void attention_kernel(AttnArgs a)
 
     // 13 query tiles over 4 waves: one wave gets four tiles, the others three.  Which wave that is rotates with the
     // workgroup index, so that the co-resident workgroups of a CU do not all put their extra tile on the same SIMD
-    for (int qt = ((wave + bh) & 3) + 4 * part; qt < ((IVIT_LAB && (a.abl & 16)) ? 4 : nqt); qt += 4 * a.parts) {
+    // the Q fragment of a wave's NEXT query tile is requested while the current tile's probabilities are multiplied with V (its
+    // registers are free there): the load's latency no longer opens every tile
+    const int qt0 = ((wave + bh) & 3) + 4 * part, qt_end = (IVIT_LAB && (a.abl & 16)) ? 4 : nqt;
+    v4i qf_next = *reinterpret_cast<const v4i*>(qg + (int64_t)min(qt0 * 16 + l15, T - 1) * HD + 16 * g);
+    for (int qt = qt0; qt < qt_end; qt += 4 * a.parts) {
         const int qrow = qt * 16 + l15;  // this lane's query
-        const int qld = min(qrow, T - 1);
-        const v4i qf = *reinterpret_cast<const v4i*>(qg + (int64_t)qld * HD + 16 * g);
+        const v4i qf = qf_next;
 
         // ---- S^T = K . Q^T, requantised to the 8-bit Shiftmax input (qact_attn1)
         // scores are kept NEGATED (nk = -k = RNE(S * -Ms): RNE is symmetric): the table index max - k = nk + max is then one
         // v_add_lshl_u32 per score instead of a subtract and a shift
         int s[NKT][4];
-        int nmin = 1000;
+        int nmin = PADK;
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
             const v4i kf = *reinterpret_cast<const v4i*>(smem + kswz(16 * kt + l15, g));
@@ -163,8 +193,14 @@ __global__ __launch_bounds__(NT, OCC) void attention_kernel(AttnArgs a)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 // |S| <= 64*128*128 = 2^20, m < 2^32: the product is exact in float64
-                int nk = (IVIT_LAB && (a.abl & 1)) ? (acc[r] & 127) : clamp_i32(requant_exact(acc[r], -a.Ms), -127, 128);
-                if (GENT || kt == NKT - 1) nk = (16 * kt + 4 * g + r < T) ? nk : 1000;
+                int nk;
+                if constexpr (RQ32) {
+                    const int tb = __float_as_int(__builtin_fmaf((float)acc[r], a.nMs32, 12582912.0f));     // RQ_OFF + RNE(-S * Ms)
+                    nk = (IVIT_LAB && (a.abl & 1)) ? SOFF + (acc[r] & 127) : clamp_i32(tb, SOFF - 127, SOFF + 128);
+                } else {
+                    nk = (IVIT_LAB && (a.abl & 1)) ? (acc[r] & 127) : clamp_i32(requant_exact(acc[r], -a.Ms), -127, 128);
+                }
+                if (GENT || kt == NKT - 1) nk = (16 * kt + 4 * g + r < T) ? nk : PADK;
                 s[kt][r] = nk;
                 nmin = min(nmin, nk);
             }
@@ -172,7 +208,7 @@ __global__ __launch_bounds__(NT, OCC) void attention_kernel(AttnArgs a)
         }
         nmin = min(nmin, __shfl_xor(nmin, 16));
         nmin = min(nmin, __shfl_xor(nmin, 32));
-        int rmax = -nmin;
+        int rmax = -nmin;                // RQ32: -(RQ_OFF + nmin), so that nk + rmax is the plain difference
         asm volatile("" : "+v"(rmax));   // opaque: keeps (nk + rmax) << 2 one v_add_lshl_u32 instead of a subtract and a shift
 
         // ---- Shiftmax (ivit_modules.py:164-175): e = exp_int(k - max), sum, factor, e*factor >> 24
@@ -317,7 +353,7 @@ __global__ __launch_bounds__(NT, OCC) void attention_kernel(AttnArgs a)
                     const int idx = min(rmax + s[kt][r], 255);
                     e = lut[idx];
                     ef = lut[256 + idx];
-                    const bool pad = s[kt][r] == 1000;
+                    const bool pad = s[kt][r] == PADK;
                     e = pad ? 0u : e;
                     ef = pad ? 0u : ef;
                 } else if (IVIT_LAB && (a.abl & 2)) {
@@ -351,6 +387,62 @@ __global__ __launch_bounds__(NT, OCC) void attention_kernel(AttnArgs a)
         // shows as the sign bit of u: the OR of all u of the tile is tested once and the tile repacked in that rare case.
         const float factor_h = factor * 0.5f;
         unsigned any_u = 0;
+        constexpr bool SDWA_PACK = MODE < 3 && PB == 8;
+        if constexpr (SDWA_PACK) {
+            // p = floor(fl32(e * factor) / 2^24) (:175) = trunc(fl32(e * (factor * 2^-24))): the scaling by a power of two commutes
+            // with the float32 rounding of the product (no operand or result is subnormal: factor >= 1, e >= 1 or e == 0), and
+            // p < 128.  v_cvt_u32_f32 with SDWA destination select writes the truncated value straight into byte r of the packed
+            // dword (UNUSED_PRESERVE keeps the other bytes; semantics checked by scripts/probes/cvt_pack_probe.hip): one
+            // instruction per score instead of a conversion plus 3/4 of a byte permute / OR.  The four dwords of a key step are
+            // written round-robin, so that no instruction reads the register the previous one wrote with a destination select
+            // (gfx940+ dst_sel forwarding hazard: one wait state, which the compiler cannot insert inside inline asm).
+            const float factor24 = factor * 5.9604644775390625e-08f;     // 2^-24, exact
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                float pf[4][4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int kt2 = 4 * ks + t < NKT ? 4 * ks + t : 0;
+                        const float ev = ef_is_float ? __int_as_float(s[kt2][r]) : (float)(unsigned)s[kt2][r];
+                        pf[t][r] = (IVIT_LAB && (a.abl & 4)) ? 1.0f : ev * factor24;     // lab bit 2: no products
+                    }
+                unsigned w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+                if (4 * ks + 3 < NKT) {
+                    // (the first write of each dword zero-fills its other bytes: UNUSED_PAD, early-clobber outputs, no initialisation)
+                    asm("v_cvt_u32_f32_sdwa %0, %4 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:DWORD\n\t"
+                        "v_cvt_u32_f32_sdwa %1, %5 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:DWORD\n\t"
+                        "v_cvt_u32_f32_sdwa %2, %6 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:DWORD\n\t"
+                        "v_cvt_u32_f32_sdwa %3, %7 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:DWORD\n\t"
+                        "v_cvt_u32_f32_sdwa %0, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\t"
+                        "v_cvt_u32_f32_sdwa %1, %9 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\t"
+                        "v_cvt_u32_f32_sdwa %2, %10 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\t"
+                        "v_cvt_u32_f32_sdwa %3, %11 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\t"
+                        "v_cvt_u32_f32_sdwa %0, %12 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\t"
+                        "v_cvt_u32_f32_sdwa %1, %13 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\t"
+                        "v_cvt_u32_f32_sdwa %2, %14 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\t"
+                        "v_cvt_u32_f32_sdwa %3, %15 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\t"
+                        "v_cvt_u32_f32_sdwa %0, %16 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\t"
+                        "v_cvt_u32_f32_sdwa %1, %17 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\t"
+                        "v_cvt_u32_f32_sdwa %2, %18 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\t"
+                        "v_cvt_u32_f32_sdwa %3, %19 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\t"
+                        "s_nop 0"
+                        : "=&v"(w0), "=&v"(w1), "=&v"(w2), "=&v"(w3)
+                        : "v"(pf[0][0]), "v"(pf[1][0]), "v"(pf[2][0]), "v"(pf[3][0]), "v"(pf[0][1]), "v"(pf[1][1]), "v"(pf[2][1]), "v"(pf[3][1]),
+                          "v"(pf[0][2]), "v"(pf[1][2]), "v"(pf[2][2]), "v"(pf[3][2]), "v"(pf[0][3]), "v"(pf[1][3]), "v"(pf[2][3]), "v"(pf[3][3]));
+                } else if (4 * ks < NKT) {      // the last key step: one key tile (13 = 3 x 4 + 1), a chain on one register
+                    static_assert(NKT % 4 == 1, "the tail key step packs exactly one key tile");
+                    asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:DWORD\n\ts_nop 0\n\t"
+                        "v_cvt_u32_f32_sdwa %0, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\ts_nop 0\n\t"
+                        "v_cvt_u32_f32_sdwa %0, %3 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\ts_nop 0\n\t"
+                        "v_cvt_u32_f32_sdwa %0, %4 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\ts_nop 0"
+                        : "=&v"(w0)
+                        : "v"(pf[0][0]), "v"(pf[0][1]), "v"(pf[0][2]), "v"(pf[0][3]));
+                }
+                pk[ks] = v4i{(int)w0, (int)w1, (int)w2, (int)w3};
+            }
+        } else
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
@@ -425,6 +517,7 @@ __global__ __launch_bounds__(NT, OCC) void attention_kernel(AttnArgs a)
         }
 
         const bool hi_pass = any_hi;
+        qf_next = *reinterpret_cast<const v4i*>(qg + (int64_t)min((qt + 4 * a.parts) * 16 + l15, T - 1) * HD + 16 * g);
         // ---- O^T = Vt . P^T, requantised (attn.qact2), 4 consecutive d per dword
         const int64_t orow_idx = (int64_t)b * T + qrow;
         const BlockRow obrow = block_row((int)orow_idx, a.heads * HD);
@@ -450,7 +543,7 @@ __global__ __launch_bounds__(NT, OCC) void attention_kernel(AttnArgs a)
                     if (hi_pass) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(vf, pkh[ks], acc, 0, 0, 0);
                 }
             }
-            unsigned w = 0;
+            int ob[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 int o;
@@ -464,9 +557,10 @@ __global__ __launch_bounds__(NT, OCC) void attention_kernel(AttnArgs a)
                     // |O| <= 208*127*128 < 2^22: exact float64 product
                     o = clamp_i32(requant_exact(acc[r], a.Mo), -128, 127);
                 }
-                w |= ((unsigned)o & 0xffu) << (8 * r);
+                ob[r] = o;
             }
-            wq[dt] = w;
+            // the four low bytes by two byte permutes and an OR (was: and / shift / or per byte)
+            wq[dt] = __builtin_amdgcn_perm((unsigned)ob[1], (unsigned)ob[0], 0x0c0c0400u) | __builtin_amdgcn_perm((unsigned)ob[3], (unsigned)ob[2], 0x04000c0cu);
         }
         // A query's 64 output bytes sit as 4 x 4 dwords in its four lanes (g = lane >> 4).  A 4 x 4 word transpose across those
         // lanes -- two v_permlane32_swap, two v_permlane16_swap -- leaves lane g with the 16 CONTIGUOUS bytes d = 16 g .. 16 g + 15:
@@ -569,6 +663,9 @@ IVIT_EXPORT int ivit_attention_fused_i8_wide(const int8_t* qkv, int8_t* out, int
     a.qkv = qkv; a.out = out; a.batch = batch; a.heads = heads; a.tokens = tokens;
     a.Ms = ivit_dyadic_to_double(m_s, e_s);
     a.Mo = ivit_dyadic_to_double(m_o, e_o);
+    // a power-of-two score multiplier (m = 2^k): the float32 requantisation of the RQ32 kernels is exact (lab bit 26: off, A/B)
+    const bool ms_pow2 = m_s != 0 && (m_s & (m_s - 1)) == 0 && a.Ms >= 1e-30 && !(IVIT_LAB && (g_ln_ablate & (1 << 26)));
+    a.nMs32 = (float)-a.Ms;
     const float x0f = __builtin_floorf((1.0f / s_attn) * -1.0f);  // ivit_modules.py:154
     IVIT_REQUIRE(x0f <= -1.0f && x0f >= -4096.0f, "ivit_attention_fused_i8: x0=%g outside [-4096,-1]", (double)x0f);
     a.x0 = (int)x0f;
@@ -597,6 +694,7 @@ IVIT_EXPORT int ivit_attention_fused_i8_wide(const int8_t* qkv, int8_t* out, int
         } else {
             if (band_w) hipLaunchKernelGGL((attention_kernel<1, 8, 4, true>), grid, blk, band_lds_bytes, st, a);
             else if (exp2d) hipLaunchKernelGGL((attention_kernel<2, 8, 4, true>), grid, blk, 0, st, a);
+            else if (ms_pow2) hipLaunchKernelGGL((attention_kernel<0, 8, 4, true, true>), grid, blk, 0, st, a);
             else hipLaunchKernelGGL((attention_kernel<0, 8, 4, true>), grid, blk, 0, st, a);
         }
         IVIT_CHECK_LAUNCH("ivit_attention_fused_i8");
@@ -609,6 +707,7 @@ IVIT_EXPORT int ivit_attention_fused_i8_wide(const int8_t* qkv, int8_t* out, int
         if (band_w) hipLaunchKernelGGL(attention_kernel<1>, grid, blk, band_lds_bytes, st, a);
         else if (exp2d) hipLaunchKernelGGL(attention_kernel<2>, grid, blk, 0, st, a);
         else if (IVIT_LAB && (g_ln_ablate & (1 << 25))) hipLaunchKernelGGL((attention_kernel<0, 8, 3>), grid, blk, 0, st, a);   // lab A/B: three workgroups per CU as before round 3
+        else if (ms_pow2) hipLaunchKernelGGL((attention_kernel<0, 8, 4, false, true>), grid, blk, 0, st, a);
         else hipLaunchKernelGGL(attention_kernel<0>, grid, blk, 0, st, a);
     }
     IVIT_CHECK_LAUNCH("ivit_attention_fused_i8");

@@ -22,7 +22,8 @@ def run():
               _lib.stream_ptr())
 
 
-for bits in [int(x) for x in (sys.argv[1:] or ["0", "1", "2", "4", "8", "3", "7", "15", "16", "31"])]:
+# bit 6 (= bit 26 of the knob): the float64 requantisation of the scores instead of the float32 one (A/B of attention_kernel<.., RQ32>)
+for bits in [int(x) for x in (sys.argv[1:] or ["0", "64", "1", "2", "4", "8", "3", "7", "15", "16", "31"])]:
     _lib.call("ivit_debug_ln_ablate", bits << 20)
     for _ in range(5):
         run()

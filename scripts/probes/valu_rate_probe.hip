@@ -72,6 +72,12 @@
 #define A_ALIGNBIT(i) asm volatile("v_alignbit_b32 %0, %0, %1, 8" : "+v"(r##i) : "v"(a));
 #define A_OR3(i) asm volatile("v_or3_b32 %0, %0, %1, %2" : "+v"(r##i) : "v"(a), "v"(b));
 #define A_SDWA(i) asm volatile("v_add_f32_sdwa %0, %1, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD" : "+v"(r##i) : "v"(a));
+#define A_CVTF64(i) asm volatile("v_cvt_f64_i32 %0, %1" : "=v"(d0) : "v"(r##i));
+#define A_CVTPKU8(i) asm volatile("v_cvt_pk_u8_f32 %0, %1, 1, %0" : "+v"(r##i) : "v"(a));
+#define A_CVTU32(i) asm volatile("v_cvt_u32_f32 %0, %0" : "+v"(r##i));
+#define A_CVTSDWAB(i) asm volatile("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(r##i) : "v"(a));
+#define A_ADDLSHL(i) asm volatile("v_add_lshl_u32 %0, %0, %1, 2" : "+v"(r##i) : "v"(a));
+#define A_MININT(i) asm volatile("v_min_i32 %0, %1, %0" : "+v"(r##i) : "v"(a));
 #define A_CVTSDWA(i) asm volatile("v_cvt_f32_u32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1" : "=v"(r##i) : "v"(a));
 
 // v_pk_fma_f32 needs 64-bit register pairs: a separate kernel body
@@ -146,6 +152,12 @@ DEF_KERNEL(k_alignbit, A_ALIGNBIT)
 DEF_KERNEL(k_or3, A_OR3)
 DEF_KERNEL(k_sdwa, A_SDWA)
 DEF_KERNEL(k_cvtsdwa, A_CVTSDWA)
+DEF_KERNEL(k_cvtf64, A_CVTF64)
+DEF_KERNEL(k_cvtpku8, A_CVTPKU8)
+DEF_KERNEL(k_cvtu32, A_CVTU32)
+DEF_KERNEL(k_cvtsdwab, A_CVTSDWAB)
+DEF_KERNEL(k_addlshl, A_ADDLSHL)
+DEF_KERNEL(k_minint, A_MININT)
 
 typedef void (*kern_t)(int, unsigned long long*, float*);
 
@@ -165,6 +177,8 @@ int main()
         {"v_cvt_i32_f32", k_cvtif}, {"v_rndne_f32", k_rndne}, {"v_fmaak_f32", k_fmaak}, {"v_fmac_f32", k_fmac}, {"v_mad_u32_u24", k_madu24},
         {"v_mov_b32", k_mov}, {"v_readlane_b32", k_readlane}, {"v_sub_f32_e64", k_subf3}, {"v_min3_i32", k_min3}, {"v_alignbit_b32", k_alignbit},
         {"v_or3_b32", k_or3}, {"v_add_f32_sdwa", k_sdwa}, {"v_cvt_f32_u32_sdwa b1", k_cvtsdwa},
+        {"v_cvt_f64_i32", k_cvtf64}, {"v_cvt_pk_u8_f32", k_cvtpku8}, {"v_cvt_u32_f32", k_cvtu32}, {"v_cvt_u32_f32_sdwa B2 keep", k_cvtsdwab},
+        {"v_add_lshl_u32", k_addlshl}, {"v_min_i32", k_minint},
     };
     const int iters = 200;
     printf("%-22s %28s %28s %28s\n", "instruction", "1 wave/SIMD: cyc/instr/wave", "2 waves/SIMD: wave | SIMD", "4 waves/SIMD: wave | SIMD");

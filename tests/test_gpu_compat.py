@@ -168,7 +168,7 @@ def _crc(a):
     return zlib.crc32(np.ascontiguousarray(a, dtype=np.int32).tobytes())
 
 
-@pytest.mark.parametrize("tag,batch", [("deit_tiny_natural", 8), ("deit_small_natural", 4), ("deit_base_natural", 2)])
+@pytest.mark.parametrize("tag,batch", [("deit_tiny_natural", 8), ("deit_small_natural", 4), ("deit_base_natural", 2), ("vit_large_natural", 2)])
 def test_natural_scale_model_matches_reference(tag, batch):
     """un-snapped calibration ranges: INT32 logits, top-1 and every materialised tap equal the reference's"""
     fs, ranges, cfg, meta, z = load_synthetic_model(tag)

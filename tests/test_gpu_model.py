@@ -28,7 +28,7 @@ def build(tag, max_batch):
     return eng, fs, ranges, cfg, meta, z
 
 
-@pytest.mark.parametrize("tag", ["deit_tiny", "deit_small", "deit_base", "vit_base"])
+@pytest.mark.parametrize("tag", ["deit_tiny", "deit_small", "deit_base", "vit_base", "vit_large"])
 def test_golden_logits_and_taps(tag):
     eng, fs, ranges, cfg, meta, z = build(tag, meta_batch(tag))
     n = meta["n_images"]
@@ -72,7 +72,7 @@ def test_ibert_engine_golden_logits_and_taps(tag):
 
 
 def meta_batch(tag):
-    return {"deit_tiny": 8, "deit_small": 4, "deit_base": 4, "vit_base": 2}[tag]
+    return {"deit_tiny": 8, "deit_small": 4, "deit_base": 4, "vit_base": 2, "vit_large": 2}[tag]
 
 
 def test_full_taps_deit_tiny():

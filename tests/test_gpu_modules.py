@@ -216,10 +216,11 @@ def test_calibration_then_freeze_runs():
 
 
 # ----------------------------------------------------------------------------------- Swin module mirror
-def test_swin_module_path_matches_reference_golden():
-    """Swin-T through the module-by-module path (reference call protocol: float views, torch roll / partition /
+@pytest.mark.parametrize("tag", ["swin_tiny", "swin_small"])
+def test_swin_module_path_matches_reference_golden(tag):
+    """Swin-T / Swin-S through the module-by-module path (reference call protocol: float views, torch roll / partition /
     mask-add between the HIP-backed modules), 1 golden image: float logits bitwise."""
-    model, meta, z = load_model("swin_tiny")
+    model, meta, z = load_model(tag)
     model.use_engine = False
     imgs = torch.from_numpy(synth.make_images(1, meta["image_seed"])).to(DEV)
     with torch.no_grad():
@@ -231,9 +232,10 @@ def test_swin_module_path_matches_reference_golden():
     assert sd["layers.1.blocks.1.attn.qact4.act_scaling_factor"].item() > 0
 
 
-def test_swin_engine_path_matches_reference_golden():
+@pytest.mark.parametrize("tag", ["swin_tiny", "swin_small"])
+def test_swin_engine_path_matches_reference_golden(tag):
     """the same frozen nn.Module, default path = fused integer engine"""
-    model, meta, z = load_model("swin_tiny")
+    model, meta, z = load_model(tag)
     imgs = torch.from_numpy(synth.make_images(meta["n_images"], meta["image_seed"])).to(DEV)
     with torch.no_grad():
         y = model(imgs)
@@ -974,7 +976,7 @@ def test_ibert_natural_scale_module_path_matches_reference():
 
 # ----------------------------------------------------------------------------------- int8-carrying module path (lazy.py)
 @pytest.mark.parametrize("tag", ["deit_tiny", "deit_tiny_natural", "deit_small_natural", "deit_base", "vit_base", "deit_tiny_ibert",
-                                 "deit_tiny_ibert_natural"])
+                                 "deit_tiny_ibert_natural", "vit_large", "vit_large_natural"])
 def test_frozen_module_path_carries_int8_and_never_syncs(tag):
     """The reference's call protocol (vit_quant.py:61-90, 142-155, 285-312: QuantLinear, QuantAct, IVITIntLayerNorm, ... one by
     one) on a frozen model, with every device -> host read-back an ERROR (torch.cuda.set_sync_debug_mode): int8 payloads move

@@ -668,14 +668,17 @@ def test_gemm_rejects_bad_shapes():
 # ----------------------------------------------------------------------------------- attention
 @pytest.mark.parametrize("B,H,T,p_at", [(2, 3, 197, -2), (1, 6, 197, -3), (1, 2, 208, -1), (1, 1, 193, -2),
                                         (2, 2, 192, -2), (1, 3, 145, -3), (2, 1, 101, -2), (1, 2, 50, -1), (1, 1, 17, -2), (1, 1, 5, -2)])
-def test_attention_fused(B, H, T, p_at):
+@pytest.mark.parametrize("s_mult", [1.0, 1.37], ids=["pow2_score_multiplier", "odd_score_multiplier"])
+def test_attention_fused(B, H, T, p_at, s_mult):
     """one (image, head) per workgroup against the oracle's matmul -> requant -> Shiftmax -> matmul -> requant; token counts 193 .. 208
-    take the tuned form (only the last key tile is partial), fewer tokens the general one (every key tile masked: other geometries)"""
+    take the tuned form (only the last key tile is partial), fewer tokens the general one (every key tile masked: other geometries).
+    A power-of-two score multiplier takes the float32 requantisation of the scores (attention_kernel<.., RQ32>), any other the
+    float64 one; scores that land exactly on .5 (ties to even) occur in both."""
     rng = np.random.default_rng(100 + B * H + T)
     hd = 64
     qkv = np.clip(np.rint(rng.normal(0, 40, size=(3, B, H, T, hd))), -128, 127).astype(np.int8)
     s_a1 = np.float32(2.0 ** -4)
-    s_S = np.float32(np.float32(s_a1 * s_a1) * np.float32(0.125))
+    s_S = np.float32(np.float32(np.float32(s_a1 * s_a1) * np.float32(0.125)) * np.float32(s_mult))
     s_at = np.float32(2.0 ** p_at)
     s_pv = np.float32(np.float32(1 / 128.0) * s_a1)
     s_a2 = np.float32(2.0 ** -3)

@@ -363,8 +363,8 @@ def test_window_attention_rejects_unsupported_geometry():
 
 
 # ----------------------------------------------------------------------------------- whole model
-def build_swin(max_batch):
-    z, meta, ranges = load_fixture("swin_tiny")
+def build_swin(max_batch, tag="swin_tiny"):
+    z, meta, ranges = load_fixture(tag)
     cfg = synth.SWIN_CONFIGS[meta["factory"]]
     fs = synth.make_swin_float_state(meta["factory"], meta["weight_seed"])
     eng = IntSwinEngine(fs, ranges, cfg["embed_dim"], cfg["depths"], cfg["num_heads"], cfg["window"], device=DEV,
@@ -372,8 +372,9 @@ def build_swin(max_batch):
     return eng, fs, ranges, cfg, meta, z
 
 
-def test_swin_golden_logits_and_taps():
-    eng, fs, ranges, cfg, meta, z = build_swin(4)
+@pytest.mark.parametrize("tag", ["swin_tiny", "swin_small"])
+def test_swin_golden_logits_and_taps(tag):
+    eng, fs, ranges, cfg, meta, z = build_swin(4, tag)
     n = meta["n_images"]
     imgs = torch.from_numpy(synth.make_images(n, meta["image_seed"])).to(DEV)
     taps = {}
@@ -486,8 +487,9 @@ def test_config5_batch_128_swin_tiny():
     assert np.array_equal(li[sub], om.forward(imgs_np[sub])["logits_int32"])
 
 
-def test_swin_natural_scales_match_reference_end_to_end():
-    """Swin-T with its ranges AS CALIBRATED against the reference itself (fixture swin_tiny_natural.npz: all 192 QuantAct /
+@pytest.mark.parametrize("tag", ["swin_tiny_natural", "swin_small_natural"])
+def test_swin_natural_scales_match_reference_end_to_end(tag):
+    """Swin-T (and, since round 4, Swin-S: 18 blocks in stage 2) with its ranges AS CALIBRATED against the reference itself (fixture swin_tiny_natural.npz: all 192 QuantAct /
     Shiftmax / ShiftGELU taps, INT32 logits, top-1 of the reference's forward), module-by-module path AND fused engine.
     The reference's patch-embed LayerNorm takes its float32 mean over a TRANSPOSED view (layers_quant.py:198-201): ATen sums such
     a row with its outer-reduction cascade, not with the 32-partial-sum order of a contiguous row, and the 69 exact-tie rows of
@@ -496,9 +498,9 @@ def test_swin_natural_scales_match_reference_end_to_end():
     import zlib
     import ivit_amd as ivit
     import ivit_amd.quantization_utils as qu
-    z, meta, ranges = load_fixture("swin_tiny_natural")
+    z, meta, ranges = load_fixture(tag)
     fs = synth.make_swin_float_state(meta["factory"], meta["weight_seed"])
-    model = ivit.swin_tiny_patch4_window7_224()
+    model = getattr(ivit, meta["factory"])()
     model.load_state_dict({k: torch.from_numpy(v) for k, v in fs.items()}, strict=False)
     for name, mod in model.named_modules():
         if isinstance(mod, qu.QuantAct) and name in ranges:
@@ -545,7 +547,7 @@ def test_swin_natural_scales_match_reference_end_to_end():
     torch.cuda.synchronize()
     bad = [n for n in order if n in taps and crc(taps[n].cpu().numpy().astype(np.int32)) != int(gold[n])]
     assert not bad, f"engine: {len(bad)} taps differ from the reference, first {bad[:4]}"
-    assert len(taps) >= 119
+    assert len(taps) >= 119 if tag == "swin_tiny_natural" else len(taps) >= 200
     assert np.array_equal(li.cpu().numpy(), z["logits_int32"])
     assert np.array_equal(t1.cpu().numpy().astype(np.int64), z["top1"])
 
@@ -623,7 +625,7 @@ def test_swin_natural_scales_engine_equals_module_path():
     import ivit_amd.quantization_utils as qu
     z, meta, ranges = load_fixture("swin_tiny_natural")
     fs = synth.make_swin_float_state(meta["factory"], meta["weight_seed"])
-    model = ivit.swin_tiny_patch4_window7_224()
+    model = getattr(ivit, meta["factory"])()
     model.load_state_dict({k: torch.from_numpy(v) for k, v in fs.items()}, strict=False)
     for name, mod in model.named_modules():
         if isinstance(mod, qu.QuantAct) and name in ranges:

@@ -368,6 +368,10 @@ def test_bench_numa_cpus_of_gpu_on_a_fake_sysfs_tree(tmp_path, monkeypatch):
     gpu("card0", "0000:05:00.0", 0)
     gpu("card2", "0000:03:00.0", 0, vendor="0x1a03", cls="0x030000")      # the BMC's VGA: not an AMD GPU
     gpu("card3", "0000:c5:00.0", -1)
+    xcp = root / "devices" / "platform" / "amdgpu_xcp_22"          # a partition node: a drm card without PCI attributes
+    xcp.mkdir(parents=True)
+    (root / "class" / "drm" / "card9").mkdir(parents=True)
+    (root / "class" / "drm" / "card9" / "device").symlink_to(xcp)
     for node, cpus in ((0, "0-3,16-19"), (1, "4-7")):
         n = root / "devices" / "system" / "node" / f"node{node}"
         n.mkdir(parents=True)

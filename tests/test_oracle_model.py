@@ -162,3 +162,8 @@ def test_compat_ln16_and_masked_shiftmax_kat(ckat):
         q, s, mask = ckat[c + "q"].astype(np.float32), np.float32(ckat[c + "s"]), ckat[c + "mask"]
         x = ((q * s).astype(np.float32) + np.where(mask, np.float32(-100.0), np.float32(0.0))).astype(np.float32)
         assert np.array_equal(orc.shiftmax_xint((x / s).astype(np.float32), s), ckat[c + "out"]), ci
+
+
+def test_oracle_vit_large_matches_reference():
+    """the widest factory (vit_quant.py:391-406; C = 1024, 24 blocks, 16 heads), one golden image, power-of-two ranges"""
+    _check_model("vit_large", False, 1)
