@@ -641,7 +641,7 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_wreg_kernel(GemmArgs g)
 
     // One work item: a full tile (128 tokens: 4 token sub-tiles per wave), a half tile (64 tokens: 2), or a narrow tile (128
     // tokens x 128 channels: 2 token sub-tiles per wave out of the wave's token half, DMA as for a full tile).
-    auto run = [&](auto mode_tag, const WrWork& cur, const WrWork& nxt, char* tab, char* tab_next, bool first) {
+    auto run = [&](auto mode_tag, const WrWork& cur, const WrWork& nxt, char* tab, char* tab_next) {
         constexpr int MODE = decltype(mode_tag)::value;
         constexpr bool HALF = MODE == 1, NARROW = MODE == 2;
         static_assert(!NARROW || S16, "narrow tiles exist for the 16x16x64 form only");
@@ -787,12 +787,10 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_wreg_kernel(GemmArgs g)
         // stage 0, weight buffer 0 and stage 1 of this item are in flight (or landed); the table was written during the last epilogue
 #pragma unroll
         for (int p = 0; p < 4; ++p) issue_w(wr1, 1, p);
-        // They were issued before the last epilogue, which waited for them (Hook::consume); only a workgroup's first item has to
-        // wait here.  (An unconditional counted wait would also drain the epilogue's stores: vmcnt counts them too.)
-        if (first) {
-            if constexpr (HALF) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // full and narrow tiles: two DMA pieces + four weight pieces newer
-        }
+        // They have landed: a workgroup's first item waits for them in the kernel prologue, every later one in the previous item's
+        // epilogue (Hook::consume).  Both waits are UNCONDITIONAL in the instruction stream (round 4): csrc/check_isa.py follows
+        // registers with loads in flight through the control flow graph without knowing which branches exclude each other.
+        // (A counted wait HERE would also drain the epilogue's stores: vmcnt counts them too.)
         asm volatile("" : "+v"(wr0[0]), "+v"(wr0[1]), "+v"(wr0[2]), "+v"(wr0[3])::"memory");
         __builtin_amdgcn_s_barrier();     // everyone's stage 0; table visible
         asm volatile("" ::: "memory");
@@ -849,7 +847,10 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_wreg_kernel(GemmArgs g)
             { if constexpr (ABL & 2048) tv[2] = __builtin_amdgcn_s_memtime(); else if (stamp) stamp[2] = __builtin_amdgcn_s_memtime(); }
         // every wave's reads of every stage returned before the barrier of the last step: the ring is free
         const bool more = nxt.m0 >= 0;   // uniform
-        if (more) prefetch(nxt);
+        // Always: a workgroup's last item requests its own first stages again (valid addresses, a free ring, nobody reads them).
+        // With the request under `if (more)` and its wait under another `if (more)`, a checker that does not correlate the two
+        // branches sees a path with the loads in flight forever; the cost of the extra request is ten loads per workgroup.
+        prefetch(more ? nxt : cur);
         struct Hook {
             decltype(table_issue)& ti;
             decltype(table_write)& tw;
@@ -862,10 +863,8 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_wreg_kernel(GemmArgs g)
             // outstanding here is older than the stores that follow): landed before the barrier at the next item's start
             IVIT_DEV void consume() const
             {
-                if (more) {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    tw(ld, dst);
-                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (more) tw(ld, dst);
             }
         };
         Hook hook{table_issue, table_write, nxt.n0, tab_next, more, PersTableLoad{0u, 0, 0, false}};
@@ -921,6 +920,10 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_wreg_kernel(GemmArgs g)
     table_write(table_issue(cur.n0), smem + WR_RING + WR_CS);
     if (g.lut) smem[WR_LUT + tid] = (char)g.lut[tid];     // BIG_NT == 256; visible after the first tile's barriers
     prefetch(cur);
+    // stage 0 and weight buffer 0 of the first item: at most ONE younger operation may stay in flight (a half tile has one
+    // stage-1 DMA piece behind the weight loads, a full tile two: the stricter count serves both without a second branch on
+    // `half`, which a checker that does not correlate branches could pair with the wrong prefetch)
+    asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
 
     for (int it = 0; cur.m0 >= 0; ++it) {
         char* tab = smem + WR_RING + WR_CS + (it & 1) * WR_TAB;
@@ -938,12 +941,12 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_wreg_kernel(GemmArgs g)
             }
         }
         if constexpr (S16 && (EPI == EPI_RQ || EPI == EPI_RESID || EPI == EPI_QKV) && !(ABL & (8192 | 32768 | 16))) {
-            if (cur.half == 2) run(std::integral_constant<int, 2>{}, cur, nxt, tab, tab_next, it == 0);
-            else if (cur.half) run(std::integral_constant<int, 1>{}, cur, nxt, tab, tab_next, it == 0);
-            else run(std::integral_constant<int, 0>{}, cur, nxt, tab, tab_next, it == 0);
+            if (cur.half == 2) run(std::integral_constant<int, 2>{}, cur, nxt, tab, tab_next);
+            else if (cur.half) run(std::integral_constant<int, 1>{}, cur, nxt, tab, tab_next);
+            else run(std::integral_constant<int, 0>{}, cur, nxt, tab, tab_next);
         } else {
-            if (cur.half) run(std::integral_constant<int, 1>{}, cur, nxt, tab, tab_next, it == 0);
-            else run(std::integral_constant<int, 0>{}, cur, nxt, tab, tab_next, it == 0);
+            if (cur.half) run(std::integral_constant<int, 1>{}, cur, nxt, tab, tab_next);
+            else run(std::integral_constant<int, 0>{}, cur, nxt, tab, tab_next);
         }
         if constexpr (ABL & 16)
             {

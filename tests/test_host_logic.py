@@ -392,3 +392,63 @@ def test_bench_numa_cpus_of_gpu_on_a_fake_sysfs_tree(tmp_path, monkeypatch):
     monkeypatch.delenv("HIP_VISIBLE_DEVICES")
     why = []
     assert bench.numa_cpus_of_gpu(0, str(tmp_path / "nothing"), every, why) is None and "no AMD GPU" in why[0]
+
+
+# ----------------------------------------------------------------------------------- csrc/check_isa.py (build-time ISA lint)
+def _isa(body):
+    """a guarded kernel's assembly text around `body` (lines; `A:` marks an inline-asm statement)"""
+    out = ["\t.text", "_ZN12_GLOBAL__N_119gemm_i8_wreg_kernelILi0ELi0ELb1EEEvNS_8GemmArgsE:"]
+    for ln in body:
+        if ln.startswith("A:"):
+            out += ["\t;;#ASMSTART", "\t" + ln[2:].strip(), "\t;;#ASMEND"]
+        elif ln.endswith(":"):
+            out.append(ln)
+        else:
+            out.append("\t" + ln)
+    out += ["\ts_endpgm", "\t.section\t.rodata"]
+    return "\n".join(out) + "\n"
+
+
+def _lint(body):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_isa", os.path.join(ROOT, "i-vit_amd", "csrc", "check_isa.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.check_text(_isa(body))[0]
+
+
+def test_isa_lint_accepts_counted_waits_and_rejects_broken_streams():
+    """csrc/check_isa.py on hand-made instruction streams: the disciplines of the inline-asm GEMM kernels hold in the accepted
+    ones and each rejected one breaks exactly one of them (the build runs the same checker on the real gemm.s)"""
+    load_a, load_b = "A: global_load_dwordx4 v[10:13], v[2:3], off", "A: global_load_dwordx4 v[14:17], v[2:3], off offset:1024"
+    mfma = "A: v_mfma_i32_16x16x64_i8 v[40:43], v[10:13], v[20:23], v[40:43]"
+    # (i) a use behind a covering wait; the younger load may stay in flight
+    assert _lint([load_a, load_b, "A: s_waitcnt vmcnt(1)", "v_add_u32_e32 v30, v10, v11"]) == []
+    # ... the same use with the count one too lenient
+    bad = _lint([load_a, load_b, "A: s_waitcnt vmcnt(2)", "v_add_u32_e32 v30, v10, v11"])
+    assert len(bad) == 1 and "rule i" in bad[0] and "v10" in bad[0]
+    # ... a compiler-scheduled copy between the load and its wait (the hazard class of round 3), reads and writes alike
+    assert any("rule i" in f for f in _lint([load_a, "v_mov_b32_e32 v50, v12", "A: s_waitcnt vmcnt(0)"]))
+    assert any("rule i" in f for f in _lint([load_a, "v_mov_b32_e32 v12, v50", "A: s_waitcnt vmcnt(0)"]))
+    # ... every vector-memory operation counts for vmcnt, whoever issued it: a store behind the loads is one more younger operation
+    assert _lint([load_a, "global_store_dword v[4:5], v60, off", load_b, "A: s_waitcnt vmcnt(2)", "v_mov_b32_e32 v50, v10"]) == []
+    assert _lint([load_a, load_b, "global_store_dword v[4:5], v60, off", "A: s_waitcnt vmcnt(1)", "v_mov_b32_e32 v50, v16"]) == []
+    assert any("rule i" in f for f in _lint([load_a, load_b, "global_store_dword v[4:5], v60, off", "A: s_waitcnt vmcnt(2)",
+                                             "v_mov_b32_e32 v50, v16"]))
+    # ... loads in flight around a loop's back edge: issued in one iteration, waited for at the top of the next
+    loop_ok = [load_a, ".LBB0_1:", "A: s_waitcnt vmcnt(0)", "v_mov_b32_e32 v50, v10", load_a, "s_cbranch_scc1 .LBB0_1", "A: s_waitcnt vmcnt(0)"]
+    assert _lint(loop_ok) == []
+    loop_bad = [load_a, ".LBB0_1:", "v_mov_b32_e32 v50, v10", "A: s_waitcnt vmcnt(0)", load_a, "s_cbranch_scc1 .LBB0_1", "A: s_waitcnt vmcnt(0)"]
+    assert any("rule i" in f for f in _lint(loop_bad))
+    # ... ds_read through lgkmcnt, and a scalar load sneaking into its window
+    ds = "A: ds_read_b128 v[20:23], v5 offset:1024"
+    assert _lint([ds, "A: s_waitcnt lgkmcnt(0)", "v_mov_b32_e32 v60, v21"]) == []
+    assert any("rule i" in f for f in _lint([ds, "v_mov_b32_e32 v60, v21", "A: s_waitcnt lgkmcnt(0)"]))
+    assert any("rule i-b" in f for f in _lint([ds, "s_load_dwordx2 s[4:5], s[0:1], 0x0", "A: s_waitcnt lgkmcnt(0)"]))
+    # (ii) an inline-asm MFMA's accumulator read by a VALU instruction too early / after the kernel's two s_nop 15
+    pre = [load_a, "A: s_waitcnt vmcnt(0)", ds, "A: s_waitcnt lgkmcnt(0)"]
+    assert any("rule ii" in f for f in _lint(pre + [mfma, "s_nop 3", "v_cvt_f32_i32_e32 v60, v41"]))
+    assert _lint(pre + [mfma, "s_nop 15", "s_nop 15", "v_cvt_f32_i32_e32 v60, v41"]) == []
+    assert any("rule ii" in f for f in _lint(pre + [mfma, mfma]))          # back to back on one accumulator
+    # (iii) an inline-asm store without its s_nop
+    assert any("rule iii" in f for f in _lint(["A: global_store_dwordx4 v[4:5], v[60:63], off"]))
