@@ -25,8 +25,8 @@ def time_us(fn, n=40):
 shapes = [(197 * 256, 768), (197 * 64, 384), (197 * 128, 768), (197 * 1024, 768), (197, 192)]
 if len(sys.argv) > 1 and sys.argv[1] == "--headline":
     shapes = shapes[:1]
-variants = [("grouped(r3)", 3, 0), ("stream", 0, 0), ("stream occ2 ng4 2wg", 0, 1 | (2 << 4)), ("stream ng3", 0, 3), ("stream ng2", 0, 4), ("stream dbuf", 0, 5),
-            ("stream 3wg/cu", 0, 3 << 4)]
+variants = [("grouped(r3)", 3, 0, 0), ("stream", 0, 0, 0), ("stream equal-prio", 0, 0, 32), ("stream ng2", 0, 4, 0), ("stream dbuf", 0, 5, 0),
+            ("stream ng3", 0, 3, 0)]
 for rows, C in shapes:
     x = t(np.clip(np.rint(rng.normal(0, 30, size=(rows, C))), -128, 127).astype(np.int8))
     lp = LayerNormParams(rng.uniform(0.5, 1.5, size=C).astype(np.float32), rng.normal(0, 0.1, size=C).astype(np.float32), np.float32(2.0 ** -4))
@@ -46,11 +46,12 @@ for rows, C in shapes:
                               _lib.ptr(out), C, blocks, _lib.stream_ptr())
             res = {}
             for rnd in range(2):
-                for name, form, cfg in variants:
+                for name, form, cfg, ablbits in variants:
                     if cfg and C != 768 and (cfg & 15):
                         continue
                     _lib.call("ivit_debug_ln_wave_per_row", form)
                     _lib.call("ivit_debug_ln_stream_cfg", cfg)
+                    _lib.call("ivit_debug_ln_ablate", ablbits)
                     out.zero_()
                     us = time_us(call)
                     res[name] = min(res.get(name, 1e9), us)
@@ -60,7 +61,7 @@ for rows, C in shapes:
                         ref[key] = got
                     elif not torch.equal(ref[key], got):
                         print(f"   MISMATCH {name} vs grouped: {(ref[key] != got).sum().item()} bytes", flush=True)
-            _lib.call("ivit_debug_ln_wave_per_row", 0); _lib.call("ivit_debug_ln_stream_cfg", 0)
+            _lib.call("ivit_debug_ln_wave_per_row", 0); _lib.call("ivit_debug_ln_stream_cfg", 0); _lib.call("ivit_debug_ln_ablate", 0)
             mb = 2 * rows * C / 1e6
             print(f"rows={rows} C={C} compat={compat} blocks={blocks} ({mb:.1f} MB): " +
                   "  ".join(f"{k} {v:.1f}us ({mb / v / 1e3 * 1e3:.2f} TB/s)" if False else f"{k} {v:.1f}" for k, v in res.items()), flush=True)
