@@ -8,7 +8,8 @@
 #include "rowsum.h"
 
 #if IVIT_LAB
-extern int g_ln_ablate;     // rowops.hip; bits 16-19: workgroup cap of the tiled 16-bit LayerNorm in units of 256 (0 = default)
+extern int g_ln_ablate;     // rowops.hip; bits 16-19: workgroup cap of the tiled 16-bit LayerNorm in units of 256 (0 = default);
+                            // bit 20: natural-scale 16-bit LayerNorm sums its rows through LDS (the round-3 form)
 #else
 constexpr int g_ln_ablate = 0;
 #endif
@@ -145,6 +146,7 @@ struct Ln16Args {
     int outer;     // compat kernels, > 0: the reference takes the mean over a transposed view of contiguous extent `outer` (the first
                    // LayerNorm behind the Swin patch embedding, whose layout travels through the elementwise QuantActs): torch's
                    // outer-reduction order (rowsum.h torch_outer_rowsum), row = image * outer + column
+    int lab_lds_sum;   // lab A/B: the row sums through LDS (the round-3 form) where the register form applies
 };
 
 __global__ __launch_bounds__(NT) void layernorm_i16_i8_kernel(Ln16Args a)
@@ -398,6 +400,12 @@ __global__ __launch_bounds__(NT) void layernorm_i16_i8_tiled_kernel(Ln16Args a)
 //   k' = trunc(phi) replaces q in everything downstream (ivit_modules.py:38);
 //   the mean is round(fl(S / C)) with S the float32 sum of the phi values in torch's CPU reduction order: the phi values of
 //   the wave's rows go through LDS once and two rows at a time are summed by the two halves of the wave (rowsum32 below).
+template <int CTRL>
+IVIT_DEV float dpp_f32(float x)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+
 template <class F>
 IVIT_DEV float rowsum32(F elem, int n, int l32, int base)
 {
@@ -438,9 +446,11 @@ __global__ __launch_bounds__(NT) void layernorm_i16_i8_tiled_compat_kernel(Ln16A
     __shared__ float s_phi[WPB][64 * 8 * NJ];      // [wave][row of the wave][channel]
     __shared__ float s_sum[WPB][64];
     constexpr int RPW = 64 / LPR;
+    constexpr bool REGSUM = LPR <= 16 && LPR * NJ < 64;      // fewer than 16 steps per vector lane, a row inside one DPP row
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane & (LPR - 1), grp = lane / LPR;
     const int C = a.C, nd = C >> 3;
+    const bool regsum = a.outer == 0 && nd == LPR * NJ && !(IVIT_LAB && a.lab_lds_sum);     // uniform
     // bias and the float32 bracket (lo, hi) of each channel's QuantAct multiplier: see layernorm_i8_kernel (rowops.hip) for
     // the certificate that replaces the literal float64 tail of the chain; uncertified wave-iterations are redone literally
     float bias[NJ][8], lo[NJ][8], hi[NJ][8];
@@ -489,28 +499,69 @@ __global__ __launch_bounds__(NT) void layernorm_i16_i8_tiled_compat_kernel(Ln16A
         const bool live = row < a.rows;
         const int16_t* xr = a.x + (int64_t)min(row, a.rows - 1) * C;
         v4i w[NJ];
-        float* prow = s_phi[wave] + grp * C;
+        float ph[NJ][8];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int d = sub + LPR * j;
             w[j] = (d < nd) ? *reinterpret_cast<const v4i*>(xr + 8 * d) : v4i{0, 0, 0, 0};
-            float ph[8];
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
                 const int qv = (c & 1) ? (w[j][c >> 1] >> 16) : (int)(int16_t)w[j][c >> 1];
                 const float x = (float)qv * s_in;                                   // quant_modules.py:387
                 const float q0 = x * r_in;                                          // :36  x / s_in (Markstein, see above)
                 const float e = __builtin_fmaf(-s_in, q0, x);
-                ph[c] = __builtin_fmaf(e, r_in, q0);
+                ph[j][c] = __builtin_fmaf(e, r_in, q0);
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {                                           // :38 .to(int32) truncates
-                const int k0 = (int)ph[2 * q], k1 = (int)ph[2 * q + 1];
+                const int k0 = (int)ph[j][2 * q], k1 = (int)ph[j][2 * q + 1];
                 w[j][q] = (k0 & 0xffff) | (k1 << 16);
             }
+        }
+        float S;
+        if (REGSUM && regsum) {
+            // torch's order without leaving the registers.  C = 8 LPR NJ < 512: 32 vector lanes p = e mod 32 each add their C / 32
+            // elements in sequence (no cascade fold below 16 steps), the 8 lanes of a vector are ((a[l] + a[l+8]) + a[l+16]) + a[l+24],
+            // the 8 results are added in sequence (rowsum.h).  Element e = 8 d + c of chunk d = sub + LPR j is vector lane
+            // 8 (sub & 3) + c, step (LPR / 4) j + (sub >> 2): lane (sub & 3) of the row's first quad accumulates its own three
+            // chunks and those of lanes sub + 4, + 8, + 12 (DPP row shifts: a row group never straddles a DPP row of 16), the quad
+            // combines, everybody reads the result from the group's first lane.
+            constexpr int H = LPR / 4;
+            float acc[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) acc[c] = ph[0][c];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int hh = 0; hh < H; ++hh) {
+                    if (j == 0 && hh == 0) continue;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        float t = ph[j][c];
+                        if (hh == 1) t = dpp_f32<0x104>(t);         // row_shl:4: lane l reads lane l + 4
+                        if (hh == 2) t = dpp_f32<0x108>(t);
+                        if (hh == 3) t = dpp_f32<0x10c>(t);
+                        acc[c] += t;
+                    }
+                }
+            float fin = 0.f;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                float v = dpp_f32<0x00>(acc[c]);                    // quad_perm [0,0,0,0]
+                v += dpp_f32<0x55>(acc[c]);
+                v += dpp_f32<0xaa>(acc[c]);
+                v += dpp_f32<0xff>(acc[c]);
+                fin = c ? fin + v : v;
+            }
+            S = __shfl(fin, lane & ~(LPR - 1));
+        } else {
+        float* prow = s_phi[wave] + grp * C;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int d = sub + LPR * j;
             if (d < nd) {
-                *reinterpret_cast<float4*>(prow + 8 * d) = make_float4(ph[0], ph[1], ph[2], ph[3]);
-                *reinterpret_cast<float4*>(prow + 8 * d + 4) = make_float4(ph[4], ph[5], ph[6], ph[7]);
+                *reinterpret_cast<float4*>(prow + 8 * d) = make_float4(ph[j][0], ph[j][1], ph[j][2], ph[j][3]);
+                *reinterpret_cast<float4*>(prow + 8 * d + 4) = make_float4(ph[j][4], ph[j][5], ph[j][6], ph[j][7]);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -528,15 +579,17 @@ __global__ __launch_bounds__(NT) void layernorm_i16_i8_tiled_compat_kernel(Ln16A
             for (int r0 = 0; r0 < RPW; r0 += 2) {
                 const int rr = min(r0 + half, RPW - 1);
                 const float* pr = s_phi[wave] + rr * C;
-                const float S = rowsum32([&](int i) { return pr[i]; }, C, l32, 32 * half);
-                if (l32 == 0 && r0 + half < RPW) s_sum[wave][rr] = S;
+                const float Sr = rowsum32([&](int i) { return pr[i]; }, C, l32, 32 * half);
+                if (l32 == 0 && r0 + half < RPW) s_sum[wave][rr] = Sr;
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const int mean_int = (int)rintf(s_sum[wave][grp] / fC);                 // :37
+        S = s_sum[wave][grp];
         __builtin_amdgcn_wave_barrier();                                        // before the next iteration overwrites s_phi
+        }
+        const int mean_int = (int)rintf(S / fC);                                // :37
         unsigned long long var = 0;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
@@ -943,7 +996,7 @@ IVIT_EXPORT int ivit_layernorm_i16_i8(const int16_t* x, int rows, int C, const f
                  "ivit_layernorm_i16_i8: bad operand");
     int rc = check_map("ivit_layernorm_i16_i8", rows, H, W, ws, shift);
     if (rc) return rc;
-    Ln16Args a{x, rows, C, bias_int, s_ln, m, e, out, ldo, WinMap{H, W, ws, shift}, 0};
+    Ln16Args a{x, rows, C, bias_int, s_ln, m, e, out, ldo, WinMap{H, W, ws, shift}, 0, 0};
     hipStream_t st = ivit_stream(stream);
     const bool tiled = C % 8 == 0 && C <= 1536 && ldo % 8 == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)out % 8 == 0) &&
                        ((uintptr_t)bias_int % 16 == 0) && ((uintptr_t)s_ln % 16 == 0) && ((uintptr_t)m % 16 == 0) &&
@@ -984,7 +1037,7 @@ IVIT_EXPORT int ivit_layernorm_i16_i8_compat(const int16_t* x, int rows, int C, 
     const int outer = fast_division >> 8;     // IVIT_LN_OUTER_MEAN(L)
     fast_division &= 255;
     IVIT_REQUIRE(outer >= 0 && (outer == 0 || rows % outer == 0) && fast_division <= 1, "ivit_layernorm_i16_i8_compat: bad flags");
-    Ln16Args b{x, rows, C, bias_int, s_ln, m, e, out, ldo, WinMap{H, W, ws, shift}, outer};
+    Ln16Args b{x, rows, C, bias_int, s_ln, m, e, out, ldo, WinMap{H, W, ws, shift}, outer, (g_ln_ablate >> 20) & 1};   // lab bit 20: sums through LDS
     hipStream_t st = ivit_stream(stream);
     const bool tiled = fast_division && C % 8 == 0 && C <= 1536 && ldo % 8 == 0 && ((uintptr_t)x % 16 == 0) &&
                        ((uintptr_t)out % 8 == 0) && ((uintptr_t)bias_int % 16 == 0) && ((uintptr_t)s_ln % 16 == 0) &&

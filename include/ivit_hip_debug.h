@@ -42,7 +42,8 @@ int ivit_debug_ln_stamp_buffer(void* buf);
 /* timing ablations of the default int8 LayerNorm kernel (results WRONG when non-zero): 1 no element chain, 2 no row
  * statistics, 4 no stores, 8 no per-workgroup table build; correct results: bits 4-5 = 1 / 2 / 3 force groups of 8 rows (oversubscribed
  * grid) / 16 rows (one resident set of workgroups) / 4 rows, bit 6 odd waves start with half a group, bit 7 + bits 8-11 delayed start of every
- * other workgroup; scripts/ln_ablate.py */
+ * other workgroup; bits 16-19 workgroup cap of the tiled 16-bit LayerNorm (x 256), bit 20 natural-scale 16-bit LayerNorm with its
+ * row sums through LDS (the round-3 form; results stay correct); scripts/ln_ablate.py, scripts/time_swin_kernels.py */
 int ivit_debug_ln_ablate(int bits);
 
 /* (lab library only since round 4: the engines never called it and it is slower than the pair it replaces)

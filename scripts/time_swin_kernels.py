@@ -2,6 +2,9 @@
 import os
 import sys
 
+if "lnc" in sys.argv[1:]:
+    os.environ.setdefault("IVIT_USE_LAB_LIBRARY", "1")
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -46,6 +49,26 @@ if "ln" in which:
             us = timeit(lambda: _lib.call("ivit_layernorm_i16_i8", _lib.ptr(x), rows, C, _lib.ptr(bi), _lib.ptr(sl), _lib.ptr(mm),
                                           _lib.ptr(ee), _lib.ptr(out), C, H, H, ws, sh if H > 7 else 0, st()))
             print(f"ln16 rows={rows:7d} C={C:5d} ws={ws} shift={sh}: {us:8.1f} us  ({3 * rows * C / us / 1e3:7.1f} GB/s algorithmic)", flush=True)
+if "lnc" in which:     # natural-scale 16-bit LayerNorm: registers (product) against the round-3 LDS sums (lab bit 20), interleaved
+    os.environ.setdefault("IVIT_USE_LAB_LIBRARY", "1")
+    for H, C, nH in STAGES:
+        rows = B * H * H
+        x = d(rng.integers(-20000, 20000, size=(rows, C)).astype(np.int16))
+        out = torch.empty(rows, C, dtype=torch.int8, device=DEV)
+        lp = LayerNormParams(rng.uniform(0.5, 1.5, C).astype(np.float32), rng.normal(0, 0.1, C).astype(np.float32), np.float32(2.0 ** -5))
+        bi, sl, mm, ee = d(lp.bias_int), d(lp.s_ln), d(lp.m.view(np.int32)), d(lp.e)
+        res = {}
+        for rnd in range(5):
+            for form in (0, 1 << 20):
+                _lib.call("ivit_debug_ln_ablate", form)
+                us = timeit(lambda: _lib.call("ivit_layernorm_i16_i8_compat", _lib.ptr(x), rows, C, 0.000913, 1, _lib.ptr(bi), _lib.ptr(sl),
+                                              _lib.ptr(mm), _lib.ptr(ee), _lib.ptr(out), C, 0, 0, 0, 0, st()), n=10)
+                res.setdefault(form, []).append(us)
+        _lib.call("ivit_debug_ln_ablate", 0)
+        us = timeit(lambda: _lib.call("ivit_layernorm_i16_i8", _lib.ptr(x), rows, C, _lib.ptr(bi), _lib.ptr(sl), _lib.ptr(mm),
+                                      _lib.ptr(ee), _lib.ptr(out), C, 0, 0, 0, 0, st()), n=10)
+        print(f"ln16 natural rows={rows:7d} C={C:4d}: registers {np.median(res[0]):7.1f} us   LDS sums {np.median(res[1 << 20]):7.1f} us   "
+              f"(power-of-two kernel {us:7.1f} us; {3 * rows * C / np.median(res[0]) / 1e3:7.1f} GB/s algorithmic)", flush=True)
 if "attn" in which:
     for H, C, nH in STAGES:
         nwin = B * (H // 7) ** 2

@@ -663,10 +663,21 @@ def test_swin_natural_scales_engine_equals_module_path():
 
 
 @pytest.mark.parametrize("rows,Cn,s", [(5000, 96, 0.000913), (3001, 192, 0.0004471), (999, 384, 0.00171), (777, 768, 0.000613),
-                                       (130, 1536, 0.0009), (64, 3072, 0.0011)])
-def test_layernorm_i16_natural_scale_random_vs_oracle(rows, Cn, s):
+                                       (130, 1536, 0.0009), (64, 3072, 0.0011), (4099, 128, 0.00077), (2050, 256, 0.0021)])
+@pytest.mark.parametrize("sum_form", ["product", "lab_sums_through_lds"])
+def test_layernorm_i16_natural_scale_random_vs_oracle(rows, Cn, s, sum_form):
     """every LPR / NJ instantiation of the tiled natural-scale kernel (and the literal kernel for C > 1536) against the oracle,
-    whose restatement is pinned by the reference KATs; a third of the rows are exact ties of the mean"""
+    whose restatement is pinned by the reference KATs; a third of the rows are exact ties of the mean.  Round 4: the float32 row
+    sums in torch's order stay in registers (DPP) for C < 512; the lab build keeps the round-3 form (through LDS) for A/B"""
+    if sum_form != "product":
+        with _lib.lab_session():
+            _lib.call("ivit_debug_ln_ablate", 1 << 20)
+            _ln16_natural_random(rows, Cn, s)
+        return
+    _ln16_natural_random(rows, Cn, s)
+
+
+def _ln16_natural_random(rows, Cn, s):
     from ivit_amd.prepare import LayerNormParams, markstein_division_ok
     rng = np.random.default_rng(rows + Cn)
     s = np.float32(s)
