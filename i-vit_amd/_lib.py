@@ -98,6 +98,7 @@ SIGNATURES = {
     "ivit_ibert_layernorm_f32_f32": [vp, i64, ci, ci, vp, ci, vp, vp, f32, vp, i64, vp],
     "ivit_window_attention_i8": [vp, vp, i64, vp, vp, ci, ci, ci, ci, ci, ci, u32, i32, u32, i32, f32, u32, i32, vp],
     "ivit_window_attention_i8_compat": [vp, vp, i64, vp, vp, ci, ci, ci, ci, ci, ci, u32, i32, u32, i32, f32, u32, i32, vp, vp, vp],
+    "ivit_window_attention_i8_band": [vp, vp, i64, vp, vp, ci, ci, ci, ci, ci, u32, i32, u32, i32, f32, u32, i32, vp, ci, ci, ci, ci, ci, ci, vp],
     "ivit_window_attention_i8_unwindow": [vp, vp, i64, vp, vp, ci, ci, ci, ci, ci, ci, u32, i32, u32, i32, f32, u32, i32, vp, vp,
                                           ci, ci, ci, ci, vp],
 }

@@ -734,6 +734,15 @@ struct WinAttnArgs {
     // divides by s), both float32 [256] on the device; NULL: power-of-two scale
     const float* phi;
     const float* phim;
+    // natural scale, table form (round 4): band[(qmax + 128) * band_w + min(qmax - q, band_w - 1)] = Shiftmax's exp_int of the score
+    // q under the row maximum qmax (prepare.shiftexp_band: the float32 sequence of ivit_modules.py:150-170 evaluated on the host for
+    // every pair; entry band_w - 1 is the saturated value).  The host hands this over only when every score under the shift mask
+    // saturates whatever the maximum and no masked score can be the maximum (prepare.window_shiftexp_band): masked scores then take
+    // the saturated entry.  NULL: the literal form above (phi / phim) or the power-of-two form.
+    const unsigned* band;
+    int band_w;
+    const unsigned* band1;  // ... and when the rows of that table do not depend on the maximum (often: prepare.window_shiftexp_band):
+                            // its one row [band_w], used like the power-of-two form's table of distances
     // ws != 0: the output rows go to their IMAGE positions (window reverse + roll back applied here): the projection is
     // row-wise, so attn.proj and the residual QuantAct behind it then need no row map (and fuse into one GEMM)
     WinMap omap;
@@ -745,15 +754,19 @@ constexpr int WVT_ROW = 64;                      // Vt row: 64 key slots
 constexpr int WVT_BYTES = WHD * WVT_ROW;         // 2 KiB per wave
 constexpr int WLUT_OFF = WPB * WVT_BYTES;
 
+constexpr int WBAND_PAD = 4;     // dwords: keeps the slices 16-byte aligned and rotates their banks
+
 __global__ __launch_bounds__(NT) void window_attention_kernel(WinAttnArgs a)
 {
     __shared__ __attribute__((aligned(16))) char smem[WLUT_OFF + 256 * 4];
     __shared__ float s_phi[2][256];
+    extern __shared__ __attribute__((aligned(16))) unsigned band_lds[];     // [4 waves][16 queries][band_w + WBAND_PAD], band form only
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, l15 = lane & 15;
     const int T = a.T;
-    reinterpret_cast<unsigned*>(smem + WLUT_OFF)[tid] = shiftexp_int(-tid, a.x0, 15);
-    const bool compat = a.phi != nullptr;      // uniform
+    reinterpret_cast<unsigned*>(smem + WLUT_OFF)[tid] = a.band1 ? a.band1[min(tid, a.band_w - 1)] : shiftexp_int(-tid, a.x0, 15);
+    const bool band = a.band != nullptr;       // uniform
+    const bool compat = a.phi != nullptr && !band;      // uniform
     if (compat) {
         s_phi[0][tid] = a.phi[tid];
         s_phi[1][tid] = a.phim[tid];
@@ -846,7 +859,7 @@ __global__ __launch_bounds__(NT) void window_attention_kernel(WinAttnArgs a)
                         ka = clamp_i32(requant_exact(kS, a.Mb) + bv[r], -128, 127);              // qact2 (two operands)
                         const bool masked = ((kreg[kt] >> (8 * r)) & 0xffu) != qreg;
                         if (compat) xv[kt][r] = s_phi[masked ? 1 : 0][ka + 128];
-                        if (masked) ka += a.mask_value;                                          // shift mask, after the clamp
+                        if (masked) ka = band ? -50000 : ka + a.mask_value;                      // shift mask, after the clamp
                     }
                     s[kt][r] = ka;
                     rmax = max(rmax, ka);
@@ -875,6 +888,35 @@ __global__ __launch_bounds__(NT) void window_attention_kernel(WinAttnArgs a)
                             const float ex = floorf((rr / 2.0f - x0f) * ldexpf(1.0f, 15 - (int)qq));   // :159-160
                             e = (unsigned)fmaxf(ex, 0.0f);
                         }
+                        s[kt][r] = (int)e;
+                        esum += e;
+                    }
+            } else if (band) {
+                // the band rows of this tile's 16 queries go through LDS (as attention.hip MODE 1): the four lanes of a query copy
+                // its row (band_w dwords, 16 bytes per lane and step), then every score is one LDS gather.  (Gathers straight from
+                // the L2-resident table were as slow as the literal float sequence: profiles/r04m_*.)
+                const int W = a.band_w, W1 = W - 1, stride = W + WBAND_PAD;
+                const int rm = max(rmax, -128);
+                unsigned* slice = band_lds + (wave * 16 + l15) * stride;
+                __builtin_amdgcn_wave_barrier();      // the previous tile's gathers are done
+                {
+                    const uint4* src = reinterpret_cast<const uint4*>(a.band + (size_t)(rm + 128) * W);
+                    uint4* dst = reinterpret_cast<uint4*>(slice);
+                    for (int i = g; i < (W >> 2); i += 4) dst[i] = src[i];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                unsigned ev[4][4];
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ev[kt][r] = slice[min(rm - max(s[kt][r], -50000), W1)];
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const unsigned e = (s[kt][r] == -100000) ? 0u : ev[kt][r];
                         s[kt][r] = (int)e;
                         esum += e;
                     }
@@ -1103,9 +1145,13 @@ static int window_attention_launch(const int8_t* qkv, int8_t* out, int64_t ldo, 
                                    const uint8_t* mask_region, int mask_value, int windows, int windows_per_image,
                                    int heads, int tokens, int head_dim, uint32_t m_s, int32_t e_s, uint32_t m_b,
                                    int32_t e_b, float s_attn, uint32_t m_o, int32_t e_o, const float* phi,
-                                   const float* phi_masked, WinMap omap, ivit_stream_t stream)
+                                   const float* phi_masked, WinMap omap, ivit_stream_t stream, const uint32_t* band = nullptr,
+                                   int band_w = 0, int band_rows = 256)
 {
     IVIT_REQUIRE(qkv && out && bias_add, "ivit_window_attention_i8: NULL operand");
+    // (16 band rows per wave in LDS: 4 x 16 x (192 + 4) dwords = 49 KB beside the kernel's 11 KB stay below the 64 KB of a default launch)
+    IVIT_REQUIRE(band_w == 0 ? band == nullptr : (band && band_w >= 16 && band_w <= 192 && band_w % 16 == 0 && (uintptr_t)band % 16 == 0),
+                 "ivit_window_attention_i8_band: the band table must be 16-byte aligned, its width a multiple of 16 in [16, 192]");
     IVIT_REQUIRE(windows > 0 && heads > 0 && windows_per_image > 0 && windows % windows_per_image == 0,
                  "ivit_window_attention_i8: bad window counts");
     if (head_dim != WHD || tokens < 2 || tokens > 64) {
@@ -1124,6 +1170,10 @@ static int window_attention_launch(const int8_t* qkv, int8_t* out, int64_t ldo, 
     for (int qv = 0; qv < 64 && omap.ws; ++qv)
         IVIT_REQUIRE(((qv * a.omap_inv) >> 16) == qv / omap.ws, "ivit_window_attention_i8_unwindow: window size %d unsupported", omap.ws);
     a.phi = phi; a.phim = phi_masked;
+    IVIT_REQUIRE(band_rows == 256 || band_rows == 1, "ivit_window_attention_i8_band: band_rows must be 256 or 1");
+    a.band = band_rows == 256 ? band : nullptr;
+    a.band1 = band_rows == 1 ? band : nullptr;
+    a.band_w = band_w;
     a.qkv = qkv; a.out = out; a.ldo = ldo; a.bias = bias_add; a.region = mask_region; a.mask_value = mask_value;
     a.nwin = windows; a.heads = heads; a.T = tokens; a.nW = windows_per_image;
     a.Ms = ivit_dyadic_to_double(m_s, e_s);
@@ -1141,9 +1191,14 @@ static int window_attention_launch(const int8_t* qkv, int8_t* out, int64_t ldo, 
         const int d = -i;
         if (d + (d >> 1) - (d >> 4) <= 15 * a.x0) { a.ksat = i; break; }
     }
+    if (a.band1) {      // one row for every maximum: the distance table of the power-of-two form, with the host's values
+        a.ksat = band_w - 1;
+        a.mask_value = -1024;       // a masked score lands beyond the last (saturated) entry whatever the maximum
+    }
     const int npairs = windows * heads;
     const int grid = (npairs + WPB - 1) / WPB;
-    hipLaunchKernelGGL(window_attention_kernel, dim3(grid < 8192 ? grid : 8192), dim3(NT), 0, ivit_stream(stream), a);
+    const size_t band_bytes = a.band ? (size_t)WPB * 16 * (band_w + WBAND_PAD) * sizeof(unsigned) : 0;
+    hipLaunchKernelGGL(window_attention_kernel, dim3(grid < 8192 ? grid : 8192), dim3(NT), band_bytes, ivit_stream(stream), a);
     IVIT_CHECK_LAUNCH("ivit_window_attention_i8");
 }
 
@@ -1155,6 +1210,23 @@ IVIT_EXPORT int ivit_window_attention_i8_compat(const int8_t* qkv, int8_t* out, 
 {
     return window_attention_launch(qkv, out, ldo, bias_add, mask_region, mask_value, windows, windows_per_image, heads, tokens,
                                    head_dim, m_s, e_s, m_b, e_b, s_attn, m_o, e_o, phi, phi_masked, WinMap{0, 0, 0, 0}, stream);
+}
+
+IVIT_EXPORT int ivit_window_attention_i8_band(const int8_t* qkv, int8_t* out, int64_t ldo, const int16_t* bias_add,
+                                              const uint8_t* mask_region, int windows, int windows_per_image, int heads, int tokens,
+                                              int head_dim, uint32_t m_s, int32_t e_s, uint32_t m_b, int32_t e_b, float s_attn,
+                                              uint32_t m_o, int32_t e_o, const uint32_t* band, int band_w, int band_rows, int H, int W,
+                                              int ws, int shift, ivit_stream_t stream)
+{
+    IVIT_REQUIRE(band && band_w > 0, "ivit_window_attention_i8_band: no band table");
+    if (ws)
+        IVIT_REQUIRE(ws > 0 && ws * ws == tokens && H > 0 && W > 0 && H % ws == 0 && W % ws == 0 && shift >= 0 && shift < ws &&
+                         windows_per_image == (H / ws) * (W / ws),
+                     "ivit_window_attention_i8_band: H=%d W=%d ws=%d shift=%d do not describe %d windows of %d tokens per image", H, W, ws,
+                     shift, windows_per_image, tokens);
+    return window_attention_launch(qkv, out, ldo, bias_add, mask_region, 0, windows, windows_per_image, heads, tokens, head_dim, m_s,
+                                   e_s, m_b, e_b, s_attn, m_o, e_o, nullptr, nullptr, ws ? WinMap{H, W, ws, shift} : WinMap{0, 0, 0, 0},
+                                   stream, band, band_w, band_rows);
 }
 
 IVIT_EXPORT int ivit_window_attention_i8_unwindow(const int8_t* qkv, int8_t* out, int64_t ldo, const int16_t* bias_add,

@@ -144,8 +144,10 @@ def shiftexp2d(s, n: int = 15) -> np.ndarray:
         return _shiftexp2d(ph, f32(s), n)
 
 
-def _shiftexp2d(ph, s, n):
-    d = (ph[None, :] - ph[:, None]).astype(f32)                        # :168  x_int - x_int_max
+def _shiftexp2d(ph, s, n, cols=None):
+    """rows: the row maximum phi(qmax); columns: phi(q), or `cols` (the values of scores under Swin's shift mask: every column
+    is then a valid pair, nothing is zeroed)"""
+    d = ((ph if cols is None else cols)[None, :] - ph[:, None]).astype(f32)   # :168  x_int - x_int_max
     x = ((d + np.floor((d / f32(2)).astype(f32))).astype(f32) - np.floor((d / f32(16)).astype(f32))).astype(f32)   # :151
     x0 = np.floor(-(f32(1.0) / f32(s)))                                # :154  floor(-1.0 / s)
     x = np.maximum(x, f32(f32(n) * x0))                                # :155
@@ -154,7 +156,8 @@ def _shiftexp2d(ph, s, n):
     ex = ((r / f32(2)).astype(f32) - x0).astype(f32)                   # :159
     ex = np.floor((ex * np.ldexp(f32(1.0), (f32(n) - qq).astype(np.int32)).astype(f32)).astype(f32))   # :160
     ex = np.maximum(ex, f32(0))
-    ex = np.where(np.arange(256)[None, :] <= np.arange(256)[:, None], ex, f32(0))
+    if cols is None:
+        ex = np.where(np.arange(256)[None, :] <= np.arange(256)[:, None], ex, f32(0))
     assert np.isfinite(ex).all() and ex.max() < 2.0 ** 32
     return ex.astype(np.uint32)
 
@@ -177,6 +180,36 @@ def shiftexp_band(tab2d: np.ndarray):
     band = np.where(q >= 0, tab2d[idx[:, None], np.clip(q, 0, 255)], np.uint32(sat)).astype(np.uint32)
     assert np.all(band[:, W - 1] == sat)
     return np.ascontiguousarray(band), W
+
+
+def window_shiftexp_band(s, masked: bool):
+    """Band table for the Swin window-attention kernel at a natural Shiftmax input scale s (ivit_window_attention_i8_band), or
+    (None, 0) when the literal float sequence has to run.  -> (band uint32 [256, W] or [1, W], W): one row when every valid
+    entry of a column (q = qmax - j >= -128) has the same value, i.e. exp_int depends on the distance to the maximum alone (true
+    for many scales: the float32 floors flip for few (qmax, q) pairs or none); band.shape[0] is the entry point's band_rows.  Unmasked scores see phi(q) = fl(fl(q*s)/s); scores under the shift
+    mask see phi_m(q) = fl(fl(fl(q*s) - 100)/s) (swin_quant.py:151-156, ivit_modules.py:165).  The table form needs, when a mask
+    is present: (a) no masked value can be the row maximum -- every query attends to itself unmasked, so max(phi_m) < min(phi)
+    is enough; (b) every masked score's exp_int is the saturated value whatever the (unmasked) maximum: checked on all 256 x 256
+    pairs with the same float32 sequence that builds the table."""
+    s = f32(s)
+    tab = shiftexp2d(s)
+    band, W = shiftexp_band(tab)
+    if band is None or W > 192:            # the kernel keeps 16 band rows per wave in LDS: widths up to 192
+        return None, 0
+    if masked:
+        ph = phi_table(s)
+        qv = np.arange(-128, 128, dtype=f32)
+        phm = ((((qv * s).astype(f32) + f32(-100.0)).astype(f32)) / s).astype(f32)
+        if not phm.max() < ph.min():
+            return None, 0
+        with np.errstate(over="ignore", invalid="ignore"):
+            em = _shiftexp2d(ph, s, 15, cols=phm)
+        if not np.all(em == tab[255, 0]):
+            return None, 0
+    valid = (np.arange(256)[:, None] - np.arange(W)[None, :]) >= 0
+    if np.all((band == band[255][None, :]) | ~valid):
+        return np.ascontiguousarray(band[255:256]), W
+    return band, W
 
 
 def markstein_division_ok(s, bits: int = 16) -> bool:

@@ -22,7 +22,7 @@ import torch
 
 from . import _lib
 from .graph import GraphReplay
-from .prepare import (IMAGENET_MEAN, IMAGENET_STD, LayerNormParams, LinearParams, dyadic, f32, input_lut_u8, markstein_division_ok, pad_head, phi_is_identity, phi_table,
+from .prepare import (IMAGENET_MEAN, IMAGENET_STD, LayerNormParams, LinearParams, dyadic, f32, input_lut_u8, markstein_division_ok, pad_head, phi_is_identity, phi_table, window_shiftexp_band,
                       phi_tables, quant_sym,
                       requant_host, sym_scale)
 from .synth import IMG_SIZE
@@ -201,14 +201,19 @@ class IntSwinEngine(GraphReplay):
                         mask_value = int(mval)
                     region = np.zeros(((H // win) * (W // win), 64), np.uint8)
                     region[:, :N] = shift_mask_regions(H, W, win, shift)
+                band, band_w = (None, 0)
                 if att_nat:
                     self.natural_sites += 1
+                    # table form of the natural-scale Shiftmax where it is provably what the reference computes (every masked score
+                    # saturated, no masked row maximum); else the kernel's literal float sequence on phi / phi_m
+                    band, band_w = window_shiftexp_band(s_A, bool(shift))
                 s_pv = f32(f32(1.0 / 128.0) * s_a1)
                 s_a3 = s(p + "attn.qact3")
                 blk["attn"] = dict(ms=sme(s_S, s_at), mb=sme(s_at, s_A), s_attn=float(s_A), mo=sme(s_pv, s_a3),
                                    bias=dev(bias_pad), region=None if region is None else dev(region),
                                    mask_value=mask_value, nW=(H // win) * (W // win),
-                                   phi=dev(phi_table(s_A)) if att_nat else None, phim=dev(phi_m) if att_nat else None)
+                                   phi=dev(phi_table(s_A)) if att_nat else None, phim=dev(phi_m) if att_nat else None,
+                                   band=None if band is None else dev(band), band_w=band_w)
                 lp, d = lin_host(p + "attn.proj", s_a3)
                 s_a4 = s(p + "attn.qact4", 16)
                 mp, ep = dyadic(lp.s_acc, s_a4)
@@ -403,7 +408,12 @@ class IntSwinEngine(GraphReplay):
                     taps[p + "attn.qact1"] = hm.permute(1, 3, 0, 2, 4).reshape(nwin, N, 3 * C).clone()
                 a = blk["attn"]
                 fuse_proj = self.proj_fused and taps is None
-                if fuse_proj:
+                if a["band"] is not None:
+                    _lib.call("ivit_window_attention_i8_band", _lib.ptr(ws["qkv"]), _lib.ptr(ws["ao"]), ld, _lib.ptr(a["bias"]),
+                              _lib.ptr(a["region"]), nwin, a["nW"], nH, N, HEAD_DIM, a["ms"][0], a["ms"][1], a["mb"][0], a["mb"][1],
+                              a["s_attn"], a["mo"][0], a["mo"][1], _lib.ptr(a["band"]), a["band_w"], int(a["band"].shape[0]), H, W,
+                              win if fuse_proj else 0, shift, st)
+                elif fuse_proj:
                     # the attention output goes straight to its image rows (window reverse + roll back in the store address):
                     # attn.proj + attn.qact4 + the residual QuantAct qact2 are then ONE GEMM, in place on the residual stream
                     _lib.call("ivit_window_attention_i8_unwindow", _lib.ptr(ws["qkv"]), _lib.ptr(ws["ao"]), ld, _lib.ptr(a["bias"]),

@@ -455,6 +455,19 @@ int ivit_window_attention_i8_compat(const int8_t* qkv, int8_t* out, int64_t ldo,
                                     int tokens, int head_dim, uint32_t m_s, int32_t e_s, uint32_t m_b, int32_t e_b,
                                     float s_attn, uint32_t m_o, int32_t e_o, const float* phi, const float* phi_masked,
                                     ivit_stream_t stream);
+/* Natural scale, table form (round 4): Shiftmax's exp_int of a score q under the row maximum qmax is read from
+ * band[(qmax + 128) * band_w + min(qmax - q, band_w - 1)] (uint32 [256][band_w] on the device, band_w a multiple of 16 in [16, 192],
+ * 16-byte aligned; prepare.shiftexp_band: the float32 sequence of ivit_modules.py:150-170 evaluated for every pair on the host, as
+ * ivit_attention_fused_i8_compat_band does for ViT).  Scores under the shift mask take the saturated entry band_w - 1: the caller
+ * hands the table over only when that is what the reference computes for every masked score and no masked score can be a row
+ * maximum (prepare.window_shiftexp_band checks both; otherwise the literal form above runs).  band_rows = 256, or 1 when the rows
+ * of the table do not depend on the maximum (the host compares them): `band` is then that one row [band_w] and the kernel runs
+ * exactly as at a power-of-two scale, on these values.  ws != 0: output rows at their image positions as in
+ * ivit_window_attention_i8_unwindow (H, W, ws, shift); ws == 0: window order. */
+int ivit_window_attention_i8_band(const int8_t* qkv, int8_t* out, int64_t ldo, const int16_t* bias_add, const uint8_t* mask_region,
+                                  int windows, int windows_per_image, int heads, int tokens, int head_dim, uint32_t m_s, int32_t e_s,
+                                  uint32_t m_b, int32_t e_b, float s_attn, uint32_t m_o, int32_t e_o, const uint32_t* band,
+                                  int band_w, int band_rows, int H, int W, int ws, int shift, ivit_stream_t stream);
 /* The same with the output rows at their IMAGE positions: window_reverse and the roll back (swin_quant.py:278-287) applied to
  * the row index here, `out` [batch * H * W, heads * head_dim].  attn.proj is row-wise, so it and the residual QuantAct behind it
  * then work on image-ordered rows without a map (ivit_gemm_i8_requant_i16_residual_i16_ex).  tokens == ws * ws, windows_per_image

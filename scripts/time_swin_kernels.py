@@ -83,6 +83,39 @@ if "attn" in which:
                                           (H // 7) ** 2, nH, 49, 32, int(ms[0]), int(es[0]), 1 << 30, 30, 0.25, int(mo[0]), int(eo[0]), st()))
             print(f"window attention windows={nwin:5d} heads={nH:2d} mask={mk is not None}: {us:8.1f} us  "
                   f"({4 * nwin * 49 * C / us / 1e3:7.1f} GB/s algorithmic, {4 * nwin * nH * 49 * 49 * 32 / us / 1e6:6.1f} TOPS)", flush=True)
+if "attnc" in which:     # natural-scale window attention: literal float Shiftmax (round 3) against the band table (round 4); power-of-two beside
+    from ivit_amd.prepare import window_shiftexp_band
+    s_at = np.float32(0.271)
+    qv = np.arange(-128, 128, dtype=np.float32)
+    phi = d(((qv * s_at).astype(np.float32) / s_at).astype(np.float32))
+    phim = d(((((qv * s_at).astype(np.float32) + np.float32(-100.0)).astype(np.float32)) / s_at).astype(np.float32))
+    band, bw = window_shiftexp_band(s_at, True)
+    bandd = d(band)                                     # one row at this scale
+    band256 = d(np.repeat(band, 256, axis=0)) if band.shape[0] == 1 else bandd
+    for H, C, nH in STAGES:
+        nwin = B * (H // 7) ** 2
+        qkv = d(np.clip(np.rint(rng.normal(0, 40, size=(3, nwin, nH, 49, 32))), -128, 127).astype(np.int8))
+        out = torch.empty(nwin * 49, C, dtype=torch.int8, device=DEV)
+        bias = d(rng.integers(-60, 61, size=(nH, 49, 64)).astype(np.int16))
+        mask = d(rng.integers(0, 3, size=((H // 7) ** 2, 64)).astype(np.uint8))
+        ms, es = dyadic(np.float32(2.0 ** -9), s_at)
+        mb, eb = dyadic(s_at * np.float32(0.75), s_at)
+        mo, eo = dyadic(np.float32(2.0 ** -11), np.float32(2.0 ** -3))
+        r = {"lit": [], "band": [], "band256": [], "pow2": []}
+        for rnd in range(5):
+            r["lit"].append(timeit(lambda: _lib.call("ivit_window_attention_i8_compat", _lib.ptr(qkv), _lib.ptr(out), C, _lib.ptr(bias), _lib.ptr(mask), -1,
+                                                     nwin, (H // 7) ** 2, nH, 49, 32, int(ms[0]), int(es[0]), int(mb[0]), int(eb[0]), float(s_at),
+                                                     int(mo[0]), int(eo[0]), _lib.ptr(phi), _lib.ptr(phim), st()), n=10))
+            r["band"].append(timeit(lambda: _lib.call("ivit_window_attention_i8_band", _lib.ptr(qkv), _lib.ptr(out), C, _lib.ptr(bias), _lib.ptr(mask),
+                                                      nwin, (H // 7) ** 2, nH, 49, 32, int(ms[0]), int(es[0]), int(mb[0]), int(eb[0]), float(s_at),
+                                                      int(mo[0]), int(eo[0]), _lib.ptr(bandd), bw, band.shape[0], 0, 0, 0, 0, st()), n=10))
+            r["band256"].append(timeit(lambda: _lib.call("ivit_window_attention_i8_band", _lib.ptr(qkv), _lib.ptr(out), C, _lib.ptr(bias), _lib.ptr(mask),
+                                                         nwin, (H // 7) ** 2, nH, 49, 32, int(ms[0]), int(es[0]), int(mb[0]), int(eb[0]), float(s_at),
+                                                         int(mo[0]), int(eo[0]), _lib.ptr(band256), bw, 256, 0, 0, 0, 0, st()), n=10))
+            r["pow2"].append(timeit(lambda: _lib.call("ivit_window_attention_i8", _lib.ptr(qkv), _lib.ptr(out), C, _lib.ptr(bias), _lib.ptr(mask), -400, nwin,
+                                                      (H // 7) ** 2, nH, 49, 32, int(ms[0]), int(es[0]), 1 << 30, 30, 0.25, int(mo[0]), int(eo[0]), st()), n=10))
+        print(f"window attention windows={nwin:5d} heads={nH:2d} masked, natural scale s={float(s_at)}: literal {np.median(r['lit']):7.1f} us   "
+              f"band table (W={bw}, {band.shape[0]} row) {np.median(r['band']):7.1f} us   256 rows through LDS {np.median(r['band256']):7.1f} us   power-of-two form {np.median(r['pow2']):7.1f} us", flush=True)
 if "res" in which:
     for H, C, nH in STAGES:
         rows = B * H * H

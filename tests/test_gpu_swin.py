@@ -574,7 +574,8 @@ def test_layernorm_i16_natural_scale_kat(golden_dir):
 
 
 @pytest.mark.parametrize("B_,nW,nH,N,s_attn,masked", [(8, 4, 3, 49, 0.271, True), (6, 1, 6, 49, 0.1173, False),
-                                                      (4, 4, 2, 16, 1.3, True), (3, 1, 4, 49, 0.25, True)])
+                                                      (4, 4, 2, 16, 1.3, True), (3, 1, 4, 49, 0.25, True), (8, 4, 2, 49, 0.0613, True),
+                                                      (4, 2, 3, 49, 0.3391, True)])
 def test_window_attention_natural_scale(B_, nW, nH, N, s_attn, masked):
     """the literal Shiftmax inside the window-attention kernel (phi tables, float shift mask) vs the oracle composition; the
     last case has a power-of-two scale with a non-integer -100/s ... which is still an integer there: covers phi = identity"""
@@ -615,6 +616,40 @@ def test_window_attention_natural_scale(B_, nW, nH, N, s_attn, masked):
     got = out.cpu().numpy().astype(np.int32).reshape(B_, N, nH * hd)
     assert np.array_equal(got, ref), f"{(got != ref).sum()} of {got.size} differ"
     assert Pm.max() > 0
+    # round 4: the table form (exp_int of every (row max, score) pair from the host) where the host can prove it equal
+    from ivit_amd.prepare import window_shiftexp_band
+    band, bw = window_shiftexp_band(s_at, masked)
+    assert (band is None) == (s_attn == 1.3), "s = 1.3: -100 / s = -77 does not push masked scores below every unmasked one"
+    if band is not None:
+        assert bw % 16 == 0 and np.all(band[:, bw - 1] == band[0, bw - 1]) and band.shape[0] in (1, 256)
+        # 0.271 and 0.25: exp_int depends on the distance to the maximum alone (one row); 0.1173, 0.0613, 0.3391: 256 rows
+        assert (band.shape[0] == 1) == (s_attn in (0.271, 0.25)), band.shape
+        out_b = torch.zeros(B_ * N, ld, dtype=torch.int8, device=DEV)
+        _lib.call("ivit_window_attention_i8_band", _lib.ptr(dev(qkv)), _lib.ptr(out_b), ld, _lib.ptr(dev(bias_pad)),
+                  _lib.ptr(None if region is None else dev(region)), B_, nW, nH, N, hd, ms[0], ms[1], mb[0], mb[1], float(s_at),
+                  mo[0], mo[1], _lib.ptr(dev(band)), bw, band.shape[0], 0, 0, 0, 0, st())
+        gb = out_b.cpu().numpy().astype(np.int32).reshape(B_, N, nH * hd)
+        assert np.array_equal(gb, ref), f"band form: {(gb != ref).sum()} of {gb.size} differ"
+        if band.shape[0] == 1:      # the same values as 256 identical rows: the per-maximum form of the kernel
+            out_r = torch.zeros(B_ * N, ld, dtype=torch.int8, device=DEV)
+            _lib.call("ivit_window_attention_i8_band", _lib.ptr(dev(qkv)), _lib.ptr(out_r), ld, _lib.ptr(dev(bias_pad)),
+                      _lib.ptr(None if region is None else dev(region)), B_, nW, nH, N, hd, ms[0], ms[1], mb[0], mb[1], float(s_at),
+                      mo[0], mo[1], _lib.ptr(dev(np.repeat(band, 256, axis=0))), bw, 256, 0, 0, 0, 0, st())
+            assert np.array_equal(out_r.cpu().numpy(), out_b.cpu().numpy())
+        ws_ = int(round(np.sqrt(N)))
+        if ws_ * ws_ == N and B_ % nW == 0:      # image-ordered rows, as the engine's fused projection wants them
+            from ivit_amd.swin_engine import window_row_map
+            gh, gw = {1: (1, 1), 2: (1, 2), 4: (2, 2)}[nW]
+            H, W = gh * ws_, gw * ws_
+            out2 = torch.zeros(B_ * N, ld, dtype=torch.int8, device=DEV)
+            _lib.call("ivit_window_attention_i8_band", _lib.ptr(dev(qkv)), _lib.ptr(out2), ld, _lib.ptr(dev(bias_pad)),
+                      _lib.ptr(None if region is None else dev(region)), B_, nW, nH, N, hd, ms[0], ms[1], mb[0], mb[1], float(s_at),
+                      mo[0], mo[1], _lib.ptr(dev(band)), bw, band.shape[0], H, W, ws_, ws_ // 2, st())
+            dst = window_row_map(B_ // nW, H, W, ws_, ws_ // 2)
+            assert np.array_equal(out2.cpu().numpy(), out_b.cpu().numpy()[dst])
+        with pytest.raises(_lib.IvitError, match="band table"):
+            _lib.call("ivit_window_attention_i8_band", _lib.ptr(dev(qkv)), _lib.ptr(out_b), ld, _lib.ptr(dev(bias_pad)), None, B_, nW, nH, N,
+                      hd, ms[0], ms[1], mb[0], mb[1], float(s_at), mo[0], mo[1], _lib.ptr(dev(band)), bw + 3, band.shape[0], 0, 0, 0, 0, st())
 
 
 def test_swin_natural_scales_engine_equals_module_path():
