@@ -451,6 +451,8 @@ __global__ __launch_bounds__(NT) void layernorm_i16_i8_tiled_compat_kernel(Ln16A
     const int sub = lane & (LPR - 1), grp = lane / LPR;
     const int C = a.C, nd = C >> 3;
     const bool regsum = a.outer == 0 && nd == LPR * NJ && !(IVIT_LAB && a.lab_lds_sum);     // uniform
+    // transposed view: groups of 16 need C < 256 (no second-level fold) and no tail columns (outer % 32 == 0: rowsum.h)
+    const bool regouter = a.outer != 0 && (a.outer & 31) == 0 && nd == LPR * NJ && C < 256 && !(IVIT_LAB && a.lab_lds_sum);
     // bias and the float32 bracket (lo, hi) of each channel's QuantAct multiplier: see layernorm_i8_kernel (rowops.hip) for
     // the certificate that replaces the literal float64 tail of the chain; uncertified wave-iterations are redone literally
     float bias[NJ][8], lo[NJ][8], hi[NJ][8];
@@ -519,7 +521,41 @@ __global__ __launch_bounds__(NT) void layernorm_i16_i8_tiled_compat_kernel(Ln16A
             }
         }
         float S;
-        if (REGSUM && regsum) {
+        if (REGSUM && regouter) {
+            // The reference's mean over the TRANSPOSED view (a.outer, every LayerNorm of Swin stage 0): torch's outer reduction adds a
+            // row's elements in sequence, 16 at a time, and the group sums in sequence (rowsum.h torch_cascade_sum: no second-level
+            // fold below 256 elements).  A group is two chunks of 8 = the chunks j of an even lane and its odd neighbour: the even
+            // lane adds its 8, the odd lane CONTINUES that sum with its own 8; the group sums sit on the odd lanes and are added in
+            // the order (j, lane) by the group's first lane.
+            float gsum[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                float p = ph[j][0];
+#pragma unroll
+                for (int c = 1; c < 8; ++c) p += ph[j][c];
+                float q = dpp_f32<0xa0>(p);                         // quad_perm [0,0,2,2]: the even neighbour's partial sum
+#pragma unroll
+                for (int c = 0; c < 8; ++c) q += ph[j][c];
+                gsum[j] = q;                                        // meaningful on odd lanes
+            }
+            float fin = 0.f;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int o = 1; o < LPR; o += 2) {
+                    float t = gsum[j];
+                    if (o == 1) t = dpp_f32<0x101>(t);              // row_shl:o -- lane l reads lane l + o
+                    if (o == 3) t = dpp_f32<0x103>(t);
+                    if (o == 5) t = dpp_f32<0x105>(t);
+                    if (o == 7) t = dpp_f32<0x107>(t);
+                    if (o == 9) t = dpp_f32<0x109>(t);
+                    if (o == 11) t = dpp_f32<0x10b>(t);
+                    if (o == 13) t = dpp_f32<0x10d>(t);
+                    if (o == 15) t = dpp_f32<0x10f>(t);
+                    fin = (j == 0 && o == 1) ? t : fin + t;
+                }
+            S = __shfl(fin, lane & ~(LPR - 1));
+        } else if (REGSUM && regsum) {
             // torch's order without leaving the registers.  C = 8 LPR NJ < 512: 32 vector lanes p = e mod 32 each add their C / 32
             // elements in sequence (no cascade fold below 16 steps), the 8 lanes of a vector are ((a[l] + a[l+8]) + a[l+16]) + a[l+24],
             // the 8 results are added in sequence (rowsum.h).  Element e = 8 d + c of chunk d = sub + LPR j is vector lane

@@ -122,6 +122,7 @@ class IntSwinEngine(GraphReplay):
         self.proj_fused = True     # attention output in image order + attn.proj / attn.qact4 / qact2 in one GEMM (False: A/B, tests)
         self.proj_i16 = True       # attn.proj writes the 16-bit attn.qact4 output instead of raw accumulators
         self.natural_sites = 0     # operators whose input scale is not a power of two: literal / table-driven kernels
+        self.window_softmax_forms = []     # per natural-scale attention block: "band1xW" / "band256xW" / "literal" (prepare.window_shiftexp_band)
 
         def ln_dev(prefix, s_out, s_in, bits_in=16):
             """s_in: scale of the LayerNorm's input.  If fl(fl(q*s_in)/s_in) != q for some q of that width, the reference's
@@ -207,6 +208,7 @@ class IntSwinEngine(GraphReplay):
                     # table form of the natural-scale Shiftmax where it is provably what the reference computes (every masked score
                     # saturated, no masked row maximum); else the kernel's literal float sequence on phi / phi_m
                     band, band_w = window_shiftexp_band(s_A, bool(shift))
+                    self.window_softmax_forms.append("literal" if band is None else f"band{band.shape[0]}x{band_w}")
                 s_pv = f32(f32(1.0 / 128.0) * s_a1)
                 s_a3 = s(p + "attn.qact3")
                 blk["attn"] = dict(ms=sme(s_S, s_at), mb=sme(s_at, s_A), s_attn=float(s_A), mo=sme(s_pv, s_a3),

@@ -60,8 +60,11 @@ def run(cid, steps=20, warmup=5, graph=False, batch=None):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / steps
     ips = B / ms * 1e3
-    print(json.dumps({"config": cid, "model": tag, "batch": B, "hip_graph": graph, "ms_per_forward": round(ms, 3), "images_per_s": round(ips, 1),
-                      "int8_tops": round(ips * GMAC[tag] * 2e9 / 1e12, 1)}), flush=True)
+    line = {"config": cid, "model": tag, "batch": B, "hip_graph": graph, "ms_per_forward": round(ms, 3), "images_per_s": round(ips, 1),
+            "int8_tops": round(ips * GMAC[tag] * 2e9 / 1e12, 1)}
+    if getattr(eng, "window_softmax_forms", None):      # natural scales: table or literal Shiftmax per attention block
+        line["window_softmax_forms"] = eng.window_softmax_forms
+    print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

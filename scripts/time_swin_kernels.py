@@ -67,6 +67,15 @@ if "lnc" in which:     # natural-scale 16-bit LayerNorm: registers (product) aga
         _lib.call("ivit_debug_ln_ablate", 0)
         us = timeit(lambda: _lib.call("ivit_layernorm_i16_i8", _lib.ptr(x), rows, C, _lib.ptr(bi), _lib.ptr(sl), _lib.ptr(mm),
                                       _lib.ptr(ee), _lib.ptr(out), C, 0, 0, 0, 0, st()), n=10)
+        if C == 96:      # stage 0: the transposed-view order (every LayerNorm of the stage)
+            ro = {}
+            for rnd in range(5):
+                for form in (0, 1 << 20):
+                    _lib.call("ivit_debug_ln_ablate", form)
+                    ro.setdefault(form, []).append(timeit(lambda: _lib.call("ivit_layernorm_i16_i8_compat", _lib.ptr(x), rows, C, 0.000913, 1 | ((H * H) << 8),
+                                                                            _lib.ptr(bi), _lib.ptr(sl), _lib.ptr(mm), _lib.ptr(ee), _lib.ptr(out), C, 0, 0, 0, 0, st()), n=10))
+            _lib.call("ivit_debug_ln_ablate", 0)
+            print(f"ln16 natural rows={rows:7d} C={C:4d} outer-reduction order: registers {np.median(ro[0]):7.1f} us   LDS sums {np.median(ro[1 << 20]):7.1f} us", flush=True)
         print(f"ln16 natural rows={rows:7d} C={C:4d}: registers {np.median(res[0]):7.1f} us   LDS sums {np.median(res[1 << 20]):7.1f} us   "
               f"(power-of-two kernel {us:7.1f} us; {3 * rows * C / np.median(res[0]) / 1e3:7.1f} GB/s algorithmic)", flush=True)
 if "attn" in which:

@@ -741,6 +741,49 @@ def _ln16_natural_random(rows, Cn, s):
     assert np.array_equal(got, exp), f"{(got != exp).sum()} of {got.size} differ"
 
 
+@pytest.mark.parametrize("rows,Cn,outer,s", [(6272, 96, 3136, 0.000913), (4096, 64, 64, 0.00171), (2048, 128, 1024, 0.0004471),
+                                             (1280, 192, 320, 0.00077), (3136, 96, 49, 0.000913)])
+def test_layernorm_i16_natural_outer_order_register_form_equals_lds_form(rows, Cn, outer, s):
+    """Swin stage 0: the mean over the patch embedding's transposed view (IVIT_LN_OUTER_MEAN: torch's outer-reduction order).  Round 4
+    keeps that sum in registers (groups of 16 in sequence across a lane pair, DPP) when the extent has no tail columns (outer % 32
+    == 0) and C < 256; the round-3 form (a lane sums a row serially from LDS: pinned by the reference's end-to-end goldens, 69
+    exact-tie rows) stays in the lab build and for outer = 49.  Half of the rows here are exact ties of the mean."""
+    from ivit_amd.prepare import LayerNormParams, markstein_division_ok
+    rng = np.random.default_rng(rows + Cn + outer)
+    s = np.float32(s)
+    assert markstein_division_ok(s, 16)
+    q = np.clip(np.rint(rng.normal(rng.normal(0, 2000, size=(rows, 1)), rng.uniform(500, 8000, size=(rows, 1)), size=(rows, Cn))),
+                -32768, 32767).astype(np.int32)
+    for r in range(0, rows, 2):
+        d = Cn // 2 + Cn * int(rng.integers(-100, 100)) - int(q[r].sum())
+        for c in rng.permutation(Cn):
+            if d == 0:
+                break
+            nv = int(np.clip(q[r, c] + d, -32768, 32767))
+            d -= nv - q[r, c]
+            q[r, c] = nv
+    lp = LayerNormParams(rng.uniform(0.5, 1.5, size=Cn).astype(np.float32), rng.normal(0, 0.1, size=Cn).astype(np.float32), np.float32(0.031))
+    qd = dev(q.astype(np.int16))
+
+    def run():
+        out = torch.empty(rows, Cn, dtype=torch.int8, device=DEV)
+        _lib.call("ivit_layernorm_i16_i8_compat", _lib.ptr(qd), rows, Cn, float(s), 1 | (outer << 8), _lib.ptr(dev(lp.bias_int)),
+                  _lib.ptr(dev(lp.s_ln)), _lib.ptr(dev(lp.m.view(np.int32))), _lib.ptr(dev(lp.e)), _lib.ptr(out), Cn, 0, 0, 0, 0, st())
+        return out.cpu().numpy()
+
+    got = run()
+    with _lib.lab_session():
+        _lib.call("ivit_debug_ln_ablate", 1 << 20)
+        ref = run()
+    assert np.array_equal(got, ref), f"{(got != ref).sum()} of {got.size} differ"
+    # and the order matters on this data: the contiguous-row order gives other bytes on some tie rows
+    out_c = torch.empty(rows, Cn, dtype=torch.int8, device=DEV)
+    _lib.call("ivit_layernorm_i16_i8_compat", _lib.ptr(qd), rows, Cn, float(s), 1, _lib.ptr(dev(lp.bias_int)), _lib.ptr(dev(lp.s_ln)),
+              _lib.ptr(dev(lp.m.view(np.int32))), _lib.ptr(dev(lp.e)), _lib.ptr(out_c), Cn, 0, 0, 0, 0, st())
+    if Cn >= 96:
+        assert (out_c.cpu().numpy() != got).any()
+
+
 def test_swin_uint8_input_equals_the_float_pipeline():
     """uint8 pixels (3 x 256 table of ToTensor + Normalize + the input QuantAct, 4 x 4 patches with the K padding) == the float32
     images the data pipeline would hand over: INT32 logits"""
