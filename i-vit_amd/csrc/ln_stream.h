@@ -35,51 +35,7 @@ IVIT_DEV int ln_row_allreduce(int v)
     return v;
 }
 
-// ivit_modules.py:45-52 for 0 <= var < 2^24 (8-bit inputs, C <= 1024: SURVEY Appendix A.5): ten steps
-// t <- floor((t + floor(var / t)) / 2) from t = 2^16, then floor(2^31 / t) / 2, all in float32 as the reference.
-// floor(fl(var / t)) == floor(var / t) exactly there (a non-integer quotient is at least 1/t below the next integer and
-// var < 2^24), so the IEEE division may be replaced by any exact integer quotient.  t >= 2^(16-k) >= 64 in step k (each step
-// at most halves t), so var / t < 2^18 and var * rcp(t) (rcp: 1 ulp) is within 2^-4 of it: its floor is off by at most one,
-// and r = fma(-q, t, var) is exact (|r| <= 2t, an integer), which tells which way.
-IVIT_DEV float ln_newton10(float varf)
-{
-    float t = 65536.0f;
-#pragma unroll
-    for (int it = 0; it < 10; ++it) {
-        float q = floorf(varf * __builtin_amdgcn_rcpf(t));
-        const float r = __builtin_fmaf(-q, t, varf);
-        q = (r >= t) ? q + 1.0f : q;
-        q = (r < 0.0f) ? q - 1.0f : q;
-        t = floorf((t + q) * 0.5f);
-    }
-    return t;
-}
-
-// The ten steps WITHOUT iterating, where that is provably the same (checked for every var in [0, 2^24) against the float32
-// recurrence: scripts/probes/ln_newton_exhaustive.py): for var >= LN_NEWTON_CONVERGED the recurrence has converged to
-// s = floor(sqrt(var)) by step ten, except when var + 1 is a perfect square, where it alternates between s and s + 1.
-// Those rows (about one in 2 s) and rows with a small variance take the literal loop -- wave-uniformly, any lane.
-// s from v_sqrt_f32 (1 ulp) with an exact remainder fix-up (s * s and var are integers below 2^24: the fma is exact).
-constexpr float LN_NEWTON_CONVERGED = 142883.0f;
-IVIT_DEV float ln_std10(int var)
-{
-    const float varf = (float)var;
-    float s = floorf(__builtin_amdgcn_sqrtf(varf));
-    float r = __builtin_fmaf(-s, s, varf);                  // var - s^2
-    // s one too large (r < 0) / one too small (r > 2 s): step d = -1 / +1 / 0, then r' = var - (s + d)^2 = r - d (2 s + d)
-    const float d = (r < 0.0f ? -1.0f : 0.0f) + (r > 2.0f * s ? 1.0f : 0.0f);
-    r = __builtin_fmaf(-d, 2.0f * s + d, r);
-    s += d;
-    const bool slow = varf < LN_NEWTON_CONVERGED || r == 2.0f * s;     // var + 1 == (s + 1)^2
-    if (__builtin_amdgcn_ballot_w64(slow) != 0) return ln_newton10(varf);
-    return s;
-}
-
-IVIT_DEV float ln_hfactor_small(int var)
-{
-    const float t = ln_std10(var);
-    return floorf((1.0f / t) * 2147483648.0f) * 0.5f;    // :51-52 (the /2 of :52 is an exact scaling)
-}
+// (ln_newton10 / ln_std10 / ln_hfactor_small: rowops.hip, beside ln_factor -- the half-wave kernel uses them too)
 
 // torch's float32 row sum (rowops.hip torch_rowsum_phi, inner-dimension form) over a row addressed through `get(i)`
 template <typename GET>

@@ -94,6 +94,53 @@ IVIT_DEV float ln_factor(long long var)
     return floorf((1.0f / t) * 2147483648.0f);
 }
 
+// ivit_modules.py:45-52 for 0 <= var < 2^24 (8-bit inputs, C <= 1024: SURVEY Appendix A.5): ten steps
+// t <- floor((t + floor(var / t)) / 2) from t = 2^16, then floor(2^31 / t) / 2, all in float32 as the reference.
+// floor(fl(var / t)) == floor(var / t) exactly there (a non-integer quotient is at least 1/t below the next integer and
+// var < 2^24), so the IEEE division may be replaced by any exact integer quotient.  t >= 2^(16-k) >= 64 in step k (each step
+// at most halves t), so var / t < 2^18 and var * rcp(t) (rcp: 1 ulp) is within 2^-4 of it: its floor is off by at most one,
+// and r = fma(-q, t, var) is exact (|r| <= 2t, an integer), which tells which way.
+IVIT_DEV float ln_newton10(float varf)
+{
+    float t = 65536.0f;
+#pragma unroll
+    for (int it = 0; it < 10; ++it) {
+        float q = floorf(varf * __builtin_amdgcn_rcpf(t));
+        const float r = __builtin_fmaf(-q, t, varf);
+        q = (r >= t) ? q + 1.0f : q;
+        q = (r < 0.0f) ? q - 1.0f : q;
+        t = floorf((t + q) * 0.5f);
+    }
+    return t;
+}
+
+// The ten steps WITHOUT iterating, where that is provably the same (checked for every var in [0, 2^24) against the float32
+// recurrence: scripts/probes/ln_newton_exhaustive.py): for var >= LN_NEWTON_CONVERGED the recurrence has converged to
+// s = floor(sqrt(var)) by step ten, except when var + 1 is a perfect square, where it alternates between s and s + 1.
+// Those rows (about one in 2 s) and rows with a small variance take the literal loop -- wave-uniformly, any lane.
+// s from v_sqrt_f32 (1 ulp) with an exact remainder fix-up (s * s and var are integers below 2^24: the fma is exact).
+constexpr float LN_NEWTON_CONVERGED = 142883.0f;
+IVIT_DEV float ln_std10(int var)
+{
+    const float varf = (float)var;
+    float s = floorf(__builtin_amdgcn_sqrtf(varf));
+    float r = __builtin_fmaf(-s, s, varf);                  // var - s^2
+    // s one too large (r < 0) / one too small (r > 2 s): step d = -1 / +1 / 0, then r' = var - (s + d)^2 = r - d (2 s + d)
+    const float d = (r < 0.0f ? -1.0f : 0.0f) + (r > 2.0f * s ? 1.0f : 0.0f);
+    r = __builtin_fmaf(-d, 2.0f * s + d, r);
+    s += d;
+    const bool slow = varf < LN_NEWTON_CONVERGED || r == 2.0f * s;     // var + 1 == (s + 1)^2
+    if (__builtin_amdgcn_ballot_w64(slow) != 0) return ln_newton10(varf);
+    return s;
+}
+
+IVIT_DEV float ln_hfactor_small(int var)
+{
+    const float t = ln_std10(var);
+    return floorf((1.0f / t) * 2147483648.0f) * 0.5f;    // :51-52 (the /2 of :52 is an exact scaling)
+}
+
+
 
 // float32 sum of phi(q_i) over one row in the order torch's CPU sum kernel uses (ATen native/cpu/SumKernel.cpp:
 // vectorized_inner_sum -> row_sum -> multi_row_sum with 8-float vectors and 4 accumulator rows: 32 partial sums, element
@@ -382,10 +429,13 @@ __global__ __launch_bounds__(NT, (NJ <= 3 && !COMPAT ? 3 : NJ <= 8 ? 2 : 1)) voi
 // (36.7 vs 29.6 us per call).  The per-channel constants (bias, requant bracket) are computed once per WORKGROUP into LDS
 // and read 16 bytes at a time per dword of channels; row sums reduce over 32 lanes; the statistics of the 8 rows are
 // evaluated in lanes 0-3 of each half.  Arithmetic exactly as layernorm_i8_kernel (certificate, literal fallback).
-template <int NJ>
+// Round 4, small launches (DeiT-S b64: 12 608 rows of 384, 25 launches per forward, 9.8 us each = a chain of latencies, not
+// bandwidth): G2 = 2 or 1 row pairs per wave instead of 4 puts 2-4 x as many waves on the chip for the same rows, the first
+// group's rows are requested BEFORE the constants table is derived (its loads and float64 arithmetic run under their flight),
+// and the ten Newton steps are the sqrt shortcut of ln_std10 where it is proven (var < 2^24: C <= 1024).
+template <int NJ, int G2 = 4>
 __global__ __launch_bounds__(NT, NJ <= 3 ? 4 : 3) void layernorm_i8_pair_kernel(LnArgs a)
 {
-    constexpr int G2 = 4;   // row pairs per wave and iteration
     extern __shared__ __attribute__((aligned(16))) float lds_tab[];   // [C] bias | [C] lo | [C] hi
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l32 = lane & 31;
@@ -393,6 +443,23 @@ __global__ __launch_bounds__(NT, NJ <= 3 ? 4 : 3) void layernorm_i8_pair_kernel(
     float* t_bias = lds_tab;
     float* t_lo = lds_tab + C;
     float* t_hi = lds_tab + 2 * C;
+    const int8_t* xin = reinterpret_cast<const int8_t*>(a.x);
+    int8_t* out = reinterpret_cast<int8_t*>(a.out);
+    const int row_first = (blockIdx.x * WPB + wave) * (2 * G2);
+    int w[G2][NJ];
+    auto load_rows = [&](int row0) {
+#pragma unroll
+        for (int q = 0; q < G2; ++q) {
+            const int row = min(row0 + 2 * q + half, a.rows - 1);
+            const int* xr = reinterpret_cast<const int*>(xin + (int64_t)row * a.ldx);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int d = l32 + 32 * j;
+                w[q][j] = (d < nd) ? xr[d] : 0;
+            }
+        }
+    };
+    load_rows(row_first);
     for (int c = tid; c < C; c += NT) {
         const double M = dyadic_mult(a.m[c], a.e[c]);
         const double lod = M * (1.0 - 1.25 / 4194304.0), hid = M * (1.0 + 1.25 / 4194304.0);
@@ -406,20 +473,15 @@ __global__ __launch_bounds__(NT, NJ <= 3 ? 4 : 3) void layernorm_i8_pair_kernel(
         t_hi[c] = ok ? hf : __builtin_inff();
     }
     __syncthreads();
-    const int8_t* xin = reinterpret_cast<const int8_t*>(a.x);
-    int8_t* out = reinterpret_cast<int8_t*>(a.out);
-    for (int row0 = (blockIdx.x * WPB + wave) * (2 * G2); row0 < a.rows; row0 += gridDim.x * WPB * (2 * G2)) {
-        int w[G2][NJ], sum[G2], sq[G2];
+    for (int row0 = row_first; row0 < a.rows; row0 += gridDim.x * WPB * (2 * G2)) {
+        if (row0 != row_first) load_rows(row0);      // uniform per wave
+        int sum[G2], sq[G2];
 #pragma unroll
         for (int q = 0; q < G2; ++q) {
-            const int row = min(row0 + 2 * q + half, a.rows - 1);
-            const int* xr = reinterpret_cast<const int*>(xin + (int64_t)row * a.ldx);
             sum[q] = 0;
             sq[q] = 0;
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                const int d = l32 + 32 * j;
-                w[q][j] = (d < nd) ? xr[d] : 0;
                 sum[q] = __builtin_amdgcn_sdot4(w[q][j], 0x01010101, sum[q], false);
                 sq[q] = __builtin_amdgcn_sdot4(w[q][j], w[q][j], sq[q], false);   // <= 1536 * 128^2 < 2^25
             }
@@ -441,7 +503,8 @@ __global__ __launch_bounds__(NT, NJ <= 3 ? 4 : 3) void layernorm_i8_pair_kernel(
         int my_mean;
         ln_mean(my_sum, C, my_mean);
         const int my_var = my_sq - 2 * my_mean * my_sum + C * my_mean * my_mean;   // exact, see layernorm_i8_kernel
-        const float my_hfactor = ln_factor((long long)my_var) * 0.5f;             // :52: the /2 folds into the factor
+        // :52: the /2 folds into the factor.  C <= 1024: var < 2^24, the range ln_std10's shortcut is proven on
+        const float my_hfactor = (NJ <= 8 && C <= 1024) ? ln_hfactor_small(my_var) : ln_factor((long long)my_var) * 0.5f;
         int mean_int[G2];
         float hfactor[G2], mean128[G2];
 #pragma unroll
@@ -1525,10 +1588,19 @@ IVIT_EXPORT int ivit_layernorm_i8_ex(const int8_t* x, int64_t ldx, int rows, int
     // C = 384 and 14.0 vs 14.9 us at C = 192, but 36 vs 30 us at C = 768 (rows = 50 432)
     if ((C <= 384 || g_ln_wave_per_row == 2) && C <= 1536 && g_ln_wave_per_row != 1) {
         const int nj2 = (C / 4 + 31) / 32;
-        int grid = grid_for_rows(rows, 8);
+        // row pairs per wave: 4 from 16 K rows (4 waves per SIMD busy either way), fewer below so that a small launch still fills the
+        // chip (lab: ln_ablate bits 21-22 = 1 / 2 / 3 force 4 / 2 / 1)
+        int g2 = rows > 16384 ? 4 : rows > 8192 ? 2 : 1;
+        if (nj2 > 3) g2 = 4;
+        if ((g_ln_ablate >> 21) & 3) g2 = nj2 > 3 ? 4 : 8 >> ((g_ln_ablate >> 21) & 3);
+        int grid = grid_for_rows(rows, 2 * g2);
         if (grid > 1024) grid = 1024;          // 4 waves per SIMD resident
         const size_t lds = (size_t)3 * C * sizeof(float);
-        if (nj2 <= 2) hipLaunchKernelGGL(layernorm_i8_pair_kernel<2>, dim3(grid), dim3(NT), lds, st, a);
+        if (nj2 <= 2 && g2 == 1) hipLaunchKernelGGL((layernorm_i8_pair_kernel<2, 1>), dim3(grid), dim3(NT), lds, st, a);
+        else if (nj2 <= 2 && g2 == 2) hipLaunchKernelGGL((layernorm_i8_pair_kernel<2, 2>), dim3(grid), dim3(NT), lds, st, a);
+        else if (nj2 <= 3 && g2 == 1) hipLaunchKernelGGL((layernorm_i8_pair_kernel<3, 1>), dim3(grid), dim3(NT), lds, st, a);
+        else if (nj2 <= 3 && g2 == 2) hipLaunchKernelGGL((layernorm_i8_pair_kernel<3, 2>), dim3(grid), dim3(NT), lds, st, a);
+        else if (nj2 <= 2) hipLaunchKernelGGL(layernorm_i8_pair_kernel<2>, dim3(grid), dim3(NT), lds, st, a);
         else if (nj2 <= 3) hipLaunchKernelGGL(layernorm_i8_pair_kernel<3>, dim3(grid), dim3(NT), lds, st, a);
         else if (nj2 <= 6) hipLaunchKernelGGL(layernorm_i8_pair_kernel<6>, dim3(grid), dim3(NT), lds, st, a);
         else if (nj2 <= 8) hipLaunchKernelGGL(layernorm_i8_pair_kernel<8>, dim3(grid), dim3(NT), lds, st, a);

@@ -27,6 +27,12 @@ if len(sys.argv) > 1 and sys.argv[1] == "--headline":
     shapes = shapes[:1]
 variants = [("grouped(r3)", 3, 0, 0), ("stream", 0, 0, 0), ("stream equal-prio", 0, 0, 32), ("stream ng2", 0, 4, 0), ("stream dbuf", 0, 5, 0),
             ("stream ng3", 0, 3, 0)]
+if len(sys.argv) > 1 and sys.argv[1] == "--small":     # launches below ~12 MB: the half-wave kernel with 4 / 2 / 1 row pairs per wave (lab bits 21-22)
+    shapes = [(197 * 64, 384), (197 * 16, 384), (197, 192), (197 * 8, 192)]
+    variants = [("grouped(r3)", 3, 0, 0), ("product", 0, 0, 0), ("half-wave 4 pairs", 0, 0, 1 << 21), ("half-wave 2 pairs", 0, 0, 2 << 21),
+                ("half-wave 1 pair", 0, 0, 3 << 21), ("stream", 4, 0, 0)]
+if len(sys.argv) > 2 and sys.argv[2] == "--first":
+    shapes = shapes[:1]
 for rows, C in shapes:
     x = t(np.clip(np.rint(rng.normal(0, 30, size=(rows, C))), -128, 127).astype(np.int8))
     lp = LayerNormParams(rng.uniform(0.5, 1.5, size=C).astype(np.float32), rng.normal(0, 0.1, size=C).astype(np.float32), np.float32(2.0 ** -4))
