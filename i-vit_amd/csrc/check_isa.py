@@ -21,15 +21,19 @@ file checks the property itself, on the final instruction stream:
         than MFMA_MFMA_GAP instructions (MFMAs the compiler issued itself are its hazard recognizer's business);
   (iii) an inline-asm vector store is preceded, inside its asm statement, by an s_nop (its data comes straight out of
         v_permlane*_swap in the epilogue; the compiler pads its own stores, not these).
+  (iv)  no VALU instruction writes an operand register of an inline-asm v_mfma within VALU_MFMA_GAP instructions in front of it
+        (round 4, measured: `v_mov_b64 acc, bias` sunk by the scheduler to just in front of a tile's first MFMA left half of the C
+        operand's dwords stale, by lane parity -- gemm_wp.h's first parity run; the hazard recognizer does not look into inline asm).
 
 Exit status 1 and one line per finding if any guarded kernel violates a rule; the guarded kernels found are listed otherwise."""
 import re
 import sys
 from collections import defaultdict
 
-GUARDED = ("gemm_i8_wreg_kernel", "gemm_i8_pers_kernel")
+GUARDED = ("gemm_i8_wreg_kernel", "gemm_i8_pers_kernel", "gemm_i8_wp_kernel")
 MFMA_VALU_WAIT = 19      # wait states between an MFMA's write and a VALU read of the result (16-pass bound: covers every shape here)
 MFMA_MFMA_GAP = 4        # instructions between two MFMAs on the same accumulator
+VALU_MFMA_GAP = 4        # instructions between a VALU write of a register and an inline-asm MFMA that reads it
 CAP = 63                 # counters saturate: vmcnt is 6 bits wide on gfx9
 
 REG = re.compile(r"\bv\[(\d+):(\d+)\]|\bv(\d+)\b")
@@ -263,6 +267,34 @@ def check_asm_stores(kname, items, findings):
                 findings.append(f"{kname}: line {inst.line}: inline-asm `{inst.text}` without an s_nop in front of it inside its asm statement (rule iii)")
 
 
+def check_valu_to_mfma(kname, items, findings):
+    """rule (iv): straight-line look-back (a label or branch in between resets it: the gap is then at least a taken branch)"""
+    recent = []      # (registers written, Inst) of the last VALU instructions
+    for it in items:
+        if isinstance(it, tuple):
+            recent = []
+            continue
+        if it.op.startswith(("s_cbranch", "s_branch", "s_endpgm", "s_barrier")):
+            recent = []
+            continue
+        if it.asm and it.op.startswith("v_mfma"):
+            ops = [a.strip() for a in it.args.split(",")]
+            reads = set()
+            for a in ops[1:4]:
+                reads |= regs_of(a)
+            for back, (wr, w) in enumerate(reversed(recent[-VALU_MFMA_GAP:])):
+                hit = wr & reads
+                if hit:
+                    findings.append(f"{kname}: line {it.line}: inline-asm `{it.text}` reads v{min(hit)}..{max(hit)} {back} instruction(s) behind "
+                                    f"`{w.text}` (line {w.line}) that writes it (rule iv)")
+        if it.op.startswith("v_") and not it.op.startswith(("v_mfma", "v_cmp", "v_readlane", "v_readfirstlane")):
+            first = it.args.split(",")[0] if it.args else ""
+            recent.append((regs_of(first), it))
+        else:
+            recent.append((set(), it))
+        recent = recent[-8:]
+
+
 def check_text(text, require_guarded=True):
     kernels = split_kernels(text)
     findings, report = [], []
@@ -270,6 +302,7 @@ def check_text(text, require_guarded=True):
         before = len(findings)
         check_async(name, items, findings)
         check_asm_stores(name, items, findings)
+        check_valu_to_mfma(name, items, findings)
         n_asm = sum(1 for it in items if not isinstance(it, tuple) and it.asm and (is_vmem(it.op) or is_ds(it.op)))
         report.append(f"{'ok  ' if len(findings) == before else 'FAIL'} {name}: {sum(1 for it in items if not isinstance(it, tuple))} instructions, "
                       f"{n_asm} inline-asm memory operations")

@@ -17,7 +17,7 @@ when they size their grids (occupancy_rules below)."""
 import re
 import sys
 
-GUARDED = ("gemm_i8_wreg_kernel", "gemm_i8_pers_kernel")
+GUARDED = ("gemm_i8_wreg_kernel", "gemm_i8_pers_kernel", "gemm_i8_wp_kernel")
 FIELDS = {"VGPRs": r"\bVGPRs: (\d+)", "AGPRs": r"AGPRs: (\d+)", "Scratch": r"ScratchSize \[bytes/lane\]: (\d+)",
           "Occupancy": r"Occupancy \[waves/SIMD\]: (\d+)", "VGPRSpill": r"VGPRs Spill: (\d+)", "SGPRSpill": r"SGPRs Spill: (\d+)",
           "LDS": r"LDS Size \[bytes/block\]: (\d+)"}

@@ -961,6 +961,8 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_wreg_kernel(GemmArgs g)
     }
 }
 
+#include "gemm_wp.h"
+
 template <int EPI>
 int launch_gemm(GemmArgs& g, const char* name, ivit_stream_t stream)
 {
@@ -1034,6 +1036,41 @@ int launch_gemm(GemmArgs& g, const char* name, ivit_stream_t stream)
                 }
             }
             const int ntiles = g.tiles_m * g.tiles_n;
+            // Round 4 experiment, LAB ONLY (flags2 bit 15): the wave-pipelined form (gemm_wp.h: one workgroup of eight waves per CU, a
+            // tile's requantisation inside the next tile's main loop).  Exact, and SLOWER than the kernel below (fc1 150 vs 116 us,
+            // qkv 121 vs 97 us): with 64 accumulator registers per wave the token fragments are re-read from LDS twice as often per
+            // MFMA, and the bare eight-wave loop alone (no epilogue at all) takes 110 us -- profiles/r04p_*, DESIGN.md section 8
+            if constexpr (IVIT_LAB != 0 && (EPI == EPI_RQ || EPI == EPI_QKV)) {
+                if (g.w_frags == 2 && !g.lut && !g.gelu_ws && !g.narrow && (g.K / BK) >= 12 && (g_debug_flags2 & 32768) && !(g_debug_flags2 & (256 | 512)) &&
+                    !(g_debug_flags & 127)) {
+                    IVIT_REQUIRE(((int64_t)g.M + 16) * (EPI == EPI_QKV ? g.N : g.ldo) < 4294967296ll,
+                                 "%s: IVIT_W_FRAGS16 addresses its output with 32-bit offsets: operand of 4 GiB or more", name);
+                    g.split_from = ntiles;
+                    if constexpr (EPI == EPI_QKV) {
+                        IVIT_REQUIRE((int64_t)g.M * g.tokens < 4294967296ll, "%s: M * tokens must stay below 2^32", name);
+                        g.tokens_magic = (unsigned)(4294967296ull / (unsigned)g.tokens) + 1u;
+                    }
+                    static bool lds_set = false;      // 94 KB of dynamic LDS: beyond the default 64 KB limit of a launch
+                    if (!lds_set) {
+                        IVIT_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_i8_wp_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                         WP_SMEM) == hipSuccess, "%s: the device refuses %d bytes of LDS per workgroup", name, WP_SMEM);
+                        lds_set = true;
+                    }
+#if IVIT_LAB
+                    if constexpr (EPI == EPI_RQ) {      // timing ablations (results wrong): flags2 bits 16-19 = ABL of gemm_wp.h
+                        const int abl = (g_debug_flags2 >> 16) & 15;
+                        if (abl) {
+#define IVIT_WP_ABL(v) if (abl == v) { hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_i8_wp_kernel<EPI_RQ, v>), hipFuncAttributeMaxDynamicSharedMemorySize, WP_SMEM); \
+                                       hipLaunchKernelGGL((gemm_i8_wp_kernel<EPI_RQ, v>), dim3(ntiles < 256 ? ntiles : 256), dim3(WP_NT), WP_SMEM, ivit_stream(stream), g); IVIT_CHECK_LAUNCH(name); }
+                            IVIT_WP_ABL(1) IVIT_WP_ABL(3) IVIT_WP_ABL(2)
+#undef IVIT_WP_ABL
+                        }
+                    }
+#endif
+                    hipLaunchKernelGGL((gemm_i8_wp_kernel<EPI>), dim3(ntiles < 256 ? ntiles : 256), dim3(WP_NT), WP_SMEM, ivit_stream(stream), g);
+                    IVIT_CHECK_LAUNCH(name);
+                }
+            }
             // A sparse last round (R tiles on 512 slots) runs as 2R half tiles of 64 tokens (wr_work) when every half tile still
             // finds a CU of its own (2R <= 256): fc1 at the headline shape, R = 120, 144 -> 136 us.  Beyond that two half tiles
             // share a CU while a lone full tile has one to itself and runs nearly twice as fast: measured slower (N = 768,

@@ -85,6 +85,8 @@ struct GemmArgs {
     const int8_t* gelu_lut;   // [256][256] (row max + 128, k + 128) -> int8: the table of ivit_shiftgelu_build_lut_ex
     int* gelu_ws;             // caller-owned arrival counters of the 128-token panels [tiles_m]: zero before the first use, left
                               // zero by every launch
+    unsigned tokens_magic;    // EPI_QKV, wave-pipelined kernel (gemm_wp.h): floor(2^32 / tokens) + 1 -- t / tokens == umulhi(t, magic) for
+                              // every row index (the launcher checks M * tokens < 2^32): no per-lane division inside the main loop
 };
 
 IVIT_DEV int nk_of(const GemmArgs& g) { return g.K / 64; }

@@ -468,6 +468,58 @@ def test_gemm_weight_fragment_layout(M, N, K, FR, wreg_tiles):
                   _lib.ptr(out), N, M, N, 128, FR, st())
 
 
+@pytest.mark.parametrize("M,N,K", [(197 * 256, 768, 768), (197 * 256, 2304, 768), (197 * 64 + 77, 3072, 768), (30000, 768, 1536),
+                                   (197 * 40, 1152, 3072), (4100, 256, 960)])
+def test_gemm_wave_pipelined_form_equals_two_workgroup_form(M, N, K):
+    """round 4 experiment, lab build only (flags2 bit 15; exact but slower): gemm_wp.h (one workgroup of eight waves
+    per CU, a tile's requantisation inside the next tile's main loop, half of its accumulators parked in LDS) against the product's
+    gemm_i8_wreg_kernel, which the oracle tests pin: the same bytes for the
+    plain and the head-major epilogue, row-major / block-layout A, block-layout output, several tiles per workgroup (A / B accumulator
+    sets alternate), partial last token tile, channel tiles beyond N, exact ties and certificate failures in the data"""
+    rng = np.random.default_rng(M + N + K)
+    A = rng.integers(-128, 128, size=(M, K)).astype(np.int8)
+    A[::7] = 1                                   # rows of ones: accumulators = bias + row sums of W -> many exact ties with m = 2^k
+    W = rng.integers(-128, 128, size=(N, K)).astype(np.int8)
+    b = rng.integers(-50000, 50000, size=N).astype(np.int32)
+    m, e = rand_me(rng, N, -16, -9)
+    m[::5] = 1 << 30                             # power-of-two multipliers: exact .5 ties -> the float64 path of a unit
+    md, ed = me_dev(m, e)
+    dA, dW, db = dev(A), dev(W), dev(b)
+    R16 = (M + 15) // 16 * 16
+    At = torch.zeros(R16 * K, dtype=torch.int8, device=DEV)
+    _lib.call("ivit_tile_operand_i8", _lib.ptr(dA), K, M, K, _lib.ptr(At), st())
+    Wf = torch.zeros((N + 63) // 64 * 64 * K, dtype=torch.int8, device=DEV)
+    _lib.call("ivit_pack_weight_frags16_i8", _lib.ptr(dW), K, N, K, _lib.ptr(Wf), st())
+    qkv = N % 192 == 0 and M % 197 == 0
+
+    def run_all():
+        outs = []
+        for lay in (16, 17, 21):                 # IVIT_W_FRAGS16 | row-major A, | block A, | block A + block output
+            out = torch.zeros(R16 * N, dtype=torch.int8, device=DEV)
+            _lib.call("ivit_gemm_i8_requant_ex", _lib.ptr(At if lay & 1 else dA), K, _lib.ptr(Wf), K, _lib.ptr(db), _lib.ptr(md), _lib.ptr(ed),
+                      _lib.ptr(out), N, M, N, K, lay, st())
+            outs.append(out.cpu().numpy())
+        if qkv:
+            hd = 64
+            out = torch.zeros(M * N, dtype=torch.int8, device=DEV)
+            _lib.call("ivit_gemm_i8_requant_qkv_ex", _lib.ptr(At), K, _lib.ptr(Wf), K, _lib.ptr(db), _lib.ptr(md), _lib.ptr(ed), _lib.ptr(out),
+                      197, N // (3 * hd), hd, M, N, K, 17, st())
+            outs.append(out.cpu().numpy())
+        return outs
+
+    ref = run_all()
+    with _lib.lab_session():
+        _lib.call("ivit_debug_set_gemm_flags2", 32768)
+        got = run_all()
+    for i, (a, r) in enumerate(zip(got, ref)):
+        assert np.array_equal(a, r), f"output {i}: {(a != r).sum()} of {a.size} bytes differ"
+    assert np.array_equal(got[0][: M * N], got[1][: M * N])
+    # and a slice against the oracle (the first 300 rows and the last 200: first and last tiles of the launch)
+    rows = np.r_[0:300, M - 200:M]
+    exp = orc.requant(orc.gemm_i8(A[rows], W, b), m.astype(np.float64), e, 8)
+    assert np.array_equal(got[0][: M * N].reshape(M, N)[rows].astype(np.int32), exp)
+
+
 def _gelu_ws(M):
     return torch.zeros((M + 127) // 128, dtype=torch.int32, device=DEV)
 

@@ -452,3 +452,9 @@ def test_isa_lint_accepts_counted_waits_and_rejects_broken_streams():
     assert any("rule ii" in f for f in _lint(pre + [mfma, mfma]))          # back to back on one accumulator
     # (iii) an inline-asm store without its s_nop
     assert any("rule iii" in f for f in _lint(["A: global_store_dwordx4 v[4:5], v[60:63], off"]))
+    # (iv) a VALU write of an MFMA operand right in front of the inline-asm MFMA (round 4: the bias copy sunk to the tile's first MFMA
+    #      left half of the accumulator stale); far enough in front, or another register, is fine
+    assert any("rule iv" in f for f in _lint(pre + ["v_mov_b64_e32 v[42:43], v[68:69]", "v_mov_b64_e32 v[40:41], v[66:67]", mfma]))
+    assert _lint(pre + ["v_mov_b64_e32 v[42:43], v[68:69]", "v_mov_b64_e32 v[40:41], v[66:67]", "s_nop 0", "v_add_u32_e32 v70, v71, v72",
+                        "v_add_u32_e32 v73, v71, v72", "v_add_u32_e32 v74, v71, v72", mfma]) == []
+    assert _lint(pre + ["v_mov_b64_e32 v[44:45], v[68:69]", mfma]) == []
