@@ -103,6 +103,39 @@ def launch(args, argv):
 
 
 # ---------------------------------------------------------------------------------------------- pieces
+_T0 = time.perf_counter()
+
+
+def progress(msg):
+    """one line on STDERR (stdout carries the JSON line alone): a harness that watches for output does not take the quiet phases
+    -- building engines, the CPU baseline's passes -- for a hang"""
+    if os.environ.get("RANK", "0") == "0":
+        sys.stderr.write(f"[bench.py +{time.perf_counter() - _T0:6.1f} s] {msg}\n")
+        sys.stderr.flush()
+
+
+def usable_cpus():
+    """CPUs this process may actually use: its affinity mask, cut to the cgroup's CPU quota when there is one (a container with a
+    16-CPU share on a 256-CPU host: 128 OpenMP threads over the NUMA node's mask only fight for the quota)"""
+    n = len(os.sched_getaffinity(0))
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(int(parts[0]) / int(parts[1]))))
+            else:
+                q = int(parts[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                        n = min(n, max(1, q // int(f.read().split()[0])))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def pmc_traffic(kernel_keys):
     """HBM bytes per launch of the dominant kernel from the newest committed rocprofv3 --pmc summary (FETCH_SIZE /
     WRITE_SIZE passes, corrected as MI355X_MICROARCH.md prescribes; scripts/summarize_profiles.py)."""
@@ -129,6 +162,10 @@ def cpu_baseline(fs, ranges, cfg):
     from ivit_amd import synth
     from oracle import oracle as orc
     om = orc.OracleViT(fs, ranges, cfg["embed_dim"], cfg["depth"], cfg["num_heads"])
+    cpus = usable_cpus()
+    if cpus < orc.max_threads():
+        orc.set_threads(cpus)
+    progress(f"cpu_baseline: C oracle on {min(cpus, orc.max_threads())} thread(s); first warm-up (8 images)")
     n = 8
     t0 = time.perf_counter()
     om.forward(synth.make_images(n, 31337))
@@ -140,9 +177,10 @@ def cpu_baseline(fs, ranges, cfg):
         t0 = time.perf_counter()
         om.forward(imgs)
         times.append(time.perf_counter() - t0)
+        progress(f"cpu_baseline: pass {i + 1} of 6 ({n} images) {times[-1]:.2f} s")
     timed = sorted(times[1:])
     med = timed[len(timed) // 2]
-    threads = orc.max_threads()
+    threads = min(cpus, orc.max_threads())
     rows = n * 197
     return {"value": round(n / med, 3), "unit": "images/s", "cores": threads, "kind": "port",
             "sample": f"DeiT-B INT8, forwards of {n} images (224x224 synthetic; {rows} token rows over {threads} OpenMP threads = "
@@ -328,6 +366,7 @@ def worker(args):
             torch.cuda.synchronize()
 
     # ---- phase 1: the timed region
+    progress(f"engine ready; {args.warmup} warm-up + {args.steps} timed steps")
     for _ in range(args.warmup):
         dp.step(images)
     if grouped:
@@ -347,6 +386,7 @@ def worker(args):
         dt = float(t.item())
 
     # ---- phase 2: dominant-kernel duration, outside the timed region
+    progress(f"timed region done: {dt / args.steps * 1e3:.3f} ms per step; probing the dominant kernel")
     roof = None
     if rank == 0 and not stub and args.probe_forwards > 0:
         from ivit_amd.hiptime import KernelProbe
@@ -405,6 +445,7 @@ def worker(args):
         torch.cuda.empty_cache()
         k_extra = max(5, min(args.steps, 20))
         # (a) the headline workload with ranges as calibrated: rank 0 alone (the other ranks wait at the barrier below)
+        progress("extras: the headline workload at natural scales")
         if rank == 0:
             fs_n, ranges_n, cfg_n, _, _ = load_synthetic_model(MODEL_TAG + "_natural")
             eng_n = IntViTEngine(fs_n, ranges_n, cfg_n["embed_dim"], cfg_n["depth"], cfg_n["num_heads"], device=dev, max_batch=batch)
@@ -417,6 +458,7 @@ def worker(args):
         if grouped:
             dist.barrier()
         # (b) config 4: ViT-B, global batch 1024 split over the ranks (strong scaling)
+        progress("extras: config 4 (ViT-B, global batch 1024)")
         lo, hi = shard_bounds(CONFIG4_BATCH, world, rank)
         fs4, ranges4, cfg4, _, _ = load_synthetic_model("vit_base")
         eng4 = IntViTEngine(fs4, ranges4, cfg4["embed_dim"], cfg4["depth"], cfg4["num_heads"], device=dev, max_batch=hi - lo)

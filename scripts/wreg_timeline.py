@@ -63,6 +63,37 @@ for name in names:
         if sel.any():
             span = s[:nb, :, 3].max(axis=1)[sel] - s[:nb, 0, 0][sel]
             print(f"workgroups with {k} tiles: {sel.sum()}, first start to last end: median {np.median(span):.0f} cycles")
+    if not one and nb == 512:
+        # phase of the two workgroups of a CU (b and b + 256: scripts/probes/xcc_map_probe.hip): which share of the time that at least
+        # one of them spends in a main loop do BOTH spend in one (1 = in phase: the MFMA pipe idles during the epilogues; 0 = they alternate)
+        both, any_ = [], []
+        for bb in range(256):
+            iv = []
+            for w in (bb, bb + 256):
+                for it in range(4):
+                    if s[w, it, 3] > 0:
+                        iv.append((w, int(s[w, it, 1]), int(s[w, it, 2])))
+            if len({w for w, _, _ in iv}) < 2:
+                continue
+            t0 = max(min(a for w, a, _ in iv if w == bb), min(a for w, a, _ in iv if w == bb + 256))       # both have started
+            t1 = min(max(e for w, _, e in iv if w == bb), max(e for w, _, e in iv if w == bb + 256))       # neither has run out of stamped tiles
+            if t1 <= t0:
+                continue
+            ev = sorted([(max(a, t0), 1) for _, a, e in iv if e > t0 and a < t1] + [(min(e, t1), -1) for _, a, e in iv if e > t0 and a < t1])
+            depth, last, b2, a1 = 0, t0, 0, 0
+            for t, d in ev:
+                if depth >= 1:
+                    a1 += t - last
+                if depth >= 2:
+                    b2 += t - last
+                depth += d
+                last = t
+            if a1:
+                both.append(b2 / a1)
+                any_.append(a1 / (t1 - t0))
+        if both:
+            print(f"CU pairs (b, b + 256), first four tiles: both workgroups in a main loop for {np.median(both):.2f} of the time at least one is "
+                  f"(quartiles {np.percentile(both, 25):.2f} / {np.percentile(both, 75):.2f}); some main loop running {np.median(any_):.2f} of the time")
     ok = (s[:nb, 3, 0] > 0)
     dt = (s[:nb, 3, 0] - s[:nb, 0, 0]).astype(np.float64)[ok]
     dr = (s[:nb, 3, 16] - s[:nb, 0, 16]).astype(np.float64)[ok]
