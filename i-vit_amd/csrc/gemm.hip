@@ -1078,7 +1078,12 @@ int launch_gemm(GemmArgs& g, const char* name, ivit_stream_t stream)
             const int rounds = ntiles / 512, R = ntiles - rounds * 512;
             const bool split = !g.narrow && rounds > 0 && R > 0 && 2 * R <= ((g_debug_flags & 2048) ? 512 : 256) && !(g_debug_flags & 134217728);
             g.split_from = split ? rounds * 512 : ntiles;
-            const dim3 grid(ntiles < 512 ? ntiles : 512);
+            // Round 4: a launch with at most 256 tiles (DeiT-S attn.proj / fc2 at batch 64: 198; Swin stage 3: 147) runs ALL of them as half
+            // tiles of 64 tokens, one per workgroup: such a launch lasts as long as ONE tile (main loop + epilogue, ~15 K cycles), and a
+            // half tile's epilogue is half as long, its K steps 16 MFMAs per wave instead of 32 (lab bit 27: off)
+            const bool all_halves = g.w_frags == 2 && !g.narrow && !g.gelu_ws && rounds == 0 && 2 * ntiles <= 512 && !(g_debug_flags & 134217728);
+            if (all_halves) g.split_from = 0;
+            const dim3 grid(all_halves ? 2 * ntiles : (ntiles < 512 ? ntiles : 512));
 #if IVIT_LAB
             if constexpr (EPI == EPI_RQ) {   // ablations (scripts/gemm_ab.py --frags): what each stream of the kernel costs
                 switch (g_debug_flags & 127) {
