@@ -239,59 +239,45 @@ __global__ __launch_bounds__(NT) void layernorm_i16_i8_literal_kernel(Ln16LitArg
     }
 }
 
+// Round 4: the per-channel constants (bias, float32 bracket (lo, hi) of the QuantAct multiplier: the certificate of
+// layernorm_i8_kernel, rowops.hip) of the tiled 16-bit kernels are derived ONCE PER WORKGROUP into LDS -- one or two channels per
+// thread -- and read per chunk of 8 channels where the element chain needs them.  Rounds 1-3 kept them in 72 registers per lane
+// (NJ = 3), derived by every lane for its 24 channels in float64: 195-244 VGPRs = two waves per SIMD, where this VALU-bound chain
+// issues its half-rate instructions at 4.4 cycles instead of 3.2, and a prologue that a launch of few rows
+// (Swin stages 2-3: 14-29 MB) spent most of its time in.
+IVIT_DEV void ln16_build_table(const Ln16Args& a, float* t_bias, float* t_lo, float* t_hi)
+{
+    for (int c = threadIdx.x; c < a.C; c += NT) {
+        const double M = dyadic_mult(a.m[c], a.e[c]);
+        const double lod = M * (1.0 - 1.25 / 4194304.0), hid = M * (1.0 + 1.25 / 4194304.0);
+        float lf = (float)lod, hf = (float)hid;
+        if ((double)lf > lod) lf = __int_as_float(__float_as_int(lf) - 1);
+        if ((double)hf < hid) hf = __int_as_float(__float_as_int(hf) + 1);
+        const float sl = a.s_ln[c];
+        const bool ok = fabsf(sl) >= 1e-30f && fabsf(sl) <= 1e30f && lod > 1e-35 && hid < 1e30;
+        t_bias[c] = a.bias_int[c];
+        t_lo[c] = ok ? lf : 0.0f;
+        t_hi[c] = ok ? hf : __builtin_inff();
+    }
+}
+
 // Sub-wave tiling of the same computation for C % 8 == 0, C <= 1536: LPR lanes share a row (64 / LPR rows per wave and
 // iteration), each lane owns NJ chunks of 8 channels (one 16-byte load each) and keeps their per-channel constants in
 // registers for the whole kernel.  The per-row scalar work (mean division, Newton steps) is evaluated once per
 // wave-iteration for all rows of the wave in parallel; with LPR = C / 24 every lane is busy (C = 96 * 2^k: NJ = 3).
 template <int LPR, int NJ>
-__global__ __launch_bounds__(NT) void layernorm_i16_i8_tiled_kernel(Ln16Args a)
+__global__ __launch_bounds__(NT, 4) void layernorm_i16_i8_tiled_kernel(Ln16Args a)
 {
+    extern __shared__ __attribute__((aligned(16))) float ln16_tab[];      // [C] bias | [C] lo | [C] hi
     constexpr int RPW = 64 / LPR;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane & (LPR - 1), grp = lane / LPR;
     const int C = a.C, nd = C >> 3;
-    // bias and the float32 bracket (lo, hi) of each channel's QuantAct multiplier: see layernorm_i8_kernel (rowops.hip) for
-    // the certificate that replaces the literal float64 tail of the chain; uncertified wave-iterations are redone literally
-    float bias[NJ][8], lo[NJ][8], hi[NJ][8];
-    {
-        // all table loads first (vector loads, independent), then the arithmetic: the waves of this kernel have little
-        // else in flight to hide a chain of dependent global-load latencies behind
-        float4 bq[NJ][2], sq[NJ][2];
-        uint4 mq[NJ][2];
-        int4 eq[NJ][2];
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int d = min(sub + LPR * j, nd - 1);
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                bq[j][h] = *reinterpret_cast<const float4*>(a.bias_int + 8 * d + 4 * h);
-                sq[j][h] = *reinterpret_cast<const float4*>(a.s_ln + 8 * d + 4 * h);
-                mq[j][h] = *reinterpret_cast<const uint4*>(a.m + 8 * d + 4 * h);
-                eq[j][h] = *reinterpret_cast<const int4*>(a.e + 8 * d + 4 * h);
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const float bb[4] = {bq[j][h].x, bq[j][h].y, bq[j][h].z, bq[j][h].w};
-                const float ss[4] = {sq[j][h].x, sq[j][h].y, sq[j][h].z, sq[j][h].w};
-                const unsigned mm[4] = {mq[j][h].x, mq[j][h].y, mq[j][h].z, mq[j][h].w};
-                const int ee[4] = {eq[j][h].x, eq[j][h].y, eq[j][h].z, eq[j][h].w};
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    bias[j][4 * h + c] = bb[c];
-                    const double M = dyadic_mult(mm[c], ee[c]);
-                    const double lod = M * (1.0 - 1.25 / 4194304.0), hid = M * (1.0 + 1.25 / 4194304.0);
-                    float lf = (float)lod, hf = (float)hid;
-                    if ((double)lf > lod) lf = __int_as_float(__float_as_int(lf) - 1);
-                    if ((double)hf < hid) hf = __int_as_float(__float_as_int(hf) + 1);
-                    const bool ok = fabsf(ss[c]) >= 1e-30f && fabsf(ss[c]) <= 1e30f && lod > 1e-35 && hid < 1e30;
-                    lo[j][4 * h + c] = ok ? lf : 0.0f;
-                    hi[j][4 * h + c] = ok ? hf : __builtin_inff();
-                }
-            }
-    }
+    float* t_bias = ln16_tab;
+    float* t_lo = ln16_tab + C;
+    float* t_hi = ln16_tab + 2 * C;
+    ln16_build_table(a, t_bias, t_lo, t_hi);
+    __syncthreads();
     const float fC = (float)C;
     for (int row0 = (blockIdx.x * WPB + wave) * RPW; row0 < a.rows; row0 += gridDim.x * WPB * RPW) {
         const int row = row0 + grp;
@@ -338,19 +324,31 @@ __global__ __launch_bounds__(NT) void layernorm_i16_i8_tiled_kernel(Ln16Args a)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             int o[8];
+            const int dt = min(sub + LPR * j, nd - 1);      // this chunk's constants: 6 x 16 bytes from the workgroup's table
+            float bias8[8], lo8[8], hi8[8];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float4 b4 = *reinterpret_cast<const float4*>(t_bias + 8 * dt + 4 * h);
+                const float4 l4 = *reinterpret_cast<const float4*>(t_lo + 8 * dt + 4 * h);
+                const float4 h4 = *reinterpret_cast<const float4*>(t_hi + 8 * dt + 4 * h);
+                bias8[4 * h] = b4.x; bias8[4 * h + 1] = b4.y; bias8[4 * h + 2] = b4.z; bias8[4 * h + 3] = b4.w;
+                lo8[4 * h] = l4.x; lo8[4 * h + 1] = l4.y; lo8[4 * h + 2] = l4.z; lo8[4 * h + 3] = l4.w;
+                hi8[4 * h] = h4.x; hi8[4 * h + 1] = h4.y; hi8[4 * h + 2] = h4.z; hi8[4 * h + 3] = h4.w;
+            }
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
                 const int xv = (c & 1) ? (w[j][c >> 1] >> 16) : (int)(int16_t)w[j][c >> 1];
                 const float dl = (float)(xv - mean_int);
                 const float v = floorf(dl * hfactor);                           // :52
-                const float y = v + bias[j][c];                                 // :61
-                const int tl = __float_as_int(__builtin_fmaf(y, lo[j][c], 12582912.0f));
-                const int th = __float_as_int(__builtin_fmaf(y, hi[j][c], 12582912.0f));
+                const float y = v + bias8[c];                                   // :61
+                const int tl = __float_as_int(__builtin_fmaf(y, lo8[c], 12582912.0f));
+                const int th = __float_as_int(__builtin_fmaf(y, hi8[c], 12582912.0f));
                 asm("v_sad_u32 %0, %1, %2, %3" : "=v"(unc) : "v"(tl), "v"(th), "v"(unc));
                 o[c] = clamp_i32(tl, 0x4B400000 - 128, 0x4B400000 + 127);       // low byte = int8 result
             }
             res[j].x = pack4(o[0], o[1], o[2], o[3]);
             res[j].y = pack4(o[4], o[5], o[6], o[7]);
+            __builtin_amdgcn_sched_barrier(0);      // one chunk's constants live at a time
         }
         if (__builtin_amdgcn_ballot_w64(unc != 0) != 0) {
             // literal evaluation (wave-uniform branch): x = y * s_ln (:63), z = round(x / s_ln) (quant_utils.py:220),
@@ -373,7 +371,7 @@ __global__ __launch_bounds__(NT) void layernorm_i16_i8_tiled_kernel(Ln16Args a)
                         const int xv = (c & 1) ? (w[j][c >> 1] >> 16) : (int)(int16_t)w[j][c >> 1];
                         const float dl = (float)(xv - mean_int);
                         const float v = floorf(dl * hfactor);
-                        const float y = v + bias[j][c];
+                        const float y = v + t_bias[8 * d + c];
                         const float x = y * ss[cc];
                         const float z = rintf((float)((double)x * (1.0 / (double)ss[cc])));   // see layernorm_i8_kernel
                         const double tt = (double)z * MM[cc] + IVIT_MAGIC;
@@ -441,7 +439,7 @@ IVIT_DEV float rowsum32(F elem, int n, int l32, int base)
 }
 
 template <int LPR, int NJ>
-__global__ __launch_bounds__(NT) void layernorm_i16_i8_tiled_compat_kernel(Ln16Args a, float s_in, float r_in)
+__global__ __launch_bounds__(NT, NJ >= 3 ? 3 : 4) void layernorm_i16_i8_tiled_compat_kernel(Ln16Args a, float s_in, float r_in)
 {
     __shared__ float s_phi[WPB][64 * 8 * NJ];      // [wave][row of the wave][channel]
     __shared__ float s_sum[WPB][64];
@@ -453,48 +451,12 @@ __global__ __launch_bounds__(NT) void layernorm_i16_i8_tiled_compat_kernel(Ln16A
     const bool regsum = a.outer == 0 && nd == LPR * NJ && !(IVIT_LAB && a.lab_lds_sum);     // uniform
     // transposed view: groups of 16 need C < 256 (no second-level fold) and no tail columns (outer % 32 == 0: rowsum.h)
     const bool regouter = a.outer != 0 && (a.outer & 31) == 0 && nd == LPR * NJ && C < 256 && !(IVIT_LAB && a.lab_lds_sum);
-    // bias and the float32 bracket (lo, hi) of each channel's QuantAct multiplier: see layernorm_i8_kernel (rowops.hip) for
-    // the certificate that replaces the literal float64 tail of the chain; uncertified wave-iterations are redone literally
-    float bias[NJ][8], lo[NJ][8], hi[NJ][8];
-    {
-        // all table loads first (vector loads, independent), then the arithmetic: the waves of this kernel have little
-        // else in flight to hide a chain of dependent global-load latencies behind
-        float4 bq[NJ][2], sq[NJ][2];
-        uint4 mq[NJ][2];
-        int4 eq[NJ][2];
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int d = min(sub + LPR * j, nd - 1);
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                bq[j][h] = *reinterpret_cast<const float4*>(a.bias_int + 8 * d + 4 * h);
-                sq[j][h] = *reinterpret_cast<const float4*>(a.s_ln + 8 * d + 4 * h);
-                mq[j][h] = *reinterpret_cast<const uint4*>(a.m + 8 * d + 4 * h);
-                eq[j][h] = *reinterpret_cast<const int4*>(a.e + 8 * d + 4 * h);
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const float bb[4] = {bq[j][h].x, bq[j][h].y, bq[j][h].z, bq[j][h].w};
-                const float ss[4] = {sq[j][h].x, sq[j][h].y, sq[j][h].z, sq[j][h].w};
-                const unsigned mm[4] = {mq[j][h].x, mq[j][h].y, mq[j][h].z, mq[j][h].w};
-                const int ee[4] = {eq[j][h].x, eq[j][h].y, eq[j][h].z, eq[j][h].w};
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    bias[j][4 * h + c] = bb[c];
-                    const double M = dyadic_mult(mm[c], ee[c]);
-                    const double lod = M * (1.0 - 1.25 / 4194304.0), hid = M * (1.0 + 1.25 / 4194304.0);
-                    float lf = (float)lod, hf = (float)hid;
-                    if ((double)lf > lod) lf = __int_as_float(__float_as_int(lf) - 1);
-                    if ((double)hf < hid) hf = __int_as_float(__float_as_int(hf) + 1);
-                    const bool ok = fabsf(ss[c]) >= 1e-30f && fabsf(ss[c]) <= 1e30f && lod > 1e-35 && hid < 1e30;
-                    lo[j][4 * h + c] = ok ? lf : 0.0f;
-                    hi[j][4 * h + c] = ok ? hf : __builtin_inff();
-                }
-            }
-    }
+    extern __shared__ __attribute__((aligned(16))) float ln16_tab[];      // [C] bias | [C] lo | [C] hi (ln16_build_table)
+    float* t_bias = ln16_tab;
+    float* t_lo = ln16_tab + C;
+    float* t_hi = ln16_tab + 2 * C;
+    ln16_build_table(a, t_bias, t_lo, t_hi);
+    __syncthreads();
     const float fC = (float)C;
     for (int row0 = (blockIdx.x * WPB + wave) * RPW; row0 < a.rows; row0 += gridDim.x * WPB * RPW) {
         const int row = row0 + grp;
@@ -655,19 +617,31 @@ __global__ __launch_bounds__(NT) void layernorm_i16_i8_tiled_compat_kernel(Ln16A
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             int o[8];
+            const int dt = min(sub + LPR * j, nd - 1);      // this chunk's constants: 6 x 16 bytes from the workgroup's table
+            float bias8[8], lo8[8], hi8[8];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float4 b4 = *reinterpret_cast<const float4*>(t_bias + 8 * dt + 4 * h);
+                const float4 l4 = *reinterpret_cast<const float4*>(t_lo + 8 * dt + 4 * h);
+                const float4 h4 = *reinterpret_cast<const float4*>(t_hi + 8 * dt + 4 * h);
+                bias8[4 * h] = b4.x; bias8[4 * h + 1] = b4.y; bias8[4 * h + 2] = b4.z; bias8[4 * h + 3] = b4.w;
+                lo8[4 * h] = l4.x; lo8[4 * h + 1] = l4.y; lo8[4 * h + 2] = l4.z; lo8[4 * h + 3] = l4.w;
+                hi8[4 * h] = h4.x; hi8[4 * h + 1] = h4.y; hi8[4 * h + 2] = h4.z; hi8[4 * h + 3] = h4.w;
+            }
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
                 const int xv = (c & 1) ? (w[j][c >> 1] >> 16) : (int)(int16_t)w[j][c >> 1];
                 const float dl = (float)(xv - mean_int);
                 const float v = floorf(dl * hfactor);                           // :52
-                const float y = v + bias[j][c];                                 // :61
-                const int tl = __float_as_int(__builtin_fmaf(y, lo[j][c], 12582912.0f));
-                const int th = __float_as_int(__builtin_fmaf(y, hi[j][c], 12582912.0f));
+                const float y = v + bias8[c];                                   // :61
+                const int tl = __float_as_int(__builtin_fmaf(y, lo8[c], 12582912.0f));
+                const int th = __float_as_int(__builtin_fmaf(y, hi8[c], 12582912.0f));
                 asm("v_sad_u32 %0, %1, %2, %3" : "=v"(unc) : "v"(tl), "v"(th), "v"(unc));
                 o[c] = clamp_i32(tl, 0x4B400000 - 128, 0x4B400000 + 127);       // low byte = int8 result
             }
             res[j].x = pack4(o[0], o[1], o[2], o[3]);
             res[j].y = pack4(o[4], o[5], o[6], o[7]);
+            __builtin_amdgcn_sched_barrier(0);      // one chunk's constants live at a time
         }
         if (__builtin_amdgcn_ballot_w64(unc != 0) != 0) {
             // literal evaluation (wave-uniform branch): x = y * s_ln (:63), z = round(x / s_ln) (quant_utils.py:220),
@@ -690,7 +664,7 @@ __global__ __launch_bounds__(NT) void layernorm_i16_i8_tiled_compat_kernel(Ln16A
                         const int xv = (c & 1) ? (w[j][c >> 1] >> 16) : (int)(int16_t)w[j][c >> 1];
                         const float dl = (float)(xv - mean_int);
                         const float v = floorf(dl * hfactor);
-                        const float y = v + bias[j][c];
+                        const float y = v + t_bias[8 * d + c];
                         const float x = y * ss[cc];
                         const float z = rintf((float)((double)x * (1.0 / (double)ss[cc])));   // see layernorm_i8_kernel
                         const double tt = (double)z * MM[cc] + IVIT_MAGIC;
@@ -1090,11 +1064,13 @@ IVIT_EXPORT int ivit_layernorm_i16_i8(const int16_t* x, int rows, int C, const f
     // persistent-style launch: the per-channel constants (24 f64 reciprocals per lane) are set up once per wave, so keep
     // the grid at the number of resident workgroups (2 per CU at ~195 VGPRs) and let each wave stride over many rows
     int nblk = grid_for_rows(rows, 64 / lpr);
-    const int cap = ((g_ln_ablate >> 16) & 15) ? 256 * ((g_ln_ablate >> 16) & 15) : 512;
+    // four workgroups per CU (128 VGPRs since the constants moved to LDS, round 4); each builds the table once and strides over rows
+    const int cap = ((g_ln_ablate >> 16) & 15) ? 256 * ((g_ln_ablate >> 16) & 15) : 1024;
     if (nblk > cap) nblk = cap;
     const dim3 grid(nblk), blk(NT);
+    const size_t tab_bytes = (size_t)3 * C * sizeof(float);
 #define LN16_CASE(L, J) \
-    if (lpr == L && nj == J) hipLaunchKernelGGL((layernorm_i16_i8_tiled_kernel<L, J>), grid, blk, 0, st, a)
+    if (lpr == L && nj == J) hipLaunchKernelGGL((layernorm_i16_i8_tiled_kernel<L, J>), grid, blk, tab_bytes, st, a)
     LN16_CASE(4, 1); LN16_CASE(4, 2); LN16_CASE(4, 3);
     LN16_CASE(8, 2); LN16_CASE(8, 3);
     LN16_CASE(16, 2); LN16_CASE(16, 3);
@@ -1126,12 +1102,13 @@ IVIT_EXPORT int ivit_layernorm_i16_i8_compat(const int16_t* x, int rows, int C, 
         while ((nd + lpr - 1) / lpr > 3) lpr *= 2;
         const int nj = (nd + lpr - 1) / lpr;
         int nblk = grid_for_rows(rows, 64 / lpr);
-        if (nblk > 512) nblk = 512;
+        if (nblk > (nj >= 3 ? 768 : 1024)) nblk = nj >= 3 ? 768 : 1024;      // = the kernel's launch bounds: 3 / 4 workgroups per CU
+        const size_t tab_bytes = (size_t)3 * C * sizeof(float);
         const float r_in = 1.0f / s_in;
         bool launched = false;
 #define LN16C_CASE(L, J)                                                                                                  \
     if (lpr == L && nj == J) {                                                                                            \
-        hipLaunchKernelGGL((layernorm_i16_i8_tiled_compat_kernel<L, J>), dim3(nblk), dim3(NT), 0, st, b, s_in, r_in);     \
+        hipLaunchKernelGGL((layernorm_i16_i8_tiled_compat_kernel<L, J>), dim3(nblk), dim3(NT), tab_bytes, st, b, s_in, r_in);     \
         launched = true;                                                                                                  \
     }
         LN16C_CASE(4, 1); LN16C_CASE(4, 2); LN16C_CASE(4, 3);
