@@ -12,7 +12,7 @@ change that breaks the budget must fail the build here, on the CPU, not on the G
 wait without spilling.  csrc/check_isa.py checks the emitted instruction stream for exactly that; the bit-exact GEMM tests on the
 GPU remain the proof of the result.
 
-Second use (`check_resources.py <remarks> attention|rowops`): the occupancy the launchers of attention.hip / rowops.hip assume
+Second use (`check_resources.py <remarks> attention|rowops|swin`): the occupancy the launchers of attention.hip / rowops.hip / swin.hip assume
 when they size their grids (occupancy_rules below)."""
 import re
 import sys
@@ -53,6 +53,14 @@ def occupancy_rules(path, what):
             # scratch-free: the forms of 193-208 tokens (14 x 14 patches + cls: every BASELINE config); the general-T forms
             # (other geometries, "not tuned") may keep a few dwords of the Q prefetch in scratch
             occ, need_no_scratch = int(m.group(3)), m.group(4) == "0"
+        elif what == "swin":
+            if "window_attention_kernel" in name:
+                occ, need_no_scratch = 4, True
+            else:
+                m = re.search(r"layernorm_i16_i8_tiled(_compat)?_kernelILi(\d+)ELi(\d+)E", name)
+                if not m:
+                    continue
+                occ, need_no_scratch = (3 if m.group(1) and int(m.group(3)) >= 3 else 4), True      # = their __launch_bounds__
         else:
             m = re.search(r"layernorm_i8_stream_kernelILi(\d+)ELi(\d+)ELi(\d+)ELb([01])ELi(\d+)E", name)
             if not m:

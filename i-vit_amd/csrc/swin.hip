@@ -9,7 +9,8 @@
 
 #if IVIT_LAB
 extern int g_ln_ablate;     // rowops.hip; bits 16-19: workgroup cap of the tiled 16-bit LayerNorm in units of 256 (0 = default);
-                            // bit 20: natural-scale 16-bit LayerNorm sums its rows through LDS (the round-3 form)
+                            // bit 20: natural-scale 16-bit LayerNorm sums its rows through LDS (the round-3 form);
+                            // bit 23: window attention requantises its scores in float64 also where float32 is exact
 #else
 constexpr int g_ln_ablate = 0;
 #endif
@@ -738,6 +739,8 @@ struct WinAttnArgs {
     int mask_value;
     int nwin, heads, T, nW;
     double Ms, Mb, Mo;      // qact_attn1; qact2 main operand; qact3
+    float Ms32, Mb32;       // rq32: the same as float32 -- both powers of two (every scale of the power-of-two regime): |S| <= 2^19 and
+    int rq32;               // |kS| <= 128 make both products exact in float32, each fma rounds once, to nearest even, as the float64 form
     int x0, ksat;
     // natural Shiftmax input scale: phi[q + 128] = fl(fl(q*s)/s) for unmasked scores and phim[q + 128] =
     // fl(fl(fl(q*s) - 100)/s) for scores under the shift mask (swin_quant.py:151-156 adds float -100 to q*s before the softmax
@@ -766,7 +769,12 @@ constexpr int WLUT_OFF = WPB * WVT_BYTES;
 
 constexpr int WBAND_PAD = 4;     // dwords: keeps the slices 16-byte aligned and rotates their banks
 
-__global__ __launch_bounds__(NT) void window_attention_kernel(WinAttnArgs a)
+// SM: Shiftmax form -- 0 the table of distances to the row maximum (power-of-two scales; natural scales whose band table has one
+// row), 1 the literal float32 sequence on the phi tables, 2 band rows per row maximum staged through LDS.  Template parameters, not
+// run-time branches: with all three forms in one body the kernel took 135 VGPRs = three workgroups per CU instead of four, and the
+// power-of-two form lost 12 % (44 -> 49.5 us per call in Swin-T, profiles/r04q vs r04h).
+template <int SM, bool RQ32>
+__global__ __launch_bounds__(NT, 4) void window_attention_kernel(WinAttnArgs a)
 {
     __shared__ __attribute__((aligned(16))) char smem[WLUT_OFF + 256 * 4];
     __shared__ float s_phi[2][256];
@@ -775,9 +783,8 @@ __global__ __launch_bounds__(NT) void window_attention_kernel(WinAttnArgs a)
     const int g = lane >> 4, l15 = lane & 15;
     const int T = a.T;
     reinterpret_cast<unsigned*>(smem + WLUT_OFF)[tid] = a.band1 ? a.band1[min(tid, a.band_w - 1)] : shiftexp_int(-tid, a.x0, 15);
-    const bool band = a.band != nullptr;       // uniform
-    const bool compat = a.phi != nullptr && !band;      // uniform
-    if (compat) {
+    constexpr bool band = SM == 2, compat = SM == 1;
+    if constexpr (compat) {
         s_phi[0][tid] = a.phi[tid];
         s_phi[1][tid] = a.phim[tid];
     }
@@ -865,10 +872,16 @@ __global__ __launch_bounds__(NT) void window_attention_kernel(WinAttnArgs a)
                     int ka = -100000;
                     xv[kt][r] = -__builtin_inff();
                     if (key < T) {
+                        if constexpr (RQ32) {      // round 4: 7 float32 / integer instructions instead of 6 float64 ones + 3 (attention.hip RQ32)
+                            const int tb = clamp_i32(__float_as_int(__builtin_fmaf((float)acc[r], a.Ms32, 12582912.0f)), 0x4B400000 - 128, 0x4B400000 + 127);
+                            const float kSf = __int_as_float(tb) - 12582912.0f;                  // qact_attn1, exact small integer
+                            ka = clamp_i32(__float_as_int(__builtin_fmaf(kSf, a.Mb32, 12582912.0f)) - 0x4B400000 + bv[r], -128, 127);
+                        } else {
                         const int kS = clamp_i32(requant_exact(acc[r], a.Ms), -128, 127);        // qact_attn1
                         ka = clamp_i32(requant_exact(kS, a.Mb) + bv[r], -128, 127);              // qact2 (two operands)
+                        }
                         const bool masked = ((kreg[kt] >> (8 * r)) & 0xffu) != qreg;
-                        if (compat) xv[kt][r] = s_phi[masked ? 1 : 0][ka + 128];
+                        if constexpr (compat) xv[kt][r] = s_phi[masked ? 1 : 0][ka + 128];
                         if (masked) ka = band ? -50000 : ka + a.mask_value;                      // shift mask, after the clamp
                     }
                     s[kt][r] = ka;
@@ -879,7 +892,7 @@ __global__ __launch_bounds__(NT) void window_attention_kernel(WinAttnArgs a)
             rmax = max(rmax, __shfl_xor(rmax, 16));
             rmax = max(rmax, __shfl_xor(rmax, 32));
             unsigned esum = 0;
-            if (compat) {
+            if constexpr (compat) {
                 // Shiftmax's float32 sequence on the phi values themselves (ivit_modules.py:150-170), per score
                 xmax = fmaxf(xmax, __shfl_xor(xmax, 16));
                 xmax = fmaxf(xmax, __shfl_xor(xmax, 32));
@@ -901,7 +914,7 @@ __global__ __launch_bounds__(NT) void window_attention_kernel(WinAttnArgs a)
                         s[kt][r] = (int)e;
                         esum += e;
                     }
-            } else if (band) {
+            } else if constexpr (band) {
                 // the band rows of this tile's 16 queries go through LDS (as attention.hip MODE 1): the four lanes of a query copy
                 // its row (band_w dwords, 16 bytes per lane and step), then every score is one LDS gather.  (Gathers straight from
                 // the L2-resident table were as slow as the literal float sequence: profiles/r04m_*.)
@@ -1193,6 +1206,11 @@ static int window_attention_launch(const int8_t* qkv, int8_t* out, int64_t ldo, 
     a.Mb = ivit_dyadic_to_double(m_b, e_b);
     a.Mo = ivit_dyadic_to_double(m_o, e_o);
     IVIT_REQUIRE(a.Ms < 2048.0 && a.Mb < 1048576.0 && a.Mo < 512.0, "ivit_window_attention_i8: requant multiplier too large");
+    // both score multipliers powers of two (m = 2^k) and in float32's range: the float32 form of the two requantisations is exact
+    a.rq32 = m_s != 0 && (m_s & (m_s - 1)) == 0 && m_b != 0 && (m_b & (m_b - 1)) == 0 && a.Ms >= 1e-30 && a.Mb >= 1e-30 && a.Mb <= 4096.0 &&
+             !(g_ln_ablate & (1 << 23));      // lab bit 23: the float64 form (A/B, parity of both forms)
+    a.Ms32 = (float)a.Ms;
+    a.Mb32 = (float)a.Mb;
     const float x0f = __builtin_floorf((1.0f / s_attn) * -1.0f);
     IVIT_REQUIRE(x0f <= -1.0f && x0f >= -4096.0f, "ivit_window_attention_i8: x0=%g outside [-4096,-1]", (double)x0f);
     a.x0 = (int)x0f;
@@ -1211,7 +1229,18 @@ static int window_attention_launch(const int8_t* qkv, int8_t* out, int64_t ldo, 
     const int npairs = windows * heads;
     const int grid = (npairs + WPB - 1) / WPB;
     const size_t band_bytes = a.band ? (size_t)WPB * 16 * (band_w + WBAND_PAD) * sizeof(unsigned) : 0;
-    hipLaunchKernelGGL(window_attention_kernel, dim3(grid < 8192 ? grid : 8192), dim3(NT), band_bytes, ivit_stream(stream), a);
+    const dim3 grd(grid < 8192 ? grid : 8192), blk(NT);
+    hipStream_t st = ivit_stream(stream);
+    if (a.band) {
+        if (a.rq32) hipLaunchKernelGGL((window_attention_kernel<2, true>), grd, blk, band_bytes, st, a);
+        else hipLaunchKernelGGL((window_attention_kernel<2, false>), grd, blk, band_bytes, st, a);
+    } else if (a.phi) {
+        if (a.rq32) hipLaunchKernelGGL((window_attention_kernel<1, true>), grd, blk, 0, st, a);
+        else hipLaunchKernelGGL((window_attention_kernel<1, false>), grd, blk, 0, st, a);
+    } else {
+        if (a.rq32) hipLaunchKernelGGL((window_attention_kernel<0, true>), grd, blk, 0, st, a);
+        else hipLaunchKernelGGL((window_attention_kernel<0, false>), grd, blk, 0, st, a);
+    }
     IVIT_CHECK_LAUNCH("ivit_window_attention_i8");
 }
 

@@ -300,18 +300,24 @@ def window_attention_ref(q8, k8, v8, bias_add, mask_add, nW, me_s, me_b, s_attn,
 @pytest.mark.parametrize("B_,nW,nH,N,s_attn,masked", [(8, 4, 3, 49, 0.25, True), (6, 1, 6, 49, 0.5, False),
                                                       (4, 4, 2, 16, 1.0, True), (3, 1, 24, 49, 2.0, False),
                                                       (5, 1, 1, 64, 0.125, False), (2, 2, 2, 9, 0.0625, True)])
-def test_window_attention(B_, nW, nH, N, s_attn, masked):
+@pytest.mark.parametrize("pow2_scores", [False, True])
+def test_window_attention(B_, nW, nH, N, s_attn, masked, pow2_scores):
+    """pow2_scores: both score multipliers powers of two, as in the power-of-two regime of the engine: the kernel's float32 form of the
+    two requantisations (round 4), compared with the oracle AND with its float64 form (lab bit 23); else the float64 form"""
     rng = np.random.default_rng(B_ * 1000 + N)
     hd = 32
     qkv = rng.integers(-128, 128, size=(3, B_, nH, N, hd)).astype(np.int8)
     qkv[0, 0, 0, 0] = 127   # saturating scores
     qkv[1, 0, 0] = 127
-    s_S = np.float32(2.0 ** -9 * 0.9)
+    s_S = np.float32(2.0 ** -9 * (1.0 if pow2_scores else 0.9))
     s_at = np.float32(s_attn)
     ms, omS = sme(s_S, s_at), ome(s_S, s_at)
     mb, omB = sme(s_at, s_at * np.float32(1.0)), ome(s_at, s_at)
-    if N == 49:  # a non-trivial qact_attn1 -> qact2 ratio too
-        mb, omB = sme(s_at * np.float32(0.75), s_at), ome(s_at * np.float32(0.75), s_at)
+    if N == 49:  # a non-trivial qact_attn1 -> qact2 ratio too (0.5: every odd kS is an exact tie of the second requantisation)
+        ratio = np.float32(0.5 if pow2_scores else 0.75)
+        mb, omB = sme(s_at * ratio, s_at), ome(s_at * ratio, s_at)
+    if pow2_scores:
+        assert int(ms[0]) & (int(ms[0]) - 1) == 0 and int(mb[0]) & (int(mb[0]) - 1) == 0
     mo, omO = sme(np.float32(2.0 ** -7 * 0.05), 0.043), ome(np.float32(2.0 ** -7 * 0.05), 0.043)
     bias_add = rng.integers(-60, 61, size=(nH, N, N)).astype(np.int16)
     bias_pad = np.full((nH, N, 64), 99, np.int16)      # pad entries must never be used
@@ -332,6 +338,14 @@ def test_window_attention(B_, nW, nH, N, s_attn, masked):
     assert np.array_equal(got[:, : nH * hd].astype(np.int32).reshape(B_, N, nH * hd), ref)
     assert not got[:, nH * hd:].any()
     assert Pm.max() > 0
+    if pow2_scores:
+        out64 = torch.zeros(B_ * N, ld, dtype=torch.int8, device=DEV)
+        with _lib.lab_session():
+            _lib.call("ivit_debug_ln_ablate", 1 << 23)
+            _lib.call("ivit_window_attention_i8", _lib.ptr(dev(qkv)), _lib.ptr(out64), ld, _lib.ptr(dev(bias_pad)),
+                      _lib.ptr(None if region is None else dev(region)), mval, B_, nW, nH, N, hd, ms[0], ms[1], mb[0], mb[1],
+                      float(s_at), mo[0], mo[1], st())
+        assert np.array_equal(out64.cpu().numpy(), got)
     # the same rows at their image positions (window reverse + roll back in the store address)
     ws_ = int(round(np.sqrt(N)))
     if ws_ * ws_ == N and B_ % nW == 0:
