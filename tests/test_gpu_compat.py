@@ -108,6 +108,40 @@ def test_layernorm_compat_random_vs_oracle(rows, Cn, s, ln_form):
     assert not np.array_equal(orc.requant(orc.roundtrip(y0, s0), m, e, 8), exp)
 
 
+@pytest.mark.parametrize("rows,Cn,outer,s", [(6272, 96, 3136, 0.0371), (4096, 64, 64, 0.0213), (1280, 192, 320, 0.0371), (3136, 96, 49, 0.0371)])
+def test_layernorm_compat_outer_order_8_bit_equals_16_bit_kernel(rows, Cn, outer, s):
+    """Swin's patch-embed LayerNorm at natural scales (8-bit input, the mean over a TRANSPOSED view: torch's outer-reduction order,
+    IVIT_LN_OUTER_MEAN).  Round 4 sums a candidate tie row's groups of 16 on one lane each instead of serially; the 16-bit kernel of
+    csrc/swin.hip computes the same LayerNorm from the same integers with its own outer-order sums (pinned by the reference's Swin
+    goldens and tests/test_gpu_swin.py): identical bytes, on rows of which half are exact ties (outer = 49: the serial form, tail
+    columns)"""
+    from ivit_amd.prepare import markstein_division_ok
+    rng = np.random.default_rng(rows + Cn)
+    s = np.float32(s)
+    tabs = phi_tables(s)
+    assert tabs is not None and markstein_division_ok(s, 16)
+    remap, phi = tabs
+    q = np.clip(np.rint(rng.normal(rng.normal(0, 20, size=(rows, 1)), rng.uniform(5, 40, size=(rows, 1)), size=(rows, Cn))), -128, 127).astype(np.int32)
+    for r in range(0, rows, 2):
+        d = Cn // 2 + Cn * int(rng.integers(-20, 20)) - int(q[r].sum())
+        for c in rng.permutation(Cn):
+            if d == 0:
+                break
+            nv = int(np.clip(q[r, c] + d, -128, 127))
+            d -= nv - q[r, c]
+            q[r, c] = nv
+    lp = LayerNormParams(rng.uniform(0.5, 1.5, size=Cn).astype(np.float32), rng.normal(0, 0.1, size=Cn).astype(np.float32), np.float32(0.031))
+    b, sl, m, e = dev(lp.bias_int), dev(lp.s_ln), dev(lp.m.view(np.int32)), dev(lp.e)
+    out8 = torch.empty(rows, Cn, dtype=torch.int8, device=DEV)
+    _lib.call("ivit_layernorm_i8_compat", _lib.ptr(dev(q.astype(np.int8))), Cn, rows, Cn, _lib.ptr(b), _lib.ptr(sl), _lib.ptr(m), _lib.ptr(e),
+              _lib.ptr(dev(remap)), _lib.ptr(dev(phi)), _lib.ptr(out8), Cn, outer << 8, st())
+    out16 = torch.empty(rows, Cn, dtype=torch.int8, device=DEV)
+    _lib.call("ivit_layernorm_i16_i8_compat", _lib.ptr(dev(q.astype(np.int16))), rows, Cn, float(s), 1 | (outer << 8), _lib.ptr(b), _lib.ptr(sl),
+              _lib.ptr(m), _lib.ptr(e), _lib.ptr(out16), Cn, 0, 0, 0, 0, st())
+    a, c = out8.cpu().numpy(), out16.cpu().numpy()
+    assert np.array_equal(a, c), f"{(a != c).sum()} of {a.size} bytes differ"
+
+
 def test_shiftgelu_compat_table(ckat):
     for ci in ckat["gelu_cases"]:
         c = f"gelu{ci}_"
