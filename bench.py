@@ -155,7 +155,7 @@ def pmc_traffic(kernel_keys):
 def cpu_baseline(fs, ranges, cfg):
     """The CPU oracle (port of the reference's integer algorithm, oracle/ivit_oracle.c) timed on this host's cores on a
     bounded sample of the same workload: 2 warm-up passes, median of ALWAYS 5 timed passes -- the sample size
-    (16, 8 or 4 images per pass) is chosen from the first warm-up so that the seven passes stay near half a minute, instead
+    (32, 16, 8 or 4 images per pass) is chosen from the first warm-up so that the seven passes stay near half a minute, instead
     of cutting the pass count on a slow host.  It is a correctness port -- OpenMP over rows, a row-blocked int8 GEMM on
     16-bit dot products, everything else scalar -- not a tuned CPU path."""
     import numpy as np
@@ -170,7 +170,7 @@ def cpu_baseline(fs, ranges, cfg):
     t0 = time.perf_counter()
     om.forward(synth.make_images(n, 31337))
     first = time.perf_counter() - t0                 # includes first-touch costs: an upper estimate of a pass of 8 images
-    n = 16 if first * 2 * 6 <= 40.0 else 8 if first * 6 <= 40.0 else 4
+    n = 32 if first * 4 * 6 <= 30.0 else 16 if first * 2 * 6 <= 40.0 else 8 if first * 6 <= 40.0 else 4      # ~10-30 s of CPU work in all
     imgs = synth.make_images(n, 31337)
     times = []
     for i in range(6):                               # one more warm-up at the chosen size, then the five timed passes
