@@ -442,6 +442,8 @@ static int launch_ln_stream(const LnArgs& a, hipStream_t st, const char* who, in
         else if (cfg == 3) IVIT_LN_STREAM(16, 3, 3, 4);
         else if (cfg == 4) IVIT_LN_STREAM(16, 3, 2, 4);
         else if (cfg == 5) IVIT_LN_STREAM(16, 3, 0, 4);
+        else if (cfg == 6 && !COMPAT) IVIT_LN_STREAM(16, 3, 1, 6);     // run with bits 4-7 = 6: six workgroups per CU (<= 85 VGPRs)
+        else if (cfg == 7 && !COMPAT) IVIT_LN_STREAM(16, 3, 1, 5);     // ... = 5
         else
 #endif
         IVIT_LN_STREAM(16, 3, 1, 4);

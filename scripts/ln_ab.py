@@ -26,7 +26,7 @@ shapes = [(197 * 256, 768), (197 * 64, 384), (197 * 128, 768), (197 * 1024, 768)
 if len(sys.argv) > 1 and sys.argv[1] == "--headline":
     shapes = shapes[:1]
 variants = [("grouped(r3)", 3, 0, 0), ("stream", 0, 0, 0), ("stream equal-prio", 0, 0, 32), ("stream ng2", 0, 4, 0), ("stream dbuf", 0, 5, 0),
-            ("stream ng3", 0, 3, 0)]
+            ("stream 5 wg/CU", 0, 7 | (5 << 4), 0), ("stream 6 wg/CU", 0, 6 | (6 << 4), 0)]
 if len(sys.argv) > 1 and sys.argv[1] == "--small":     # launches below ~12 MB: the half-wave kernel with 4 / 2 / 1 row pairs per wave (lab bits 21-22)
     shapes = [(197 * 64, 384), (197 * 16, 384), (197, 192), (197 * 8, 192)]
     variants = [("grouped(r3)", 3, 0, 0), ("product", 0, 0, 0), ("half-wave 4 pairs", 0, 0, 1 << 21), ("half-wave 2 pairs", 0, 0, 2 << 21),

@@ -165,7 +165,7 @@ int main()
 {
     unsigned long long* cyc;
     float* sink;
-    CHECK(hipMalloc(&cyc, 256 * 16 * sizeof(unsigned long long)));
+    CHECK(hipMalloc(&cyc, 512 * 16 * sizeof(unsigned long long)));
     CHECK(hipMalloc(&sink, 64));
     struct { const char* name; kern_t k; } ks[] = {
         {"v_fma_f32", k_fma}, {"v_pk_fma_f32", k_pkfma}, {"v_pk_mul_f32", k_pkmul}, {"v_mul_f32", k_mul}, {"v_add_f32", k_add}, {"v_floor_f32", k_floor},
@@ -181,13 +181,14 @@ int main()
         {"v_add_lshl_u32", k_addlshl}, {"v_min_i32", k_minint},
     };
     const int iters = 200;
-    printf("%-22s %28s %28s %28s\n", "instruction", "1 wave/SIMD: cyc/instr/wave", "2 waves/SIMD: wave | SIMD", "4 waves/SIMD: wave | SIMD");
+    printf("%-22s %28s %28s %28s %28s\n", "instruction", "1 wave/SIMD: cyc/instr/wave", "2 waves/SIMD: wave | SIMD", "4 waves/SIMD: wave | SIMD",
+           "8 waves/SIMD: wave | SIMD");
     for (auto& e : ks) {
         printf("%-22s", e.name);
-        for (int wps : {1, 2, 4}) {
-            const int threads = 256 * wps, nw = 256 * 4 * wps;
+        for (int wps : {1, 2, 4, 8}) {      // 8: two workgroups of 1024 threads per CU
+            const int threads = 256 * (wps > 4 ? 4 : wps), nw = 256 * 4 * wps, grid = wps > 4 ? 512 : 256;
             for (int rep = 0; rep < 2; ++rep) {
-                hipLaunchKernelGGL(e.k, dim3(256), dim3(threads), 0, 0, iters, cyc, sink);
+                hipLaunchKernelGGL(e.k, dim3(grid), dim3(threads), 0, 0, iters, cyc, sink);
                 CHECK(hipDeviceSynchronize());
             }
             std::vector<unsigned long long> h(nw);
