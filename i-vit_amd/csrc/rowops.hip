@@ -1750,6 +1750,64 @@ IVIT_EXPORT int ivit_shiftgelu_build_lut_ex(float s, uint32_t m, int32_t e, cons
     IVIT_CHECK_LAUNCH("ivit_shiftgelu_build_lut");
 }
 
+// Short rows (L <= 384: Swin stage 0, 401 408 rows of 384 bytes per launch at batch 128): HALF a wave per row, four rows per wave and
+// iteration.  With a whole wave per row only 96 of 2 x 192 lane-dwords carry data at L = 384, every row pays its own 256-byte table
+// slice and reduction chain, and the launch ran at 3.4 TB/s (90 us) where the wide rows of the ViT MLP reach 5.9 (round 4).
+template <int NJ>
+__global__ __launch_bounds__(NT) void shiftgelu_lut_apply_half_kernel(GeluArgs a)
+{
+    constexpr int RP = 2;                      // row pairs per wave and iteration
+    __shared__ __attribute__((aligned(16))) unsigned char tab[WPB][2 * RP][256];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int half = lane >> 5, l32 = lane & 31;
+    const int nd = a.L >> 2;
+    for (int row0 = (blockIdx.x * WPB + wave) * (2 * RP); row0 < a.rows; row0 += gridDim.x * WPB * (2 * RP)) {
+        int w[RP][NJ], kmax[RP];
+#pragma unroll
+        for (int p = 0; p < RP; ++p) {
+            const int row = min(row0 + 2 * p + half, a.rows - 1);
+            kmax[p] = -128;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int d = l32 + 32 * j;
+                if (a.in_blocks) w[p][j] = (d < nd) ? *reinterpret_cast<const int*>(a.x + block_off(block_row(row, a.L), block_col(4 * d))) : (int)0x80808080;
+                else w[p][j] = (d < nd) ? reinterpret_cast<const int*>(a.x + (int64_t)row * a.ldx)[d] : (int)0x80808080;
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < RP; ++p)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                kmax[p] = max(max(kmax[p], sx8(w[p][j], 0)), max(sx8(w[p][j], 1), max(sx8(w[p][j], 2), sx8(w[p][j], 3))));
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1)       // within the half wave
+#pragma unroll
+            for (int p = 0; p < RP; ++p) kmax[p] = max(kmax[p], __shfl_xor(kmax[p], o));
+#pragma unroll
+        for (int p = 0; p < RP; ++p)           // each half wave fetches its row's 256-byte slice: 8 bytes per lane
+            reinterpret_cast<int2*>(tab[wave][2 * p + half])[l32] = reinterpret_cast<const int2*>(a.lut + (int64_t)(kmax[p] + 128) * 256)[l32];
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);    // lgkmcnt(0): the table slices are in LDS
+#pragma unroll
+        for (int p = 0; p < RP; ++p) {
+            const int row = row0 + 2 * p + half;
+            const unsigned char* tb = tab[wave][2 * p + half];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int d = l32 + 32 * j;
+                if (d < nd && row < a.rows) {
+                    const unsigned v = (unsigned)w[p][j] ^ 0x80808080u;      // k + 128 per byte
+                    const unsigned o = (unsigned)tb[v & 255] | ((unsigned)tb[(v >> 8) & 255] << 8) | ((unsigned)tb[(v >> 16) & 255] << 16) |
+                                       ((unsigned)tb[v >> 24] << 24);
+                    const int64_t off = a.out_blocks ? (int64_t)block_off(block_row(row, a.L), block_col(4 * d)) : (int64_t)row * a.ldo + 4 * d;
+                    *reinterpret_cast<int*>(reinterpret_cast<int8_t*>(a.out) + off) = (int)o;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 IVIT_EXPORT int ivit_shiftgelu_lut_i8_ex(const int8_t* x, int64_t ldx, int rows, int L, const int8_t* lut, int8_t* out,
                                          int64_t ldo, int layouts, ivit_stream_t stream)
 {
@@ -1768,6 +1826,13 @@ IVIT_EXPORT int ivit_shiftgelu_lut_i8_ex(const int8_t* x, int64_t ldx, int rows,
     const dim3 grid(grid_for_rows(rows, 2)), blk(NT);
     hipStream_t st = ivit_stream(stream);
     const int nj = (L / 4 + 63) / 64;
+    if (L <= 384 && rows >= 4096 && !(g_ln_ablate & (1 << 24))) {      // lab bit 24: the whole-wave-per-row form (A/B, parity of both)
+        const dim3 gridh(grid_for_rows(rows, 4));
+        if (L <= 128) hipLaunchKernelGGL(shiftgelu_lut_apply_half_kernel<1>, gridh, blk, 0, st, a);
+        else if (L <= 256) hipLaunchKernelGGL(shiftgelu_lut_apply_half_kernel<2>, gridh, blk, 0, st, a);
+        else hipLaunchKernelGGL(shiftgelu_lut_apply_half_kernel<3>, gridh, blk, 0, st, a);
+        IVIT_CHECK_LAUNCH("ivit_shiftgelu_lut_i8");
+    }
     if (nj <= 3) hipLaunchKernelGGL(shiftgelu_lut_apply_kernel<3>, grid, blk, 0, st, a);
     else if (nj <= 6) hipLaunchKernelGGL(shiftgelu_lut_apply_kernel<6>, grid, blk, 0, st, a);
     else if (nj <= 12) hipLaunchKernelGGL(shiftgelu_lut_apply_kernel<12>, grid, blk, 0, st, a);

@@ -1001,6 +1001,35 @@ def test_shiftgelu_all_row_maxima():
     assert np.array_equal(out8.cpu().numpy().astype(np.int32), exp8)
 
 
+@pytest.mark.parametrize("rows,L", [(5003, 384), (4096, 256), (4100, 128), (6000, 96), (4097, 320)])
+def test_shiftgelu_table_short_rows(rows, L):
+    """round 4: rows of at most 384 bytes (Swin stage 0) take half a wave each, four rows per wave; against the oracle, against the
+    whole-wave-per-row form (lab bit 24), row-major and block-layout, in place"""
+    rng = np.random.default_rng(rows + L)
+    s = np.float32(2.0 ** -4)
+    k = np.clip(np.rint(rng.normal(0, 35, size=(rows, L))), -128, 127).astype(np.int8)
+    k[::7] = np.minimum(k[::7], -3)                      # rows with a negative maximum
+    exp, s_go = orc.shiftgelu(k.astype(np.int32), s)
+    m, e = dyadic(s_go, np.float32(2.0 ** -4))
+    exp8 = orc.requant(exp, m.astype(np.float64), e, 8).astype(np.int8)
+    lut = torch.empty(65536, dtype=torch.int8, device=DEV)
+    _lib.call("ivit_shiftgelu_build_lut", float(s), int(m[0]), int(e[0]), _lib.ptr(lut), st())
+    out = torch.empty(rows, L, dtype=torch.int8, device=DEV)
+    _lib.call("ivit_shiftgelu_lut_i8", _lib.ptr(dev(k)), L, rows, L, _lib.ptr(lut), _lib.ptr(out), L, st())
+    assert np.array_equal(out.cpu().numpy(), exp8)
+    with _lib.lab_session():
+        _lib.call("ivit_debug_ln_ablate", 1 << 24)
+        out_w = torch.empty(rows, L, dtype=torch.int8, device=DEV)
+        _lib.call("ivit_shiftgelu_lut_i8", _lib.ptr(dev(k)), L, rows, L, _lib.ptr(lut), _lib.ptr(out_w), L, st())
+    assert np.array_equal(out_w.cpu().numpy(), exp8)
+    if L % 64 == 0:                                        # block layout in and out, in place (what the Swin engine does)
+        R16 = (rows + 15) // 16 * 16
+        kb = torch.zeros(R16 * L, dtype=torch.int8, device=DEV)
+        _lib.call("ivit_tile_operand_i8", _lib.ptr(dev(k)), L, rows, L, _lib.ptr(kb), st())
+        _lib.call("ivit_shiftgelu_lut_i8_ex", _lib.ptr(kb), L, rows, L, _lib.ptr(lut), _lib.ptr(kb), L, 3, st())
+        assert np.array_equal(kb.cpu().numpy()[: R16 * L], _block_layout_host(exp8)[: R16 * L])
+
+
 # ----------------------------------------------------------------------------------- Shiftmax
 def test_shiftmax_kat(kat):
     for ci in kat["sm_cases"]:
