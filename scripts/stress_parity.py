@@ -15,7 +15,7 @@ from ivit_amd.swin_engine import IntSwinEngine  # noqa: E402
 
 DEV = "cuda:0"
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 300
-for tag, B in (("deit_base", 256), ("deit_base_natural", 256), ("vit_base", 128), ("deit_small", 64), ("swin_tiny", 128)):
+for tag, B in (("deit_base", 256), ("deit_base_natural", 256), ("vit_base", 128), ("deit_small", 64), ("swin_tiny", 128), ("swin_tiny_natural", 128)):
     fs, ranges, cfg, meta, z = load_synthetic_model(tag)
     if tag.startswith("swin"):
         eng = IntSwinEngine(fs, ranges, cfg["embed_dim"], cfg["depths"], cfg["num_heads"], cfg["window"], device=DEV, max_batch=B)
