@@ -458,3 +458,26 @@ def test_isa_lint_accepts_counted_waits_and_rejects_broken_streams():
     assert _lint(pre + ["v_mov_b64_e32 v[42:43], v[68:69]", "v_mov_b64_e32 v[40:41], v[66:67]", "s_nop 0", "v_add_u32_e32 v70, v71, v72",
                         "v_add_u32_e32 v73, v71, v72", "v_add_u32_e32 v74, v71, v72", mfma]) == []
     assert _lint(pre + ["v_mov_b64_e32 v[44:45], v[68:69]", mfma]) == []
+
+
+def test_window_shiftexp_band_conditions():
+    """prepare.window_shiftexp_band (round 4): when may the Swin window attention read Shiftmax's exp_int from a table?  One row when
+    it depends on the distance to the maximum alone, 256 rows otherwise, nothing when a score under the shift mask could be a row
+    maximum or fails to saturate (-100 / s too small) or the band is wider than the kernel's LDS slices"""
+    import numpy as np
+    from ivit_amd.prepare import phi_table, shiftexp2d, window_shiftexp_band
+    band, W = window_shiftexp_band(0.271, True)
+    assert band is not None and band.shape == (1, W) and W % 16 == 0 and W <= 192
+    tab = shiftexp2d(np.float32(0.271))
+    for qmax in (0, 100, 255):                      # the one row reproduces every row of the full table, saturated beyond W - 1
+        for j in range(0, min(qmax + 1, 256)):
+            assert band[0, min(j, W - 1)] == tab[qmax, qmax - j]
+    band, W = window_shiftexp_band(0.1173, True)
+    assert band is not None and band.shape == (256, W)
+    assert np.all(band[:, W - 1] == band[0, W - 1])
+    assert window_shiftexp_band(1.3, True) == (None, 0)             # -100 / 1.3 = -77: a masked score can exceed an unmasked one
+    band, W = window_shiftexp_band(1.3, False)
+    assert band is not None                                         # ... without a mask the table is fine
+    assert window_shiftexp_band(0.01, False) == (None, 0)           # band wider than 192 entries (or than the table)
+    assert np.array_equal(phi_table(0.25), np.arange(-128, 128, dtype=np.float32))
+
