@@ -961,6 +961,143 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_wreg_kernel(GemmArgs g)
     }
 }
 
+// ================================================================================================
+// Skinny-K form (round 4): K <= 128, N <= 320 -- Swin stage 0 (patch embedding K = 64 / N = 96, qkv K = 128 / N = 288; 401 408 rows at batch
+// 128).  Such a GEMM is a streaming pass: 154-193 MB of HBM traffic against 22 GOP.  In the tile kernels above it ran at 1.6-2.1 x its
+// HBM time, because their epilogues (LDS-staged, two waves per SIMD, N = 288 padded to 384) -- not their two K steps -- fill the time.
+// Here the whole weight matrix sits in LDS in v_mfma_i32_16x16x32_i8 fragment order (<= 48 KB), a wave takes strips of 16 tokens:
+// K / 32 eight-byte loads per lane, N / 16 x K / 32 MFMAs with the weight fragment read from LDS, the requantisation (float32 bracket
+// certificate, float64 on a failed batch: epilogue_direct_16's arithmetic) straight on the accumulators, one 16-byte store per lane and
+// batch of four channel sub-tiles.  No inline asm: the compiler schedules it; two workgroups of eight waves per CU.  EPI_RQ (row-major
+// output) and EPI_QKV.  Measured (Swin-T b128, profiles/r04x_*): patch embedding 37 -> 24 us, qkv 65.6 -> 62-64 us; at N = 384 (fc1) it lost
+// (72 against 63 us) and the tile kernel keeps that shape.
+// ================================================================================================
+constexpr int SK_MAXN = 320, SK_MAXK = 128, SK_NT = 512, SK_WPB = SK_NT / 64;
+constexpr int SK_SMEM = SK_MAXN * SK_MAXK + SK_MAXN * 12 + (SK_MAXN / 4) * 4;      // fragments | float2 lohi[N] | int bias[N] | u32 coff[N / 4]
+
+template <int EPI>
+__global__ __launch_bounds__(SK_NT, 2) void gemm_i8_skinny_kernel(GemmArgs g)
+{
+    static_assert(EPI == EPI_RQ || EPI == EPI_QKV, "skinny-K form: int8 outputs");
+    __shared__ __attribute__((aligned(16))) char smem[SK_SMEM];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g4 = lane >> 4, l15 = lane & 15;
+    const int nks = g.K >> 5, nsub = g.N >> 4;
+    float2* const lohi = reinterpret_cast<float2*>(smem + SK_MAXN * SK_MAXK);
+    int* const bias = reinterpret_cast<int*>(smem + SK_MAXN * SK_MAXK + SK_MAXN * 8);
+    unsigned* const coff = reinterpret_cast<unsigned*>(smem + SK_MAXN * SK_MAXK + SK_MAXN * 12);      // EPI_QKV: head-major offset of channels 4 j ..
+    // ---- weights: fragment (i, ks) = 512 bytes.  The MFMA's K slots are a permutation of the K index (a dot product does not care):
+    //      slot (ks, g4, b) = k index 8 nks g4 + 8 ks + b, so that a lane's token bytes are 8 nks CONTIGUOUS bytes of its row (one or
+    //      two 16-byte loads, four lanes = the whole row) instead of nks pieces of 8; lane L of a fragment holds W[16 i + (L & 15)][..]
+    for (int q = tid; q < nsub * nks * 64; q += SK_NT) {
+        const int f = q >> 6, L = q & 63, i = f / nks, ks = f - i * nks;
+        *reinterpret_cast<long*>(smem + (size_t)q * 8) =
+            *reinterpret_cast<const long*>(g.W + (int64_t)(16 * i + (L & 15)) * g.ldw + 8 * nks * (L >> 4) + 8 * ks);
+    }
+    if constexpr (EPI == EPI_QKV) {
+        const int cdim = g.heads * g.head_dim, nb = g.M / g.tokens;
+        for (int j = tid; j < (g.N >> 2); j += SK_NT) {
+            const int c = 4 * j, which = c / cdim, rem = c - which * cdim;
+            const int hh = rem / g.head_dim, d0 = rem - hh * g.head_dim;
+            coff[j] = (unsigned)(((which * nb * g.heads + hh) * g.tokens) * g.head_dim + d0);
+        }
+    }
+    for (int c = tid; c < g.N; c += SK_NT) {
+        const double M = dyadic_mult(g.m[c], g.e[c]);
+        const float mf = (float)M;
+        const int bits = __float_as_int(mf);
+        float lo = ((double)mf > M) ? __int_as_float(bits - 1) : mf, hi = ((double)mf < M) ? __int_as_float(bits + 1) : mf;
+        lo = __int_as_float(__float_as_int(lo) - 2);      // widened by two float32 steps: no range test on the accumulator
+        hi = __int_as_float(__float_as_int(hi) + 2);      // (gemm_common.h epilogue_i8_16)
+        lohi[c] = make_float2(lo, hi);
+        bias[c] = g.bias ? g.bias[c] : 0;
+    }
+    __syncthreads();
+    int8_t* const out = reinterpret_cast<int8_t*>(g.out);
+    const int nstrips = (g.M + 15) >> 4;
+    for (int strip = blockIdx.x * SK_WPB + wave; strip < nstrips; strip += gridDim.x * SK_WPB) {
+        const int t = 16 * strip + l15;                   // this lane's token
+        const int8_t* arow = g.A + (int64_t)min(t, g.M - 1) * g.lda + 8 * nks * g4;
+        long bf[SK_MAXK / 32] = {0l, 0l, 0l, 0l};
+        if (nks == 4) {          // uniform: K = 128, 32 bytes per lane
+            const int4 u0 = *reinterpret_cast<const int4*>(arow), u1 = *reinterpret_cast<const int4*>(arow + 16);
+            bf[0] = ((long)(unsigned)u0.y << 32) | (unsigned)u0.x; bf[1] = ((long)(unsigned)u0.w << 32) | (unsigned)u0.z;
+            bf[2] = ((long)(unsigned)u1.y << 32) | (unsigned)u1.x; bf[3] = ((long)(unsigned)u1.w << 32) | (unsigned)u1.z;
+        } else if (nks == 2) {   // K = 64, 16 bytes per lane
+            const int4 u0 = *reinterpret_cast<const int4*>(arow);
+            bf[0] = ((long)(unsigned)u0.y << 32) | (unsigned)u0.x; bf[1] = ((long)(unsigned)u0.w << 32) | (unsigned)u0.z;
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < SK_MAXK / 32; ++ks) bf[ks] = ks < nks ? *reinterpret_cast<const long*>(arow + 8 * ks) : 0l;
+        }
+        // EPI_QKV: image and token of this lane's row (one division per strip)
+        unsigned qrow_off = 0;
+        if constexpr (EPI == EPI_QKV) {
+            const int tt = min(t, g.M - 1);
+            const int qb = tt / g.tokens, qtok = tt - qb * g.tokens;
+            qrow_off = (unsigned)((qb * g.heads * g.tokens + qtok) * g.head_dim);
+        }
+        for (int i0 = 0; i0 < nsub; i0 += 4) {            // four channel sub-tiles per batch: 16 outputs per lane under one certificate
+            v4i acc[4];
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) {
+                const int i = min(i0 + ii, nsub - 1);
+                acc[ii] = *reinterpret_cast<const v4i*>(bias + 16 * i + 4 * g4);
+#pragma unroll
+                for (int ks = 0; ks < SK_MAXK / 32; ++ks)
+                    if (ks < nks)
+                        acc[ii] = __builtin_amdgcn_mfma_i32_16x16x32_i8(*reinterpret_cast<const long*>(smem + ((size_t)(i * nks + ks) * 64 + lane) * 8),
+                                                                         bf[ks], acc[ii], 0, 0, 0);
+            }
+            int b[4][4];
+            unsigned unc = 0;
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) {
+                const int i = min(i0 + ii, nsub - 1);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float2 lh = lohi[16 * i + 4 * g4 + r];
+                    const float a = (float)acc[ii][r];
+                    const int tl = __float_as_int(__builtin_fmaf(a, lh.x, 12582912.0f));
+                    const int th = __float_as_int(__builtin_fmaf(a, lh.y, 12582912.0f));
+                    asm("v_sad_u32 %0, %1, %2, %3" : "=v"(unc) : "v"(tl), "v"(th), "v"(unc));
+                    b[ii][r] = clamp_i32(tl, 0x4B400000 - 128, 0x4B400000 + 127);       // low byte = int8 result
+                }
+            }
+            if (__builtin_amdgcn_ballot_w64(unc != 0) != 0) {      // rare: exact float64 evaluation of the batch (quant_utils.py:229-230)
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii) {
+                    const int c0 = 16 * min(i0 + ii, nsub - 1) + 4 * g4;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const double tq = (double)acc[ii][r] * dyadic_mult(g.m[c0 + r], g.e[c0 + r]) + IVIT_MAGIC;
+                        b[ii][r] = clamp_i32((int)(unsigned)__double_as_longlong(tq), -128, 127);
+                    }
+                }
+            }
+            // a lane holds one dword (4 channels) per sub-tile; the 4 x 4 dword transpose over the token's four lanes (epilogue_direct_16)
+            // leaves lane g4 with the 16 bytes of sub-tile i0 + g4: one 16-byte store per lane, 64 contiguous bytes per row (dword
+            // stores from the MFMA layout -- 16-byte pieces of 16 rows per instruction -- made this kernel SLOWER than the tile kernels)
+            unsigned D[4];
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii)
+                D[ii] = __builtin_amdgcn_perm((unsigned)b[ii][1], (unsigned)b[ii][0], 0x0c0c0400u) |
+                        __builtin_amdgcn_perm((unsigned)b[ii][3], (unsigned)b[ii][2], 0x04000c0cu);
+            typedef unsigned v2u __attribute__((ext_vector_type(2)));
+            const v2u ab = __builtin_amdgcn_permlane32_swap(D[0], D[2], false, false);
+            const v2u cd = __builtin_amdgcn_permlane32_swap(D[1], D[3], false, false);
+            const v2u ac = __builtin_amdgcn_permlane16_swap(ab.x, cd.x, false, false);
+            const v2u bd = __builtin_amdgcn_permlane16_swap(ab.y, cd.y, false, false);
+            const int ci = i0 + g4;            // this lane's sub-tile after the transpose
+            if (ci < nsub && t < g.M) {
+                const int4 v = make_int4((int)ac.x, (int)ac.y, (int)bd.x, (int)bd.y);
+                if constexpr (EPI == EPI_QKV) *reinterpret_cast<int4*>(out + coff[4 * ci] + qrow_off) = v;
+                else *reinterpret_cast<int4*>(out + (int64_t)t * g.ldo + 16 * ci) = v;
+            }
+        }
+    }
+}
+
 #include "gemm_wp.h"
 
 template <int EPI>
@@ -1009,6 +1146,18 @@ int launch_gemm(GemmArgs& g, const char* name, ivit_stream_t stream)
     g.stamp = reinterpret_cast<unsigned long long*>(g_stamp_buf);
 #endif
     const bool blocks = g.a_blocks || g.w_blocks;
+    if constexpr (EPI == EPI_RQ || EPI == EPI_QKV) {
+        // skinny-K form: a streaming pass with the whole weight matrix in LDS (Swin stage 0); lab flags2 bit 20: off (A/B, parity of both)
+        if (!blocks && !g.w_frags && !g.out_blocks && !g.lut && !g.gelu_ws && g.M >= 8192 && g.K >= 32 && g.K <= SK_MAXK && g.K % 32 == 0 && g.N >= 16 &&
+            g.N <= SK_MAXN && g.N % 16 == 0 && g.lda % 16 == 0 && g.ldw % 8 == 0 && ((uintptr_t)g.A % 16 == 0) && ((uintptr_t)g.W % 8 == 0) &&
+            ((uintptr_t)g.out % 16 == 0) && (EPI == EPI_QKV || g.ldo % 16 == 0) && (EPI != EPI_QKV || g.head_dim % 16 == 0) && (int64_t)g.M * (EPI == EPI_QKV ? g.N : g.ldo) < 4294967296ll &&
+            !g_force_small && !(IVIT_LAB && ((g_debug_flags2 & (1 << 20)) || (g_debug_flags & (31 | 128 | 256 | 512 | 1024))))) {
+            const int nstrips = (g.M + 15) >> 4;
+            const int grid = (nstrips + SK_WPB - 1) / SK_WPB < 512 ? (nstrips + SK_WPB - 1) / SK_WPB : 512;      // two workgroups of 8 waves per CU
+            hipLaunchKernelGGL((gemm_i8_skinny_kernel<EPI>), dim3(grid), dim3(SK_NT), 0, ivit_stream(stream), g);
+            IVIT_CHECK_LAUNCH(name);
+        }
+    }
     if (blocks && !g.w_frags) {
         IVIT_REQUIRE(EPI != EPI_I32 && EPI != EPI_RQ16 && g.M >= 2048 && g.N >= BCH && !g_force_small,
                      "%s: block-layout operands need the persistent kernel (M >= 2048, N >= 128, requantising epilogue)", name);

@@ -315,6 +315,8 @@ class IntSwinEngine(GraphReplay):
         """(weight pointer, layouts) -- the block-layout copy when the call goes to the persistent kernel"""
         if lin.get("Wf") is not None and M >= 2048:
             return _lib.ptr(lin["Wf"]), lin["Wf_bit"]
+        if lin["K"] <= 128 and lin["N"] <= 320 and M >= 8192:
+            return _lib.ptr(lin["W"]), 0          # row-major operands: the skinny-K form (csrc/gemm.hip, round 4) keeps the whole W in LDS
         if lin["Wb"] is not None and M >= 2048:
             return _lib.ptr(lin["Wb"]), 2
         return _lib.ptr(lin["W"]), 0

@@ -520,6 +520,45 @@ def test_gemm_wave_pipelined_form_equals_two_workgroup_form(M, N, K):
     assert np.array_equal(got[0][: M * N].reshape(M, N)[rows].astype(np.int32), exp)
 
 
+@pytest.mark.parametrize("M,N,K", [(49 * 256, 288, 128), (20003, 320, 128), (9000, 96, 64), (8192, 16, 64), (49 * 200, 192, 128)])
+def test_gemm_skinny_k_form(M, N, K):
+    """round 4: K <= 128, N <= 320, M >= 8192 (Swin stage 0) -- the whole weight matrix in LDS, strips of 16 tokens per wave, requantisation
+    on the MFMA accumulators: against the oracle (slices), against the tile kernels (lab flags2 bit 20) byte for byte, plain and
+    head-major epilogue, exact ties and certificate failures, a partial last strip"""
+    rng = np.random.default_rng(M + N + K)
+    A = rng.integers(-128, 128, size=(M, K)).astype(np.int8)
+    A[::5] = 1
+    W = rng.integers(-128, 128, size=(N, K)).astype(np.int8)
+    b = rng.integers(-50000, 50000, size=N).astype(np.int32)
+    m, e = rand_me(rng, N, -14, -8)
+    m[::3] = 1 << 30                             # power-of-two multipliers: exact ties -> the float64 path
+    md, ed = me_dev(m, e)
+    dA, dW, db = dev(A), dev(W), dev(b)
+    qkv = N % 96 == 0 and M % 49 == 0
+
+    def run_all():
+        out = torch.zeros(M, N + 16, dtype=torch.int8, device=DEV)         # ldo > N: the pad columns must stay untouched
+        _lib.call("ivit_gemm_i8_requant_ex", _lib.ptr(dA), K, _lib.ptr(dW), K, _lib.ptr(db), _lib.ptr(md), _lib.ptr(ed), _lib.ptr(out), N + 16, M, N, K, 0, st())
+        outs = [out.cpu().numpy()]
+        if qkv:
+            o2 = torch.zeros(M * N, dtype=torch.int8, device=DEV)
+            _lib.call("ivit_gemm_i8_requant_qkv_ex", _lib.ptr(dA), K, _lib.ptr(dW), K, _lib.ptr(db), _lib.ptr(md), _lib.ptr(ed), _lib.ptr(o2),
+                      49, N // 96, 32, M, N, K, 0, st())
+            outs.append(o2.cpu().numpy())
+        return outs
+
+    got = run_all()
+    with _lib.lab_session():
+        _lib.call("ivit_debug_set_gemm_flags2", 1 << 20)
+        ref = run_all()
+    for i, (a, r) in enumerate(zip(got, ref)):
+        assert np.array_equal(a, r), f"output {i}: {(a != r).sum()} of {a.size} bytes differ"
+    assert not got[0][:, N:].any()
+    rows = np.r_[0:200, M - 150:M]
+    exp = orc.requant(orc.gemm_i8(A[rows], W, b), m.astype(np.float64), e, 8)
+    assert np.array_equal(got[0][rows, :N].astype(np.int32), exp)
+
+
 def _gelu_ws(M):
     return torch.zeros((M + 127) // 128, dtype=torch.int32, device=DEV)
 
