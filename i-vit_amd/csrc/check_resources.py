@@ -60,7 +60,7 @@ def occupancy_rules(path, what):
                 m = re.search(r"layernorm_i16_i8_tiled(_compat)?_kernelILi(\d+)ELi(\d+)E", name)
                 if not m:
                     continue
-                occ, need_no_scratch = (3 if m.group(1) and int(m.group(3)) >= 3 else 4), True      # = their __launch_bounds__
+                occ, need_no_scratch = (3 if m.group(1) and int(m.group(3)) >= 2 else 4), True      # = their __launch_bounds__
         else:
             m = re.search(r"layernorm_i8_stream_kernelILi(\d+)ELi(\d+)ELi(\d+)ELb([01])ELi(\d+)E", name)
             if not m:

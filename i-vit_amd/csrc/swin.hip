@@ -246,6 +246,29 @@ __global__ __launch_bounds__(NT) void layernorm_i16_i8_literal_kernel(Ln16LitArg
 // (NJ = 3), derived by every lane for its 24 channels in float64: 195-244 VGPRs = two waves per SIMD, where this VALU-bound chain
 // issues its half-rate instructions at 4.4 cycles instead of 3.2, and a prologue that a launch of few rows
 // (Swin stages 2-3: 14-29 MB) spent most of its time in.
+// The ten float32 Newton steps of ivit_modules.py:45-49 on varf = RN24(var) WITHOUT iterating, where that is provably the same
+// (round 4; scripts/probes/ln16_newton_exhaustive.py walks every float32 value in [2^24, 2^37), ln_newton_exhaustive.py every
+// integer below 2^24): t10 == floor(sqrt(varf)) unless varf lies within 2^(ex - 22) below the next square (then t10 is that or one
+// more).  Those rows (<= 3 %), and rows below 2^24 that rowops.hip's rule sends there, run the literal loop -- wave-uniformly.
+// 40 % of the instructions of a C = 384 / 768 row group were this loop (ten IEEE divisions per group of 4 / 2 rows).
+IVIT_DEV float ln16_std10(float varf)
+{
+    const double v = (double)varf;                          // an integer below 2^37, exact
+    double s = __builtin_floor(__builtin_sqrt(v));
+    s = (s * s > v) ? s - 1.0 : s;                          // (exact products: s < 2^19)
+    s = ((s + 1.0) * (s + 1.0) <= v) ? s + 1.0 : s;
+    const double gap = (s + 1.0) * (s + 1.0) - v;
+    const bool slow = varf < 16777216.0f ? (varf < 142883.0f || gap == 1.0)      // rowops.hip LN_NEWTON_CONVERGED, ln_std10
+                                          : gap <= (double)(varf * 2.384185791015625e-07f);   // 2^-22
+    if (__builtin_amdgcn_ballot_w64(slow) != 0) {
+        float t = 65536.0f;
+#pragma unroll 1
+        for (int it = 0; it < 10; ++it) t = floorf((t + floorf(varf / t)) * 0.5f);
+        return t;
+    }
+    return (float)s;
+}
+
 IVIT_DEV void ln16_build_table(const Ln16Args& a, float* t_bias, float* t_lo, float* t_hi)
 {
     for (int c = threadIdx.x; c < a.C; c += NT) {
@@ -315,9 +338,7 @@ __global__ __launch_bounds__(NT, 4) void layernorm_i16_i8_tiled_kernel(Ln16Args 
             const unsigned vhi = (unsigned)__shfl_xor((int)(var >> 32), o);
             var += ((unsigned long long)vhi << 32) | vlo;
         }
-        float varf = (float)var, t = 65536.0f;                                  // :45-49
-#pragma unroll 1
-        for (int it = 0; it < 10; ++it) t = floorf((t + floorf(varf / t)) * 0.5f);
+        const float t = ln16_std10((float)var);                                 // :45-49
         const float hfactor = floorf((1.0f / t) * 2147483648.0f) * 0.5f;        // :51; the /2 of :52 commutes (exact scaling)
         int8_t* orow = a.out + win_row(a.map, min(row, a.rows - 1)) * a.ldo;
         int2 res[NJ];
@@ -440,7 +461,7 @@ IVIT_DEV float rowsum32(F elem, int n, int l32, int base)
 }
 
 template <int LPR, int NJ>
-__global__ __launch_bounds__(NT, NJ >= 3 ? 3 : 4) void layernorm_i16_i8_tiled_compat_kernel(Ln16Args a, float s_in, float r_in)
+__global__ __launch_bounds__(NT, NJ >= 2 ? 3 : 4) void layernorm_i16_i8_tiled_compat_kernel(Ln16Args a, float s_in, float r_in)
 {
     __shared__ float s_phi[WPB][64 * 8 * NJ];      // [wave][row of the wave][channel]
     __shared__ float s_sum[WPB][64];
@@ -608,9 +629,7 @@ __global__ __launch_bounds__(NT, NJ >= 3 ? 3 : 4) void layernorm_i16_i8_tiled_co
             const unsigned vhi = (unsigned)__shfl_xor((int)(var >> 32), o);
             var += ((unsigned long long)vhi << 32) | vlo;
         }
-        float varf = (float)var, t = 65536.0f;                                  // :45-49
-#pragma unroll 1
-        for (int it = 0; it < 10; ++it) t = floorf((t + floorf(varf / t)) * 0.5f);
+        const float t = ln16_std10((float)var);                                 // :45-49
         const float hfactor = floorf((1.0f / t) * 2147483648.0f) * 0.5f;        // :51; the /2 of :52 commutes (exact scaling)
         int8_t* orow = a.out + win_row(a.map, min(row, a.rows - 1)) * a.ldo;
         int2 res[NJ];
@@ -1115,7 +1134,7 @@ IVIT_EXPORT int ivit_layernorm_i16_i8_compat(const int16_t* x, int rows, int C, 
         while ((nd + lpr - 1) / lpr > 3) lpr *= 2;
         const int nj = (nd + lpr - 1) / lpr;
         int nblk = grid_for_rows(rows, 64 / lpr);
-        if (nblk > (nj >= 3 ? 768 : 1024)) nblk = nj >= 3 ? 768 : 1024;      // = the kernel's launch bounds: 3 / 4 workgroups per CU
+        if (nblk > (nj >= 2 ? 768 : 1024)) nblk = nj >= 2 ? 768 : 1024;      // = the kernel's launch bounds: 3 / 4 workgroups per CU
         const size_t tab_bytes = (size_t)3 * C * sizeof(float);
         const float r_in = 1.0f / s_in;
         bool launched = false;
