@@ -1618,7 +1618,15 @@ IVIT_EXPORT int ivit_layernorm_i8_ex(const int8_t* x, int64_t ldx, int rows, int
         int grid = grid_for_rows(rows, 2 * g2);
         if (grid > 1024) grid = 1024;          // 4 waves per SIMD resident
         const size_t lds = (size_t)3 * C * sizeof(float);
-        if (nj2 <= 2 && g2 == 1) hipLaunchKernelGGL((layernorm_i8_pair_kernel<2, 1>), dim3(grid), dim3(NT), lds, st, a);
+        // C <= 128 (Swin's patch norm, 401 408 rows of 96): one dword per lane -- the NJ = 2 form computes a second, fully masked one
+        // -- and 8 row pairs per wave from 64 K rows (the row statistics of 16 rows in one pass of lanes 0-7)
+        const bool one = nj2 == 1 && g2 == 4 && !(g_ln_ablate & (1u << 25));
+        if (one && rows > 65536 && !(g_ln_ablate & (1u << 26))) {
+            grid = grid_for_rows(rows, 16);
+            if (grid > 1024) grid = 1024;
+            hipLaunchKernelGGL((layernorm_i8_pair_kernel<1, 8>), dim3(grid), dim3(NT), lds, st, a);
+        } else if (one) hipLaunchKernelGGL((layernorm_i8_pair_kernel<1, 4>), dim3(grid), dim3(NT), lds, st, a);
+        else if (nj2 <= 2 && g2 == 1) hipLaunchKernelGGL((layernorm_i8_pair_kernel<2, 1>), dim3(grid), dim3(NT), lds, st, a);
         else if (nj2 <= 2 && g2 == 2) hipLaunchKernelGGL((layernorm_i8_pair_kernel<2, 2>), dim3(grid), dim3(NT), lds, st, a);
         else if (nj2 <= 3 && g2 == 1) hipLaunchKernelGGL((layernorm_i8_pair_kernel<3, 1>), dim3(grid), dim3(NT), lds, st, a);
         else if (nj2 <= 3 && g2 == 2) hipLaunchKernelGGL((layernorm_i8_pair_kernel<3, 2>), dim3(grid), dim3(NT), lds, st, a);

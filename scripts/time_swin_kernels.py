@@ -2,7 +2,7 @@
 import os
 import sys
 
-if "lnc" in sys.argv[1:]:
+if "lnc" in sys.argv[1:] or "pn" in sys.argv[1:]:
     os.environ.setdefault("IVIT_USE_LAB_LIBRARY", "1")
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -78,6 +78,23 @@ if "lnc" in which:     # natural-scale 16-bit LayerNorm: registers (product) aga
             print(f"ln16 natural rows={rows:7d} C={C:4d} outer-reduction order: registers {np.median(ro[0]):7.1f} us   LDS sums {np.median(ro[1 << 20]):7.1f} us", flush=True)
         print(f"ln16 natural rows={rows:7d} C={C:4d}: registers {np.median(res[0]):7.1f} us   LDS sums {np.median(res[1 << 20]):7.1f} us   "
               f"(power-of-two kernel {us:7.1f} us; {3 * rows * C / np.median(res[0]) / 1e3:7.1f} GB/s algorithmic)", flush=True)
+if "pn" in which:      # the patch norm (8-bit LayerNorm over 96 channels): one-dword half-wave kernel against the two-dword one (lab bits 25 / 26)
+    rows, C = B * 56 * 56, 96
+    x = d(rng.integers(-128, 128, size=(rows, C)).astype(np.int8))
+    out = torch.empty(rows, C, dtype=torch.int8, device=DEV)
+    lp = LayerNormParams(rng.uniform(0.5, 1.5, C).astype(np.float32), rng.normal(0, 0.1, C).astype(np.float32), np.float32(2.0 ** -5))
+    bi, sl, mm, ee = d(lp.bias_int), d(lp.s_ln), d(lp.m.view(np.int32)), d(lp.e)
+    res, outs = {}, {}
+    for rnd in range(5):
+        for form in (0, 1 << 26, 1 << 25):
+            _lib.call("ivit_debug_ln_ablate", form)
+            res.setdefault(form, []).append(timeit(lambda: _lib.call("ivit_layernorm_i8", _lib.ptr(x), C, rows, C, _lib.ptr(bi), _lib.ptr(sl), _lib.ptr(mm),
+                                                                     _lib.ptr(ee), _lib.ptr(out), C, st()), n=10))
+            outs[form] = out.clone()
+    _lib.call("ivit_debug_ln_ablate", 0)
+    assert torch.equal(outs[0], outs[1 << 25]) and torch.equal(outs[0], outs[1 << 26])
+    print(f"patch norm rows={rows} C={C}: one dword, 8 row pairs {np.median(res[0]):7.1f} us   one dword, 4 row pairs {np.median(res[1 << 26]):7.1f} us   "
+          f"two dwords (round 3) {np.median(res[1 << 25]):7.1f} us   ({2 * rows * C / np.median(res[0]) / 1e3:7.1f} GB/s algorithmic)", flush=True)
 if "attn" in which:
     for H, C, nH in STAGES:
         nwin = B * (H // 7) ** 2

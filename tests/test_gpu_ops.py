@@ -889,7 +889,8 @@ def test_layernorm_f32_module_form_kat(kat):
         assert np.array_equal(out.cpu().numpy().view(np.int32), kat[c + "y_bits"]), ci
 
 
-@pytest.mark.parametrize("rows,Cn", [(1000, 768), (513, 192), (64, 384), (7, 1024), (20000, 768), (3000, 2048)])
+@pytest.mark.parametrize("rows,Cn", [(1000, 768), (513, 192), (64, 384), (7, 1024), (20000, 768), (3000, 2048),
+                                     (20001, 96), (70003, 96), (66001, 128)])   # the last three: one dword per lane (4 / 8 row pairs per wave)
 def test_layernorm_random_vs_oracle(rows, Cn, ln_form):
     rng = np.random.default_rng(rows + Cn)
     k = np.clip(np.rint(rng.normal(rng.normal(0, 10, size=(rows, 1)), rng.uniform(1, 50, size=(rows, 1)),
