@@ -455,6 +455,21 @@ __global__ __launch_bounds__(NT, (NJ <= 3 && !COMPAT ? 3 : NJ <= 8 ? 2 : 1)) voi
 // bandwidth): G2 = 2 or 1 row pairs per wave instead of 4 puts 2-4 x as many waves on the chip for the same rows, the first
 // group's rows are requested BEFORE the constants table is derived (its loads and float64 arithmetic run under their flight),
 // and the ten Newton steps are the sqrt shortcut of ln_std10 where it is proven (var < 2^24: C <= 1024).
+// Sum over the 32 lanes of a half wave, every lane ends with the total: four DPP steps inside the rows of 16 lanes and one
+// v_permlane16_swap of the value with itself (odd rows of the one copy against even rows of the other: the two copies then hold
+// row 0 | row 0 and row 1 | row 1 of each half).  No LDS instruction: the __shfl_xor form was five ds_bpermute_b32 round trips per
+// value, 12 per row pair with the broadcasts -- at 401 408 rows of 96 channels the LDS pipe, not the VALU, set the pace.
+IVIT_DEV int half_wave_allreduce(int v)
+{
+    typedef unsigned v2u_ __attribute__((ext_vector_type(2)));
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);    // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);    // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false);   // row_half_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false);   // row_mirror
+    const v2u_ r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+    return (int)(r.x + r.y);
+}
+
 template <int NJ, int G2 = 4>
 __global__ __launch_bounds__(NT, NJ <= 3 ? 4 : 3) void layernorm_i8_pair_kernel(LnArgs a)
 {
@@ -508,13 +523,21 @@ __global__ __launch_bounds__(NT, NJ <= 3 ? 4 : 3) void layernorm_i8_pair_kernel(
                 sq[q] = __builtin_amdgcn_sdot4(w[q][j], w[q][j], sq[q], false);   // <= 1536 * 128^2 < 2^25
             }
         }
+        if (IVIT_LAB && (a.abl & (1 << 27))) {      // lab A/B: the ds_bpermute butterfly of rounds 2-4
 #pragma unroll
-        for (int o = 16; o > 0; o >>= 1)   // within the half wave
+            for (int o = 16; o > 0; o >>= 1)
+#pragma unroll
+                for (int q = 0; q < G2; ++q) {
+                    sum[q] += __shfl_xor(sum[q], o);
+                    sq[q] += __shfl_xor(sq[q], o);
+                }
+        } else {
 #pragma unroll
             for (int q = 0; q < G2; ++q) {
-                sum[q] += __shfl_xor(sum[q], o);
-                sq[q] += __shfl_xor(sq[q], o);
+                sum[q] = half_wave_allreduce(sum[q]);
+                sq[q] = half_wave_allreduce(sq[q]);
             }
+        }
         // lane (half, l32 = q) : statistics of row 2q + half, computed once; ivit_modules.py:37, 40-51
         int my_sum = sum[0], my_sq = sq[0];
 #pragma unroll

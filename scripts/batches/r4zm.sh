@@ -9,5 +9,5 @@ timeout -k 10 900 python -m pytest tests/test_gpu_swin.py -m gpu -x -q > $O/test
 tail -3 $O/tests.log
 timeout -k 10 300 python scripts/time_swin_kernels.py pn > $O/pn.txt 2>&1 || { tail -30 $O/pn.txt; exit 1; }
 cat $O/pn.txt
-timeout -k 10 300 python3 scripts/bench_configs.py --graph 5 15 > $O/configs.jsonl 2> $O/configs.err || { tail -5 $O/configs.err; exit 1; }
+timeout -k 10 300 python3 scripts/bench_configs.py --graph 2 5 15 > $O/configs.jsonl 2> $O/configs.err || { tail -5 $O/configs.err; exit 1; }
 cut -c1-200 $O/configs.jsonl

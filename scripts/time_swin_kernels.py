@@ -86,14 +86,14 @@ if "pn" in which:      # the patch norm (8-bit LayerNorm over 96 channels): one-
     bi, sl, mm, ee = d(lp.bias_int), d(lp.s_ln), d(lp.m.view(np.int32)), d(lp.e)
     res, outs = {}, {}
     for rnd in range(5):
-        for form in (0, 1 << 26, 1 << 25):
+        for form in (0, 1 << 27, 1 << 26, 1 << 25):
             _lib.call("ivit_debug_ln_ablate", form)
             res.setdefault(form, []).append(timeit(lambda: _lib.call("ivit_layernorm_i8", _lib.ptr(x), C, rows, C, _lib.ptr(bi), _lib.ptr(sl), _lib.ptr(mm),
                                                                      _lib.ptr(ee), _lib.ptr(out), C, st()), n=10))
             outs[form] = out.clone()
     _lib.call("ivit_debug_ln_ablate", 0)
-    assert torch.equal(outs[0], outs[1 << 25]) and torch.equal(outs[0], outs[1 << 26])
-    print(f"patch norm rows={rows} C={C}: one dword, 8 row pairs {np.median(res[0]):7.1f} us   one dword, 4 row pairs {np.median(res[1 << 26]):7.1f} us   "
+    assert all(torch.equal(outs[0], o) for o in outs.values())
+    print(f"patch norm rows={rows} C={C}: one dword, 8 row pairs {np.median(res[0]):7.1f} us   one dword, 4 row pairs {np.median(res[1 << 26]):7.1f} us   ds_bpermute row sums {np.median(res[1 << 27]):7.1f} us   "
           f"two dwords (round 3) {np.median(res[1 << 25]):7.1f} us   ({2 * rows * C / np.median(res[0]) / 1e3:7.1f} GB/s algorithmic)", flush=True)
 if "attn" in which:
     for H, C, nH in STAGES:
