@@ -1056,7 +1056,11 @@ __global__ __launch_bounds__(NT) void shiftgelu_lut_kernel(GeluArgs a)
 // table form: row max by wave reduction, the row's 256-byte table slice staged in LDS, byte gather.
 // NJ dwords per lane stay in registers between the max pass and the gather (one HBM read per byte); two rows per
 // wave and iteration keep twice the loads in flight (the kernel is HBM-latency bound).  NJ = 0: generic re-read form.
-template <int NJ>
+// INB: the input is in the GEMM block layout (compile time: with a run-time `a.in_blocks ? .. : ..` around every load the compiler
+// branched per load and put an s_waitcnt vmcnt(0) in front of each row-major one -- NJ x RW serial HBM latencies per iteration; Swin's
+// row-major MLP ran at 2.5-4.2 TB/s where the block-layout path of the ViT engines reached 6).  Loads are unconditional: a dword
+// beyond the row clamps to the row's last one and is replaced by -128 bytes afterwards.
+template <int NJ, bool INB = false>
 __global__ __launch_bounds__(NT) void shiftgelu_lut_apply_kernel(GeluArgs a)
 {
     constexpr int RW = 2;
@@ -1078,12 +1082,11 @@ __global__ __launch_bounds__(NT) void shiftgelu_lut_apply_kernel(GeluArgs a)
             for (int j = 0; j < NJ; ++j)
 #pragma unroll
                 for (int r = 0; r < RW; ++r) {
-                    const int d = lane + 64 * j;
-                    if (a.in_blocks)
-                        w[r][j] = (d < nd) ? *reinterpret_cast<const int*>(a.x + block_off(block_row(min(row0 + r, a.rows - 1), a.L), block_col(4 * d)))
-                                           : (int)0x80808080;
-                    else
-                        w[r][j] = (d < nd) ? xr[r][d] : (int)0x80808080;
+                    const int d = lane + 64 * j, dd = min(d, nd - 1);
+                    int v;
+                    if constexpr (INB) v = *reinterpret_cast<const int*>(a.x + block_off(block_row(min(row0 + r, a.rows - 1), a.L), block_col(4 * dd)));
+                    else v = xr[r][dd];
+                    w[r][j] = (d < nd) ? v : (int)0x80808080;
                 }
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
@@ -1118,6 +1121,12 @@ __global__ __launch_bounds__(NT) void shiftgelu_lut_apply_kernel(GeluArgs a)
                    ((unsigned)tb[v >> 24] << 24);
         };
         if constexpr (NJ > 0) {
+            if constexpr (!INB) {      // all gathers first (in place over the inputs; every byte indexes inside the slice), then the stores
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int r = 0; r < RW; ++r) w[r][j] = (int)map4(r, (unsigned)w[r][j]);
+            }
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
 #pragma unroll
@@ -1125,7 +1134,7 @@ __global__ __launch_bounds__(NT) void shiftgelu_lut_apply_kernel(GeluArgs a)
                     const int d = lane + 64 * j;
                     if (d < nd && row0 + r < a.rows) {
                         const int64_t off = a.out_blocks ? (int64_t)block_off(brow[r], block_col(4 * d)) : (int64_t)(row0 + r) * a.ldo + 4 * d;
-                        *reinterpret_cast<int*>(reinterpret_cast<int8_t*>(a.out) + off) = (int)map4(r, (unsigned)w[r][j]);
+                        *reinterpret_cast<int*>(reinterpret_cast<int8_t*>(a.out) + off) = INB ? (int)map4(r, (unsigned)w[r][j]) : w[r][j];
                     }
                 }
         } else {
@@ -1784,7 +1793,23 @@ IVIT_EXPORT int ivit_shiftgelu_build_lut_ex(float s, uint32_t m, int32_t e, cons
 // Short rows (L <= 384: Swin stage 0, 401 408 rows of 384 bytes per launch at batch 128): HALF a wave per row, four rows per wave and
 // iteration.  With a whole wave per row only 96 of 2 x 192 lane-dwords carry data at L = 384, every row pays its own 256-byte table
 // slice and reduction chain, and the launch ran at 3.4 TB/s (90 us) where the wide rows of the ViT MLP reach 5.9 (round 4).
-template <int NJ>
+// Maximum over the 32 lanes of a half wave in every lane (DPP inside the rows of 16, v_permlane16_swap across them: half_wave_allreduce)
+IVIT_DEV int half_wave_allmax(int v)
+{
+    typedef unsigned v2u_ __attribute__((ext_vector_type(2)));
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false));   // row_half_mirror
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xf, 0xf, false));   // row_mirror
+    const v2u_ r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+    return max((int)r.x, (int)r.y);
+}
+
+// PIPE (lab bit 28; measured 57.2 us against 55.3 without at 401 408 rows of 384, so not the product form): the rows of the NEXT
+// iteration are requested right after this iteration's table slices -- the slices are the older loads, so the wait for them leaves the
+// rows in flight (loads return in order).  What the launch was missing were unconditional loads (shiftgelu_lut_apply_kernel): 72.8 ->
+// 55-57 us (5.4-5.6 TB/s) with them, eight waves per SIMD hide the chain of an iteration without a prefetch.
+template <int NJ, bool INB, bool PIPE = false>
 __global__ __launch_bounds__(NT) void shiftgelu_lut_apply_half_kernel(GeluArgs a)
 {
     constexpr int RP = 2;                      // row pairs per wave and iteration
@@ -1792,50 +1817,72 @@ __global__ __launch_bounds__(NT) void shiftgelu_lut_apply_half_kernel(GeluArgs a
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int half = lane >> 5, l32 = lane & 31;
     const int nd = a.L >> 2;
-    for (int row0 = (blockIdx.x * WPB + wave) * (2 * RP); row0 < a.rows; row0 += gridDim.x * WPB * (2 * RP)) {
-        int w[RP][NJ], kmax[RP];
+    const int stride = gridDim.x * WPB * (2 * RP);
+    int w[RP][NJ];
+    auto load_rows = [&](int (&dst)[RP][NJ], int row0) {
 #pragma unroll
         for (int p = 0; p < RP; ++p) {
             const int row = min(row0 + 2 * p + half, a.rows - 1);
-            kmax[p] = -128;
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                const int d = l32 + 32 * j;
-                if (a.in_blocks) w[p][j] = (d < nd) ? *reinterpret_cast<const int*>(a.x + block_off(block_row(row, a.L), block_col(4 * d))) : (int)0x80808080;
-                else w[p][j] = (d < nd) ? reinterpret_cast<const int*>(a.x + (int64_t)row * a.ldx)[d] : (int)0x80808080;
+                const int d = l32 + 32 * j, dd = min(d, nd - 1);      // unconditional loads: see shiftgelu_lut_apply_kernel
+                int v;
+                if constexpr (INB) v = *reinterpret_cast<const int*>(a.x + block_off(block_row(row, a.L), block_col(4 * dd)));
+                else v = reinterpret_cast<const int*>(a.x + (int64_t)row * a.ldx)[dd];
+                dst[p][j] = (d < nd) ? v : (int)0x80808080;
             }
         }
+    };
+    const int row_first = (blockIdx.x * WPB + wave) * (2 * RP);
+    if (PIPE && row_first < a.rows) load_rows(w, row_first);
+    for (int row0 = row_first; row0 < a.rows; row0 += stride) {
+        if (!PIPE) load_rows(w, row0);
+        int kmax[RP];
 #pragma unroll
-        for (int p = 0; p < RP; ++p)
+        for (int p = 0; p < RP; ++p) {
+            kmax[p] = -128;
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
                 kmax[p] = max(max(kmax[p], sx8(w[p][j], 0)), max(sx8(w[p][j], 1), max(sx8(w[p][j], 2), sx8(w[p][j], 3))));
+        }
 #pragma unroll
-        for (int o = 16; o > 0; o >>= 1)       // within the half wave
-#pragma unroll
-            for (int p = 0; p < RP; ++p) kmax[p] = max(kmax[p], __shfl_xor(kmax[p], o));
+        for (int p = 0; p < RP; ++p) kmax[p] = half_wave_allmax(kmax[p]);
+        int2 slice[RP];
 #pragma unroll
         for (int p = 0; p < RP; ++p)           // each half wave fetches its row's 256-byte slice: 8 bytes per lane
-            reinterpret_cast<int2*>(tab[wave][2 * p + half])[l32] = reinterpret_cast<const int2*>(a.lut + (int64_t)(kmax[p] + 128) * 256)[l32];
+            slice[p] = reinterpret_cast<const int2*>(a.lut + (int64_t)(kmax[p] + 128) * 256)[l32];
+        int wn[RP][NJ];
+        if (PIPE) load_rows(wn, row0 + stride);      // unconditional (rows clamp to the last one: the final iteration's prefetch is not used)
+#pragma unroll
+        for (int p = 0; p < RP; ++p) reinterpret_cast<int2*>(tab[wave][2 * p + half])[l32] = slice[p];
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_s_waitcnt(0xc07f);    // lgkmcnt(0): the table slices are in LDS
 #pragma unroll
         for (int p = 0; p < RP; ++p) {
             const int row = row0 + 2 * p + half;
             const unsigned char* tb = tab[wave][2 * p + half];
+            unsigned o[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {        // the gathers of the whole row first (every byte indexes inside the slice), then the stores
+                const unsigned v = (unsigned)w[p][j] ^ 0x80808080u;      // k + 128 per byte
+                o[j] = (unsigned)tb[v & 255] | ((unsigned)tb[(v >> 8) & 255] << 8) | ((unsigned)tb[(v >> 16) & 255] << 16) | ((unsigned)tb[v >> 24] << 24);
+            }
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 const int d = l32 + 32 * j;
                 if (d < nd && row < a.rows) {
-                    const unsigned v = (unsigned)w[p][j] ^ 0x80808080u;      // k + 128 per byte
-                    const unsigned o = (unsigned)tb[v & 255] | ((unsigned)tb[(v >> 8) & 255] << 8) | ((unsigned)tb[(v >> 16) & 255] << 16) |
-                                       ((unsigned)tb[v >> 24] << 24);
                     const int64_t off = a.out_blocks ? (int64_t)block_off(block_row(row, a.L), block_col(4 * d)) : (int64_t)row * a.ldo + 4 * d;
-                    *reinterpret_cast<int*>(reinterpret_cast<int8_t*>(a.out) + off) = (int)o;
+                    *reinterpret_cast<int*>(reinterpret_cast<int8_t*>(a.out) + off) = (int)o[j];
                 }
             }
         }
         __builtin_amdgcn_wave_barrier();
+        if (PIPE) {
+#pragma unroll
+            for (int p = 0; p < RP; ++p)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) w[p][j] = wn[p][j];
+        }
     }
 }
 
@@ -1859,15 +1906,22 @@ IVIT_EXPORT int ivit_shiftgelu_lut_i8_ex(const int8_t* x, int64_t ldx, int rows,
     const int nj = (L / 4 + 63) / 64;
     if (L <= 384 && rows >= 4096 && !(g_ln_ablate & (1 << 24))) {      // lab bit 24: the whole-wave-per-row form (A/B, parity of both)
         const dim3 gridh(grid_for_rows(rows, 4));
-        if (L <= 128) hipLaunchKernelGGL(shiftgelu_lut_apply_half_kernel<1>, gridh, blk, 0, st, a);
-        else if (L <= 256) hipLaunchKernelGGL(shiftgelu_lut_apply_half_kernel<2>, gridh, blk, 0, st, a);
-        else hipLaunchKernelGGL(shiftgelu_lut_apply_half_kernel<3>, gridh, blk, 0, st, a);
+#define IVIT_GELU_HALF(NJ_, ...) do { if (in_blocks) hipLaunchKernelGGL((shiftgelu_lut_apply_half_kernel<NJ_, true, ##__VA_ARGS__>), gridh, blk, 0, st, a); \
+                                      else hipLaunchKernelGGL((shiftgelu_lut_apply_half_kernel<NJ_, false, ##__VA_ARGS__>), gridh, blk, 0, st, a); } while (0)
+        if (L <= 128) IVIT_GELU_HALF(1);
+        else if (L <= 256) IVIT_GELU_HALF(2);
+        else if (IVIT_LAB && (g_ln_ablate & (1 << 28))) IVIT_GELU_HALF(3, true);   // lab A/B: with the prefetch of the next iteration's rows
+        else IVIT_GELU_HALF(3);
+#undef IVIT_GELU_HALF
         IVIT_CHECK_LAUNCH("ivit_shiftgelu_lut_i8");
     }
-    if (nj <= 3) hipLaunchKernelGGL(shiftgelu_lut_apply_kernel<3>, grid, blk, 0, st, a);
-    else if (nj <= 6) hipLaunchKernelGGL(shiftgelu_lut_apply_kernel<6>, grid, blk, 0, st, a);
-    else if (nj <= 12) hipLaunchKernelGGL(shiftgelu_lut_apply_kernel<12>, grid, blk, 0, st, a);
+#define IVIT_GELU_WAVE(NJ_) do { if (in_blocks) hipLaunchKernelGGL((shiftgelu_lut_apply_kernel<NJ_, true>), grid, blk, 0, st, a); \
+                                 else hipLaunchKernelGGL((shiftgelu_lut_apply_kernel<NJ_, false>), grid, blk, 0, st, a); } while (0)
+    if (nj <= 3) IVIT_GELU_WAVE(3);
+    else if (nj <= 6) IVIT_GELU_WAVE(6);
+    else if (nj <= 12) IVIT_GELU_WAVE(12);
     else hipLaunchKernelGGL(shiftgelu_lut_apply_kernel<0>, grid, blk, 0, st, a);
+#undef IVIT_GELU_WAVE
     IVIT_CHECK_LAUNCH("ivit_shiftgelu_lut_i8");
 }
 

@@ -52,7 +52,8 @@ int ivit_debug_ln_stamp_buffer(void* buf);
  * form is exact (power-of-two multipliers), bit 24 the ShiftGELU table pass takes a whole wave per row also for rows of at most 384
  * bytes, bit 25 rows of at most 128 channels on the two-dword half-wave kernel (the form before round 4's one-dword one), bit 26
  * the one-dword kernel with 4 row pairs per wave also from 64 K rows, bit 27 the half-wave kernel's row sums by ds_bpermute butterflies
- * (the form before the DPP / v_permlane16_swap one); scripts/ln_ablate.py, scripts/ln_ab.py --small, scripts/time_swin_kernels.py */
+ * (the form before the DPP / v_permlane16_swap one), bit 28 the short-row ShiftGELU table pass with a prefetch of the next
+ * iteration's rows (measured: no gain); scripts/ln_ablate.py, scripts/ln_ab.py --small, scripts/time_swin_kernels.py */
 int ivit_debug_ln_ablate(int bits);
 
 /* (lab library only since round 4: the engines never called it and it is slower than the pair it replaces)

@@ -2,7 +2,7 @@
 import os
 import sys
 
-if "lnc" in sys.argv[1:] or "pn" in sys.argv[1:]:
+if {"lnc", "pn", "gelu"} & set(sys.argv[1:]):
     os.environ.setdefault("IVIT_USE_LAB_LIBRARY", "1")
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -95,6 +95,25 @@ if "pn" in which:      # the patch norm (8-bit LayerNorm over 96 channels): one-
     assert all(torch.equal(outs[0], o) for o in outs.values())
     print(f"patch norm rows={rows} C={C}: one dword, 8 row pairs {np.median(res[0]):7.1f} us   one dword, 4 row pairs {np.median(res[1 << 26]):7.1f} us   ds_bpermute row sums {np.median(res[1 << 27]):7.1f} us   "
           f"two dwords (round 3) {np.median(res[1 << 25]):7.1f} us   ({2 * rows * C / np.median(res[0]) / 1e3:7.1f} GB/s algorithmic)", flush=True)
+if "gelu" in which:    # ShiftGELU table pass, row-major rows (the Swin MLP) and the ViT shapes in both layouts; lab bits 24 / 28: whole wave per short row / prefetch of the next rows
+    lut = torch.empty(65536, dtype=torch.int8, device=DEV)
+    mg, eg = dyadic(np.float32(0.05 * 0.05 / 128), np.float32(0.02))
+    _lib.call("ivit_shiftgelu_build_lut", 0.05, int(mg[0]), int(eg[0]), _lib.ptr(lut), st())
+    for rows, L in [(B * 3136, 384), (B * 784, 768), (B * 196, 1536), (B * 49, 3072), (64 * 197, 1536), (256 * 197, 3072)]:
+        x = d(np.clip(np.rint(rng.normal(0, 30, size=(rows, L))), -128, 127).astype(np.int8))
+        out = torch.empty_like(x)
+        line = f"ShiftGELU table pass rows={rows:7d} L={L:5d}:"
+        forms = [("row-major", 0, 0)] + ([("with prefetch", 0, 1 << 28), ("wave per row", 0, 1 << 24)] if L <= 384 else []) + ([("block layout", 3, 0)] if L % 64 == 0 else [])
+        res = {}
+        for rnd in range(5):
+            for name, lay, bits in forms:
+                _lib.call("ivit_debug_ln_ablate", bits)
+                res.setdefault(name, []).append(timeit(lambda: _lib.call("ivit_shiftgelu_lut_i8_ex", _lib.ptr(x), L, rows, L, _lib.ptr(lut), _lib.ptr(out), L, lay, st()), n=10))
+        _lib.call("ivit_debug_ln_ablate", 0)
+        for name, _, _ in forms:
+            us = np.median(res[name])
+            line += f"   {name} {us:6.1f} us ({2 * rows * L / us / 1e6:4.2f} TB/s)"
+        print(line, flush=True)
 if "attn" in which:
     for H, C, nH in STAGES:
         nwin = B * (H // 7) ** 2

@@ -1062,6 +1062,16 @@ def test_shiftgelu_table_short_rows(rows, L):
         out_w = torch.empty(rows, L, dtype=torch.int8, device=DEV)
         _lib.call("ivit_shiftgelu_lut_i8", _lib.ptr(dev(k)), L, rows, L, _lib.ptr(lut), _lib.ptr(out_w), L, st())
     assert np.array_equal(out_w.cpu().numpy(), exp8)
+    if L > 256:                                            # lab bit 28: the form that prefetches the next iteration's rows (many iterations per wave)
+        big = np.tile(k, (14, 1))[: 4096 * 16 + 37]
+        with _lib.lab_session():
+            _lib.call("ivit_debug_ln_ablate", 1 << 28)
+            out_p = torch.empty(big.shape[0], L, dtype=torch.int8, device=DEV)
+            _lib.call("ivit_shiftgelu_lut_i8", _lib.ptr(dev(big)), L, big.shape[0], L, _lib.ptr(lut), _lib.ptr(out_p), L, st())
+        out_b = torch.empty(big.shape[0], L, dtype=torch.int8, device=DEV)
+        _lib.call("ivit_shiftgelu_lut_i8", _lib.ptr(dev(big)), L, big.shape[0], L, _lib.ptr(lut), _lib.ptr(out_b), L, st())
+        exp_big = np.tile(exp8, (14, 1))[: big.shape[0]]
+        assert np.array_equal(out_p.cpu().numpy(), exp_big) and np.array_equal(out_b.cpu().numpy(), exp_big)
     if L % 64 == 0:                                        # block layout in and out, in place (what the Swin engine does)
         R16 = (rows + 15) // 16 * 16
         kb = torch.zeros(R16 * L, dtype=torch.int8, device=DEV)
