@@ -975,14 +975,17 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_i8_wreg_kernel(GemmArgs g)
 constexpr int SK_MAXN = 320, SK_MAXK = 128, SK_NT = 512, SK_WPB = SK_NT / 64;
 constexpr int SK_SMEM = SK_MAXN * SK_MAXK + SK_MAXN * 12 + (SK_MAXN / 4) * 4;      // fragments | float2 lohi[N] | int bias[N] | u32 coff[N / 4]
 
-template <int EPI>
+// NKS = K / 32 at compile time (2: patch embedding, 4: stage-0 qkv; 0: any K, run time).  With a run-time K the `ks < nks` test around
+// every MFMA became a scalar branch and each weight fragment a ds_read_b64 / s_waitcnt lgkmcnt(0) / v_mfma triple: 16 exposed LDS
+// latencies per batch of four channel sub-tiles.  Straight-line, a batch's fragment reads are issued together (late round 4).
+template <int EPI, int NKS = 0>
 __global__ __launch_bounds__(SK_NT, 2) void gemm_i8_skinny_kernel(GemmArgs g)
 {
     static_assert(EPI == EPI_RQ || EPI == EPI_QKV, "skinny-K form: int8 outputs");
     __shared__ __attribute__((aligned(16))) char smem[SK_SMEM];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g4 = lane >> 4, l15 = lane & 15;
-    const int nks = g.K >> 5, nsub = g.N >> 4;
+    const int nks = NKS ? NKS : (g.K >> 5), nsub = g.N >> 4;
     float2* const lohi = reinterpret_cast<float2*>(smem + SK_MAXN * SK_MAXK);
     int* const bias = reinterpret_cast<int*>(smem + SK_MAXN * SK_MAXK + SK_MAXN * 8);
     unsigned* const coff = reinterpret_cast<unsigned*>(smem + SK_MAXN * SK_MAXK + SK_MAXN * 12);      // EPI_QKV: head-major offset of channels 4 j ..
@@ -1154,7 +1157,10 @@ int launch_gemm(GemmArgs& g, const char* name, ivit_stream_t stream)
             !g_force_small && !(IVIT_LAB && ((g_debug_flags2 & (1 << 20)) || (g_debug_flags & (31 | 128 | 256 | 512 | 1024))))) {
             const int nstrips = (g.M + 15) >> 4;
             const int grid = (nstrips + SK_WPB - 1) / SK_WPB < 512 ? (nstrips + SK_WPB - 1) / SK_WPB : 512;      // two workgroups of 8 waves per CU
-            hipLaunchKernelGGL((gemm_i8_skinny_kernel<EPI>), dim3(grid), dim3(SK_NT), 0, ivit_stream(stream), g);
+            const bool any_k = IVIT_LAB && (g_debug_flags2 & (1 << 21));      // lab A/B: the run-time-K instantiation for every K
+            if (g.K == 128 && !any_k) hipLaunchKernelGGL((gemm_i8_skinny_kernel<EPI, 4>), dim3(grid), dim3(SK_NT), 0, ivit_stream(stream), g);
+            else if (g.K == 64 && !any_k) hipLaunchKernelGGL((gemm_i8_skinny_kernel<EPI, 2>), dim3(grid), dim3(SK_NT), 0, ivit_stream(stream), g);
+            else hipLaunchKernelGGL((gemm_i8_skinny_kernel<EPI, 0>), dim3(grid), dim3(SK_NT), 0, ivit_stream(stream), g);
             IVIT_CHECK_LAUNCH(name);
         }
     }

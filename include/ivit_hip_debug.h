@@ -25,7 +25,8 @@ int ivit_debug_set_gemm_flags(int flags);
  * wave-pipelined form of csrc/gemm_wp.h (one workgroup of eight waves per CU, a tile's epilogue inside the next tile's main loop;
  * plain and head-major int8 epilogues, K >= 768; exact, measured slower), bits 16-17 its timing ablations (results WRONG: 1 no
  * epilogue work inside the loop, 2 no barrier per K step); scripts/gemm_ab.py --frags16 ... -- 0:0 0:32768 0:98304; bit 20: no
- * skinny-K form (K <= 128, N <= 320, M >= 8192: the tile kernels instead; A/B and parity of both) */
+ * skinny-K form (K <= 128, N <= 320, M >= 8192: the tile kernels instead; A/B and parity of both), bit 21: the skinny-K form's
+ * run-time-K instantiation also for K = 64 / 128 (the form before the compile-time ones) */
 int ivit_debug_set_gemm_flags2(int flags);
 /* Diagnostic timeline buffer (8 x uint64 per workgroup) for the stamped build (flags = 512); scripts/gemm_timeline.py */
 int ivit_debug_set_stamp_buffer(void* buf);

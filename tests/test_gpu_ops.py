@@ -551,8 +551,11 @@ def test_gemm_skinny_k_form(M, N, K):
     with _lib.lab_session():
         _lib.call("ivit_debug_set_gemm_flags2", 1 << 20)
         ref = run_all()
-    for i, (a, r) in enumerate(zip(got, ref)):
+        _lib.call("ivit_debug_set_gemm_flags2", 1 << 21)      # the skinny-K kernel's run-time-K instantiation (the product takes K = 64 / 128 at compile time)
+        anyk = run_all()
+    for i, (a, r, k) in enumerate(zip(got, ref, anyk)):
         assert np.array_equal(a, r), f"output {i}: {(a != r).sum()} of {a.size} bytes differ"
+        assert np.array_equal(a, k), f"output {i}, run-time K: {(a != k).sum()} of {a.size} bytes differ"
     assert not got[0][:, N:].any()
     rows = np.r_[0:200, M - 150:M]
     exp = orc.requant(orc.gemm_i8(A[rows], W, b), m.astype(np.float64), e, 8)
