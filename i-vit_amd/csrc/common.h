@@ -51,6 +51,45 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 
 IVIT_DEV double dyadic_mult(uint32_t m, int32_t e) { return __builtin_ldexp((double)m, -e); }
 
+// The per-channel constants of the int8-output LayerNorm kernels, once per workgroup into LDS: bias_int and the float32 bracket
+// [lo, hi] of the output requantiser's multiplier (the certificate of layernorm_i8_kernel, rowops.hip).  ALL global loads of a pass
+// (two channels per thread: C <= 2 x NTHREADS is one pass) are issued before the first use -- written as one loop with the loads where
+// they are consumed, the compiler waited for m / e / s_ln, did the float64 arithmetic, then requested bias_int and waited again: two
+// global latencies per channel and thread, 3-4 us of an 8.6 us launch at 12 608 rows of 384 channels (DeiT-S, late round 4).
+template <int NTHREADS>
+IVIT_DEV void ln_build_table(const uint32_t* m, const int32_t* e, const float* s_ln, const float* bias_int, int C, float* t_bias, float* t_lo,
+                             float* t_hi)
+{
+    for (int c0 = threadIdx.x; c0 < C; c0 += 2 * NTHREADS) {
+        uint32_t mm[2];
+        int32_t ee[2];
+        float sl[2], bb[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int c = min(c0 + u * NTHREADS, C - 1);      // unconditional, clamped
+            mm[u] = m[c];
+            ee[u] = e[c];
+            sl[u] = s_ln[c];
+            bb[u] = bias_int[c];
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int c = c0 + u * NTHREADS;
+            const double M = dyadic_mult(mm[u], ee[u]);
+            const double lod = M * (1.0 - 1.25 / 4194304.0), hid = M * (1.0 + 1.25 / 4194304.0);
+            float lf = (float)lod, hf = (float)hid;
+            if ((double)lf > lod) lf = __int_as_float(__float_as_int(lf) - 1);   // largest float32 <= lod (lod > 0)
+            if ((double)hf < hid) hf = __int_as_float(__float_as_int(hf) + 1);   // smallest float32 >= hid
+            const bool ok = fabsf(sl[u]) >= 1e-30f && fabsf(sl[u]) <= 1e30f && lod > 1e-35 && hid < 1e30;   // see layernorm_i8_kernel
+            if (c < C) {
+                t_bias[c] = bb[u];
+                t_lo[c] = ok ? lf : 0.0f;
+                t_hi[c] = ok ? hf : __builtin_inff();
+            }
+        }
+    }
+}
+
 IVIT_DEV int clamp_i32(int v, int lo, int hi) { return min(max(v, lo), hi); }
 
 // ---- "block" operand layout (IVIT_LAYOUT_BLOCKS, include/ivit_hip.h): an int8 matrix X[rows][K], K % 64 == 0, stored as

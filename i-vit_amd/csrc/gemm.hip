@@ -1006,6 +1006,7 @@ __global__ __launch_bounds__(SK_NT, 2) void gemm_i8_skinny_kernel(GemmArgs g)
         }
     }
     for (int c = tid; c < g.N; c += SK_NT) {
+        const int bv = g.bias ? g.bias[c] : 0;      // requested with m / e, not after the float64 arithmetic on them (common.h ln_build_table)
         const double M = dyadic_mult(g.m[c], g.e[c]);
         const float mf = (float)M;
         const int bits = __float_as_int(mf);
@@ -1013,7 +1014,7 @@ __global__ __launch_bounds__(SK_NT, 2) void gemm_i8_skinny_kernel(GemmArgs g)
         lo = __int_as_float(__float_as_int(lo) - 2);      // widened by two float32 steps: no range test on the accumulator
         hi = __int_as_float(__float_as_int(hi) + 2);      // (gemm_common.h epilogue_i8_16)
         lohi[c] = make_float2(lo, hi);
-        bias[c] = g.bias ? g.bias[c] : 0;
+        bias[c] = bv;
     }
     __syncthreads();
     int8_t* const out = reinterpret_cast<int8_t*>(g.out);

@@ -497,18 +497,7 @@ __global__ __launch_bounds__(NT, NJ <= 3 ? 4 : 3) void layernorm_i8_pair_kernel(
         }
     };
     load_rows(row_first);
-    for (int c = tid; c < C; c += NT) {
-        const double M = dyadic_mult(a.m[c], a.e[c]);
-        const double lod = M * (1.0 - 1.25 / 4194304.0), hid = M * (1.0 + 1.25 / 4194304.0);
-        float lf = (float)lod, hf = (float)hid;
-        if ((double)lf > lod) lf = __int_as_float(__float_as_int(lf) - 1);   // largest float32 <= lod (lod > 0)
-        if ((double)hf < hid) hf = __int_as_float(__float_as_int(hf) + 1);   // smallest float32 >= hid
-        const float sl = a.s_ln[c];
-        const bool ok = fabsf(sl) >= 1e-30f && fabsf(sl) <= 1e30f && lod > 1e-35 && hid < 1e30;   // see layernorm_i8_kernel
-        t_bias[c] = a.bias_int[c];
-        t_lo[c] = ok ? lf : 0.0f;
-        t_hi[c] = ok ? hf : __builtin_inff();
-    }
+    ln_build_table<NT>(a.m, a.e, a.s_ln, a.bias_int, C, t_bias, t_lo, t_hi);
     __syncthreads();
     for (int row0 = row_first; row0 < a.rows; row0 += gridDim.x * WPB * (2 * G2)) {
         if (row0 != row_first) load_rows(row0);      // uniform per wave
@@ -667,18 +656,7 @@ __global__ __launch_bounds__(NT, (G == 4 && NJ <= 3 ? 5 : G == 8 && NJ <= 3 ? (C
     float* t_lo = lds_tab + C;
     float* t_hi = lds_tab + 2 * C;
     const int abl = IVIT_LAB ? a.abl : 0;
-    for (int c = tid; c < ((abl & 8) ? 0 : C); c += NT) {
-        const double M = dyadic_mult(a.m[c], a.e[c]);
-        const double lod = M * (1.0 - 1.25 / 4194304.0), hid = M * (1.0 + 1.25 / 4194304.0);
-        float lf = (float)lod, hf = (float)hid;
-        if ((double)lf > lod) lf = __int_as_float(__float_as_int(lf) - 1);   // largest float32 <= lod (lod > 0)
-        if ((double)hf < hid) hf = __int_as_float(__float_as_int(hf) + 1);   // smallest float32 >= hid
-        const float sl = a.s_ln[c];
-        const bool ok = fabsf(sl) >= 1e-30f && fabsf(sl) <= 1e30f && lod > 1e-35 && hid < 1e30;   // see layernorm_i8_kernel
-        t_bias[c] = a.bias_int[c];
-        t_lo[c] = ok ? lf : 0.0f;
-        t_hi[c] = ok ? hf : __builtin_inff();
-    }
+    if (!(abl & 8)) ln_build_table<NT>(a.m, a.e, a.s_ln, a.bias_int, C, t_bias, t_lo, t_hi);
     if constexpr (COMPAT) {
         s_remap[tid] = (unsigned char)a.remap[tid];   // NT == 256
         s_phi[tid] = a.phi[tid];

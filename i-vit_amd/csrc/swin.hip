@@ -271,18 +271,7 @@ IVIT_DEV float ln16_std10(float varf)
 
 IVIT_DEV void ln16_build_table(const Ln16Args& a, float* t_bias, float* t_lo, float* t_hi)
 {
-    for (int c = threadIdx.x; c < a.C; c += NT) {
-        const double M = dyadic_mult(a.m[c], a.e[c]);
-        const double lod = M * (1.0 - 1.25 / 4194304.0), hid = M * (1.0 + 1.25 / 4194304.0);
-        float lf = (float)lod, hf = (float)hid;
-        if ((double)lf > lod) lf = __int_as_float(__float_as_int(lf) - 1);
-        if ((double)hf < hid) hf = __int_as_float(__float_as_int(hf) + 1);
-        const float sl = a.s_ln[c];
-        const bool ok = fabsf(sl) >= 1e-30f && fabsf(sl) <= 1e30f && lod > 1e-35 && hid < 1e30;
-        t_bias[c] = a.bias_int[c];
-        t_lo[c] = ok ? lf : 0.0f;
-        t_hi[c] = ok ? hf : __builtin_inff();
-    }
+    ln_build_table<NT>(a.m, a.e, a.s_ln, a.bias_int, a.C, t_bias, t_lo, t_hi);      // common.h: every load before the first use
 }
 
 // Sub-wave tiling of the same computation for C % 8 == 0, C <= 1536: LPR lanes share a row (64 / LPR rows per wave and
