@@ -206,8 +206,7 @@ __global__ __launch_bounds__(NT, OCC) void attention_kernel(AttnArgs a)
             }
             if ((kt & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // at most 4 K fragments in flight (registers)
         }
-        nmin = min(nmin, __shfl_xor(nmin, 16));
-        nmin = min(nmin, __shfl_xor(nmin, 32));
+        nmin = rows_allmin_i32(nmin);      // over the four lanes of a query (common.h: permlane swaps, no LDS round trip)
         int rmax = -nmin;                // RQ32: -(RQ_OFF + nmin), so that nk + rmax is the plain difference
         asm volatile("" : "+v"(rmax));   // opaque: keeps (nk + rmax) << 2 one v_add_lshl_u32 instead of a subtract and a shift
 
@@ -371,8 +370,7 @@ __global__ __launch_bounds__(NT, OCC) void attention_kernel(AttnArgs a)
         if constexpr (MODE >= 3) {
             factor = floorf(4294967296.0f / __int_as_float((int)esum));        // ibert_modules.py:313
         } else {
-            esum += __shfl_xor(esum, 16);
-            esum += __shfl_xor(esum, 32);
+            esum = rows_allsum_u32(esum);
             float S = (float)esum;                                     // exp_int.sum (:171)
             S = fminf(S, 2147483648.0f);                               // clamp_max_(2**31-1) in float32 (:173)
             factor = floorf((1.0f / S) * 2147483648.0f);               // (:174)

@@ -51,6 +51,21 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 
 IVIT_DEV double dyadic_mult(uint32_t m, int32_t e) { return __builtin_ldexp((double)m, -e); }
 
+// Combine a value over the four lanes l, l ^ 16, l ^ 32, l ^ 48 (the four 16-lane rows of the wave), every lane ends with the result:
+// v_permlane16_swap / v_permlane32_swap of the value with itself instead of two ds_bpermute_b32 round trips (__shfl_xor).
+template <typename Op>
+IVIT_DEV unsigned rows_allreduce_u32(unsigned v, Op op)
+{
+    typedef unsigned v2u_ __attribute__((ext_vector_type(2)));
+    const v2u_ a = __builtin_amdgcn_permlane16_swap(v, v, false, false);     // .x: rows 0 0 2 2, .y: rows 1 1 3 3
+    v = op(a.x, a.y);
+    const v2u_ b = __builtin_amdgcn_permlane32_swap(v, v, false, false);     // .x: lower half twice, .y: upper half twice
+    return op(b.x, b.y);
+}
+IVIT_DEV int rows_allmin_i32(int v) { return (int)rows_allreduce_u32((unsigned)v, [](unsigned x, unsigned y) { return (unsigned)min((int)x, (int)y); }); }
+IVIT_DEV int rows_allmax_i32(int v) { return (int)rows_allreduce_u32((unsigned)v, [](unsigned x, unsigned y) { return (unsigned)max((int)x, (int)y); }); }
+IVIT_DEV unsigned rows_allsum_u32(unsigned v) { return rows_allreduce_u32(v, [](unsigned x, unsigned y) { return x + y; }); }
+
 // The per-channel constants of the int8-output LayerNorm kernels, once per workgroup into LDS: bias_int and the float32 bracket
 // [lo, hi] of the output requantiser's multiplier (the certificate of layernorm_i8_kernel, rowops.hip).  ALL global loads of a pass
 // (two channels per thread: C <= 2 x NTHREADS is one pass) are issued before the first use -- written as one loop with the loads where

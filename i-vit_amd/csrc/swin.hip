@@ -897,8 +897,7 @@ __global__ __launch_bounds__(NT, 4) void window_attention_kernel(WinAttnArgs a)
                     xmax = fmaxf(xmax, xv[kt][r]);
                 }
             }
-            rmax = max(rmax, __shfl_xor(rmax, 16));
-            rmax = max(rmax, __shfl_xor(rmax, 32));
+            rmax = rows_allmax_i32(rmax);      // over the four lanes of a query (common.h: permlane swaps, no LDS round trip)
             unsigned esum = 0;
             if constexpr (compat) {
                 // Shiftmax's float32 sequence on the phi values themselves (ivit_modules.py:150-170), per score
@@ -960,8 +959,7 @@ __global__ __launch_bounds__(NT, 4) void window_attention_kernel(WinAttnArgs a)
                     s[kt][r] = (int)e;
                     esum += e;
                 }
-            esum += __shfl_xor(esum, 16);
-            esum += __shfl_xor(esum, 32);
+            esum = rows_allsum_u32(esum);
             float S = fminf((float)esum, 2147483648.0f);                 // ivit_modules.py:171-173
             const float factor = floorf((1.0f / S) * 2147483648.0f);     // :174
             v4i pk;
