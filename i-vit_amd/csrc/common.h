@@ -66,6 +66,58 @@ IVIT_DEV int rows_allmin_i32(int v) { return (int)rows_allreduce_u32((unsigned)v
 IVIT_DEV int rows_allmax_i32(int v) { return (int)rows_allreduce_u32((unsigned)v, [](unsigned x, unsigned y) { return (unsigned)max((int)x, (int)y); }); }
 IVIT_DEV unsigned rows_allsum_u32(unsigned v) { return rows_allreduce_u32(v, [](unsigned x, unsigned y) { return x + y; }); }
 
+// All-reduce butterflies without LDS (a __shfl_xor with a constant offset compiles to ds_bpermute_b32: an LDS round trip per step).
+// Steps 1 / 2: DPP quad permutes; 4 / 8: row_half_mirror / row_mirror (the partner lies in the other half of the group, whose lanes
+// all hold that half's total by then); 16 / 32: v_permlane16_swap / v_permlane32_swap of the value with itself.  LPR = lanes that
+// share a result (power of two, groups aligned to LPR).
+#define IVIT_DPP_U32(x, CTRL) ((unsigned)__builtin_amdgcn_update_dpp(0, (int)(x), CTRL, 0xf, 0xf, false))
+template <int LPR>
+IVIT_DEV int lanes_allsum_i32(int v)
+{
+    typedef unsigned v2u_ __attribute__((ext_vector_type(2)));
+    if constexpr (LPR >= 2) v += (int)IVIT_DPP_U32(v, 0xB1);
+    if constexpr (LPR >= 4) v += (int)IVIT_DPP_U32(v, 0x4E);
+    if constexpr (LPR >= 8) v += (int)IVIT_DPP_U32(v, 0x141);
+    if constexpr (LPR >= 16) v += (int)IVIT_DPP_U32(v, 0x140);
+    if constexpr (LPR >= 32) { const v2u_ r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false); v = (int)(r.x + r.y); }
+    if constexpr (LPR >= 64) { const v2u_ r = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false); v = (int)(r.x + r.y); }
+    return v;
+}
+template <int LPR>
+IVIT_DEV unsigned long long lanes_allsum_u64(unsigned long long v)
+{
+    typedef unsigned v2u_ __attribute__((ext_vector_type(2)));
+#define IVIT_STEP64(CTRL) { const unsigned lo_ = IVIT_DPP_U32((unsigned)v, CTRL), hi_ = IVIT_DPP_U32((unsigned)(v >> 32), CTRL); v += ((unsigned long long)hi_ << 32) | lo_; }
+    if constexpr (LPR >= 2) IVIT_STEP64(0xB1)
+    if constexpr (LPR >= 4) IVIT_STEP64(0x4E)
+    if constexpr (LPR >= 8) IVIT_STEP64(0x141)
+    if constexpr (LPR >= 16) IVIT_STEP64(0x140)
+#undef IVIT_STEP64
+    if constexpr (LPR >= 32) {
+        const v2u_ a = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+        const v2u_ b = __builtin_amdgcn_permlane16_swap((unsigned)(v >> 32), (unsigned)(v >> 32), false, false);
+        v = (((unsigned long long)b.x << 32) | a.x) + (((unsigned long long)b.y << 32) | a.y);
+    }
+    if constexpr (LPR >= 64) {
+        const v2u_ a = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+        const v2u_ b = __builtin_amdgcn_permlane32_swap((unsigned)(v >> 32), (unsigned)(v >> 32), false, false);
+        v = (((unsigned long long)b.x << 32) | a.x) + (((unsigned long long)b.y << 32) | a.y);
+    }
+    return v;
+}
+IVIT_DEV int wave_allmax_i32(int v)
+{
+    typedef unsigned v2u_ __attribute__((ext_vector_type(2)));
+    v = max(v, (int)IVIT_DPP_U32(v, 0xB1));
+    v = max(v, (int)IVIT_DPP_U32(v, 0x4E));
+    v = max(v, (int)IVIT_DPP_U32(v, 0x141));
+    v = max(v, (int)IVIT_DPP_U32(v, 0x140));
+    const v2u_ r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+    v = max((int)r.x, (int)r.y);
+    const v2u_ q = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+    return max((int)q.x, (int)q.y);
+}
+
 // The per-channel constants of the int8-output LayerNorm kernels, once per workgroup into LDS: bias_int and the float32 bracket
 // [lo, hi] of the output requantiser's multiplier (the certificate of layernorm_i8_kernel, rowops.hip).  ALL global loads of a pass
 // (two channels per thread: C <= 2 x NTHREADS is one pass) are issued before the first use -- written as one loop with the loads where

@@ -1082,9 +1082,7 @@ __global__ __launch_bounds__(NT) void shiftgelu_lut_apply_kernel(GeluArgs a)
             }
         }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-            for (int r = 0; r < RW; ++r) kmax[r] = max(kmax[r], __shfl_xor(kmax[r], o));
+        for (int r = 0; r < RW; ++r) kmax[r] = wave_allmax_i32(kmax[r]);      // common.h: DPP + permlane swaps, no LDS round trips
 #pragma unroll
         for (int r = 0; r < RW; ++r)
             reinterpret_cast<int*>(tab[wave][r])[lane] =

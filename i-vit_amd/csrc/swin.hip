@@ -305,8 +305,7 @@ __global__ __launch_bounds__(NT, 4) void layernorm_i16_i8_tiled_kernel(Ln16Args 
 #pragma unroll
             for (int q = 0; q < 4; ++q) sum += (int)(int16_t)w[j][q] + (w[j][q] >> 16);
         }
-#pragma unroll
-        for (int o = LPR / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        sum = lanes_allsum_i32<LPR>(sum);      // common.h: DPP / permlane swaps instead of ds_bpermute butterflies
         const int mean_int = (int)rintf((float)sum / fC);                       // :37
         unsigned long long var = 0;
 #pragma unroll
@@ -321,12 +320,7 @@ __global__ __launch_bounds__(NT, 4) void layernorm_i16_i8_tiled_kernel(Ln16Args 
                 }
             }
         }
-#pragma unroll
-        for (int o = LPR / 2; o > 0; o >>= 1) {
-            const unsigned vlo = (unsigned)__shfl_xor((int)(unsigned)var, o);
-            const unsigned vhi = (unsigned)__shfl_xor((int)(var >> 32), o);
-            var += ((unsigned long long)vhi << 32) | vlo;
-        }
+        var = lanes_allsum_u64<LPR>(var);
         const float t = ln16_std10((float)var);                                 // :45-49
         const float hfactor = floorf((1.0f / t) * 2147483648.0f) * 0.5f;        // :51; the /2 of :52 commutes (exact scaling)
         int8_t* orow = a.out + win_row(a.map, min(row, a.rows - 1)) * a.ldo;
@@ -612,12 +606,7 @@ __global__ __launch_bounds__(NT, NJ >= 2 ? 3 : 4) void layernorm_i16_i8_tiled_co
                 }
             }
         }
-#pragma unroll
-        for (int o = LPR / 2; o > 0; o >>= 1) {
-            const unsigned vlo = (unsigned)__shfl_xor((int)(unsigned)var, o);
-            const unsigned vhi = (unsigned)__shfl_xor((int)(var >> 32), o);
-            var += ((unsigned long long)vhi << 32) | vlo;
-        }
+        var = lanes_allsum_u64<LPR>(var);
         const float t = ln16_std10((float)var);                                 // :45-49
         const float hfactor = floorf((1.0f / t) * 2147483648.0f) * 0.5f;        // :51; the /2 of :52 commutes (exact scaling)
         int8_t* orow = a.out + win_row(a.map, min(row, a.rows - 1)) * a.ldo;
