@@ -200,19 +200,9 @@ IVIT_DEV double requant_double(double z, double M)
     return __builtin_rint(p);
 }
 
-IVIT_DEV int wave_reduce_max_i32(int v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
-    return v;
-}
+IVIT_DEV int wave_reduce_max_i32(int v) { return wave_allmax_i32(v); }      // every lane ends with the result (DPP / permlane swaps, no LDS)
 
-IVIT_DEV int wave_reduce_sum_i32(int v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
+IVIT_DEV int wave_reduce_sum_i32(int v) { return lanes_allsum_i32<64>(v); }
 
 // int_exp_shift of the reference (ivit_modules.py:89-103 / :150-162) for one integer d <= 0,
 // x0 = floor(-1/s) (negative), n = 23 (GELU) or 15 (softmax).  Every intermediate is an exact
