@@ -481,3 +481,20 @@ def test_window_shiftexp_band_conditions():
     assert window_shiftexp_band(0.01, False) == (None, 0)           # band wider than 192 entries (or than the table)
     assert np.array_equal(phi_table(0.25), np.arange(-128, 128, dtype=np.float32))
 
+
+
+def test_serial_load_scan_flags_a_wait_between_independent_loads(tmp_path):
+    """scripts/scan_serial_loads.py (advisory ISA scan): a kernel whose loads are separated by s_waitcnt vmcnt(0) is
+    listed, one whose loads are issued together and waited for once is not"""
+    import subprocess
+    import sys
+    serial = "\n".join(["global_load_dword v1, v[2:3], off", "s_waitcnt vmcnt(0)", "ds_write_b32 v9, v1"] * 3)
+    batched = "\n".join(["global_load_dword v%d, v[2:3], off" % i for i in range(1, 4)] + ["s_waitcnt vmcnt(0)", "ds_write_b32 v9, v1"])
+    text = ""
+    for name, body in (("_Z6serialv", serial), ("_Z7batchedv", batched)):
+        text += f"\t.type\t{name},@function\n{name}:\n{body}\n\ts_endpgm\n.Lfunc_end_{name}:\n"
+    src = tmp_path / "k.s"
+    src.write_text(text)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "scripts", "scan_serial_loads.py"), str(src)], capture_output=True, text=True, check=True).stdout
+    assert "_Z6serialv" in out and "_Z7batchedv" not in out
