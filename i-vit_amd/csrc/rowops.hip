@@ -1209,6 +1209,22 @@ __global__ __launch_bounds__(NT) void patchify_kernel(const float* img, int8_t* 
     const int g = hw / patch;
     const int pw4 = patch >> 2;
     const int64_t total = (int64_t)batch * chans * hw * (hw >> 2);  // groups of 4 pixels
+    if (total < 2147483648ll) {      // uniform: 32-bit index arithmetic (the 64-bit divisions below cost more than the 20 bytes they place)
+        const unsigned w4 = (unsigned)(hw >> 2), tot = (unsigned)total;
+        for (unsigned q = blockIdx.x * NT + threadIdx.x; q < tot; q += gridDim.x * NT) {
+            const unsigned r = q / w4, x4 = q - r * w4;
+            const unsigned r2 = r / (unsigned)hw, y = r - r2 * (unsigned)hw;
+            const unsigned b = r2 / (unsigned)chans, c = r2 - b * (unsigned)chans;
+            const float4 v = *reinterpret_cast<const float4*>(img + (size_t)r * hw + 4 * x4);      // r = (b * chans + c) * hw + y
+            const unsigned px = x4 / (unsigned)pw4, kw = (x4 - px * pw4) * 4;
+            const unsigned py = y / (unsigned)patch, kh = y - py * patch;
+            const int64_t row = ((int64_t)b * g + py) * g + px;
+            const unsigned col = (c * patch + kh) * patch + kw;
+            *reinterpret_cast<int*>(A + row * lda + col) = pack4(quant_sym_i8(v.x, inv_scale), quant_sym_i8(v.y, inv_scale),
+                                                                 quant_sym_i8(v.z, inv_scale), quant_sym_i8(v.w, inv_scale));
+        }
+        return;
+    }
     for (int64_t q = (int64_t)blockIdx.x * NT + threadIdx.x; q < total; q += (int64_t)gridDim.x * NT) {
         // source order (coalesced float4 reads): b, c, y, x4
         int x4 = (int)(q % (hw >> 2));
